@@ -1,0 +1,153 @@
+/*
+ * pfx_oracle.h — CPU restatement ("oracle") of PaintFE's raster pixel hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker / the timed CPU baseline.
+ * The product path (paintfe_amd/csrc, libpfx.so) never links or calls it.
+ *
+ * Parity status: PINNED.  Every function here is checked (tests/test_oracle_*.py,
+ * `-m "not gpu"`) against the reference's own committed golden images
+ * (reference tests/golden/<category>/<name>.png, converted to tests/golden/golden.npz by
+ * tests/golden/make_fixtures.py) with tolerance 0, exactly as the reference's
+ * assert_golden does (reference tests/common/mod.rs:181-186,211-263).
+ * The reference itself (Rust, edition 2024) cannot be compiled in this image
+ * (no cargo/rustc), so there is no oracle/_ref build.
+ *
+ * Arithmetic rules followed throughout (reference is Rust, which never
+ * contracts a*b+c into an FMA and evaluates f32 expressions in f32):
+ *   - build with -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile);
+ *   - `x as u8` on f32  = saturating truncation toward zero, NaN -> 0;
+ *   - f32::round()      = roundf (half away from zero);
+ *   - f32::exp/powf/sqrt = glibc expf/powf/sqrtf (what Rust calls on Linux).
+ *
+ * All images are tight row-major straight-alpha RGBA8 (image::RgbaImage layout).
+ * File:line citations are relative to the reference checkout.
+ */
+#ifndef PFX_ORACLE_H
+#define PFX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFXO_CHUNK 64 /* src/canvas/defs.rs:7 CHUNK_SIZE */
+
+/* ---- A0: TiledImage sparsity (src/canvas/tiled_image.rs:50-104, 271-293) ---- */
+/* One byte per 64x64 chunk: 1 iff any pixel in the chunk has alpha != 0. */
+void pfxo_chunk_populated(const uint8_t* rgba, uint32_t w, uint32_t h, uint8_t* populated);
+/* from_rgba_image followed by to_rgba_image: unpopulated chunks become all-zero. */
+void pfxo_tiled_roundtrip(const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst);
+
+/* ---- A1/A2/A14: compositor (src/canvas/canvas_state.rs:505-698,1246-1505) ---- */
+enum { PFXO_LAYER_RASTER = 0, PFXO_ADJ_EXPOSURE = 1, PFXO_ADJ_BRIGHTNESS_CONTRAST = 2,
+       PFXO_ADJ_INVERT = 3, PFXO_ADJ_CHANNEL_MIXER = 4 };
+
+typedef struct pfxo_layer {
+    const uint8_t* pixels;   /* w*h*4 RGBA8 (raster layers); may be NULL for adjustment layers */
+    const uint8_t* mask;     /* optional w*h bytes: "conceal" (= mask TiledImage alpha), NULL = none */
+    float opacity;
+    uint8_t blend_mode;      /* BlendMode::to_u8, src/canvas/layers.rs:125-153 */
+    uint8_t visible;         /* layer_effectively_visible */
+    uint8_t kind;            /* PFXO_LAYER_RASTER or PFXO_ADJ_* (src/canvas/layers.rs:249-262) */
+    uint8_t _pad;
+    float adj[16];           /* Exposure: [ev]; B/C: [brightness, contrast]; ChannelMixer: red[4] green[4] blue[4] alpha[4] */
+} pfxo_layer;
+
+void pfxo_blend_pixel(const uint8_t base[4], const uint8_t top[4], int mode, float opacity, uint8_t out[4]);
+/* CanvasState::composite(): flatten bottom->top.  threads<=0 -> all cores (chunk-parallel like rayon). */
+void pfxo_composite(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t h, uint8_t* dst, int threads);
+/* dense flavour used by the benchmark baseline: n layers stored back to back (layer stride w*h*4) */
+void pfxo_flatten_stack(const uint8_t* stack, int n_layers, const uint8_t* modes, const float* opacities,
+                        uint32_t w, uint32_t h, uint8_t* dst, int threads);
+
+/* ---- A3: Gaussian blur (src/ops/filters.rs:141-316) ---- */
+/* returns kernel length (2r+1) written to `out` (caller provides >= 2*ceil(3*sigma)+1 floats) */
+int  pfxo_gaussian_kernel(float sigma, float* out, int cap);
+void pfxo_gaussian_blur(const uint8_t* src, uint32_t w, uint32_t h, float sigma, uint8_t* dst, int threads);
+void pfxo_blur_with_selection(const uint8_t* src, uint32_t w, uint32_t h, float sigma,
+                              const uint8_t* mask /* w*h or NULL */, uint8_t* dst, int threads);
+
+/* ---- A4/A5/A6: box blur, median, pixelate (src/ops/effects/{blur,noise,distort}.rs) ---- */
+void pfxo_box_blur(const uint8_t* src, uint32_t w, uint32_t h, float radius, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_median(const uint8_t* src, uint32_t w, uint32_t h, uint32_t radius, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_pixelate(const uint8_t* src, uint32_t w, uint32_t h, uint32_t block, const uint8_t* mask, uint8_t* dst, int threads);
+
+/* ---- A7/A8: ops::adjustments flavour (f32, .round()) (src/ops/adjustments.rs, src/ops/filters.rs:321) ---- */
+enum {
+    PFXO_OP_INVERT = 0, PFXO_OP_INVERT_ALPHA, PFXO_OP_SEPIA, PFXO_OP_BRIGHTNESS_CONTRAST, PFXO_OP_HSL,
+    PFXO_OP_EXPOSURE, PFXO_OP_HIGHLIGHTS_SHADOWS, PFXO_OP_TEMPERATURE_TINT, PFXO_OP_THRESHOLD, PFXO_OP_POSTERIZE,
+    PFXO_OP_COLOR_BALANCE, PFXO_OP_GRADIENT_MAP, PFXO_OP_BLACK_AND_WHITE, PFXO_OP_VIBRANCE, PFXO_OP_LUT_RGBA,
+    PFXO_OP_DESATURATE, PFXO_OP_COUNT
+};
+enum { PFXO_DENSE = 0, PFXO_FROM_FLAT = 1, PFXO_IN_PLACE = 2 };
+/* One driver for the whole bank; `params` layout per op is documented in o_adjust.c:px_fn.
+ * `lut`: 4x256 (PFXO_OP_LUT_RGBA) or 256x4 RGBA (PFXO_OP_GRADIENT_MAP), else NULL. mask: w*h, 0 = keep. */
+void pfxo_adjust(const uint8_t* src, uint32_t w, uint32_t h, int op, const float* params, const uint8_t* lut,
+                 const uint8_t* mask, int sparse_mode, uint8_t* dst, int threads);
+/* LUT builders (host-side in the reference too) */
+void pfxo_levels_lut(float in_black, float in_white, float gamma, float out_black, float out_white, uint8_t lut[256]);
+void pfxo_rhai_levels_lut(float in_black, float in_white, float gamma, uint8_t lut[256]);
+void pfxo_stretch_lut(uint8_t min, uint8_t max, uint8_t lut[256]);
+void pfxo_curves_lut(const float* pts_xy, int n_pts, uint8_t lut[256]);
+void pfxo_curves_luts_multi(const float* const pts[5], const int n[5], const int enabled[5], uint8_t out[4 * 256]);
+void pfxo_auto_levels_luts(const uint8_t* src, uint32_t w, uint32_t h, const uint8_t* mask, uint8_t out[4 * 256]);
+void pfxo_rgb_to_hsl(float r, float g, float b, float* h, float* s, float* l);
+void pfxo_hsl_to_rgb(float h, float s, float l, float* r, float* g, float* b);
+
+/* ---- A9: Rhai-inline flavour (truncating `as u8`, alpha untouched, mask ignored) (src/ops/scripting.rs:869-1075) ---- */
+enum {
+    PFXO_RHAI_INVERT = 0, PFXO_RHAI_DESATURATE, PFXO_RHAI_SEPIA, PFXO_RHAI_SEPIA_STRENGTH,
+    PFXO_RHAI_BRIGHTNESS_CONTRAST, PFXO_RHAI_HSL, PFXO_RHAI_EXPOSURE, PFXO_RHAI_LEVELS, PFXO_RHAI_COUNT
+};
+void pfxo_rhai_adjust(uint8_t* px, size_t n_px, int op, const float* params);
+
+/* ---- A10-A12: warp (src/ops/transform.rs:1015-1345,1558-1761) ---- */
+void pfxo_catmull_rom_weights(float t, float w[4]);
+void pfxo_catmull_rom_surface(const float* pts_xy, uint32_t cols, uint32_t rows, float u_global, float v_global,
+                              float out[2]);
+void pfxo_mesh_displacement(const float* orig_pts_xy, const float* def_pts_xy, uint32_t cols, uint32_t rows,
+                            uint32_t w, uint32_t h, float* disp_xy /* w*h*2 */, int threads);
+void pfxo_mesh_displacement_fast(const float* def_pts_xy, uint32_t cols, uint32_t rows, uint32_t w, uint32_t h,
+                                 float* disp_xy, int threads);
+void pfxo_warp_displacement(const uint8_t* src, uint32_t w, uint32_t h, const float* disp_xy, uint8_t* dst, int threads);
+void pfxo_warp_displacement_ex(const uint8_t* src, uint32_t sw, uint32_t sh, const float* disp_xy,
+                               uint32_t w, uint32_t h, uint8_t* dst, int threads);
+void pfxo_warp_mesh_catmull_rom(const uint8_t* src, const float* orig_pts_xy, const float* def_pts_xy,
+                                uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* dst, int threads);
+/* DisplacementField brushes; mode: 0 push, 1 expand, 2 contract, 3 twirl cw, 4 twirl ccw */
+void pfxo_displacement_brush(float* disp_xy, uint32_t w, uint32_t h, int mode, float cx, float cy,
+                             float delta_x, float delta_y, float radius, float strength);
+
+/* ---- A13: brush stamps (src/ui/panels/tools/behavior/raster/brush_render.rs) ---- */
+enum { PFXO_BRUSH_NORMAL = 0, PFXO_BRUSH_DODGE = 1, PFXO_BRUSH_BURN = 2, PFXO_BRUSH_SPONGE = 3 };
+typedef struct pfxo_brush {
+    float size;          /* diameter (ToolProperties::size) */
+    float hardness;      /* 0..1 */
+    float flow;          /* 0..1 */
+    float color[4];      /* brush colour, straight RGBA in 0..1 (primary/secondary_color_f32) */
+    int   anti_aliased;
+    int   is_eraser;
+    int   mode;          /* PFXO_BRUSH_* (BrushMode) */
+} pfxo_brush;
+float pfxo_brush_alpha(float dist, float radius, float hardness, int anti_aliased);
+void pfxo_brush_lut(float size, float hardness, int anti_aliased, uint8_t lut[256]);
+void pfxo_brush_stamp(uint8_t* target, uint32_t w, uint32_t h, const pfxo_brush* b, float cx, float cy,
+                      const uint8_t* selection /* w*h or NULL */);
+int  pfxo_brush_line_points(float x0, float y0, float x1, float y1, uint32_t w, uint32_t h, float* out_xy, int cap);
+void pfxo_brush_line(uint8_t* target, uint32_t w, uint32_t h, const pfxo_brush* b,
+                     float x0, float y0, float x1, float y1, const uint8_t* selection);
+/* stroke commit = blend_pixel_static(layer, preview, mode, 1.0) where preview.a>0 (bezier_commit.rs:103-161) */
+void pfxo_brush_commit(uint8_t* layer, const uint8_t* preview, uint32_t w, uint32_t h, int mode,
+                       const uint8_t* selection);
+void pfxo_eraser_commit(uint8_t* layer, const uint8_t* preview, uint32_t w, uint32_t h, const uint8_t* selection);
+
+int pfxo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""Two interchangeable back-ends for the known-answer table in golden_cases.py.
+
+OracleBackend  -> oracle/libpfx_oracle.so (CPU restatement; the checker)
+GpuBackend     -> libpfx.so through its C-ABI (the product; HIP kernels on cuda:0)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import golden_cases as GC
+from . import oracle_lib as O
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def composite(self, layers, w, h):
+        return O.composite(layers, w, h)
+
+    def gaussian_blur(self, img, sigma, mask=None):
+        return O.gaussian_blur(img, sigma, mask)
+
+    def box_blur(self, img, radius, mask=None):
+        return O.box_blur(img, radius, mask)
+
+    def median(self, img, radius, mask=None):
+        return O.median(img, radius, mask)
+
+    def pixelate(self, img, block, mask=None):
+        return O.pixelate(img, block, mask)
+
+    def rhai_adjust(self, img, op, params=()):
+        return O.rhai_adjust(img, op, params)
+
+    def adjust(self, img, op, params=(), lut=None, mask=None, sparse=0):
+        return O.adjust(img, op, params, lut, mask, sparse)
+
+    def auto_levels(self, img, mask=None):
+        return O.adjust(img, "lut_rgba", lut=O.auto_levels_luts(img, mask), mask=mask, sparse=O.FROM_FLAT)
+
+    def levels(self, img, in_black, in_white, gamma, out_black, out_white, mask=None):
+        lv = O.levels_lut(in_black, in_white, gamma, out_black, out_white)
+        luts = np.stack([lv, lv, lv, np.arange(256, dtype=np.uint8)])
+        return O.adjust(img, "lut_rgba", lut=luts, mask=mask, sparse=O.FROM_FLAT)
+
+    def warp_push(self, img, brushes):
+        h, w = img.shape[:2]
+        d = np.zeros((h, w, 2), np.float32)
+        for (mode, cx, cy, dx, dy, radius, strength) in brushes:
+            O.displacement_brush(d, mode, cx, cy, dx, dy, radius, strength)
+        return O.warp_displacement(img, d)
+
+    def warp_displacement(self, img, disp):
+        return O.warp_displacement(img, disp)
+
+    def warp_mesh(self, img, orig, deformed, cols, rows):
+        return O.warp_mesh_catmull_rom(img, orig, deformed, cols, rows)
+
+    def brush_stamps(self, target, brush, points, selection=None):
+        t = GC.brush_target(target) if isinstance(target, str) else np.ascontiguousarray(target).copy()
+        b = O.make_brush(**brush)
+        for (x, y) in points:
+            O.brush_stamp(t, b, x, y, selection)
+        return t
+
+    def brush_line(self, target, brush, p0, p1, selection=None):
+        t = GC.brush_target(target) if isinstance(target, str) else np.ascontiguousarray(target).copy()
+        return O.brush_line(t, O.make_brush(**brush), p0, p1, selection)

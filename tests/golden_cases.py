@@ -1,0 +1,203 @@
+"""Known-answer cases: (golden key) -> how to reproduce it.
+
+Each case restates the *call* the reference's own test makes (file:line cited) on the
+reference's deterministic input generator, so the same table drives
+  * tests/test_oracle_golden.py  (oracle vs golden, CPU, pins the oracle), and
+  * tests/test_gpu_golden.py     (HIP path through the C-ABI vs golden, GPU).
+
+A case is ``(key, backend_method, kwargs)`` where ``backend_method`` names a method that both
+back-ends implement (tests/backends.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import inputs as I
+
+f32 = np.float32
+W = H = 64
+
+BLEND_MODES = ["normal", "multiply", "screen", "additive", "reflect", "glow", "color_burn", "color_dodge",
+               "overlay", "difference", "negation", "lighten", "darken", "xor", "overwrite", "hard_light",
+               "soft_light", "exclusion", "subtract", "divide", "linear_burn", "vivid_light", "linear_light",
+               "pin_light", "hard_mix"]
+
+
+def _grad():
+    return I.create_test_gradient(64, 64)
+
+
+def _gradient_map_lut():
+    i = np.arange(256, dtype=f32)
+    t = i / f32(255.0)
+    lut = np.zeros((256, 4), np.uint8)
+    lut[:, 0] = (t * f32(255.0)).astype(np.uint8)
+    lut[:, 1] = (t * t * f32(200.0)).astype(np.uint8)
+    lut[:, 2] = (t * t * t * f32(150.0)).astype(np.uint8)
+    lut[:, 3] = 255
+    return lut
+
+
+def _swirl_field():
+    """tests/transform_ops.rs:345-358"""
+    x = np.arange(32, dtype=f32)[None, :]
+    y = np.arange(32, dtype=f32)[:, None]
+    dx = x - f32(16.0)
+    dy = y - f32(16.0)
+    r = np.maximum(np.sqrt(dx * dx + dy * dy), f32(0.001))
+    s = np.maximum(f32(1.0) - r / f32(16.0), f32(0.0))
+    d = np.zeros((32, 32, 2), f32)
+    d[..., 0] = -dy * s * f32(0.5)
+    d[..., 1] = dx * s * f32(0.5)
+    return d
+
+
+BLACK = (0.0, 0.0, 0.0, 1.0)
+WHITE = (1.0, 1.0, 1.0, 1.0)
+RED = (1.0, 0.0, 0.0, 1.0)
+BLUE_SEMI = (0.0, 0.0, 1.0, 0.5)
+
+
+def blend_cases():
+    """tests/visual_blend.rs:19-106"""
+    bg = I.create_test_checkerboard(64, 64)
+    fg = I.blend_foreground()
+    out = []
+    for m, name in enumerate(BLEND_MODES):
+        out.append((f"blend/{name}", "composite",
+                    dict(layers=[dict(pixels=bg), dict(pixels=fg, mode=m)], w=64, h=64)))
+    out.append(("blend/normal_half_opacity", "composite",
+                dict(layers=[dict(pixels=bg), dict(pixels=_grad(), opacity=0.5)], w=64, h=64)))
+    return out
+
+
+def filter_cases():
+    """tests/visual_filters.rs:30-62,90-94,143-147 and tests/scripting.rs:119-152"""
+    t = _grad()
+    return [
+        ("filters/gaussian_blur_s2", "gaussian_blur", dict(img=t, sigma=2.0)),
+        ("filters/gaussian_blur_s5", "gaussian_blur", dict(img=t, sigma=5.0)),
+        ("scripting/apply_blur", "gaussian_blur", dict(img=t, sigma=2.0)),
+        ("filters/box_blur_r3", "box_blur", dict(img=t, radius=3.0)),
+        ("filters/median_r2", "median", dict(img=t, radius=2)),
+        ("filters/pixelate_8", "pixelate", dict(img=t, block=8)),
+        ("scripting/apply_pixelate", "pixelate", dict(img=t, block=4)),
+    ]
+
+
+def rhai_cases():
+    """tests/scripting.rs:125-146 (Rhai-inline flavour, src/ops/scripting.rs:869-965)"""
+    t = _grad()
+    return [
+        ("scripting/apply_invert", "rhai_adjust", dict(img=t, op="invert")),
+        ("scripting/for_each_pixel_invert", "rhai_adjust", dict(img=t, op="invert")),
+        ("scripting/map_channels_invert", "rhai_adjust", dict(img=t, op="invert")),
+        ("scripting/apply_sepia", "rhai_adjust", dict(img=t, op="sepia")),
+        ("scripting/apply_desaturate", "rhai_adjust", dict(img=t, op="desaturate")),
+        ("scripting/apply_brightness_contrast", "rhai_adjust",
+         dict(img=t, op="brightness_contrast", params=[20.0, 10.0])),
+    ]
+
+
+def adjustment_cases():
+    """tests/visual_adjustments.rs:50-333.  sparse: 2 = in-place (apply_pixel_transform), 1 = *_from_flat."""
+    t = _grad()
+    A = "adjustments/"
+    return [
+        (A + "invert_colors", "adjust", dict(img=t, op="invert", sparse=2)),
+        (A + "invert_alpha", "adjust", dict(img=t, op="invert_alpha", sparse=1)),
+        (A + "invert_alpha_double", "adjust", dict(img=t, op="invert_alpha", sparse=1)),
+        (A + "sepia", "adjust", dict(img=t, op="sepia", sparse=2)),
+        (A + "auto_levels", "auto_levels", dict(img=t)),
+        (A + "desaturate", "adjust", dict(img=t, op="desaturate", sparse=1)),
+        (A + "brightness_30_contrast_20", "adjust", dict(img=t, op="brightness_contrast", params=[30.0, 20.0], sparse=1)),
+        (A + "hsl_h30_s-20_l10", "adjust", dict(img=t, op="hsl", params=[30.0, -20.0, 10.0], sparse=1)),
+        (A + "exposure_1ev", "adjust", dict(img=t, op="exposure", params=[1.0], sparse=1)),
+        (A + "highlights_shadows", "adjust", dict(img=t, op="highlights_shadows", params=[30.0, -20.0], sparse=1)),
+        (A + "levels", "levels", dict(img=t, in_black=20.0, in_white=235.0, gamma=1.2, out_black=0.0, out_white=255.0)),
+        (A + "temperature_tint", "adjust", dict(img=t, op="temperature_tint", params=[30.0, 10.0], sparse=1)),
+        (A + "threshold_128", "adjust", dict(img=t, op="threshold", params=[128.0], sparse=1)),
+        (A + "posterize_4", "adjust", dict(img=t, op="posterize", params=[4.0], sparse=1)),
+        (A + "color_balance", "adjust",
+         dict(img=t, op="color_balance", params=[10.0, 0.0, -10.0, 0.0, 0.0, 0.0, -10.0, 0.0, 10.0], sparse=1)),
+        (A + "gradient_map", "adjust", dict(img=t, op="gradient_map", lut=_gradient_map_lut(), sparse=1)),
+        (A + "black_and_white", "adjust",
+         dict(img=I.create_color_bands(64, 64), op="black_and_white", params=[0.3, 0.59, 0.11], sparse=1)),
+        (A + "vibrance_50", "adjust", dict(img=t, op="vibrance", params=[50.0], sparse=1)),
+    ]
+
+
+def warp_cases():
+    """tests/transform_ops.rs:162-169,201-209,345-360"""
+    g = I.gradient_32()
+    orig = I.uniform_grid(2, 2, 32.0, 32.0)
+    deformed = orig.copy()
+    deformed[4] = [20.0, 20.0]
+    return [
+        ("transform/displacement_radial_push", "warp_push",
+         dict(img=g, brushes=[(0, 16.0, 16.0, 3.0, 0.0, 10.0, 0.8)])),
+        ("transform/displacement_swirl", "warp_displacement", dict(img=g, disp=_swirl_field())),
+        ("transform/mesh_warp_deformed", "warp_mesh", dict(img=g, orig=orig, deformed=deformed, cols=2, rows=2)),
+    ]
+
+
+def _stamp(key, size, hard, aa, pos=(32.0, 32.0), color=BLACK, target="blank", eraser=False, mode=0, selection=None):
+    return (f"tools/{key}", "brush_stamps",
+            dict(target=target, brush=dict(size=size, hardness=hard, anti_aliased=aa, color=color,
+                                           is_eraser=eraser, mode=mode),
+                 points=[pos], selection=selection))
+
+
+def _line(key, size, hard, aa, p0, p1, color=BLACK, target="blank", eraser=False):
+    return (f"tools/{key}", "brush_line",
+            dict(target=target, brush=dict(size=size, hardness=hard, anti_aliased=aa, color=color,
+                                           is_eraser=eraser, mode=0), p0=p0, p1=p1))
+
+
+def brush_cases():
+    """tests/tool_strokes.rs:65-570"""
+    left_half = np.zeros((64, 64), np.uint8)
+    left_half[:, :32] = 255
+    multi = ("tools/stroke_multiple_stamps", "brush_stamps",
+             dict(target="blank", brush=dict(size=10.0, hardness=0.8, anti_aliased=True, color=BLACK,
+                                             is_eraser=False, mode=0),
+                  points=[(float(f32(8.0) + f32(i) * f32(7.0)), 32.0) for i in range(8)], selection=None))
+    return [
+        _stamp("brush_circle_center", 20.0, 1.0, True),
+        _stamp("brush_circle_soft", 30.0, 0.0, True),
+        _stamp("brush_circle_hard", 20.0, 1.0, False),
+        _stamp("brush_circle_tiny", 3.0, 1.0, True, color=RED),
+        _stamp("brush_circle_large", 60.0, 0.5, True),
+        _stamp("brush_semi_transparent", 20.0, 1.0, True, color=BLUE_SEMI),
+        _stamp("brush_secondary_color", 20.0, 1.0, True, color=RED),
+        _stamp("eraser_circle", 20.0, 1.0, True, target="white", eraser=True),
+        _stamp("eraser_soft", 30.0, 0.0, True, target="white", eraser=True),
+        _line("line_horizontal", 8.0, 1.0, True, (4.0, 32.0), (60.0, 32.0)),
+        _line("line_vertical", 8.0, 1.0, True, (32.0, 4.0), (32.0, 60.0)),
+        _line("line_diagonal", 6.0, 0.8, True, (4.0, 4.0), (60.0, 60.0)),
+        _line("line_soft_thick", 16.0, 0.3, True, (10.0, 50.0), (54.0, 10.0), color=RED),
+        _line("line_eraser", 10.0, 1.0, True, (4.0, 32.0), (60.0, 32.0), target="white", eraser=True),
+        _stamp("brush_with_selection_mask", 40.0, 1.0, True, selection=left_half),
+        multi,
+        _stamp("brush_at_origin", 10.0, 1.0, True, pos=(0.0, 0.0)),
+        _stamp("brush_at_corner", 20.0, 1.0, True, pos=(63.0, 63.0)),
+        _line("line_zero_length", 12.0, 1.0, True, (32.0, 32.0), (32.0, 32.0)),
+        _stamp("brush_dodge_mode", 24.0, 1.0, True, target="gradient", mode=1),
+        _stamp("brush_burn_mode", 24.0, 1.0, True, target="gradient", mode=2),
+        _stamp("pencil_circle", 12.0, 1.0, False),
+        _line("pencil_line", 4.0, 1.0, False, (4.0, 4.0), (60.0, 60.0), color=RED),
+    ]
+
+
+def brush_target(kind: str) -> np.ndarray:
+    if kind == "blank":
+        return I.create_transparent(W, H)
+    if kind == "white":
+        return I.create_solid(W, H, (255, 255, 255, 255))
+    if kind == "gradient":
+        return I.create_test_gradient(W, H)
+    raise ValueError(kind)
+
+
+def all_cases():
+    return (blend_cases() + filter_cases() + rhai_cases() + adjustment_cases() + warp_cases() + brush_cases())
