@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mpixels/sec on "8K x 32-layer flatten + Gaussian sigma=16" (BASELINE.json).
+
+One "step" = one pass of the hot path over one synthetic 8K document that is already resident in HBM:
+    flatten 32 RGBA8 layers (all 25 blend modes, S2 of SURVEY.md §8d)  ->  Gaussian blur sigma=16 of the result.
+Both results are materialised (140 algorithmic bytes per output pixel).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU; documents are independent units (the reference's CLI batch loops over files,
+src/cli.rs:159), so rank r processes its own 8K document with no data-path collective ("scaling": "weak").
+`value` = pixels all ranks produced / max-over-ranks wall time between two barrier+synchronize brackets.
+
+PyTorch is plumbing only (device buffers, the synthetic generator, torch.distributed).  The product path is
+libpfx.so through its C ABI; the CPU oracle is used here only (a) to check one crop of the GPU result and
+(b) as the timed `cpu_baseline` on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+W8K, H8K, NLAYERS, SIGMA = 7680, 4320, 32, 16.0
+
+
+def synth_stack(torch, device, w, h, n, seed):
+    """S2 generator on the device: uniform RGB; alpha 25% = 0, 25% = 255, 50% uniform 1..254; layer 0 opaque;
+    mode k -> k mod 25; opacity 1.0 for even k, 0.25 + 0.75*u for odd k."""
+    g = torch.Generator(device=device)
+    stack = torch.empty((n, h, w, 4), dtype=torch.uint8, device=device)
+    modes = np.zeros(n, np.uint8)
+    opac = np.ones(n, np.float32)
+    rng = np.random.default_rng(seed)
+    for k in range(n):
+        g.manual_seed(seed + k)
+        px = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=device, generator=g)
+        sel = torch.randint(0, 4, (h, w), dtype=torch.uint8, device=device, generator=g)
+        a = torch.randint(1, 255, (h, w), dtype=torch.uint8, device=device, generator=g)
+        a = torch.where(sel == 0, torch.zeros_like(a), torch.where(sel == 1, torch.full_like(a, 255), a))
+        px[..., 3] = 255 if k == 0 else a
+        stack[k] = px
+        modes[k] = k % 25
+        if k % 2 == 1:
+            opac[k] = np.float32(0.25) + np.float32(0.75) * np.float32(rng.random())
+        del px, sel, a
+    return stack, modes, opac
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=W8K)
+    ap.add_argument("--height", type=int, default=H8K)
+    ap.add_argument("--layers", type=int, default=NLAYERS)
+    ap.add_argument("--sigma", type=float, default=SIGMA)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact", action="store_true", help="Gaussian without FMA contraction (bit-exact with the CPU path)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from paintfe_amd import GpuRenderer
+    r = GpuRenderer(local_rank)
+    r.set_exact(args.exact)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)  # HIP events + kernels on the stream torch synchronises
+
+    w, h, n = args.width, args.height, args.layers
+    stack, modes, opac = synth_stack(torch, device, w, h, n, seed=0x5EED0002 + 1000 * rank)
+    flat = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
+    blurred = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
+    tmp = torch.empty((h, w, 4), dtype=torch.float32, device=device)  # f32 horizontal-pass intermediate
+    info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+    ptrs = [stack[k].data_ptr() for k in range(n)]
+
+    def step():
+        r.flatten_dev(ptrs, info, w, h, flat.data_ptr())
+        r.gaussian_blur_dev(flat.data_ptr(), blurred.data_ptr(), w, h, args.sigma, tmp.data_ptr())
+
+    def bracket():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    bracket()
+    r.timing_reset()
+    r.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    bracket()
+    elapsed = time.perf_counter() - t0
+    r.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    px_per_step = w * h
+    value = px_per_step * args.steps * world / elapsed / 1e6  # whole-job Mpx/s
+
+    # per-kernel launch durations from HIP events recorded on the launch stream during the timed region
+    kern = {}
+    for name in ("flatten", "gauss_h", "gauss_v"):
+        ms, cnt = r.timing_read(name)
+        kern[name] = (ms / max(cnt, 1), cnt)
+    alg_bytes = {"flatten": (4 * n + 4) * px_per_step, "gauss_h": 8 * px_per_step // 2, "gauss_v": 8 * px_per_step // 2}
+    dominant = "flatten"  # carries 132 of the 140 algorithmic bytes/px; named in DESIGN.md
+    d_ms = kern[dominant][0]
+    achieved = alg_bytes[dominant] / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
+    pipeline_bytes = (4 * n + 4 + 8) * px_per_step
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel_ms": {k: round(v[0], 4) for k, v in kern.items()},
+                "pipeline_achieved_GBs": round(pipeline_bytes * args.steps / elapsed / 1e9, 1),
+                "pipeline_frac": round(pipeline_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+
+    out = {"metric": "Mpixels/sec: 8K 32-layer flatten + Gaussian sigma=16; HBM GB/s vs peak", "value": round(value, 1),
+           "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{w}x{h} RGBA8 x {n} layers (25 blend modes cycling, S2) flatten -> Gaussian sigma={args.sigma:g}",
+                      "width": w, "height": h, "layers": n, "sigma": args.sigma, "gaussian_mode": "exact" if args.exact else "fma",
+                      "sharding": "one document per GPU, no collective" if world > 1 else "single GPU"},
+           "roofline": roofline}
+
+    if rank == 0:
+        # correctness spot check of the timed result against the oracle on a crop (flatten is per-pixel, so a crop
+        # of the full-size flatten equals the flatten of the cropped stack)
+        from tests import oracle_lib as O
+        cy, cx, ch, cw = 1000, 2000, 256, 512
+        crop_stack = stack[:, cy:cy + ch, cx:cx + cw, :].contiguous().cpu().numpy() if h >= cy + ch and w >= cx + cw else None
+        if crop_stack is not None:
+            ref = O.flatten_stack(crop_stack, modes, opac)
+            got = flat[cy:cy + ch, cx:cx + cw, :].contiguous().cpu().numpy()
+            out["check"] = {"flatten_crop_bitexact": bool(np.array_equal(ref, got))}
+            if not out["check"]["flatten_crop_bitexact"]:
+                out["check"]["mismatching_px"] = int((ref != got).any(-1).sum())
+
+        if not args.no_cpu_baseline and world == 1:
+            # bounded sample of the same workload: a 1920x1080 window of the same 32-layer stack
+            sh, sw = min(1080, h), min(1920, w)
+            sample = stack[:, :sh, :sw, :].contiguous().cpu().numpy()
+            cores = os.cpu_count() or 1
+            t1 = time.perf_counter()
+            f = O.flatten_stack(sample, modes, opac, threads=cores)
+            t2 = time.perf_counter()
+            O.gaussian_blur(f, args.sigma, threads=cores)
+            t3 = time.perf_counter()
+            out["cpu_baseline"] = {"value": round(sw * sh / (t3 - t1) / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                                   "sample": f"{sw}x{sh} window of the same {n}-layer stack, flatten {t2 - t1:.2f}s + gaussian {t3 - t2:.2f}s, "
+                                             f"OpenMP restatement of PaintFE's rayon CPU path (oracle/)"}
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

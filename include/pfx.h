@@ -1,0 +1,278 @@
+/*
+ * pfx.h — C ABI of libpfx: the MI355X (gfx950) raster pixel pipeline behind PaintFE's operator surface.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one reference interface (cited as
+ * `ref: file:line`, relative to the PaintFE checkout) and keeps its argument meaning and results:
+ *   - numerics are those of the reference's **CPU** path (src/ops, src/canvas), not of its WGSL shaders:
+ *     bit-exact for the compositor and the integer filters, +-1 LSB worst case (normally 0) for the
+ *     float-intermediate filters;
+ *   - images are tight row-major straight-alpha RGBA8 (`image::RgbaImage`), `w*h*4` bytes;
+ *   - selection masks are `w*h` bytes (`image::GrayImage`), 0 = leave the pixel alone (ref: src/ops/effects.rs:34-41);
+ *   - all calls are blocking with respect to the host (like the reference's `device.poll(Wait)` readback,
+ *     ref: src/gpu/compute/helpers.rs:147-206) unless the name ends in `_dev`;
+ *   - on any error the function returns a negative pfx_status and leaves `dst` untouched, so the caller
+ *     can fall back to its CPU path (the reference's own contract, ref: src/ops/adjustments.rs:1045).
+ *
+ * Two tiers:
+ *   host-buffer calls   (`pfx_blur_rgba`, ...)   = the literal `GpuRenderer` / `_core` signatures;
+ *   device-resident calls (`..._dev`)            = same kernels on caller-owned device memory and the
+ *                                                  context's HIP stream: upload once, chain ops, download once.
+ *
+ * One pfx_ctx = one HIP device + one stream.  A context is not thread-safe (neither is the reference's
+ * `&mut GpuRenderer`); distinct contexts are independent.  No torch / C++ types cross this boundary.
+ */
+#ifndef PFX_H
+#define PFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFX_ABI_VERSION 1
+#define PFX_CHUNK 64   /* ref: src/canvas/defs.rs:7 CHUNK_SIZE */
+#define PFX_MAX_LAYERS 256 /* ref: src/io.rs:503 MAX_LAYERS */
+
+typedef enum pfx_status {
+    PFX_OK = 0,
+    PFX_ERR_INVALID = -1,     /* bad argument (null pointer, zero size, unknown id) */
+    PFX_ERR_NO_DEVICE = -2,   /* no usable HIP device: GpuRenderer::try_new -> None (ref: src/gpu/renderer.rs:261) */
+    PFX_ERR_HIP = -3,         /* a HIP call failed; pfx_last_error() has the text */
+    PFX_ERR_OOM = -4,
+    PFX_ERR_UNSUPPORTED = -5, /* e.g. median radius beyond the device path: caller uses its CPU path (ref: renderer.rs:945) */
+    PFX_ERR_SCRIPT = -6       /* script front-end error; see pfx_script_result */
+} pfx_status;
+
+typedef struct pfx_ctx pfx_ctx;
+
+/* ---- context (ref: GpuRenderer::try_new / new / Drop, src/gpu/renderer.rs:249-300,969) ---- */
+int         pfx_ctx_create(int device, pfx_ctx** out);
+void        pfx_ctx_destroy(pfx_ctx* ctx);
+const char* pfx_last_error(const pfx_ctx* ctx);          /* never NULL */
+int         pfx_device_count(void);
+int         pfx_abi_version(void);
+/* Numeric mode for the float-intermediate stencil (Gaussian): 0 = fused multiply-add allowed (default,
+ * +-1 LSB class), 1 = reference evaluation order without FMA contraction (bit-exact with the CPU path). */
+int         pfx_ctx_set_exact(pfx_ctx* ctx, int exact);
+void*       pfx_ctx_stream(pfx_ctx* ctx);                 /* hipStream_t of this context */
+int         pfx_ctx_set_stream(pfx_ctx* ctx, void* hip_stream); /* adopt a caller stream (e.g. torch's); NULL restores own */
+int         pfx_ctx_synchronize(pfx_ctx* ctx);
+
+/* ---- device memory helpers for the `_dev` tier ---- */
+int pfx_dev_alloc(pfx_ctx* ctx, size_t bytes, void** out_dev);
+int pfx_dev_free(pfx_ctx* ctx, void* dev);
+int pfx_dev_upload(pfx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);   /* async on ctx stream + sync */
+int pfx_dev_download(pfx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int pfx_dev_memset(pfx_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* ================= B1: GpuRenderer filter methods (ref: src/gpu/renderer.rs:915-947) ================= */
+/* blur_rgba(&[u8], w, h, sigma) -> Vec<u8>; numerics: ops::filters::parallel_gaussian_blur (ref: src/ops/filters.rs:242-316) */
+int pfx_blur_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float sigma);
+/* brightness_contrast_rgba; numerics: ops::adjustments::brightness_contrast (ref: src/ops/adjustments.rs:265-294) */
+int pfx_brightness_contrast_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h,
+                                 float brightness, float contrast);
+/* hsl_rgba(hue deg, sat, light); numerics: hue_saturation_lightness (ref: src/ops/adjustments.rs:300-347) */
+int pfx_hsl_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float hue, float sat, float light);
+/* invert_rgba; numerics: invert_colors (ref: src/ops/adjustments.rs:115) */
+int pfx_invert_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h);
+/* median_rgba(radius) -> Option<Vec<u8>>; numerics: median_core (ref: src/ops/effects/noise.rs:357-410).
+ * The reference returns None for radius > 7; here PFX_ERR_UNSUPPORTED is returned beyond PFX_MEDIAN_MAX_RADIUS. */
+#define PFX_MEDIAN_MAX_RADIUS 24
+int pfx_median_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t radius);
+
+/* ================= B4: pure `_core` functions with optional selection mask ================= */
+/* blur_with_selection_pub (ref: src/ops/filters.rs:130-207) */
+int pfx_gaussian_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float sigma,
+                           const uint8_t* mask);
+/* box_blur_core (ref: src/ops/effects/blur.rs:233-318) */
+int pfx_box_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float radius,
+                      const uint8_t* mask);
+/* median_core (ref: src/ops/effects/noise.rs:357-410) */
+int pfx_median_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t radius,
+                    const uint8_t* mask);
+/* pixelate_core (ref: src/ops/effects/distort.rs:333-373) */
+int pfx_pixelate_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t block_size,
+                      const uint8_t* mask);
+
+/* ---- the pointwise adjustment bank: one entry point, op id + parameter block ----
+ * ops::adjustments flavour (f32, `.round().clamp(0,255) as u8`), ref: src/ops/adjustments.rs:21-108 */
+typedef enum pfx_adjust_op {
+    PFX_OP_INVERT = 0,           /* :115   params: -                                   */
+    PFX_OP_INVERT_ALPHA,         /* :123   params: -                                   */
+    PFX_OP_SEPIA,                /* :133   params: -                                   */
+    PFX_OP_BRIGHTNESS_CONTRAST,  /* :265   params: brightness, contrast                */
+    PFX_OP_HSL,                  /* :300   params: hue_shift(deg), saturation, lightness */
+    PFX_OP_EXPOSURE,             /* :352   params: ev  (gain = powf(2, ev) on the host) */
+    PFX_OP_HIGHLIGHTS_SHADOWS,   /* :374   params: shadows, highlights                 */
+    PFX_OP_TEMPERATURE_TINT,     /* :517   params: temperature, tint                   */
+    PFX_OP_THRESHOLD,            /* :1240  params: level                               */
+    PFX_OP_POSTERIZE,            /* :1267  params: levels (>= 2)                       */
+    PFX_OP_COLOR_BALANCE,        /* :1294  params: shadows[3], midtones[3], highlights[3] */
+    PFX_OP_GRADIENT_MAP,         /* :1344  lut: 256 x RGBA                             */
+    PFX_OP_BLACK_AND_WHITE,      /* :1373  params: r_weight, g_weight, b_weight        */
+    PFX_OP_VIBRANCE,             /* :1408  params: amount                              */
+    PFX_OP_LUT_RGBA,             /* levels :465 / curves :584 / auto-levels :144; lut: R[256] G[256] B[256] A[256] */
+    PFX_OP_DESATURATE,           /* filters.rs:321 (BT.709, round)                     */
+    PFX_OP_COUNT
+} pfx_adjust_op;
+
+/* How TiledImage sparsity leaks into the result (ref: src/canvas/tiled_image.rs:50-104,905-932):
+ *   PFX_DENSE      arithmetic on every pixel, no chunk effects;
+ *   PFX_FROM_FLAT  `*_from_flat` + `TiledImage::from_rgba_image(&out)`: 64x64 chunks of the result whose alpha is
+ *                  all zero read back as zeros (ref: src/ops/adjustments.rs:105);
+ *   PFX_IN_PLACE   `apply_pixel_transform`: only chunks populated in the input are visited, the others read
+ *                  back as zeros (ref: src/ops/adjustments.rs:21-42). */
+typedef enum pfx_sparse_mode { PFX_DENSE = 0, PFX_FROM_FLAT = 1, PFX_IN_PLACE = 2 } pfx_sparse_mode;
+
+int pfx_adjust(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, int op,
+               const float* params, uint32_t n_params, const uint8_t* lut, const uint8_t* mask, int sparse_mode);
+
+/* Rhai-inline flavour (truncating `as u8`, alpha untouched, selection ignored), ref: src/ops/scripting.rs:869-1075 */
+typedef enum pfx_rhai_op {
+    PFX_RHAI_INVERT = 0, PFX_RHAI_DESATURATE, PFX_RHAI_SEPIA, PFX_RHAI_SEPIA_STRENGTH,
+    PFX_RHAI_BRIGHTNESS_CONTRAST, PFX_RHAI_HSL, PFX_RHAI_EXPOSURE, PFX_RHAI_LEVELS, PFX_RHAI_COUNT
+} pfx_rhai_op;
+int pfx_rhai_adjust(pfx_ctx* ctx, uint8_t* pixels_inout, uint32_t w, uint32_t h, int op, const float* params,
+                    uint32_t n_params);
+
+/* LUT builders (host-side in the reference as well; glibc powf/sqrtf like Rust's f32 methods on Linux) */
+void pfx_build_levels_lut(float in_black, float in_white, float gamma, float out_black, float out_white,
+                          uint8_t lut[256]);                                   /* ref: adjustments.rs:465-488 */
+void pfx_build_curves_lut(const float* points_xy, uint32_t n_points, uint8_t lut[256]); /* ref: adjustments.rs:640-729 */
+void pfx_build_stretch_lut(uint8_t min, uint8_t max, uint8_t lut[256]);        /* ref: adjustments.rs:235-256 */
+/* auto_levels: device min/max reduction over selected non-transparent pixels, then stretch LUTs (ref: :144-233) */
+int  pfx_auto_levels(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, const uint8_t* mask);
+
+/* ================= B2: compositor (ref: src/gpu/renderer.rs:324-586, numerics src/canvas/canvas_state.rs:505-698) ===== */
+/* ensure_layer_texture(idx, w, h, data, generation): upload skipped when (generation, w, h) unchanged */
+int pfx_layer_upload(pfx_ctx* ctx, uint32_t layer_idx, uint32_t w, uint32_t h, const uint8_t* rgba, uint64_t generation);
+/* update_layer_rect(idx, region, data): `data` is the tight region (rw*rh*4) */
+int pfx_layer_update_rect(pfx_ctx* ctx, uint32_t layer_idx, uint32_t x, uint32_t y, uint32_t rw, uint32_t rh,
+                          const uint8_t* rgba);
+/* optional live layer mask ("conceal" alpha, w*h bytes; NULL removes it) (ref: src/canvas/layers.rs:606-620) */
+int pfx_layer_set_mask(pfx_ctx* ctx, uint32_t layer_idx, const uint8_t* conceal);
+int pfx_layer_remove(pfx_ctx* ctx, uint32_t layer_idx);
+int pfx_layer_clear(pfx_ctx* ctx);
+uint32_t pfx_layer_count(const pfx_ctx* ctx);
+size_t   pfx_layer_memory(const pfx_ctx* ctx);     /* active_texture_memory, ref: renderer.rs:956 */
+
+typedef enum pfx_layer_kind { /* ref: src/canvas/layers.rs:249-262 AdjustmentKind */
+    PFX_LAYER_RASTER = 0, PFX_ADJ_EXPOSURE = 1, PFX_ADJ_BRIGHTNESS_CONTRAST = 2, PFX_ADJ_INVERT = 3, PFX_ADJ_CHANNEL_MIXER = 4
+} pfx_layer_kind;
+
+typedef struct pfx_layer_info { /* the `(layer_idx, opacity, visible, blend_mode_u8)` tuple, bottom -> top */
+    uint32_t layer_idx;
+    float    opacity;
+    uint8_t  visible;
+    uint8_t  blend_mode;   /* BlendMode::to_u8, ref: src/canvas/layers.rs:125-153; unknown ids = Normal */
+    uint8_t  kind;         /* pfx_layer_kind; adjustment layers need no uploaded pixels */
+    uint8_t  _pad;
+    float    adj[16];      /* Exposure [ev]; B/C [brightness, contrast]; ChannelMixer red[4] green[4] blue[4] alpha[4] */
+} pfx_layer_info;
+
+/* composite(canvas_w, canvas_h, layer_info) -> Option<Vec<u8>>; `dst` = w*h*4 */
+int pfx_composite(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* layers, uint32_t n_layers, uint8_t* dst);
+/* composite_dirty_readback: composite, read back only (x, y, rw, rh) into the tight `dst_region` */
+int pfx_composite_region(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* layers, uint32_t n_layers,
+                         uint32_t x, uint32_t y, uint32_t rw, uint32_t rh, uint8_t* dst_region);
+/* one blend_pixel_static on the host-visible side of the ABI (kept for spot checks; runs a 1-pixel launch) */
+int pfx_blend_pixels(pfx_ctx* ctx, const uint8_t* base, const uint8_t* top, uint8_t* dst, size_t n_pixels,
+                     uint8_t blend_mode, float opacity);
+
+/* ================= B3: warp pipelines ================= */
+/* GpuLiquifyPipeline::warp_into (ref: src/gpu/compute/liquify.rs:176); numerics warp_displacement_full
+ * (ref: src/ops/transform.rs:1288-1345).  Field and output are w*h; source is sw*sh. */
+int pfx_warp_displacement(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_t sh, const float* disp_xy,
+                          uint32_t w, uint32_t h, uint8_t* dst);
+/* generate_displacement_from_mesh (ref: src/ops/transform.rs:1670-1705); orig_pts may be NULL =>
+ * generate_displacement_from_mesh_fast / GpuMeshWarpDisplacementPipeline::generate_displacement
+ * (ref: src/ops/transform.rs:1712, src/gpu/compute/mesh_warp.rs:131) */
+int pfx_mesh_displacement(pfx_ctx* ctx, const float* orig_pts_xy, const float* deformed_pts_xy, uint32_t cols,
+                          uint32_t rows, uint32_t w, uint32_t h, float* disp_xy_out);
+/* warp_mesh_catmull_rom (ref: src/ops/transform.rs:1743-1761): fused field + gather, no field in memory */
+int pfx_warp_mesh_catmull_rom(pfx_ctx* ctx, const uint8_t* src, const float* orig_pts_xy, const float* deformed_pts_xy,
+                              uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* dst);
+/* DisplacementField::apply_push/expand/contract/twirl (ref: src/ops/transform.rs:1051-1200): host-side scatter-add
+ * exactly as in the reference (serial, glibc expf). mode: 0 push, 1 expand, 2 contract, 3 twirl cw, 4 twirl ccw */
+void pfx_displacement_brush(float* disp_xy, uint32_t w, uint32_t h, int mode, float cx, float cy,
+                            float delta_x, float delta_y, float radius, float strength);
+
+/* ================= brush stamp loop (ref: src/ui/panels/tools/behavior/raster/brush_render.rs) ================= */
+typedef enum pfx_brush_mode { PFX_BRUSH_NORMAL = 0, PFX_BRUSH_DODGE = 1, PFX_BRUSH_BURN = 2, PFX_BRUSH_SPONGE = 3 } pfx_brush_mode;
+typedef struct pfx_brush { /* the ToolProperties fields the circle-tip path reads (ref: state.rs:98-157) */
+    float size, hardness, flow;
+    float color[4];       /* straight RGBA in 0..1 (primary/secondary_color_f32) */
+    int32_t anti_aliased;
+    int32_t is_eraser;
+    int32_t mode;         /* pfx_brush_mode */
+} pfx_brush;
+/* draw_circle_no_dirty for every point of `points_xy` in order (ref: brush_render.rs:135-400) into `target_inout` */
+int pfx_brush_stamps(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush,
+                     const float* points_xy, uint32_t n_points, const uint8_t* selection);
+/* draw_line_no_dirty (ref: brush_render.rs:762-835): dense 1-px stepping, then the stamp loop */
+int pfx_brush_line(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush,
+                   float x0, float y0, float x1, float y1, const uint8_t* selection);
+/* commit_bezier_to_layer / commit_eraser_to_layer (ref: bezier_commit.rs:103-225) */
+int pfx_brush_commit(pfx_ctx* ctx, uint8_t* layer_inout, const uint8_t* preview, uint32_t w, uint32_t h,
+                     uint8_t blend_mode, int is_eraser, const uint8_t* selection);
+
+/* ================= A0: TiledImage import/export rule ================= */
+/* from_rgba_image + to_rgba_image: chunks with no alpha read back as zeros (ref: tiled_image.rs:50-104,271-293) */
+int pfx_tiled_roundtrip(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h);
+/* chunk_keys(): one byte per 64x64 chunk, row-major, 1 = populated */
+int pfx_chunk_populated(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* populated);
+
+/* ================= device-resident tier (`_dev`): same kernels, caller-owned device memory, asynchronous ========= */
+int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev /* may be NULL */,
+                    const pfx_layer_info* layers, uint32_t n_layers, uint32_t w, uint32_t h, void* dst_dev);
+/* `tmp_dev` = w*h*16 bytes of scratch for the f32 horizontal pass (ref: filters.rs:255 buf_h); NULL = context scratch */
+int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma,
+                          void* tmp_dev);
+int pfx_box_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius,
+                     const void* mask_dev, void* tmp_dev /* w*h*4 or NULL */);
+int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius,
+                   const void* mask_dev);
+int pfx_pixelate_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t block_size,
+                     const void* mask_dev);
+int pfx_adjust_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, int op,
+                   const float* params, uint32_t n_params, const uint8_t* lut_host, const void* mask_dev, int sparse_mode);
+int pfx_rhai_adjust_dev(pfx_ctx* ctx, void* pixels_dev, uint32_t w, uint32_t h, int op, const float* params,
+                        uint32_t n_params);
+int pfx_warp_displacement_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, uint32_t sh, const void* disp_dev,
+                              uint32_t w, uint32_t h, void* dst_dev);
+int pfx_mesh_displacement_dev(pfx_ctx* ctx, const float* orig_pts_xy, const float* deformed_pts_xy, uint32_t cols,
+                              uint32_t rows, uint32_t w, uint32_t h, void* disp_dev);
+int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float* orig_pts_xy,
+                                  const float* deformed_pts_xy, uint32_t cols, uint32_t rows, uint32_t w, uint32_t h,
+                                  void* dst_dev);
+int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush,
+                         const float* points_xy, uint32_t n_points, const void* selection_dev);
+int pfx_tiled_roundtrip_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h);
+
+/* per-launch timing of the most recent `_dev` call family, measured with HIP events on the context stream
+ * (used by bench.py for the roofline line).  Enable, run, then read the accumulated milliseconds / launches. */
+int pfx_timing_enable(pfx_ctx* ctx, int on);
+int pfx_timing_read(pfx_ctx* ctx, const char* kernel_name, double* total_ms, uint64_t* launches);
+int pfx_timing_reset(pfx_ctx* ctx);
+
+/* ================= B5/B6: script front-end and CLI (ref: src/ops/scripting.rs:1733-1821, src/cli.rs) ================= */
+typedef struct pfx_script_result {
+    char     error[512];      /* ScriptError::friendly_message-style text, empty on success */
+    int32_t  error_line;      /* 1-based, 0 if unknown */
+    int32_t  error_col;
+    uint32_t ops_executed;
+    char     console[2048];   /* print_line output, '\n' separated (truncated) */
+} pfx_script_result;
+/* execute_script_sync(source, pixels, w, h, mask): runs the Effect-API call statements of a Rhai script against
+ * `pixels_inout`.  Names, arity and numeric flavour per registered function follow scripting.rs:822-1165. */
+int pfx_script_run(pfx_ctx* ctx, const char* source, uint8_t* pixels_inout, uint32_t w, uint32_t h,
+                   const uint8_t* mask, pfx_script_result* result);
+/* the `pfx` batch CLI main (same flags as src/cli.rs:43-89); returns the process exit code */
+int pfx_cli_main(int argc, char** argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFX_H */

@@ -245,8 +245,8 @@ static void px_fn(int op, const float* p, const uint8_t* lut, float r, float g, 
         o[0] = v; o[1] = v; o[2] = v; o[3] = a;
         return;
     }
-    case PFXO_OP_POSTERIZE: { /* p[0] = levels (already max(2)) */
-        float factor = p[0];
+    case PFXO_OP_POSTERIZE: { /* p[0] = levels; `levels.max(2) as f32` (adjustments.rs:1268) */
+        float factor = p[0] < 2.0f ? 2.0f : p[0];
         o[0] = roundf(r / 255.0f * (factor - 1.0f)) / (factor - 1.0f) * 255.0f;
         o[1] = roundf(g / 255.0f * (factor - 1.0f)) / (factor - 1.0f) * 255.0f;
         o[2] = roundf(b / 255.0f * (factor - 1.0f)) / (factor - 1.0f) * 255.0f;

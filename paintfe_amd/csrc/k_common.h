@@ -1,0 +1,76 @@
+// k_common.h — device-side helpers shared by the gfx950 kernels.
+//
+// Parity rules: the reference is Rust — every f32 expression is evaluated in
+// f32 with one rounding per operation and NO fused multiply-add.  The bit-exact kernels are therefore
+// compiled with -ffp-contract=off and use '/' and sqrtf, which hipcc lowers to the IEEE-correct
+// sequences (-fhip-fp32-correctly-rounded-divide-sqrt, f32 denormals on).  Where an FMA is used it is
+// written explicitly (__builtin_fmaf) in a place where it is *proved* to round like the reference's
+// expression (div255).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PFX_DEV __device__ __forceinline__
+
+namespace pfxk {
+
+// x / 255.0f for integer-valued x in [0,255], correctly rounded, in 2 VALU ops instead of an IEEE divide.
+// 1/255 = C_HI + C_LO (C_HI = RN(1/255), C_LO = RN(1/255 - C_HI)); RN(x*C_HI + RN(x*C_LO)) == RN(x/255)
+// for all 256 inputs (exhaustively checked on the host at context creation, pfx_ctx.cpp:selfcheck_div255,
+// and in tests/test_host_logic.py).
+PFX_DEV float div255(float x)
+{
+    const float C_HI = __builtin_bit_cast(float, 998277249u);   // 0x3B808081
+    const float C_LO = __builtin_bit_cast(float, 2944335615u);  // 0xAF7EFEFF
+    return __builtin_fmaf(x, C_HI, x * C_LO);
+}
+
+// Rust `v.clamp(0.0, 255.0) as u8` kept as an integer-valued float (0..255), NaN -> 0.
+PFX_DEV float quant255(float v)
+{
+    // fmaxf(NaN, 0) = 0 on AMDGPU (v_max_f32 returns the non-NaN operand), matching `NaN as u8 == 0`.
+    return __builtin_fabsf(__builtin_truncf(__builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f)));
+}
+// Rust `v as u8` (saturating truncation) without a prior clamp
+PFX_DEV float trunc_u8f(float v) { return quant255(v); }
+// Rust `v.round().clamp(0.0, 255.0) as u8` (round half away from zero)
+PFX_DEV float round_u8f(float v)
+{
+    // roundf(x) = trunc(x + copysign(0.5, x)) is NOT exact for |x| just below .5 boundaries; use the
+    // two-step form: t = trunc(x); if (|x - t| >= 0.5) t += copysign(1, x).
+    float t = __builtin_truncf(v);
+    float d = v - t; // exact (Sterbenz / same binade)
+    if (__builtin_fabsf(d) >= 0.5f) t += __builtin_copysignf(1.0f, v);
+    return __builtin_fabsf(__builtin_fminf(__builtin_fmaxf(t, 0.0f), 255.0f));
+}
+
+PFX_DEV float ubyte0(uint32_t p) { return (float)(p & 0xffu); }
+PFX_DEV float ubyte1(uint32_t p) { return (float)((p >> 8) & 0xffu); }
+PFX_DEV float ubyte2(uint32_t p) { return (float)((p >> 16) & 0xffu); }
+PFX_DEV float ubyte3(uint32_t p) { return (float)(p >> 24); }
+
+PFX_DEV uint32_t pack_rgba(float r, float g, float b, float a)
+{
+    return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | ((uint32_t)a << 24);
+}
+
+// Rust f32::clamp
+PFX_DEV float rs_clamp(float x, float lo, float hi)
+{
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+
+// XCD-aware block remap: blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), so give each
+// XCD a contiguous range of tiles: neighbouring tiles (shared halo rows/columns) then hit the same L2.
+PFX_DEV uint32_t xcd_swizzle(uint32_t bid, uint32_t nblocks)
+{
+    const uint32_t NXCD = 8;
+    uint32_t per = nblocks / NXCD;
+    uint32_t main = per * NXCD;
+    if (bid >= main) return bid; // ragged tail keeps its position
+    return (bid % NXCD) * per + (bid / NXCD);
+}
+
+} // namespace pfxk

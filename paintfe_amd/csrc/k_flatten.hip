@@ -1,0 +1,382 @@
+// k_flatten.hip — the layer compositor: CanvasState::composite() as ONE streaming gfx950 kernel.
+//
+// Reference: src/canvas/canvas_state.rs:505-698 (composite_viewport) and :1246-1505 (blend_pixel_static and the
+// per-channel helpers); adjustment layers src/canvas/layers.rs:276-325; live mask :660-665.
+//
+// Design (HBM-bound streaming, no LDS, no MFMA):
+//   * one lane owns 4 consecutive pixels: every layer is read with one 16-byte load per lane (1 KiB per wave
+//     instruction, fully coalesced), the result is written with one 16-byte store;
+//   * the accumulator ("pixels[idx]" in the reference, a u8 RGBA re-quantised after every layer) lives in
+//     registers for the whole layer stack as integer-valued floats — nothing but the N layer reads and the one
+//     result write touches HBM: 4*N + 4 bytes per pixel, the algorithmic minimum;
+//   * the blend mode is uniform per layer, so the 25-way dispatch is a scalar branch outside the pixel code and
+//     each mode is its own straight-line specialisation;
+//   * arithmetic is the reference's f32 sequence, operation for operation, without FMA contraction
+//     (this file is compiled with -ffp-contract=off); u8/255 uses the proved 2-op form (k_common.h:div255).
+#include "k_common.h"
+#include "pfx_kernels.h"
+
+using namespace pfxk;
+
+namespace {
+
+enum : uint32_t {
+    M_NORMAL = 0, M_MULTIPLY, M_SCREEN, M_ADDITIVE, M_REFLECT, M_GLOW, M_COLOR_BURN, M_COLOR_DODGE, M_OVERLAY,
+    M_DIFFERENCE, M_NEGATION, M_LIGHTEN, M_DARKEN, M_XOR, M_OVERWRITE, M_HARD_LIGHT, M_SOFT_LIGHT, M_EXCLUSION,
+    M_SUBTRACT, M_DIVIDE, M_LINEAR_BURN, M_VIVID_LIGHT, M_LINEAR_LIGHT, M_PIN_LIGHT, M_HARD_MIX
+};
+
+// ---- canvas_state.rs:1425-1505 ----
+PFX_DEV float overlay_channel(float base, float top)
+{
+    return (base < 0.5f) ? 2.0f * base * top : 1.0f - 2.0f * (1.0f - base) * (1.0f - top);
+}
+PFX_DEV float color_burn_channel(float base, float top)
+{
+    return (top == 0.0f) ? 0.0f : __builtin_fmaxf(1.0f - (1.0f - base) / top, 0.0f);
+}
+PFX_DEV float color_dodge_channel(float base, float top)
+{
+    return (top >= 1.0f) ? 1.0f : __builtin_fminf(base / (1.0f - top), 1.0f);
+}
+PFX_DEV float reflect_channel(float base, float top)
+{
+    return (top >= 1.0f) ? 1.0f : __builtin_fminf(base * base / (1.0f - top), 1.0f);
+}
+PFX_DEV float soft_light_channel(float base, float top)
+{
+    if (top <= 0.5f) return base - (1.0f - 2.0f * top) * base * (1.0f - base);
+    float d = (base <= 0.25f) ? ((16.0f * base - 12.0f) * base + 4.0f) * base : __builtin_sqrtf(base);
+    return base + (2.0f * top - 1.0f) * (d - base);
+}
+PFX_DEV float divide_channel(float base, float top)
+{
+    return (top <= 0.0f) ? 1.0f : __builtin_fminf(base / top, 1.0f);
+}
+PFX_DEV float vivid_light_channel(float base, float top)
+{
+    if (top <= 0.5f) {
+        float t2 = 2.0f * top;
+        return (t2 <= 0.0f) ? 0.0f : __builtin_fmaxf(1.0f - (1.0f - base) / t2, 0.0f);
+    }
+    float t2 = 2.0f * (top - 0.5f);
+    return (t2 >= 1.0f) ? 1.0f : __builtin_fminf(base / (1.0f - t2), 1.0f);
+}
+PFX_DEV float pin_light_channel(float base, float top)
+{
+    return (top <= 0.5f) ? __builtin_fminf(base, 2.0f * top) : __builtin_fmaxf(base, 2.0f * (top - 0.5f));
+}
+
+template <uint32_t M>
+PFX_DEV float blend_fn(float b, float t)
+{
+    if constexpr (M == M_NORMAL) return t;
+    else if constexpr (M == M_MULTIPLY) return b * t;
+    else if constexpr (M == M_SCREEN) return 1.0f - (1.0f - b) * (1.0f - t);
+    else if constexpr (M == M_ADDITIVE) return __builtin_fminf(b + t, 1.0f);
+    else if constexpr (M == M_REFLECT) return reflect_channel(b, t);
+    else if constexpr (M == M_GLOW) return reflect_channel(t, b);
+    else if constexpr (M == M_COLOR_BURN) return color_burn_channel(b, t);
+    else if constexpr (M == M_COLOR_DODGE) return color_dodge_channel(b, t);
+    else if constexpr (M == M_OVERLAY) return overlay_channel(b, t);
+    else if constexpr (M == M_DIFFERENCE) return __builtin_fabsf(b - t);
+    else if constexpr (M == M_NEGATION) return 1.0f - __builtin_fabsf(1.0f - b - t);
+    else if constexpr (M == M_LIGHTEN) return __builtin_fmaxf(b, t);
+    else if constexpr (M == M_DARKEN) return __builtin_fminf(b, t);
+    else if constexpr (M == M_HARD_LIGHT) return overlay_channel(t, b);
+    else if constexpr (M == M_SOFT_LIGHT) return soft_light_channel(b, t);
+    else if constexpr (M == M_EXCLUSION) return b + t - 2.0f * b * t;
+    else if constexpr (M == M_SUBTRACT) return __builtin_fmaxf(b - t, 0.0f);
+    else if constexpr (M == M_DIVIDE) return divide_channel(b, t);
+    else if constexpr (M == M_LINEAR_BURN) return __builtin_fmaxf(b + t - 1.0f, 0.0f);
+    else if constexpr (M == M_VIVID_LIGHT) return vivid_light_channel(b, t);
+    else if constexpr (M == M_LINEAR_LIGHT) return rs_clamp(b + 2.0f * t - 1.0f, 0.0f, 1.0f);
+    else if constexpr (M == M_PIN_LIGHT) return pin_light_channel(b, t);
+    else if constexpr (M == M_HARD_MIX) return (b + t >= 1.0f) ? 1.0f : 0.0f;
+    else return t;
+}
+
+// One blend_pixel_static (canvas_state.rs:1246-1422).  `acc` = base as integer-valued floats (r,g,b,a);
+// `top` = packed RGBA8 of the layer pixel (alpha already masked); `opacity_raw` = layer.opacity as stored,
+// `opc` = opacity.clamp(0,1).
+template <uint32_t M>
+PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float opc)
+{
+    const uint32_t ta8 = top >> 24;
+    if (ta8 == 0u) return;                                             // :1253
+    if (M == M_NORMAL && opacity_raw >= 1.0f && ta8 == 255u) {         // :1258
+        acc[0] = ubyte0(top); acc[1] = ubyte1(top); acc[2] = ubyte2(top); acc[3] = 255.0f;
+        return;
+    }
+    const float top_r = div255(ubyte0(top)), top_g = div255(ubyte1(top)), top_b = div255(ubyte2(top));
+    const float top_a = div255((float)ta8) * opc;                      // :1272
+
+    if constexpr (M == M_OVERWRITE) {                                  // :1275
+        acc[0] = trunc_u8f(top_r * 255.0f);
+        acc[1] = trunc_u8f(top_g * 255.0f);
+        acc[2] = trunc_u8f(top_b * 255.0f);
+        acc[3] = trunc_u8f(top_a * 255.0f);
+        return;
+    }
+    const float base_r = div255(acc[0]), base_g = div255(acc[1]), base_b = div255(acc[2]), base_a = div255(acc[3]);
+    if constexpr (M == M_XOR) {                                        // :1283
+        const float ita = 1.0f - top_a, iba = 1.0f - base_a;
+        const float xor_a = base_a * ita + top_a * iba;
+        if (xor_a == 0.0f) { acc[0] = acc[1] = acc[2] = acc[3] = 0.0f; return; }
+        const float xr = (base_r * base_a * ita + top_r * top_a * iba) / xor_a;
+        const float xg = (base_g * base_a * ita + top_g * top_a * iba) / xor_a;
+        const float xb = (base_b * base_a * ita + top_b * top_a * iba) / xor_a;
+        acc[0] = quant255(xr * 255.0f); acc[1] = quant255(xg * 255.0f); acc[2] = quant255(xb * 255.0f);
+        acc[3] = quant255(xor_a * 255.0f);
+        return;
+    }
+    const float r = blend_fn<M>(base_r, top_r);
+    const float g = blend_fn<M>(base_g, top_g);
+    const float b = blend_fn<M>(base_b, top_b);
+    const float ita = 1.0f - top_a;
+    const float out_a = top_a + base_a * ita;                          // :1407
+    if (out_a == 0.0f) { acc[0] = acc[1] = acc[2] = acc[3] = 0.0f; return; }
+    const float out_r = (r * top_a + base_r * base_a * ita) / out_a;   // :1412
+    const float out_g = (g * top_a + base_g * base_a * ita) / out_a;
+    const float out_b = (b * top_a + base_b * base_a * ita) / out_a;
+    acc[0] = quant255(out_r * 255.0f); acc[1] = quant255(out_g * 255.0f); acc[2] = quant255(out_b * 255.0f);
+    acc[3] = quant255(out_a * 255.0f);
+}
+
+template <uint32_t M>
+PFX_DEV void blend4(float (&acc)[4][4], const uint32_t (&top)[4], float opacity_raw, float opc)
+{
+#pragma unroll
+    for (int p = 0; p < 4; ++p) blend_px<M>(acc[p], top[p], opacity_raw, opc);
+}
+
+PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[4][4], const uint32_t (&top)[4], float opacity_raw, float opc)
+{
+    switch (mode) { // wave-uniform: one scalar branch per layer
+#define PFX_CASE(M) case M: blend4<M>(acc, top, opacity_raw, opc); break;
+        PFX_CASE(M_NORMAL) PFX_CASE(M_MULTIPLY) PFX_CASE(M_SCREEN) PFX_CASE(M_ADDITIVE) PFX_CASE(M_REFLECT)
+        PFX_CASE(M_GLOW) PFX_CASE(M_COLOR_BURN) PFX_CASE(M_COLOR_DODGE) PFX_CASE(M_OVERLAY) PFX_CASE(M_DIFFERENCE)
+        PFX_CASE(M_NEGATION) PFX_CASE(M_LIGHTEN) PFX_CASE(M_DARKEN) PFX_CASE(M_XOR) PFX_CASE(M_OVERWRITE)
+        PFX_CASE(M_HARD_LIGHT) PFX_CASE(M_SOFT_LIGHT) PFX_CASE(M_EXCLUSION) PFX_CASE(M_SUBTRACT) PFX_CASE(M_DIVIDE)
+        PFX_CASE(M_LINEAR_BURN) PFX_CASE(M_VIVID_LIGHT) PFX_CASE(M_LINEAR_LIGHT) PFX_CASE(M_PIN_LIGHT)
+        PFX_CASE(M_HARD_MIX)
+#undef PFX_CASE
+    default: blend4<M_NORMAL>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
+    }
+}
+
+// live layer mask: top.a = (a * (255 - conceal)) / 255, integer (canvas_state.rs:660-665)
+PFX_DEV uint32_t apply_conceal(uint32_t px, uint32_t conceal)
+{
+    if (conceal == 0u) return px;
+    uint32_t a = ((px >> 24) * (255u - conceal)) / 255u;
+    return (px & 0x00ffffffu) | (a << 24);
+}
+
+// AdjustmentLayerData::apply_to_pixel_with_opacity (layers.rs:276-325) on one accumulator pixel
+PFX_DEV void adjust_px(float (&p)[4], uint32_t kind, const float* __restrict__ adj, float opacity)
+{
+    float o[4] = {p[0], p[1], p[2], p[3]};
+    switch (kind) {
+    case PFXK_ADJ_EXPOSURE: { // adj[0] = gain = powf(2, ev), computed on the host with glibc like the reference
+        const float gain = adj[0];
+        o[0] = quant255(p[0] * gain); o[1] = quant255(p[1] * gain); o[2] = quant255(p[2] * gain);
+        break;
+    }
+    case PFXK_ADJ_BRIGHTNESS_CONTRAST: { // adj[0]=brightness, adj[1]=factor (host-computed)
+        const float br = adj[0], factor = adj[1];
+        o[0] = quant255(factor * (p[0] + br - 128.0f) + 128.0f);
+        o[1] = quant255(factor * (p[1] + br - 128.0f) + 128.0f);
+        o[2] = quant255(factor * (p[2] + br - 128.0f) + 128.0f);
+        break;
+    }
+    case PFXK_ADJ_INVERT: o[0] = 255.0f - p[0]; o[1] = 255.0f - p[1]; o[2] = 255.0f - p[2]; break;
+    case PFXK_ADJ_CHANNEL_MIXER:
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            o[c] = quant255(p[0] * adj[c * 4 + 0] + p[1] * adj[c * 4 + 1] + p[2] * adj[c * 4 + 2] + p[3] * adj[c * 4 + 3]);
+        break;
+    default: break;
+    }
+    const float t = rs_clamp(opacity, 0.0f, 1.0f), inv = 1.0f - t;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[c] = round_u8f(p[c] * inv + o[c] * t); // `.round() as u8`
+}
+
+template <bool GENERAL>
+__global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
+                                                      const float* __restrict__ adj_table,
+                                                      const uint8_t* __restrict__ chunk_active, uint32_t w, uint32_t h,
+                                                      uint8_t* __restrict__ dst)
+{
+    const size_t n_px = (size_t)w * h;
+    const size_t n_quads = (n_px + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t p0 = q * 4;
+        const bool full = p0 + 4 <= n_px;
+        float acc[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0f; // :573
+
+        bool act[4] = {true, true, true, true};
+        if (GENERAL && chunk_active) { // adjustment layers only touch chunks populated in some visible layer (:529-550)
+            const uint32_t cxn = (w + 63u) / 64u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                size_t pi = p0 + p;
+                if (pi >= n_px) pi = n_px - 1;
+                uint32_t y = (uint32_t)(pi / w), x = (uint32_t)(pi - (size_t)y * w);
+                act[p] = chunk_active[(y >> 6) * cxn + (x >> 6)] != 0;
+            }
+        }
+
+        for (uint32_t li = 0; li < n_layers; ++li) {
+            const pfxk_layer_desc L = layers[li]; // uniform -> scalar loads
+            if (GENERAL && L.kind != PFXK_LAYER_RASTER) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (act[p]) adjust_px(acc[p], L.kind, adj_table + L.adj_off, L.opacity);
+                continue;
+            }
+            uint32_t top[4];
+            if (full) {
+                const uint4 v = *reinterpret_cast<const uint4*>(L.pixels + p0 * 4);
+                top[0] = v.x; top[1] = v.y; top[2] = v.z; top[3] = v.w;
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    top[p] = (p0 + p < n_px) ? reinterpret_cast<const uint32_t*>(L.pixels)[p0 + p] : 0u;
+            }
+            if (GENERAL && L.mask) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (p0 + p < n_px) top[p] = apply_conceal(top[p], L.mask[p0 + p]);
+            }
+            blend4_dispatch(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
+        }
+
+        uint32_t out[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) out[p] = pack_rgba(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+        if (full) {
+            *reinterpret_cast<uint4*>(dst + p0 * 4) = make_uint4(out[0], out[1], out[2], out[3]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (p0 + p < n_px) reinterpret_cast<uint32_t*>(dst)[p0 + p] = out[p];
+        }
+    }
+}
+
+// chunk activity = union over visible raster layers of "chunk has any alpha != 0" (canvas_state.rs:529-550)
+__global__ __launch_bounds__(256) void chunk_active_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
+                                                           uint32_t w, uint32_t h, uint8_t* __restrict__ chunk_active)
+{
+    const uint32_t cxn = (w + 63u) / 64u;
+    const uint32_t cx = blockIdx.x % cxn, cy = blockIdx.x / cxn;
+    const uint32_t bx = cx * 64u, by = cy * 64u;
+    const uint32_t cw = min(64u, w - bx), ch = min(64u, h - by);
+    int any = 0;
+    for (uint32_t li = 0; li < n_layers && !any; ++li) {
+        const pfxk_layer_desc L = layers[li];
+        if (L.kind != PFXK_LAYER_RASTER || !L.pixels) continue;
+        int mine = 0;
+        for (uint32_t i = threadIdx.x; i < cw * ch; i += blockDim.x) {
+            uint32_t lx = i % cw, ly = i / cw;
+            mine |= L.pixels[((size_t)(by + ly) * w + bx + lx) * 4 + 3] != 0;
+        }
+        any = __syncthreads_or(mine);
+    }
+    if (threadIdx.x == 0) chunk_active[blockIdx.x] = (uint8_t)(any != 0);
+}
+
+// dst[i] = blend_pixel_static(base[i], top[i], mode, opacity) — element-wise form (spot checks)
+__global__ __launch_bounds__(256) void blend_arrays_kernel(const uint32_t* __restrict__ base, const uint32_t* __restrict__ top,
+                                                           uint32_t* __restrict__ dst, size_t n, uint32_t mode, float opacity)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t b = base[i];
+        float acc[4][4];
+        acc[0][0] = ubyte0(b); acc[0][1] = ubyte1(b); acc[0][2] = ubyte2(b); acc[0][3] = ubyte3(b);
+#pragma unroll
+        for (int p = 1; p < 4; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0f;
+        const uint32_t t[4] = {top[i], 0u, 0u, 0u};
+        blend4_dispatch(mode, acc, t, opacity, rs_clamp(opacity, 0.0f, 1.0f));
+        dst[i] = pack_rgba(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+    }
+}
+
+// Stroke commit (ref: src/ui/panels/tools/behavior/raster/bezier_commit.rs:103-225):
+//   brush : layer = blend_pixel_static(layer, preview, mode, 1.0) where preview.a > 0 and selection != 0
+//   eraser: layer.a = ((a/255) * (1 - m/255)).max(0) * 255 as u8 where m = preview.a > 0
+__global__ __launch_bounds__(256) void brush_commit_kernel(uint32_t* __restrict__ layer, const uint32_t* __restrict__ preview,
+                                                           const uint8_t* __restrict__ selection, size_t n, uint32_t mode,
+                                                           int is_eraser)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (selection && selection[i] == 0) continue;
+        const uint32_t pp = preview[i];
+        if ((pp >> 24) == 0u) continue;
+        const uint32_t lp = layer[i];
+        if (is_eraser) {
+            const float mask_strength = div255(ubyte3(pp));
+            const float current_a = div255(ubyte3(lp));
+            const float new_a = __builtin_fmaxf(current_a * (1.0f - mask_strength), 0.0f);
+            layer[i] = (lp & 0x00ffffffu) | ((uint32_t)trunc_u8f(new_a * 255.0f) << 24);
+        } else {
+            float acc[4][4];
+            acc[0][0] = ubyte0(lp); acc[0][1] = ubyte1(lp); acc[0][2] = ubyte2(lp); acc[0][3] = ubyte3(lp);
+#pragma unroll
+            for (int p = 1; p < 4; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0f;
+            const uint32_t t[4] = {pp, 0u, 0u, 0u};
+            blend4_dispatch(mode, acc, t, 1.0f, 1.0f);
+            layer[i] = pack_rgba(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+        }
+    }
+}
+
+} // namespace
+
+extern "C" hipError_t pfxk_blend_arrays(hipStream_t s, const uint8_t* d_base, const uint8_t* d_top, uint8_t* d_dst,
+                                        size_t n_px, uint32_t mode, float opacity)
+{
+    if (n_px == 0) return hipSuccess;
+    size_t blocks = (n_px + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    blend_arrays_kernel<<<(uint32_t)blocks, 256, 0, s>>>((const uint32_t*)d_base, (const uint32_t*)d_top, (uint32_t*)d_dst,
+                                                         n_px, mode, opacity);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const uint8_t* d_preview,
+                                        const uint8_t* d_selection, uint32_t w, uint32_t h, uint32_t mode, int is_eraser)
+{
+    const size_t n = (size_t)w * h;
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    brush_commit_kernel<<<(uint32_t)blocks, 256, 0, s>>>((uint32_t*)d_layer, (const uint32_t*)d_preview, d_selection, n, mode,
+                                                         is_eraser);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
+                                   const float* d_adj_table, int general, uint8_t* d_chunk_active, uint32_t w,
+                                   uint32_t h, uint8_t* d_dst)
+{
+    const size_t n_quads = ((size_t)w * h + 3) / 4;
+    if (n_quads == 0) return hipSuccess;
+    if (general && d_chunk_active) {
+        const uint32_t nchunks = ((w + 63u) / 64u) * ((h + 63u) / 64u);
+        chunk_active_kernel<<<nchunks, 256, 0, stream>>>(d_layers, n_layers, w, h, d_chunk_active);
+    }
+    const uint32_t block = 256;
+    size_t blocks = (n_quads + block - 1) / block;
+    const size_t cap = 256u * 8u * 4u; // 256 CUs x 8 blocks, x4 waves of grid-stride work granularity
+    if (blocks > cap) blocks = cap;
+    if (general)
+        flatten_kernel<true><<<(uint32_t)blocks, block, 0, stream>>>(d_layers, n_layers, d_adj_table, d_chunk_active, w, h, d_dst);
+    else
+        flatten_kernel<false><<<(uint32_t)blocks, block, 0, stream>>>(d_layers, n_layers, nullptr, nullptr, w, h, d_dst);
+    return hipGetLastError();
+}

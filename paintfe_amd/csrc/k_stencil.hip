@@ -1,0 +1,177 @@
+// k_stencil.hip — the integer stencil filters: box blur, median, pixelate.  All bit-exact classes.
+//
+// Reference: box_blur_core src/ops/effects/blur.rs:233-318 (separable sliding window, u8 intermediate,
+//            `((sum + d/2) / d) as u8` on both passes, clamp-to-edge, selection applied in the vertical pass);
+//            median_core src/ops/effects/noise.rs:357-410 (per-channel element len/2 of the sorted clamped window);
+//            pixelate_core src/ops/effects/distort.rs:333-373 (block-centre nearest sample).
+// Integer sums are order-independent, so the reference's serial sliding sums become direct window sums for the
+// first output of a lane and a 2-term slide for the following ones.
+#include "k_common.h"
+#include "pfx_kernels.h"
+
+using namespace pfxk;
+
+namespace {
+
+// ---------------------------------------------------------------- box blur
+constexpr int BX_THREADS = 256;
+constexpr int BX_PX = 8;                       // consecutive outputs per lane
+constexpr int BX_TILE = BX_THREADS * BX_PX;    // 2048
+
+struct u4 { uint32_t c[4]; };
+PFX_DEV void add_px(u4& s, uint32_t px) { s.c[0] += px & 0xffu; s.c[1] += (px >> 8) & 0xffu; s.c[2] += (px >> 16) & 0xffu; s.c[3] += px >> 24; }
+PFX_DEV void sub_px(u4& s, uint32_t px) { s.c[0] -= px & 0xffu; s.c[1] -= (px >> 8) & 0xffu; s.c[2] -= (px >> 16) & 0xffu; s.c[3] -= px >> 24; }
+// (sum + d/2) / d with a host-built reciprocal: exact while sum * d < 2^32 (255 * d^2 < 2^32 <=> d < 4104)
+PFX_DEV uint32_t div_round(uint32_t sum, uint32_t half, uint32_t magic) { return __umulhi(sum + half, magic); }
+PFX_DEV uint32_t avg_px(const u4& s, uint32_t half, uint32_t magic)
+{
+    return div_round(s.c[0], half, magic) | (div_round(s.c[1], half, magic) << 8) |
+           (div_round(s.c[2], half, magic) << 16) | (div_round(s.c[3], half, magic) << 24);
+}
+
+__global__ __launch_bounds__(BX_THREADS) void box_h_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                          int r, uint32_t half, uint32_t magic, int w, int h)
+{
+    extern __shared__ uint32_t row_tile[]; // BX_TILE + 2r
+    const int y = blockIdx.y, x_tile = blockIdx.x * BX_TILE;
+    const int n_in = min(BX_TILE, w - x_tile) + 2 * r;
+    const uint32_t* row = src + (size_t)y * w;
+    for (int i = threadIdx.x; i < n_in; i += BX_THREADS) row_tile[i] = row[min(max(x_tile - r + i, 0), w - 1)];
+    __syncthreads();
+    const int lx0 = threadIdx.x * BX_PX, x0 = x_tile + lx0;
+    if (x0 >= w) return;
+    u4 s = {{0, 0, 0, 0}};
+    for (int k = 0; k <= 2 * r; ++k) add_px(s, row_tile[lx0 + k]);
+    uint32_t* out = dst + (size_t)y * w + x0;
+#pragma unroll
+    for (int o = 0; o < BX_PX; ++o) {
+        if (x0 + o >= w) break;
+        out[o] = avg_px(s, half, magic);
+        if (x0 + o + 1 < w) { sub_px(s, row_tile[lx0 + o]); add_px(s, row_tile[lx0 + o + 2 * r + 1]); }
+    }
+}
+
+constexpr int BV_PY = 16; // consecutive rows per lane
+__global__ __launch_bounds__(256) void box_v_kernel(const uint32_t* __restrict__ hbuf, const uint32_t* __restrict__ src,
+                                                    const uint8_t* __restrict__ mask, uint32_t* __restrict__ dst, int r,
+                                                    uint32_t half, uint32_t magic, int w, int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * BV_PY;
+    if (x >= w || y0 >= h) return;
+    u4 s = {{0, 0, 0, 0}};
+    for (int k = -r; k <= r; ++k) add_px(s, hbuf[(size_t)min(max(y0 + k, 0), h - 1) * w + x]);
+    for (int o = 0; o < BV_PY; ++o) {
+        const int y = y0 + o;
+        if (y >= h) break;
+        const size_t i = (size_t)y * w + x;
+        dst[i] = (mask && mask[i] == 0) ? src[i] : avg_px(s, half, magic); // blur.rs:296-303
+        if (y + 1 < h) {
+            sub_px(s, hbuf[(size_t)min(max(y - r, 0), h - 1) * w + x]);
+            add_px(s, hbuf[(size_t)min(max(y + r + 1, 0), h - 1) * w + x]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- median
+constexpr int MD_TX = 32, MD_TY = 8; // outputs per block: one per lane
+
+// count, per byte lane, of window elements >= candidate; even bytes in lo16/hi16 of `ce`, odd bytes in `co`
+PFX_DEV void count_ge(uint32_t px, uint32_t tce, uint32_t tco, uint32_t& ce, uint32_t& co)
+{
+    // (x + 256 - t) has bit 8 set  <=>  x >= t   (x, t in 0..255), two 16-bit lanes at a time
+    ce += (((px & 0x00ff00ffu) + tce) >> 8) & 0x00010001u;
+    co += ((((px >> 8) & 0x00ff00ffu) + tco) >> 8) & 0x00010001u;
+}
+
+__global__ __launch_bounds__(MD_TX* MD_TY) void median_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                              const uint8_t* __restrict__ mask, int r, int w, int h)
+{
+    extern __shared__ uint32_t win_tile[]; // (MD_TY + 2r) x (MD_TX + 2r)
+    const int tw = MD_TX + 2 * r, th = MD_TY + 2 * r;
+    const int bx = blockIdx.x * MD_TX, by = blockIdx.y * MD_TY;
+    for (int i = threadIdx.x; i < tw * th; i += MD_TX * MD_TY) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const int sx = min(max(bx - r + tx, 0), w - 1), sy = min(max(by - r + ty, 0), h - 1); // noise.rs:389-392
+        win_tile[i] = src[(size_t)sy * w + sx];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % MD_TX, ly = threadIdx.x / MD_TX;
+    const int x = bx + lx, y = by + ly;
+    if (x >= w || y >= h) return;
+    const size_t oi = (size_t)y * w + x;
+    if (mask && mask[oi] == 0) { dst[oi] = src[oi]; return; }
+    const int side = 2 * r + 1;
+    const uint32_t n = (uint32_t)(side * side);
+    const uint32_t need = n - n / 2; // elements >= the median (element len/2 of the ascending sort)
+    // per-channel binary search, MSB first: largest t with count(x >= t) >= need
+    uint32_t te = 0, to = 0; // thresholds: even bytes (R,B) and odd bytes (G,A) in 16-bit lanes
+    for (int bit = 7; bit >= 0; --bit) {
+        const uint32_t cand_e = te | (0x00010001u << bit), cand_o = to | (0x00010001u << bit);
+        const uint32_t tce = 0x01000100u - cand_e, tco = 0x01000100u - cand_o;
+        uint32_t ce = 0, co = 0;
+        for (int dy = 0; dy < side; ++dy) {
+            const uint32_t* rowp = win_tile + (ly + dy) * tw + lx;
+            for (int dx = 0; dx < side; ++dx) count_ge(rowp[dx], tce, tco, ce, co);
+        }
+        const uint32_t b = 1u << bit;
+        if ((ce & 0xffffu) >= need) te |= b;
+        if ((ce >> 16) >= need) te |= b << 16;
+        if ((co & 0xffffu) >= need) to |= b;
+        if ((co >> 16) >= need) to |= b << 16;
+    }
+    dst[oi] = (te & 0x00ff00ffu) | ((to & 0x00ff00ffu) << 8);
+}
+
+// ---------------------------------------------------------------- pixelate
+__global__ __launch_bounds__(256) void pixelate_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                       const uint8_t* __restrict__ mask, uint32_t bs, uint32_t w, uint32_t h)
+{
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t i = (size_t)y * w + x;
+    if (mask && mask[i] == 0) { dst[i] = src[i]; return; }
+    const uint32_t sx = min((x / bs) * bs + bs / 2u, w - 1u), sy = min((y / bs) * bs + bs / 2u, h - 1u);
+    dst[i] = src[(size_t)sy * w + sx];
+}
+
+} // namespace
+
+extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst,
+                                    const uint8_t* d_mask, int radius, uint32_t w, uint32_t h)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    const uint32_t d = (uint32_t)(2 * radius + 1);
+    if (d >= 4096u) return hipErrorInvalidValue;
+    const uint32_t magic = (uint32_t)((0x100000000ull / d) + 1ull), half = d / 2u;
+    dim3 gh((w + BX_TILE - 1) / BX_TILE, h);
+    const size_t lds = (size_t)(BX_TILE + 2 * radius + BX_PX) * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)box_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e) return e;
+    box_h_kernel<<<gh, BX_THREADS, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_tmp, radius, half, magic, (int)w, (int)h);
+    dim3 gv((w + 63) / 64, (h + 4 * BV_PY - 1) / (4 * BV_PY));
+    box_v_kernel<<<gv, 256, 0, s>>>((const uint32_t*)d_tmp, (const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, half,
+                                    magic, (int)w, (int)h);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, int radius,
+                                  uint32_t w, uint32_t h)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    const size_t lds = (size_t)(MD_TX + 2 * radius) * (MD_TY + 2 * radius) * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)median_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e) return e;
+    dim3 g((w + MD_TX - 1) / MD_TX, (h + MD_TY - 1) / MD_TY);
+    median_kernel<<<g, MD_TX * MD_TY, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, (int)w, (int)h);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_pixelate(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, uint32_t bs,
+                                    uint32_t w, uint32_t h)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    dim3 g((w + 63) / 64, (h + 3) / 4);
+    pixelate_kernel<<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, bs, w, h);
+    return hipGetLastError();
+}

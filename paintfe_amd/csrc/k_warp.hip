@@ -1,0 +1,161 @@
+// k_warp.hip — Liquify displacement warp and Catmull-Rom mesh warp (gather kernels, +-1 LSB class; in practice
+// bit-exact because the f32 expressions are evaluated in the reference's order without FMA contraction).
+//
+// Reference: warp_displacement_full src/ops/transform.rs:1288-1345 (bilinear, texels outside the source are 0,
+//            output left transparent when floor(sx) < -1 || floor(sy) < -1 || >= size);
+//            catmull_rom_weights :1558-1567, catmull_rom_surface :1589-1646,
+//            generate_displacement_from_mesh :1670-1705 / _fast :1712-1740, warp_mesh_catmull_rom :1743-1761.
+// Design: one lane per output pixel, a wave covers 64 consecutive x of one row, so the four bilinear taps of
+// neighbouring lanes fall in the same or adjacent 128-byte lines for any smooth field (L1/L2-served gather; the
+// source is read roughly once from HBM).  The fused mesh warp evaluates the two bicubic surfaces in registers from
+// control points staged in LDS and never materialises the 8 B/px displacement field.
+#include "k_common.h"
+#include "pfx_kernels.h"
+
+using namespace pfxk;
+
+namespace {
+
+PFX_DEV int32_t rs_f32_as_i32(float v) // Rust `as i32`: saturating, NaN -> 0
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)v;
+}
+
+PFX_DEV uint32_t sample_bilinear(const uint32_t* __restrict__ src, int32_t src_w, int32_t src_h, float x, float y,
+                                 float ddx, float ddy)
+{
+    const float sx = x - ddx, sy = y - ddy;
+    const int32_t x0 = rs_f32_as_i32(__builtin_floorf(sx)), y0 = rs_f32_as_i32(__builtin_floorf(sy));
+    if (x0 < -1 || y0 < -1 || x0 >= src_w || y0 >= src_h) return 0u; // :1310
+    const float fx = sx - (float)x0, fy = sy - (float)y0;
+    auto tap = [&](int32_t tx, int32_t ty) -> uint32_t {
+        return (tx < 0 || ty < 0 || tx >= src_w || ty >= src_h) ? 0u : src[(size_t)ty * src_w + tx];
+    };
+    const uint32_t tl = tap(x0, y0), tr = tap(x0 + 1, y0), bl = tap(x0, y0 + 1), br = tap(x0 + 1, y0 + 1);
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float ftl = (float)((tl >> (8 * c)) & 0xffu), ftr = (float)((tr >> (8 * c)) & 0xffu);
+        const float fbl = (float)((bl >> (8 * c)) & 0xffu), fbr = (float)((br >> (8 * c)) & 0xffu);
+        const float top = ftl + (ftr - ftl) * fx; // :1337-1339, lerp form a + (b-a)*t
+        const float bot = fbl + (fbr - fbl) * fx;
+        o[c] = round_u8f(top + (bot - top) * fy);
+    }
+    return pack_rgba(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restrict__ src, int32_t sw, int32_t sh,
+                                                        const float2* __restrict__ disp, uint32_t w, uint32_t h,
+                                                        uint32_t* __restrict__ dst)
+{
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t i = (size_t)y * w + x;
+    const float2 d = disp[i];
+    dst[i] = sample_bilinear(src, sw, sh, (float)x, (float)y, d.x, d.y);
+}
+
+PFX_DEV void cr_weights(float t, float (&wt)[4]) // :1558-1567
+{
+    const float t2 = t * t, t3 = t2 * t;
+    wt[0] = -0.5f * t3 + t2 - 0.5f * t;
+    wt[1] = 1.5f * t3 - 2.5f * t2 + 1.0f;
+    wt[2] = -1.5f * t3 + 2.0f * t2 + 0.5f * t;
+    wt[3] = 0.5f * t3 - 0.5f * t2;
+}
+
+// :1589-1646; pts = (rows+1) x (cols+1) xy pairs (LDS or global)
+PFX_DEV float2 cr_surface(const float2* __restrict__ pts, uint32_t cols, uint32_t rows, float u_global, float v_global)
+{
+    const uint32_t ppr = cols + 1u, num_rows = rows + 1u;
+    const float col_f = rs_clamp(u_global, 0.0f, (float)cols - 0.0001f);
+    const float row_f = rs_clamp(v_global, 0.0f, (float)rows - 0.0001f);
+    const uint32_t ci = min((uint32_t)col_f, cols - 1u), ri = min((uint32_t)row_f, rows - 1u);
+    const float u_local = col_f - (float)ci, v_local = row_f - (float)ri;
+    float wv[4], wu[4];
+    cr_weights(v_local, wv);
+    cr_weights(u_local, wu);
+    const uint32_t rv[4] = {ri == 0u ? 0u : ri - 1u, ri, min(ri + 1u, num_rows - 1u), min(ri + 2u, num_rows - 1u)};
+    const uint32_t cu[4] = {ci == 0u ? 0u : ci - 1u, ci, min(ci + 1u, ppr - 1u), min(ci + 2u, ppr - 1u)};
+    float rx[4], ry[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2* base = pts + rv[j] * ppr;
+        const float2 p0 = base[cu[0]], p1 = base[cu[1]], p2 = base[cu[2]], p3 = base[cu[3]];
+        rx[j] = wu[0] * p0.x + wu[1] * p1.x + wu[2] * p2.x + wu[3] * p3.x;
+        ry[j] = wu[0] * p0.y + wu[1] * p1.y + wu[2] * p2.y + wu[3] * p3.y;
+    }
+    return make_float2(wv[0] * rx[0] + wv[1] * rx[1] + wv[2] * rx[2] + wv[3] * rx[3],
+                       wv[0] * ry[0] + wv[1] * ry[1] + wv[2] * ry[2] + wv[3] * ry[3]);
+}
+
+constexpr uint32_t MESH_LDS_PTS = 2048; // control points per grid staged in LDS (2 grids x 16 KiB)
+
+// MODE 0: write displacement field; MODE 1: fused field + gather
+template <int MODE>
+__global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ g_orig,
+                                                   const float2* __restrict__ g_def, uint32_t cols, uint32_t rows,
+                                                   uint32_t w, uint32_t h, float2* __restrict__ disp,
+                                                   uint32_t* __restrict__ dst)
+{
+    __shared__ float2 s_orig[MESH_LDS_PTS];
+    __shared__ float2 s_def[MESH_LDS_PTS];
+    const uint32_t npts = (cols + 1u) * (rows + 1u);
+    const bool in_lds = npts <= MESH_LDS_PTS;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < npts; i += 256u) {
+            if (g_orig) s_orig[i] = g_orig[i];
+            s_def[i] = g_def[i];
+        }
+        __syncthreads();
+    }
+    const float2* orig = g_orig ? (in_lds ? s_orig : g_orig) : nullptr;
+    const float2* def = in_lds ? s_def : g_def;
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float u = ((float)x + 0.5f) / (float)w * (float)cols; // :1687-1688
+    const float v = ((float)y + 0.5f) / (float)h * (float)rows;
+    const float2 d = cr_surface(def, cols, rows, u, v);
+    float2 o;
+    if (orig) o = cr_surface(orig, cols, rows, u, v);
+    else o = make_float2((float)x + 0.5f, (float)y + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
+    const float ddx = d.x - o.x, ddy = d.y - o.y;
+    const size_t i = (size_t)y * w + x;
+    if constexpr (MODE == 0) disp[i] = make_float2(ddx, ddy);
+    else dst[i] = sample_bilinear(src, (int32_t)w, (int32_t)h, (float)x, (float)y, ddx, ddy);
+}
+
+} // namespace
+
+extern "C" hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh,
+                                             const float* d_disp, uint32_t w, uint32_t h, uint8_t* d_dst)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    dim3 g((w + 63) / 64, (h + 3) / 4);
+    warp_disp_kernel<<<g, 256, 0, s>>>((const uint32_t*)d_src, (int32_t)sw, (int32_t)sh, (const float2*)d_disp, w, h,
+                                       (uint32_t*)d_dst);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig, const float* d_def, uint32_t cols,
+                                             uint32_t rows, uint32_t w, uint32_t h, float* d_disp)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    dim3 g((w + 63) / 64, (h + 3) / 4);
+    mesh_kernel<0><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h,
+                                     (float2*)d_disp, nullptr);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const float* d_orig, const float* d_def,
+                                     uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    dim3 g((w + 63) / 64, (h + 3) / 4);
+    mesh_kernel<1><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h,
+                                     nullptr, (uint32_t*)d_dst);
+    return hipGetLastError();
+}

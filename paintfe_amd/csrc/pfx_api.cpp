@@ -1,0 +1,701 @@
+// pfx_api.cpp — the C ABI (include/pfx.h): argument checking, host<->device staging, kernel sequencing.
+// Host-buffer entry points = upload -> the `_dev` entry point -> download -> stream sync; `dst` is written only
+// after every step succeeded (the reference's "never poison the document" rule).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pfx_internal.h"
+
+void pfx_host_brush_lut(float size, float hardness, bool anti_aliased, uint8_t lut[256]);
+void pfx_host_line_points(float x0, float y0, float x1, float y1, uint32_t w, uint32_t h, std::vector<float>& out);
+void pfx_host_rhai_levels_lut(float in_black, float in_white, float gamma, uint8_t lut[256]);
+
+static_assert((int)PFX_OP_COUNT == (int)PFXK_OP_COUNT && (int)PFX_OP_DESATURATE == (int)PFXK_OP_DESATURATE, "op ids out of sync");
+static_assert((int)PFX_RHAI_COUNT == (int)PFXK_RHAI_COUNT && (int)PFX_RHAI_LEVELS == (int)PFXK_RHAI_LEVELS, "rhai ids out of sync");
+static_assert((int)PFX_ADJ_CHANNEL_MIXER == (int)PFXK_ADJ_CHANNEL_MIXER, "layer kinds out of sync");
+
+namespace {
+
+inline size_t img_bytes(uint32_t w, uint32_t h) { return (size_t)w * h * 4; }
+
+int check_img(pfx_ctx* ctx, const void* src, const void* dst, uint32_t w, uint32_t h, const char* who)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    if (!src || !dst) return pfx_fail(ctx, PFX_ERR_INVALID, "%s: null image pointer", who);
+    if (w == 0 || h == 0) return pfx_fail(ctx, PFX_ERR_INVALID, "%s: zero-sized image", who);
+    if ((uint64_t)w * h > 256000000ull) // TiledImage::new clamps beyond 256 M px (ref: tiled_image.rs:15-26)
+        return pfx_fail(ctx, PFX_ERR_INVALID, "%s: %ux%u exceeds the 256 Mpx document limit", who, w, h);
+    return pfx_use(ctx);
+}
+
+// stage host src (+ optional mask) into the context's device buffers
+int stage_in(pfx_ctx* ctx, const uint8_t* src, const uint8_t* mask, uint32_t w, uint32_t h, const void** d_mask)
+{
+    PFX_TRY(pfx_reserve(ctx, ctx->st_in, img_bytes(w, h)));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_in.p, src, img_bytes(w, h)));
+    *d_mask = nullptr;
+    if (mask) {
+        PFX_TRY(pfx_reserve(ctx, ctx->st_mask, (size_t)w * h));
+        PFX_TRY(pfx_h2d(ctx, ctx->st_mask.p, mask, (size_t)w * h));
+        *d_mask = ctx->st_mask.p;
+    }
+    return PFX_OK;
+}
+
+int finish_out(pfx_ctx* ctx, uint8_t* dst, uint32_t w, uint32_t h)
+{
+    PFX_TRY(pfx_d2h(ctx, dst, ctx->st_out.p, img_bytes(w, h)));
+    return pfx_sync(ctx);
+}
+
+// host-side parameter preparation for the pointwise bank: everything that is uniform per call is folded here with
+// the same f32 expressions the reference evaluates per pixel (so the kernels see identical constants)
+int prepare_adjust(pfx_ctx* ctx, int op, const float* p, uint32_t n, pfxk_params& P, bool& needs_lut)
+{
+    std::memset(&P, 0, sizeof P);
+    needs_lut = false;
+    auto need = [&](uint32_t k) { return n >= k && p != nullptr; };
+    switch (op) {
+    case PFX_OP_INVERT: case PFX_OP_INVERT_ALPHA: case PFX_OP_SEPIA: case PFX_OP_DESATURATE: return PFX_OK;
+    case PFX_OP_BRIGHTNESS_CONTRAST:
+        if (!need(2)) break;
+        P.p[0] = p[0]; P.p[1] = pfx_host_bc_factor(p[1]); return PFX_OK;
+    case PFX_OP_HSL:
+        if (!need(3)) break;
+        P.p[0] = p[0] / 360.0f;            // hue_shift / 360.0   (adjustments.rs:310)
+        P.p[1] = 1.0f + p[1] / 100.0f;     // sat_factor          (:307)
+        P.p[2] = p[2] * 255.0f / 100.0f;   // light_offset        (:308)
+        return PFX_OK;
+    case PFX_OP_EXPOSURE:
+        if (!need(1)) break;
+        P.p[0] = pfx_host_exposure_gain(p[0]); return PFX_OK;
+    case PFX_OP_HIGHLIGHTS_SHADOWS:
+        if (!need(2)) break;
+        P.p[0] = p[0] / 100.0f; P.p[1] = p[1] / 100.0f; return PFX_OK;
+    case PFX_OP_TEMPERATURE_TINT:
+        if (!need(2)) break;
+        P.p[0] = p[0] * 1.5f; P.p[1] = p[1] * 1.0f; return PFX_OK;
+    case PFX_OP_THRESHOLD:
+        if (!need(1)) break;
+        P.p[0] = p[0]; return PFX_OK;
+    case PFX_OP_POSTERIZE:
+        if (!need(1)) break;
+        P.p[0] = std::max(p[0], 2.0f); return PFX_OK; // levels.max(2) as f32
+    case PFX_OP_COLOR_BALANCE:
+        if (!need(9)) break;
+        for (int i = 0; i < 9; ++i) P.p[i] = p[i];
+        return PFX_OK;
+    case PFX_OP_BLACK_AND_WHITE:
+        if (!need(3)) break;
+        P.p[0] = p[0]; P.p[1] = p[1]; P.p[2] = p[2]; return PFX_OK;
+    case PFX_OP_VIBRANCE:
+        if (!need(1)) break;
+        P.p[0] = p[0] / 100.0f; return PFX_OK;
+    case PFX_OP_GRADIENT_MAP: case PFX_OP_LUT_RGBA: needs_lut = true; return PFX_OK;
+    default: return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_adjust: unknown op %d", op);
+    }
+    return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_adjust: op %d needs more parameters (got %u)", op, n);
+}
+
+int upload_lut(pfx_ctx* ctx, const uint8_t* lut_host, size_t bytes)
+{
+    uint8_t padded[1024] = {0};
+    std::memcpy(padded, lut_host, std::min<size_t>(bytes, 1024));
+    PFX_TRY(pfx_reserve(ctx, ctx->d_lut, 1024));
+    return pfx_h2d(ctx, ctx->d_lut.p, padded, 1024);
+}
+
+// layer stack -> device descriptors
+int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
+                uint32_t n, uint32_t w, uint32_t h, bool from_store, uint32_t* n_desc, bool* general, bool* has_adj)
+{
+    std::vector<pfxk_layer_desc> desc;
+    std::vector<float> adj;
+    desc.reserve(n);
+    *general = false;
+    *has_adj = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pfx_layer_info& L = layers[i];
+        if (!L.visible) continue; // layer_effectively_visible == false: skipped entirely (canvas_state.rs:576)
+        pfxk_layer_desc d{};
+        d.opacity = L.opacity;
+        d.mode = L.blend_mode > 24 ? 0u : (uint32_t)L.blend_mode; // BlendMode::from_u8 fallback
+        d.kind = L.kind;
+        if (L.kind != PFX_LAYER_RASTER) {
+            if (L.kind > PFX_ADJ_CHANNEL_MIXER) return pfx_fail(ctx, PFX_ERR_INVALID, "layer %u: unknown kind %u", i, L.kind);
+            d.adj_off = (uint32_t)adj.size();
+            float a[16];
+            std::memcpy(a, L.adj, sizeof a);
+            if (L.kind == PFX_ADJ_EXPOSURE) a[0] = pfx_host_exposure_gain(L.adj[0]);
+            if (L.kind == PFX_ADJ_BRIGHTNESS_CONTRAST) a[1] = pfx_host_bc_factor(L.adj[1]);
+            adj.insert(adj.end(), a, a + 16);
+            *general = true;
+            *has_adj = true;
+        } else if (from_store) {
+            auto it = ctx->layers.find(L.layer_idx);
+            if (it == ctx->layers.end()) continue; // not uploaded: skipped like the reference (renderer.rs:556)
+            if (it->second.w != w || it->second.h != h)
+                return pfx_fail(ctx, PFX_ERR_INVALID, "layer %u is %ux%u, canvas is %ux%u", L.layer_idx, it->second.w, it->second.h, w, h);
+            d.pixels = (const uint8_t*)it->second.pixels.p;
+            if (it->second.has_mask) { d.mask = (const uint8_t*)it->second.mask.p; *general = true; }
+        } else {
+            d.pixels = (const uint8_t*)layer_ptrs[i];
+            if (!d.pixels) return pfx_fail(ctx, PFX_ERR_INVALID, "layer %u: null device pointer", i);
+            if (mask_ptrs && mask_ptrs[i]) { d.mask = (const uint8_t*)mask_ptrs[i]; *general = true; }
+        }
+        desc.push_back(d);
+    }
+    *n_desc = (uint32_t)desc.size();
+    PFX_TRY(pfx_reserve(ctx, ctx->d_desc, std::max<size_t>(desc.size(), 1) * sizeof(pfxk_layer_desc)));
+    PFX_TRY(pfx_h2d(ctx, ctx->d_desc.p, desc.data(), desc.size() * sizeof(pfxk_layer_desc)));
+    if (!adj.empty()) {
+        PFX_TRY(pfx_reserve(ctx, ctx->d_adj, adj.size() * sizeof(float)));
+        PFX_TRY(pfx_h2d(ctx, ctx->d_adj.p, adj.data(), adj.size() * sizeof(float)));
+    }
+    return PFX_OK;
+}
+
+int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
+                   uint32_t n_layers, uint32_t w, uint32_t h, bool from_store, void* dst_dev)
+{
+    PFX_REQUIRE(ctx, n_layers <= PFX_MAX_LAYERS, "too many layers");
+    PFX_REQUIRE(ctx, n_layers == 0 || layers, "null layer list");
+    uint32_t n_desc = 0;
+    bool general = false, has_adj = false;
+    PFX_TRY(build_stack(ctx, layer_ptrs, mask_ptrs, layers, n_layers, w, h, from_store, &n_desc, &general, &has_adj));
+    uint8_t* d_chunks = nullptr;
+    if (has_adj) { // adjustment layers only run on chunks populated in some visible layer (canvas_state.rs:529-550)
+        const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
+        PFX_TRY(pfx_reserve(ctx, ctx->d_chunks, nchunks));
+        d_chunks = (uint8_t*)ctx->d_chunks.p;
+    }
+    pfx_timer t(ctx, "flatten");
+    PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
+                              general ? 1 : 0, d_chunks, w, h, (uint8_t*)dst_dev));
+    return PFX_OK;
+}
+
+int brush_prepare(pfx_ctx* ctx, const pfx_brush* b, pfxk_brush& B, bool& skip)
+{
+    PFX_REQUIRE(ctx, b != nullptr, "null brush");
+    std::memset(&B, 0, sizeof B);
+    skip = false;
+    B.radius = b->size / 2.0f;                 // pressure_size() / 2 (brush_render.rs:196)
+    B.radius_sq = B.radius * B.radius;
+    if (B.radius_sq < 0.001f) { skip = true; return PFX_OK; }
+    B.draw_radius = b->anti_aliased ? B.radius + 0.5f : B.radius;
+    B.draw_radius_sq = B.draw_radius * B.draw_radius;
+    B.use_direct_alpha = B.draw_radius > B.radius;
+    B.inv_radius_sq = 1.0f / B.radius_sq;
+    B.hardness = b->hardness;
+    B.flow = b->flow;
+    B.src_r = b->color[0]; B.src_g = b->color[1]; B.src_b = b->color[2]; B.src_a = b->color[3];
+    auto u8 = [](float v) -> uint32_t { return !(v > 0.0f) ? 0u : (v >= 255.0f ? 255u : (uint32_t)(int)v); };
+    B.rgb8 = u8(B.src_r * 255.0f) | (u8(B.src_g * 255.0f) << 8) | (u8(B.src_b * 255.0f) << 16); // :223-225 truncating
+    B.anti_aliased = b->anti_aliased != 0;
+    B.is_eraser = b->is_eraser != 0;
+    B.mode = b->mode;
+    PFX_REQUIRE(ctx, b->mode >= 0 && b->mode <= 3, "unknown brush mode");
+    return PFX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// ======================================================================= device tier
+int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev,
+                    const pfx_layer_info* layers, uint32_t n_layers, uint32_t w, uint32_t h, void* dst_dev)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, dst_dev && w && h && (n_layers == 0 || layer_ptrs_dev), "pfx_flatten_dev: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    return flatten_common(ctx, layer_ptrs_dev, mask_ptrs_dev, layers, n_layers, w, h, false, dst_dev);
+}
+
+int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, void* tmp_dev)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_gaussian_blur_dev"));
+    std::vector<float> k;
+    const int radius = pfx_host_gaussian_kernel(sigma, k);
+    if (radius > pfxk_gauss_max_radius())
+        return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "gaussian radius %d beyond the device tile limit %d", radius, pfxk_gauss_max_radius());
+    std::vector<float> padded(k.size() + 16, 0.0f);
+    std::copy(k.begin(), k.end(), padded.begin() + 8);
+    PFX_TRY(pfx_reserve(ctx, ctx->d_wts, padded.size() * sizeof(float)));
+    PFX_TRY(pfx_h2d(ctx, ctx->d_wts.p, padded.data(), padded.size() * sizeof(float)));
+    if (!tmp_dev) {
+        PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 16));
+        tmp_dev = ctx->st_tmp.p;
+    }
+    const float* wts = (const float*)ctx->d_wts.p + 8;
+    {
+        pfx_timer t(ctx, "gauss_h");
+        PFX_HIP(ctx, pfxk_gauss_h(ctx->stream, (const uint8_t*)src_dev, (float*)tmp_dev, wts, radius, w, h, ctx->exact ? 1 : 0));
+    }
+    {
+        pfx_timer t(ctx, "gauss_v");
+        PFX_HIP(ctx, pfxk_gauss_v(ctx->stream, (const float*)tmp_dev, (uint8_t*)dst_dev, wts, radius, w, h, ctx->exact ? 1 : 0));
+    }
+    return PFX_OK;
+}
+
+int pfx_box_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius,
+                     const void* mask_dev, void* tmp_dev)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_box_blur_dev"));
+    if (radius < 0.5f) { // blur.rs:234: returns flat.clone()
+        PFX_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, img_bytes(w, h), hipMemcpyDeviceToDevice, ctx->stream));
+        return PFX_OK;
+    }
+    const float rc = ceilf(radius);
+    PFX_REQUIRE(ctx, rc < 2040.0f, "box blur radius too large");
+    if (!tmp_dev) {
+        PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, img_bytes(w, h)));
+        tmp_dev = ctx->st_tmp.p;
+    }
+    pfx_timer t(ctx, "box_blur");
+    PFX_HIP(ctx, pfxk_box_blur(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)tmp_dev, (uint8_t*)dst_dev,
+                               (const uint8_t*)mask_dev, (int)rc, w, h));
+    return PFX_OK;
+}
+
+int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius, const void* mask_dev)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_median_dev"));
+    const uint32_t r = std::max(radius, 1u); // noise.rs:364
+    if (r > PFX_MEDIAN_MAX_RADIUS) return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "median radius %u > %d", r, PFX_MEDIAN_MAX_RADIUS);
+    pfx_timer t(ctx, "median");
+    PFX_HIP(ctx, pfxk_median(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint8_t*)mask_dev, (int)r, w, h));
+    return PFX_OK;
+}
+
+int pfx_pixelate_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t block_size, const void* mask_dev)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_pixelate_dev"));
+    pfx_timer t(ctx, "pixelate");
+    PFX_HIP(ctx, pfxk_pixelate(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint8_t*)mask_dev,
+                               std::max(block_size, 2u), w, h)); // distort.rs:334
+    return PFX_OK;
+}
+
+int pfx_adjust_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, int op, const float* params,
+                   uint32_t n_params, const uint8_t* lut_host, const void* mask_dev, int sparse_mode)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_adjust_dev"));
+    PFX_REQUIRE(ctx, sparse_mode >= PFX_DENSE && sparse_mode <= PFX_IN_PLACE, "unknown sparse mode");
+    pfxk_params P;
+    bool needs_lut = false;
+    PFX_TRY(prepare_adjust(ctx, op, params, n_params, P, needs_lut));
+    if (needs_lut) {
+        PFX_REQUIRE(ctx, lut_host != nullptr, "this op needs a LUT");
+        PFX_TRY(upload_lut(ctx, lut_host, 1024));
+    }
+    pfx_timer t(ctx, "adjust");
+    PFX_HIP(ctx, pfxk_adjust(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint8_t*)mask_dev,
+                             (const uint8_t*)ctx->d_lut.p, op, &P, sparse_mode, w, h));
+    return PFX_OK;
+}
+
+int pfx_rhai_adjust_dev(pfx_ctx* ctx, void* pixels_dev, uint32_t w, uint32_t h, int op, const float* p, uint32_t n)
+{
+    PFX_TRY(check_img(ctx, pixels_dev, pixels_dev, w, h, "pfx_rhai_adjust_dev"));
+    pfxk_params P;
+    std::memset(&P, 0, sizeof P);
+    auto need = [&](uint32_t k) { return n >= k && p != nullptr; };
+    bool ok = true;
+    switch (op) {
+    case PFX_RHAI_INVERT: case PFX_RHAI_DESATURATE: case PFX_RHAI_SEPIA: break;
+    case PFX_RHAI_SEPIA_STRENGTH: // strength.clamp(0,1) as f32; inv = 1 - strength (scripting.rs:923-924)
+        if ((ok = need(1))) { P.p[0] = (float)std::min(std::max((double)p[0], 0.0), 1.0); P.p[1] = 1.0f - P.p[0]; }
+        break;
+    case PFX_RHAI_BRIGHTNESS_CONTRAST:
+        if ((ok = need(2))) { P.p[0] = p[0]; P.p[1] = pfx_host_bc_factor(p[1]); }
+        break;
+    case PFX_RHAI_HSL:
+        if ((ok = need(3))) { P.p[0] = p[0] / 360.0f; P.p[1] = 1.0f + p[1] / 100.0f; P.p[2] = p[2] * 255.0f / 100.0f; }
+        break;
+    case PFX_RHAI_EXPOSURE:
+        if ((ok = need(1))) P.p[0] = pfx_host_exposure_gain(p[0]);
+        break;
+    case PFX_RHAI_LEVELS:
+        if ((ok = need(3))) {
+            uint8_t lut[256];
+            pfx_host_rhai_levels_lut(p[0], p[1], p[2], lut);
+            PFX_TRY(upload_lut(ctx, lut, 256));
+        }
+        break;
+    default: return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_rhai_adjust: unknown op %d", op);
+    }
+    if (!ok) return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_rhai_adjust: op %d needs more parameters", op);
+    pfx_timer t(ctx, "rhai_adjust");
+    PFX_HIP(ctx, pfxk_rhai_adjust(ctx->stream, (uint8_t*)pixels_dev, (const uint8_t*)ctx->d_lut.p, op, &P, w, h));
+    return PFX_OK;
+}
+
+int pfx_warp_displacement_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, uint32_t sh, const void* disp_dev, uint32_t w,
+                              uint32_t h, void* dst_dev)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_warp_displacement_dev"));
+    PFX_REQUIRE(ctx, disp_dev && sw && sh, "pfx_warp_displacement_dev: bad arguments");
+    pfx_timer t(ctx, "warp_displacement");
+    PFX_HIP(ctx, pfxk_warp_displacement(ctx->stream, (const uint8_t*)src_dev, sw, sh, (const float*)disp_dev, w, h, (uint8_t*)dst_dev));
+    return PFX_OK;
+}
+
+static int upload_points(pfx_ctx* ctx, const float* orig, const float* def, uint32_t cols, uint32_t rows, const float** d_orig,
+                         const float** d_def)
+{
+    PFX_REQUIRE(ctx, def && cols >= 1 && rows >= 1 && cols <= 4096 && rows <= 4096, "mesh: bad grid");
+    const size_t npts = (size_t)(cols + 1) * (rows + 1);
+    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, npts * 2 * sizeof(float) * 2));
+    float* base = (float*)ctx->d_pts.p;
+    PFX_TRY(pfx_h2d(ctx, base, def, npts * 2 * sizeof(float)));
+    *d_def = base;
+    *d_orig = nullptr;
+    if (orig) {
+        PFX_TRY(pfx_h2d(ctx, base + npts * 2, orig, npts * 2 * sizeof(float)));
+        *d_orig = base + npts * 2;
+    }
+    return PFX_OK;
+}
+
+int pfx_mesh_displacement_dev(pfx_ctx* ctx, const float* orig_pts_xy, const float* deformed_pts_xy, uint32_t cols, uint32_t rows,
+                              uint32_t w, uint32_t h, void* disp_dev)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, disp_dev && w && h, "pfx_mesh_displacement_dev: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    const float *d_orig, *d_def;
+    PFX_TRY(upload_points(ctx, orig_pts_xy, deformed_pts_xy, cols, rows, &d_orig, &d_def));
+    pfx_timer t(ctx, "mesh_displacement");
+    PFX_HIP(ctx, pfxk_mesh_displacement(ctx->stream, d_orig, d_def, cols, rows, w, h, (float*)disp_dev));
+    return PFX_OK;
+}
+
+int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float* orig_pts_xy, const float* deformed_pts_xy,
+                                  uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, void* dst_dev)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_warp_mesh_catmull_rom_dev"));
+    const float *d_orig, *d_def;
+    PFX_TRY(upload_points(ctx, orig_pts_xy, deformed_pts_xy, cols, rows, &d_orig, &d_def));
+    pfx_timer t(ctx, "warp_mesh");
+    PFX_HIP(ctx, pfxk_warp_mesh(ctx->stream, (const uint8_t*)src_dev, d_orig, d_def, cols, rows, w, h, (uint8_t*)dst_dev));
+    return PFX_OK;
+}
+
+int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush, const float* points_xy,
+                         uint32_t n_points, const void* selection_dev)
+{
+    PFX_TRY(check_img(ctx, target_dev, target_dev, w, h, "pfx_brush_stamps_dev"));
+    if (n_points == 0) return PFX_OK;
+    PFX_REQUIRE(ctx, points_xy != nullptr, "null stamp list");
+    pfxk_brush B;
+    bool skip;
+    PFX_TRY(brush_prepare(ctx, brush, B, skip));
+    if (skip) return PFX_OK; // radius_sq < 0.001 (brush_render.rs:198)
+    // bounding box of the whole stroke (union of the per-stamp boxes, brush_render.rs:209-215)
+    float minx = points_xy[0], maxx = minx, miny = points_xy[1], maxy = miny;
+    for (uint32_t i = 1; i < n_points; ++i) {
+        minx = std::min(minx, points_xy[2 * i]); maxx = std::max(maxx, points_xy[2 * i]);
+        miny = std::min(miny, points_xy[2 * i + 1]); maxy = std::max(maxy, points_xy[2 * i + 1]);
+    }
+    const float pad = B.draw_radius + 2.0f;
+    const int bx0 = (int)std::max(0.0f, floorf(minx - pad)), by0 = (int)std::max(0.0f, floorf(miny - pad));
+    const int bx1 = (int)std::min((float)(w - 1), ceilf(maxx + pad)), by1 = (int)std::min((float)(h - 1), ceilf(maxy + pad));
+    if (bx1 < bx0 || by1 < by0) return PFX_OK;
+    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, (size_t)n_points * 2 * sizeof(float) + 512));
+    PFX_TRY(pfx_h2d(ctx, ctx->d_pts.p, points_xy, (size_t)n_points * 2 * sizeof(float)));
+    const uint8_t* d_lut = nullptr;
+    if (!B.use_direct_alpha) { // LUT path only when AA is off (brush_render.rs:329-337)
+        uint8_t lut[256];
+        pfx_host_brush_lut(brush->size, brush->hardness, brush->anti_aliased != 0, lut);
+        PFX_TRY(upload_lut(ctx, lut, 256));
+        d_lut = (const uint8_t*)ctx->d_lut.p;
+    }
+    pfx_timer t(ctx, "brush_stamps");
+    PFX_HIP(ctx, pfxk_brush_stamps(ctx->stream, (uint8_t*)target_dev, w, h, &B, (const float*)ctx->d_pts.p, n_points, d_lut,
+                                   (const uint8_t*)selection_dev, bx0, by0, bx1, by1));
+    return PFX_OK;
+}
+
+int pfx_tiled_roundtrip_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_tiled_roundtrip_dev"));
+    pfx_timer t(ctx, "tiled_roundtrip");
+    PFX_HIP(ctx, pfxk_tiled_roundtrip(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, w, h));
+    return PFX_OK;
+}
+
+// ======================================================================= host-buffer tier
+int pfx_gaussian_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float sigma, const uint8_t* mask)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_gaussian_blur_core"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, mask, w, h, &d_mask));
+    if (!mask) {
+        PFX_TRY(pfx_gaussian_blur_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h, sigma, nullptr));
+    } else {
+        // blur_with_selection (filters.rs:141-207) blurs the selection's bounding box padded by the kernel radius and
+        // copies back where mask > 0.  For selected pixels that equals blurring the whole image (the crop only drops
+        // pixels farther than the radius from every selected pixel... except that clamp-to-edge then happens at the
+        // crop border), so the crop is reproduced exactly: blur the crop rectangle as its own image.
+        uint32_t min_x = w, min_y = h, max_x = 0, max_y = 0;
+        for (uint32_t y = 0; y < h; ++y)
+            for (uint32_t x = 0; x < w; ++x)
+                if (mask[(size_t)y * w + x] > 0) {
+                    min_x = std::min(min_x, x); min_y = std::min(min_y, y);
+                    max_x = std::max(max_x, x); max_y = std::max(max_y, y);
+                }
+        if (min_x > max_x || min_y > max_y) { // nothing selected: flat.clone()
+            PFX_HIP(ctx, hipMemcpyAsync(ctx->st_out.p, ctx->st_in.p, img_bytes(w, h), hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            const float padf = ceilf(sigma * 3.0f);
+            const uint32_t pad = !(padf > 0.0f) ? 0u : (padf >= 4294967296.0f ? 0xffffffffu : (uint32_t)padf);
+            const uint32_t cx0 = min_x > pad ? min_x - pad : 0, cy0 = min_y > pad ? min_y - pad : 0;
+            const uint32_t cx1 = (uint32_t)std::min<uint64_t>((uint64_t)max_x + 1 + pad, w);
+            const uint32_t cy1 = (uint32_t)std::min<uint64_t>((uint64_t)max_y + 1 + pad, h);
+            const uint32_t cw = cx1 - cx0, ch = cy1 - cy0;
+            PFX_TRY(pfx_reserve(ctx, ctx->st_aux, img_bytes(cw, ch)));
+            PFX_TRY(pfx_reserve(ctx, ctx->st_aux2, img_bytes(w, h)));
+            PFX_HIP(ctx, hipMemcpy2DAsync(ctx->st_aux.p, (size_t)cw * 4, (const uint8_t*)ctx->st_in.p + ((size_t)cy0 * w + cx0) * 4,
+                                          (size_t)w * 4, (size_t)cw * 4, ch, hipMemcpyDeviceToDevice, ctx->stream));
+            // blurred crop -> st_aux (in place is not allowed: H pass reads src while V writes dst; use aux2 as dst)
+            PFX_TRY(pfx_gaussian_blur_dev(ctx, ctx->st_aux.p, ctx->st_aux2.p, cw, ch, sigma, nullptr));
+            // paste the blurred crop over a copy of the source, then select by mask
+            PFX_HIP(ctx, hipMemcpyAsync(ctx->st_out.p, ctx->st_in.p, img_bytes(w, h), hipMemcpyDeviceToDevice, ctx->stream));
+            PFX_HIP(ctx, hipMemcpy2DAsync((uint8_t*)ctx->st_out.p + ((size_t)cy0 * w + cx0) * 4, (size_t)w * 4, ctx->st_aux2.p,
+                                          (size_t)cw * 4, (size_t)cw * 4, ch, hipMemcpyDeviceToDevice, ctx->stream));
+            PFX_HIP(ctx, pfxk_select_by_mask(ctx->stream, (const uint8_t*)ctx->st_in.p, (const uint8_t*)ctx->st_out.p,
+                                             (const uint8_t*)d_mask, (uint8_t*)ctx->st_out.p, w, h));
+        }
+    }
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_blur_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float sigma)
+{
+    return pfx_gaussian_blur_core(ctx, src, dst, w, h, sigma, nullptr);
+}
+
+int pfx_box_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float radius, const uint8_t* mask)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_box_blur_core"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, mask, w, h, &d_mask));
+    PFX_TRY(pfx_box_blur_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h, radius, d_mask, nullptr));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_median_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t radius, const uint8_t* mask)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_median_core"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, mask, w, h, &d_mask));
+    PFX_TRY(pfx_median_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h, radius, d_mask));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_median_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t radius)
+{
+    return pfx_median_core(ctx, src, dst, w, h, radius, nullptr);
+}
+
+int pfx_pixelate_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t block_size, const uint8_t* mask)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_pixelate_core"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, mask, w, h, &d_mask));
+    PFX_TRY(pfx_pixelate_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h, block_size, d_mask));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_adjust(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, int op, const float* params,
+               uint32_t n_params, const uint8_t* lut, const uint8_t* mask, int sparse_mode)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_adjust"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, mask, w, h, &d_mask));
+    PFX_TRY(pfx_adjust_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h, op, params, n_params, lut, d_mask, sparse_mode));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_brightness_contrast_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float brightness, float contrast)
+{
+    const float p[2] = {brightness, contrast};
+    return pfx_adjust(ctx, src, dst, w, h, PFX_OP_BRIGHTNESS_CONTRAST, p, 2, nullptr, nullptr, PFX_DENSE);
+}
+
+int pfx_hsl_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float hue, float sat, float light)
+{
+    const float p[3] = {hue, sat, light};
+    return pfx_adjust(ctx, src, dst, w, h, PFX_OP_HSL, p, 3, nullptr, nullptr, PFX_DENSE);
+}
+
+int pfx_invert_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h)
+{
+    return pfx_adjust(ctx, src, dst, w, h, PFX_OP_INVERT, nullptr, 0, nullptr, nullptr, PFX_DENSE);
+}
+
+int pfx_rhai_adjust(pfx_ctx* ctx, uint8_t* pixels_inout, uint32_t w, uint32_t h, int op, const float* params, uint32_t n_params)
+{
+    PFX_TRY(check_img(ctx, pixels_inout, pixels_inout, w, h, "pfx_rhai_adjust"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, pixels_inout, nullptr, w, h, &d_mask));
+    PFX_TRY(pfx_rhai_adjust_dev(ctx, ctx->st_in.p, w, h, op, params, n_params));
+    PFX_TRY(pfx_d2h(ctx, pixels_inout, ctx->st_in.p, img_bytes(w, h)));
+    return pfx_sync(ctx);
+}
+
+int pfx_auto_levels(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, const uint8_t* mask)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_auto_levels"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, mask, w, h, &d_mask));
+    PFX_TRY(pfx_reserve(ctx, ctx->d_misc, 64));
+    {
+        pfx_timer t(ctx, "minmax");
+        PFX_HIP(ctx, pfxk_minmax_rgb(ctx->stream, (const uint8_t*)ctx->st_in.p, (const uint8_t*)d_mask, w, h, (uint32_t*)ctx->d_misc.p));
+    }
+    uint32_t mm[6];
+    PFX_TRY(pfx_d2h(ctx, mm, ctx->d_misc.p, sizeof mm));
+    PFX_TRY(pfx_sync(ctx));
+    uint8_t luts[1024];
+    for (int c = 0; c < 3; ++c) pfx_build_stretch_lut((uint8_t)mm[c * 2], (uint8_t)mm[c * 2 + 1], luts + c * 256);
+    for (int i = 0; i < 256; ++i) luts[768 + i] = (uint8_t)i;
+    // auto_levels writes through from_rgba_image (adjustments.rs:230-232) => FROM_FLAT
+    PFX_TRY(pfx_adjust_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h, PFX_OP_LUT_RGBA, nullptr, 0, luts, d_mask, PFX_FROM_FLAT));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_composite_region(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* layers, uint32_t n_layers, uint32_t x,
+                         uint32_t y, uint32_t rw, uint32_t rh, uint8_t* dst_region)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, dst_region && w && h && rw && rh && x + rw <= w && y + rh <= h, "pfx_composite: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
+    PFX_TRY(flatten_common(ctx, nullptr, nullptr, layers, n_layers, w, h, true, ctx->st_out.p));
+    if (rw == w && rh == h) return finish_out(ctx, dst_region, w, h);
+    PFX_HIP(ctx, hipMemcpy2DAsync(dst_region, (size_t)rw * 4, (const uint8_t*)ctx->st_out.p + ((size_t)y * w + x) * 4, (size_t)w * 4,
+                                  (size_t)rw * 4, rh, hipMemcpyDeviceToHost, ctx->stream));
+    return pfx_sync(ctx);
+}
+
+int pfx_composite(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* layers, uint32_t n_layers, uint8_t* dst)
+{
+    return pfx_composite_region(ctx, w, h, layers, n_layers, 0, 0, w, h, dst);
+}
+
+int pfx_blend_pixels(pfx_ctx* ctx, const uint8_t* base, const uint8_t* top, uint8_t* dst, size_t n_pixels, uint8_t blend_mode, float opacity)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, base && top && dst && n_pixels, "pfx_blend_pixels: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_in, n_pixels * 4));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_aux, n_pixels * 4));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, n_pixels * 4));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_in.p, base, n_pixels * 4));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_aux.p, top, n_pixels * 4));
+    PFX_HIP(ctx, pfxk_blend_arrays(ctx->stream, (const uint8_t*)ctx->st_in.p, (const uint8_t*)ctx->st_aux.p, (uint8_t*)ctx->st_out.p,
+                                   n_pixels, blend_mode > 24 ? 0u : blend_mode, opacity));
+    PFX_TRY(pfx_d2h(ctx, dst, ctx->st_out.p, n_pixels * 4));
+    return pfx_sync(ctx);
+}
+
+int pfx_warp_displacement(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_t sh, const float* disp_xy, uint32_t w, uint32_t h, uint8_t* dst)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_warp_displacement"));
+    PFX_REQUIRE(ctx, disp_xy && sw && sh, "pfx_warp_displacement: bad arguments");
+    PFX_TRY(pfx_reserve(ctx, ctx->st_in, img_bytes(sw, sh)));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 8));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_in.p, src, img_bytes(sw, sh)));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_tmp.p, disp_xy, (size_t)w * h * 8));
+    PFX_TRY(pfx_warp_displacement_dev(ctx, ctx->st_in.p, sw, sh, ctx->st_tmp.p, w, h, ctx->st_out.p));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_mesh_displacement(pfx_ctx* ctx, const float* orig_pts_xy, const float* deformed_pts_xy, uint32_t cols, uint32_t rows,
+                          uint32_t w, uint32_t h, float* disp_xy_out)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, disp_xy_out && w && h, "pfx_mesh_displacement: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 8));
+    PFX_TRY(pfx_mesh_displacement_dev(ctx, orig_pts_xy, deformed_pts_xy, cols, rows, w, h, ctx->st_tmp.p));
+    PFX_TRY(pfx_d2h(ctx, disp_xy_out, ctx->st_tmp.p, (size_t)w * h * 8));
+    return pfx_sync(ctx);
+}
+
+int pfx_warp_mesh_catmull_rom(pfx_ctx* ctx, const uint8_t* src, const float* orig_pts_xy, const float* deformed_pts_xy,
+                              uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* dst)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_warp_mesh_catmull_rom"));
+    PFX_REQUIRE(ctx, orig_pts_xy != nullptr, "warp_mesh_catmull_rom needs the original grid (transform.rs:1743)");
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, nullptr, w, h, &d_mask));
+    PFX_TRY(pfx_warp_mesh_catmull_rom_dev(ctx, ctx->st_in.p, orig_pts_xy, deformed_pts_xy, cols, rows, w, h, ctx->st_out.p));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_brush_stamps(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, const float* points_xy,
+                     uint32_t n_points, const uint8_t* selection)
+{
+    PFX_TRY(check_img(ctx, target_inout, target_inout, w, h, "pfx_brush_stamps"));
+    const void* d_sel;
+    PFX_TRY(stage_in(ctx, target_inout, selection, w, h, &d_sel));
+    PFX_TRY(pfx_brush_stamps_dev(ctx, ctx->st_in.p, w, h, brush, points_xy, n_points, d_sel));
+    PFX_TRY(pfx_d2h(ctx, target_inout, ctx->st_in.p, img_bytes(w, h)));
+    return pfx_sync(ctx);
+}
+
+int pfx_brush_line(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, float x0, float y0,
+                   float x1, float y1, const uint8_t* selection)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    std::vector<float> pts;
+    pfx_host_line_points(x0, y0, x1, y1, w, h, pts);
+    if (pts.empty()) return PFX_OK;
+    return pfx_brush_stamps(ctx, target_inout, w, h, brush, pts.data(), (uint32_t)(pts.size() / 2), selection);
+}
+
+int pfx_brush_commit(pfx_ctx* ctx, uint8_t* layer_inout, const uint8_t* preview, uint32_t w, uint32_t h, uint8_t blend_mode,
+                     int is_eraser, const uint8_t* selection)
+{
+    PFX_TRY(check_img(ctx, layer_inout, layer_inout, w, h, "pfx_brush_commit"));
+    PFX_REQUIRE(ctx, preview != nullptr, "null preview");
+    const void* d_sel;
+    PFX_TRY(stage_in(ctx, layer_inout, selection, w, h, &d_sel));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_out.p, preview, img_bytes(w, h)));
+    PFX_HIP(ctx, pfxk_brush_commit(ctx->stream, (uint8_t*)ctx->st_in.p, (const uint8_t*)ctx->st_out.p, (const uint8_t*)d_sel, w, h,
+                                   blend_mode > 24 ? 0u : blend_mode, is_eraser));
+    PFX_TRY(pfx_d2h(ctx, layer_inout, ctx->st_in.p, img_bytes(w, h)));
+    return pfx_sync(ctx);
+}
+
+int pfx_tiled_roundtrip(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h)
+{
+    PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_tiled_roundtrip"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, nullptr, w, h, &d_mask));
+    PFX_TRY(pfx_tiled_roundtrip_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_chunk_populated(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* populated)
+{
+    PFX_TRY(check_img(ctx, src, populated, w, h, "pfx_chunk_populated"));
+    const void* d_mask;
+    PFX_TRY(stage_in(ctx, src, nullptr, w, h, &d_mask));
+    const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
+    PFX_TRY(pfx_reserve(ctx, ctx->d_chunks, nchunks));
+    PFX_HIP(ctx, pfxk_chunk_populated(ctx->stream, (const uint8_t*)ctx->st_in.p, w, h, (uint8_t*)ctx->d_chunks.p));
+    PFX_TRY(pfx_d2h(ctx, populated, ctx->d_chunks.p, nchunks));
+    return pfx_sync(ctx);
+}
+
+} // extern "C"

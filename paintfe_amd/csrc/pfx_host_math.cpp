@@ -1,0 +1,220 @@
+// pfx_host_math.cpp — the pieces of the path that the reference itself computes on the host, once per call:
+// tap weights, LUTs, scalar gains, displacement-brush scatter, stroke point lists.  They use glibc's
+// expf/powf/sqrtf, which is what Rust's f32::exp/powf/sqrt call on Linux, so the device kernels receive
+// bit-identical constants.  Compiled with -ffp-contract=off: every f32 operation rounds once, as in Rust.
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "k_brush_math.h"
+#include "pfx_internal.h"
+
+namespace {
+
+inline uint8_t f32_as_u8(float v) // Rust `as u8`
+{
+    if (!(v > 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)(int)v;
+}
+inline uint32_t f32_as_u32(float v)
+{
+    if (!(v > 0.0f)) return 0;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+inline int32_t f32_as_i32(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)v;
+}
+inline uint8_t round_u8(float v) { return f32_as_u8(pfx_clampf(roundf(v), 0.0f, 255.0f)); }
+
+} // namespace
+
+// ref: build_gaussian_kernel, src/ops/filters.rs:214-234
+int pfx_host_gaussian_kernel(float sigma, std::vector<float>& out)
+{
+    const uint32_t radius = f32_as_u32(ceilf(sigma * 3.0f));
+    out.clear();
+    if (radius == 0) { out.push_back(1.0f); return 0; }
+    const size_t len = (size_t)radius * 2 + 1;
+    out.resize(len);
+    const float s2 = 2.0f * sigma * sigma;
+    float sum = 0.0f;
+    for (size_t i = 0; i < len; ++i) {
+        const float x = (float)i - (float)radius;
+        const float v = expf(-x * x / s2);
+        out[i] = v;
+        sum += v;
+    }
+    const float inv = 1.0f / sum;
+    for (float& v : out) v *= inv;
+    return (int)radius;
+}
+
+// ref: src/ops/adjustments.rs:273 / src/canvas/layers.rs:293
+float pfx_host_bc_factor(float contrast) { return (259.0f * (contrast + 255.0f)) / (255.0f * (259.0f - contrast)); }
+// ref: src/ops/adjustments.rs:353 (`2.0f32.powf(exposure)`)
+float pfx_host_exposure_gain(float ev) { return powf(2.0f, ev); }
+
+extern "C" {
+
+// ref: build_levels_lut, src/ops/adjustments.rs:465-488
+void pfx_build_levels_lut(float in_black, float in_white, float gamma, float out_black, float out_white, uint8_t lut[256])
+{
+    const float in_range = fmaxf(in_white - in_black, 1.0f);
+    const float out_range = out_white - out_black;
+    const float inv_gamma = 1.0f / fmaxf(gamma, 0.01f);
+    for (int i = 0; i < 256; ++i) {
+        const float normalized = pfx_clampf(((float)i - in_black) / in_range, 0.0f, 1.0f);
+        const float gamma_corrected = powf(normalized, inv_gamma);
+        lut[i] = round_u8(out_black + gamma_corrected * out_range);
+    }
+}
+
+// ref: build_stretch_lut, src/ops/adjustments.rs:235-256
+void pfx_build_stretch_lut(uint8_t mn, uint8_t mx, uint8_t lut[256])
+{
+    if (mx <= mn) { for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i; return; }
+    const float range = (float)(mx - mn);
+    for (int i = 0; i < 256; ++i) {
+        float v;
+        if ((uint8_t)i <= mn) v = 0.0f;
+        else if ((uint8_t)i >= mx) v = 255.0f;
+        else v = ((float)i - (float)mn) / range * 255.0f;
+        lut[i] = round_u8(v);
+    }
+}
+
+// ref: build_curves_lut (Fritsch–Carlson monotone cubic), src/ops/adjustments.rs:640-729
+void pfx_build_curves_lut(const float* pts, uint32_t n, uint8_t lut[256])
+{
+    if (!pts || n < 2) { for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i; return; }
+    auto X = [&](uint32_t i) { return pts[i * 2]; };
+    auto Y = [&](uint32_t i) { return pts[i * 2 + 1]; };
+    std::vector<float> delta(n - 1), m(n, 0.0f);
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        const float dx = X(i + 1) - X(i), dy = Y(i + 1) - Y(i);
+        delta[i] = (fabsf(dx) < 1e-6f) ? 0.0f : dy / dx;
+    }
+    m[0] = delta[0];
+    m[n - 1] = delta[n - 2];
+    for (uint32_t i = 1; i + 1 < n; ++i) m[i] = (delta[i - 1] * delta[i] <= 0.0f) ? 0.0f : (delta[i - 1] + delta[i]) / 2.0f;
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        if (fabsf(delta[i]) < 1e-6f) { m[i] = 0.0f; m[i + 1] = 0.0f; continue; }
+        const float alpha = m[i] / delta[i], beta = m[i + 1] / delta[i];
+        const float s = alpha * alpha + beta * beta;
+        if (s > 9.0f) {
+            const float tau = 3.0f / sqrtf(s);
+            m[i] = tau * alpha * delta[i];
+            m[i + 1] = tau * beta * delta[i];
+        }
+    }
+    for (int i = 0; i < 256; ++i) {
+        const float x = (float)i;
+        uint32_t seg = 0;
+        for (uint32_t j = 0; j + 1 < n; ++j) if (x >= X(j)) seg = j;
+        float val;
+        if (x <= X(0)) val = Y(0);
+        else if (x >= X(n - 1)) val = Y(n - 1);
+        else {
+            const float x0 = X(seg), x1 = X(seg + 1), y0 = Y(seg), y1 = Y(seg + 1), hh = x1 - x0;
+            if (fabsf(hh) < 1e-6f) val = y0;
+            else {
+                const float t = (x - x0) / hh, t2 = t * t, t3 = t2 * t;
+                const float h00 = 2.0f * t3 - 3.0f * t2 + 1.0f, h10 = t3 - 2.0f * t2 + t;
+                const float h01 = -2.0f * t3 + 3.0f * t2, h11 = t3 - t2;
+                val = h00 * y0 + h10 * hh * m[seg] + h01 * y1 + h11 * hh * m[seg + 1];
+            }
+        }
+        lut[i] = round_u8(val);
+    }
+}
+
+// ref: DisplacementField::apply_push / apply_expand / apply_contract / apply_twirl, src/ops/transform.rs:1051-1200
+void pfx_displacement_brush(float* disp, uint32_t w, uint32_t h, int mode, float cx, float cy, float delta_x, float delta_y,
+                            float radius, float strength)
+{
+    if (!disp) return;
+    const float r = fmaxf(radius, 1.0f);
+    const float sigma = r / 3.0f;
+    const float sigma_sq_2 = 2.0f * sigma * sigma;
+    const float dir = (mode == 3) ? 1.0f : -1.0f;
+    const int32_t x0 = std::max(f32_as_i32(floorf(cx - r)), 0), y0 = std::max(f32_as_i32(floorf(cy - r)), 0);
+    const int32_t x1 = std::min(f32_as_i32(ceilf(cx + r)), (int32_t)w), y1 = std::min(f32_as_i32(ceilf(cy + r)), (int32_t)h);
+    for (int32_t py = y0; py < y1; ++py)
+        for (int32_t px = x0; px < x1; ++px) {
+            const float dx = (float)px - cx, dy = (float)py - cy;
+            const float dist_sq = dx * dx + dy * dy;
+            if (dist_sq > r * r) continue;
+            float* d = disp + ((size_t)py * w + (size_t)px) * 2;
+            if (mode == 0) {
+                const float weight = expf(-dist_sq / sigma_sq_2) * strength;
+                d[0] += delta_x * weight;
+                d[1] += delta_y * weight;
+            } else if (mode == 1) {
+                const float dist = fmaxf(sqrtf(dist_sq), 0.001f);
+                const float t = dist / r;
+                const float weight = (1.0f - t) * (1.0f - t) * strength * 3.0f;
+                d[0] += dx / dist * weight;
+                d[1] += dy / dist * weight;
+            } else if (mode == 2) {
+                const float dist = fmaxf(sqrtf(dist_sq), 0.001f);
+                const float weight = expf(-dist_sq / sigma_sq_2) * strength;
+                d[0] += -dx / dist * weight * 2.0f;
+                d[1] += -dy / dist * weight * 2.0f;
+            } else {
+                const float weight = expf(-dist_sq / sigma_sq_2) * strength * dir;
+                d[0] += -dy * weight * 0.1f;
+                d[1] += dx * weight * 0.1f;
+            }
+        }
+}
+
+} // extern "C"
+
+// ref: rebuild_brush_lut, src/ui/panels/tools/behavior/raster/brush_render.rs:27-50
+void pfx_host_brush_lut(float size, float hardness, bool anti_aliased, uint8_t lut[256])
+{
+    const float radius = size / 2.0f;
+    if (radius < 0.001f) { for (int i = 0; i < 256; ++i) lut[i] = 0; return; }
+    for (int i = 0; i < 256; ++i) {
+        const float t_sq = (float)i / 255.0f;
+        const float dist = sqrtf(t_sq) * radius;
+        const float alpha = pfx_brush_alpha(dist, radius, hardness, anti_aliased);
+        lut[i] = f32_as_u8(fminf(roundf(alpha * 255.0f), 255.0f));
+    }
+}
+
+// ref: draw_line_no_dirty, src/ui/panels/tools/behavior/raster/brush_render.rs:762-835 (circle tip: step 1.0)
+void pfx_host_line_points(float x0, float y0, float x1, float y1, uint32_t width, uint32_t height, std::vector<float>& out)
+{
+    out.clear();
+    const float dx = x1 - x0, dy = y1 - y0;
+    const float distance = sqrtf(dx * dx + dy * dy);
+    auto inside = [&](float x, float y) { return x >= 0.0f && f32_as_u32(x) < width && y >= 0.0f && f32_as_u32(y) < height; };
+    if (distance < 0.1f) {
+        if (inside(x0, y0)) { out.push_back(x0); out.push_back(y0); }
+        return;
+    }
+    const size_t steps = (size_t)f32_as_u32(ceilf(distance / 1.0f));
+    for (size_t i = 0; i <= steps; ++i) {
+        const float t = (float)i / (float)steps;
+        const float x = x0 + dx * t, y = y0 + dy * t;
+        if (inside(x, y)) { out.push_back(x); out.push_back(y); }
+    }
+}
+
+// ref: apply_levels LUT, src/ops/scripting.rs:1050-1061 (truncating, output range 0..255)
+void pfx_host_rhai_levels_lut(float in_black, float in_white, float gamma, uint8_t lut[256])
+{
+    const float in_range = fmaxf(in_white - in_black, 1.0f);
+    const float inv_gamma = 1.0f / fmaxf(gamma, 0.01f);
+    for (int i = 0; i < 256; ++i) {
+        const float normalized = pfx_clampf(((float)i - in_black) / in_range, 0.0f, 1.0f);
+        lut[i] = f32_as_u8(pfx_clampf(powf(normalized, inv_gamma) * 255.0f, 0.0f, 255.0f));
+    }
+}

@@ -1,0 +1,86 @@
+// pfx_internal.h — context object and host-side helpers behind the C ABI (include/pfx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pfx.h"
+#include "pfx_kernels.h"
+
+struct pfx_devbuf { // grow-on-demand device allocation (never shrinks; freed with the context)
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct pfx_layer_state { // GpuLayerState (ref: src/gpu/renderer.rs:206-209): device-resident, versioned
+    pfx_devbuf pixels;
+    pfx_devbuf mask;
+    bool has_mask = false;
+    uint32_t w = 0, h = 0;
+    uint64_t generation = 0;
+};
+
+struct pfx_timing_rec {
+    std::string name;
+    hipEvent_t start, stop;
+};
+
+struct pfx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool exact = false;
+    std::string err;
+    // staging for the host-buffer tier (the reference keeps cached staging/ping-pong textures the same way,
+    // ref: src/gpu/renderer.rs:232-236)
+    pfx_devbuf st_in, st_out, st_mask, st_tmp, st_aux, st_aux2;
+    // small parameter buffers
+    pfx_devbuf d_desc, d_adj, d_chunks, d_wts, d_lut, d_pts, d_misc;
+    std::map<uint32_t, pfx_layer_state> layers;
+    bool timing = false;
+    std::vector<pfx_timing_rec> timings;
+};
+
+// ---- error plumbing ----
+int pfx_fail(pfx_ctx* ctx, int status, const char* fmt, ...);
+#define PFX_HIP(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (call);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return pfx_fail((ctx), _e == hipErrorOutOfMemory ? PFX_ERR_OOM : PFX_ERR_HIP,       \
+                            "%s failed: %s", #call, hipGetErrorString(_e));                     \
+    } while (0)
+#define PFX_TRY(expr)            \
+    do {                         \
+        int _s = (expr);         \
+        if (_s != PFX_OK) return _s; \
+    } while (0)
+#define PFX_REQUIRE(ctx, cond, msg) \
+    do {                            \
+        if (!(cond)) return pfx_fail((ctx), PFX_ERR_INVALID, "%s", (msg)); \
+    } while (0)
+
+// ---- helpers (pfx_ctx.cpp) ----
+int pfx_use(pfx_ctx* ctx);                                     // hipSetDevice
+int pfx_reserve(pfx_ctx* ctx, pfx_devbuf& b, size_t bytes);    // grow-on-demand
+int pfx_h2d(pfx_ctx* ctx, void* dst, const void* src, size_t bytes);
+int pfx_d2h(pfx_ctx* ctx, void* dst, const void* src, size_t bytes);
+int pfx_sync(pfx_ctx* ctx);
+
+// RAII-less timing scope: records two events around a launch sequence when ctx->timing is on
+struct pfx_timer {
+    pfx_ctx* ctx;
+    bool on;
+    pfx_timing_rec rec;
+    pfx_timer(pfx_ctx* c, const char* name);
+    ~pfx_timer();
+};
+
+// host-side restatements that the reference also runs on the host (pfx_host_math.cpp)
+int  pfx_host_gaussian_kernel(float sigma, std::vector<float>& out);  // ref: src/ops/filters.rs:214-234
+float pfx_host_bc_factor(float contrast);                             // ref: src/ops/adjustments.rs:273
+float pfx_host_exposure_gain(float ev);                               // ref: src/ops/adjustments.rs:353

@@ -1,0 +1,98 @@
+// pfx_kernels.h — launch entry points of the gfx950 kernels (internal; the public ABI is include/pfx.h).
+// Every launcher enqueues on `stream`, never synchronises, and returns hipGetLastError().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PFXK_LAYER_RASTER = 0, PFXK_ADJ_EXPOSURE = 1, PFXK_ADJ_BRIGHTNESS_CONTRAST = 2, PFXK_ADJ_INVERT = 3,
+       PFXK_ADJ_CHANNEL_MIXER = 4 };
+
+// one entry of the layer stack, bottom -> top (32 bytes, read with scalar loads: uniform per wave)
+typedef struct pfxk_layer_desc {
+    const uint8_t* pixels; // device RGBA8, tight w*h*4 (NULL for adjustment layers)
+    const uint8_t* mask;   // device w*h "conceal" bytes or NULL
+    float    opacity;      // as stored (unclamped: the >= 1.0 fast path looks at the raw value)
+    uint32_t mode;         // BlendMode::to_u8
+    uint32_t kind;         // PFXK_LAYER_RASTER or PFXK_ADJ_*
+    uint32_t adj_off;      // offset (floats) of this layer's 16 parameters in the adj table
+} pfxk_layer_desc;
+
+// parameter block of the pointwise kernels (passed by value: lands in SGPRs)
+typedef struct pfxk_params { float p[12]; } pfxk_params;
+
+// ids mirror include/pfx.h (pfx_adjust_op / pfx_rhai_op); static_asserts in pfx_api.cpp keep them in sync
+enum { PFXK_OP_INVERT = 0, PFXK_OP_INVERT_ALPHA, PFXK_OP_SEPIA, PFXK_OP_BRIGHTNESS_CONTRAST, PFXK_OP_HSL,
+       PFXK_OP_EXPOSURE, PFXK_OP_HIGHLIGHTS_SHADOWS, PFXK_OP_TEMPERATURE_TINT, PFXK_OP_THRESHOLD, PFXK_OP_POSTERIZE,
+       PFXK_OP_COLOR_BALANCE, PFXK_OP_GRADIENT_MAP, PFXK_OP_BLACK_AND_WHITE, PFXK_OP_VIBRANCE, PFXK_OP_LUT_RGBA,
+       PFXK_OP_DESATURATE, PFXK_OP_COUNT };
+enum { PFXK_RHAI_INVERT = 0, PFXK_RHAI_DESATURATE, PFXK_RHAI_SEPIA, PFXK_RHAI_SEPIA_STRENGTH,
+       PFXK_RHAI_BRIGHTNESS_CONTRAST, PFXK_RHAI_HSL, PFXK_RHAI_EXPOSURE, PFXK_RHAI_LEVELS, PFXK_RHAI_COUNT };
+
+// ---- k_flatten.hip ----
+hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
+                        const float* d_adj_table, int general, uint8_t* d_chunk_active, uint32_t w, uint32_t h,
+                        uint8_t* d_dst);
+
+// ---- k_gauss.hip ---- (d_wts_tap0 points at tap 0 of a device array with 8 zeros of padding on both sides)
+int        pfxk_gauss_max_radius(void);
+hipError_t pfxk_gauss_h(hipStream_t stream, const uint8_t* d_src, float* d_tmp, const float* d_wts_tap0, int radius,
+                        uint32_t w, uint32_t h, int exact);
+hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8_t* d_dst, const float* d_wts_tap0, int radius,
+                        uint32_t w, uint32_t h, int exact);
+
+// ---- k_pointwise.hip ---- (d_lut: 1024 readable bytes when the op uses a LUT)
+hipError_t pfxk_adjust(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, const uint8_t* d_lut,
+                       int op, const pfxk_params* P, int sparse_mode, uint32_t w, uint32_t h);
+hipError_t pfxk_rhai_adjust(hipStream_t s, uint8_t* d_px, const uint8_t* d_lut, int op, const pfxk_params* P,
+                            uint32_t w, uint32_t h);
+
+// ---- k_tiled.hip ----
+hipError_t pfxk_chunk_populated(hipStream_t s, const uint8_t* d_src, uint32_t w, uint32_t h, uint8_t* d_populated);
+hipError_t pfxk_tiled_roundtrip(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, uint32_t w, uint32_t h);
+// dst = mask ? blurred : src   (blur_with_selection's copy-back, ref: src/ops/filters.rs:186-200)
+hipError_t pfxk_select_by_mask(hipStream_t s, const uint8_t* d_src, const uint8_t* d_fx, const uint8_t* d_mask,
+                               uint8_t* d_dst, uint32_t w, uint32_t h);
+// per-channel min/max over selected pixels with alpha != 0 -> out[6] = {minR,maxR,minG,maxG,minB,maxB} (u32)
+hipError_t pfxk_minmax_rgb(hipStream_t s, const uint8_t* d_src, const uint8_t* d_mask, uint32_t w, uint32_t h,
+                           uint32_t* d_out6);
+
+// ---- k_stencil.hip ---- box blur / median / pixelate
+hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst, const uint8_t* d_mask,
+                         int radius, uint32_t w, uint32_t h);
+hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, int radius,
+                       uint32_t w, uint32_t h);
+hipError_t pfxk_pixelate(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, uint32_t bs,
+                         uint32_t w, uint32_t h);
+
+// ---- k_warp.hip ----
+hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, const float* d_disp,
+                                  uint32_t w, uint32_t h, uint8_t* d_dst);
+// d_pts: orig points (may be NULL => "fast" identity original) then deformed points, (cols+1)*(rows+1) xy pairs each
+hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig, const float* d_def, uint32_t cols, uint32_t rows,
+                                  uint32_t w, uint32_t h, float* d_disp);
+hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const float* d_orig, const float* d_def, uint32_t cols,
+                          uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst);
+
+// ---- k_brush.hip ----
+typedef struct pfxk_brush {
+    float radius, radius_sq, draw_radius, draw_radius_sq, inv_radius_sq, hardness, flow;
+    float src_r, src_g, src_b, src_a;
+    uint32_t rgb8;          // (c*255) as u8, packed r | g<<8 | b<<16
+    int32_t anti_aliased, use_direct_alpha, is_eraser, mode;
+} pfxk_brush;
+hipError_t pfxk_brush_stamps(hipStream_t s, uint8_t* d_target, uint32_t w, uint32_t h, const pfxk_brush* B,
+                             const float* d_points_xy, uint32_t n_points, const uint8_t* d_lut256,
+                             const uint8_t* d_selection, int bx0, int by0, int bx1, int by1);
+hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const uint8_t* d_preview, const uint8_t* d_selection,
+                             uint32_t w, uint32_t h, uint32_t mode, int is_eraser);
+// element-wise blend_pixel_static over two pixel arrays (spot checks / stroke commit)
+hipError_t pfxk_blend_arrays(hipStream_t s, const uint8_t* d_base, const uint8_t* d_top, uint8_t* d_dst, size_t n_px,
+                             uint32_t mode, float opacity);
+
+#ifdef __cplusplus
+}
+#endif

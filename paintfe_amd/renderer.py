@@ -1,0 +1,409 @@
+"""Host-side mirror of the reference's operator surface, over the C ABI.
+
+``GpuRenderer`` keeps the method names and argument meaning of ``paintfe::gpu::GpuRenderer``
+(ref: src/gpu/renderer.rs:249-947) and of the pure ``_core`` functions the dialogs / Rhai host call
+(ref: SURVEY.md §8b B1-B4).  Images are ``numpy.uint8`` arrays of shape (h, w, 4) — the Python spelling of the
+reference's ``&[u8]`` + ``(w, h)``.  All pixel work happens in libpfx.so's HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import Brush, LayerInfo, PfxError, ScriptResult
+
+DENSE, FROM_FLAT, IN_PLACE = 0, 1, 2
+
+ADJUST_OPS = ["invert", "invert_alpha", "sepia", "brightness_contrast", "hsl", "exposure", "highlights_shadows",
+              "temperature_tint", "threshold", "posterize", "color_balance", "gradient_map", "black_and_white",
+              "vibrance", "lut_rgba", "desaturate"]
+RHAI_OPS = ["invert", "desaturate", "sepia", "sepia_strength", "brightness_contrast", "hsl", "exposure", "levels"]
+BLEND_MODES = ["normal", "multiply", "screen", "additive", "reflect", "glow", "color_burn", "color_dodge", "overlay",
+               "difference", "negation", "lighten", "darken", "xor", "overwrite", "hard_light", "soft_light",
+               "exclusion", "subtract", "divide", "linear_burn", "vivid_light", "linear_light", "pin_light",
+               "hard_mix"]  # BlendMode::to_u8 order, ref: src/canvas/layers.rs:125-153
+LAYER_RASTER, ADJ_EXPOSURE, ADJ_BRIGHTNESS_CONTRAST, ADJ_INVERT, ADJ_CHANNEL_MIXER = range(5)
+
+
+def _u8(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _fparams(params: Sequence[float]):
+    arr = (C.c_float * max(len(params), 1))(*[float(x) for x in params])
+    return arr, C.c_uint32(len(params))
+
+
+class GpuRenderer:
+    """One HIP device + stream (ref: GpuRenderer::try_new, src/gpu/renderer.rs:261)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        st = self._lib.pfx_ctx_create(C.c_int(device), C.byref(h))
+        if st != _lib.OK:
+            raise PfxError(st, self._lib.pfx_last_error(None).decode())
+        self._h = h
+        self.available = True  # ref: renderer.rs:241
+
+    @classmethod
+    def try_new(cls, device: int = 0) -> Optional["GpuRenderer"]:
+        try:
+            return cls(device)
+        except (PfxError, ImportError, OSError):
+            return None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pfx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, st: int):
+        if st != _lib.OK:
+            raise PfxError(st, self._lib.pfx_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.pfx_ctx_stream(self._h) or 0)
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.pfx_ctx_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_exact(self, exact: bool):
+        self._check(self._lib.pfx_ctx_set_exact(self._h, C.c_int(int(exact))))
+
+    def synchronize(self):
+        self._check(self._lib.pfx_ctx_synchronize(self._h))
+
+    def _img_call(self, fn, img, *args, mask=None, has_mask=True):
+        src = _u8(img)
+        h, w = src.shape[:2]
+        dst = np.empty_like(src)
+        m = None if mask is None else _u8(mask)
+        a = [self._h, _p(src), _p(dst), C.c_uint32(w), C.c_uint32(h), *args]
+        if has_mask:
+            a.append(_p(m))
+        self._check(fn(*a))
+        return dst
+
+    # ------------------------------------------------------------------ B1: GpuRenderer filter methods
+    def blur_rgba(self, data, sigma: float):
+        return self._img_call(self._lib.pfx_blur_rgba, data, C.c_float(sigma), has_mask=False)
+
+    def brightness_contrast_rgba(self, data, brightness: float, contrast: float):
+        return self._img_call(self._lib.pfx_brightness_contrast_rgba, data, C.c_float(brightness), C.c_float(contrast),
+                              has_mask=False)
+
+    def hsl_rgba(self, data, hue: float, sat: float, light: float):
+        return self._img_call(self._lib.pfx_hsl_rgba, data, C.c_float(hue), C.c_float(sat), C.c_float(light),
+                              has_mask=False)
+
+    def invert_rgba(self, data):
+        return self._img_call(self._lib.pfx_invert_rgba, data, has_mask=False)
+
+    def median_rgba(self, data, radius: int):
+        """Returns None where the reference does (device path does not cover the radius)."""
+        try:
+            return self._img_call(self._lib.pfx_median_rgba, data, C.c_uint32(radius), has_mask=False)
+        except PfxError as e:
+            if e.status == _lib.ERR_UNSUPPORTED:
+                return None
+            raise
+
+    # ------------------------------------------------------------------ B4: `_core` functions
+    def gaussian_blur_core(self, img, sigma: float, mask=None):
+        return self._img_call(self._lib.pfx_gaussian_blur_core, img, C.c_float(sigma), mask=mask)
+
+    def box_blur_core(self, img, radius: float, mask=None):
+        return self._img_call(self._lib.pfx_box_blur_core, img, C.c_float(radius), mask=mask)
+
+    def median_core(self, img, radius: int, mask=None):
+        return self._img_call(self._lib.pfx_median_core, img, C.c_uint32(radius), mask=mask)
+
+    def pixelate_core(self, img, block_size: int, mask=None):
+        return self._img_call(self._lib.pfx_pixelate_core, img, C.c_uint32(block_size), mask=mask)
+
+    def adjust(self, img, op, params: Sequence[float] = (), lut=None, mask=None, sparse: int = DENSE):
+        opi = ADJUST_OPS.index(op) if isinstance(op, str) else int(op)
+        src = _u8(img)
+        h, w = src.shape[:2]
+        dst = np.empty_like(src)
+        arr, n = _fparams(params)
+        l = None if lut is None else _u8(lut)
+        m = None if mask is None else _u8(mask)
+        self._check(self._lib.pfx_adjust(self._h, _p(src), _p(dst), C.c_uint32(w), C.c_uint32(h), C.c_int(opi), arr, n,
+                                         _p(l), _p(m), C.c_int(sparse)))
+        return dst
+
+    def rhai_adjust(self, img, op, params: Sequence[float] = ()):
+        opi = RHAI_OPS.index(op) if isinstance(op, str) else int(op)
+        px = _u8(img).copy()
+        h, w = px.shape[:2]
+        arr, n = _fparams(params)
+        self._check(self._lib.pfx_rhai_adjust(self._h, _p(px), C.c_uint32(w), C.c_uint32(h), C.c_int(opi), arr, n))
+        return px
+
+    def auto_levels(self, img, mask=None):
+        return self._img_call(self._lib.pfx_auto_levels, img, mask=mask)
+
+    def levels(self, img, in_black, in_white, gamma, out_black, out_white, mask=None, sparse=FROM_FLAT):
+        lv = self.build_levels_lut(in_black, in_white, gamma, out_black, out_white)
+        luts = np.stack([lv, lv, lv, np.arange(256, dtype=np.uint8)])
+        return self.adjust(img, "lut_rgba", lut=luts, mask=mask, sparse=sparse)
+
+    def build_levels_lut(self, in_black, in_white, gamma, out_black, out_white) -> np.ndarray:
+        lut = np.zeros(256, np.uint8)
+        self._lib.pfx_build_levels_lut(C.c_float(in_black), C.c_float(in_white), C.c_float(gamma), C.c_float(out_black),
+                                       C.c_float(out_white), _p(lut))
+        return lut
+
+    def build_curves_lut(self, points) -> np.ndarray:
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        lut = np.zeros(256, np.uint8)
+        self._lib.pfx_build_curves_lut(_p(pts), C.c_uint32(len(pts)), _p(lut))
+        return lut
+
+    def tiled_roundtrip(self, img):
+        return self._img_call(self._lib.pfx_tiled_roundtrip, img, has_mask=False)
+
+    def chunk_populated(self, img):
+        src = _u8(img)
+        h, w = src.shape[:2]
+        out = np.zeros(((h + 63) // 64, (w + 63) // 64), np.uint8)
+        self._check(self._lib.pfx_chunk_populated(self._h, _p(src), C.c_uint32(w), C.c_uint32(h), _p(out)))
+        return out
+
+    # ------------------------------------------------------------------ B2: compositor
+    def ensure_layer_texture(self, layer_idx: int, data, generation: int):
+        src = _u8(data)
+        h, w = src.shape[:2]
+        self._check(self._lib.pfx_layer_upload(self._h, C.c_uint32(layer_idx), C.c_uint32(w), C.c_uint32(h), _p(src),
+                                               C.c_uint64(generation)))
+
+    def update_layer_rect(self, layer_idx: int, x: int, y: int, data):
+        reg = _u8(data)
+        rh, rw = reg.shape[:2]
+        self._check(self._lib.pfx_layer_update_rect(self._h, C.c_uint32(layer_idx), C.c_uint32(x), C.c_uint32(y),
+                                                    C.c_uint32(rw), C.c_uint32(rh), _p(reg)))
+
+    def set_layer_mask(self, layer_idx: int, conceal):
+        m = None if conceal is None else _u8(conceal)
+        self._check(self._lib.pfx_layer_set_mask(self._h, C.c_uint32(layer_idx), _p(m)))
+
+    def remove_layer(self, layer_idx: int):
+        self._check(self._lib.pfx_layer_remove(self._h, C.c_uint32(layer_idx)))
+
+    def clear_layers(self):
+        self._check(self._lib.pfx_layer_clear(self._h))
+
+    def active_texture_count(self) -> int:
+        return int(self._lib.pfx_layer_count(self._h))
+
+    def active_texture_memory(self) -> int:
+        return int(self._lib.pfx_layer_memory(self._h))
+
+    @staticmethod
+    def _infos(layer_info: Iterable):
+        """layer_info: tuples (layer_idx, opacity, visible, blend_mode_u8[, kind, adj]) bottom -> top."""
+        items = list(layer_info)
+        arr = (LayerInfo * max(len(items), 1))()
+        for i, t in enumerate(items):
+            arr[i].layer_idx, arr[i].opacity, arr[i].visible, arr[i].blend_mode = int(t[0]), float(t[1]), int(bool(t[2])), int(t[3])
+            if len(t) > 4:
+                arr[i].kind = int(t[4])
+                for j, v in enumerate(t[5] if len(t) > 5 else ()):
+                    arr[i].adj[j] = float(v)
+        return arr, len(items)
+
+    def composite(self, canvas_w: int, canvas_h: int, layer_info: Iterable):
+        arr, n = self._infos(layer_info)
+        dst = np.empty((canvas_h, canvas_w, 4), np.uint8)
+        self._check(self._lib.pfx_composite(self._h, C.c_uint32(canvas_w), C.c_uint32(canvas_h), arr, C.c_uint32(n), _p(dst)))
+        return dst
+
+    def composite_dirty_readback(self, canvas_w, canvas_h, layer_info, rect):
+        x, y, rw, rh = rect
+        arr, n = self._infos(layer_info)
+        dst = np.empty((rh, rw, 4), np.uint8)
+        self._check(self._lib.pfx_composite_region(self._h, C.c_uint32(canvas_w), C.c_uint32(canvas_h), arr, C.c_uint32(n),
+                                                   C.c_uint32(x), C.c_uint32(y), C.c_uint32(rw), C.c_uint32(rh), _p(dst)))
+        return dst
+
+    def blend_pixels(self, base, top, mode: int, opacity: float):
+        b, t = _u8(base).reshape(-1, 4), _u8(top).reshape(-1, 4)
+        dst = np.empty_like(b)
+        self._check(self._lib.pfx_blend_pixels(self._h, _p(b), _p(t), _p(dst), C.c_size_t(len(b)), C.c_uint8(mode),
+                                               C.c_float(opacity)))
+        return dst
+
+    # ------------------------------------------------------------------ B3: warp
+    def warp_displacement(self, src, disp):
+        s = _u8(src)
+        d = np.ascontiguousarray(disp, np.float32)
+        sh, sw = s.shape[:2]
+        h, w = d.shape[:2]
+        dst = np.empty((h, w, 4), np.uint8)
+        self._check(self._lib.pfx_warp_displacement(self._h, _p(s), C.c_uint32(sw), C.c_uint32(sh), _p(d), C.c_uint32(w),
+                                                    C.c_uint32(h), _p(dst)))
+        return dst
+
+    def generate_displacement(self, deformed_points, cols, rows, w, h, original_points=None):
+        d = np.ascontiguousarray(deformed_points, np.float32)
+        o = None if original_points is None else np.ascontiguousarray(original_points, np.float32)
+        out = np.empty((h, w, 2), np.float32)
+        self._check(self._lib.pfx_mesh_displacement(self._h, _p(o), _p(d), C.c_uint32(cols), C.c_uint32(rows), C.c_uint32(w),
+                                                    C.c_uint32(h), _p(out)))
+        return out
+
+    def warp_mesh_catmull_rom(self, src, original_points, deformed_points, cols, rows):
+        s = _u8(src)
+        h, w = s.shape[:2]
+        o = np.ascontiguousarray(original_points, np.float32)
+        d = np.ascontiguousarray(deformed_points, np.float32)
+        dst = np.empty_like(s)
+        self._check(self._lib.pfx_warp_mesh_catmull_rom(self._h, _p(s), _p(o), _p(d), C.c_uint32(cols), C.c_uint32(rows),
+                                                        C.c_uint32(w), C.c_uint32(h), _p(dst)))
+        return dst
+
+    def displacement_brush(self, disp: np.ndarray, mode, cx, cy, dx, dy, radius, strength):
+        assert disp.dtype == np.float32 and disp.flags.c_contiguous
+        h, w = disp.shape[:2]
+        self._lib.pfx_displacement_brush(_p(disp), C.c_uint32(w), C.c_uint32(h), C.c_int(mode), C.c_float(cx), C.c_float(cy),
+                                         C.c_float(dx), C.c_float(dy), C.c_float(radius), C.c_float(strength))
+        return disp
+
+    # ------------------------------------------------------------------ brush
+    @staticmethod
+    def make_brush(size, hardness, anti_aliased, color=(0, 0, 0, 1), flow=1.0, is_eraser=False, mode=0) -> Brush:
+        b = Brush()
+        b.size, b.hardness, b.flow = size, hardness, flow
+        for i in range(4):
+            b.color[i] = color[i]
+        b.anti_aliased, b.is_eraser, b.mode = int(anti_aliased), int(is_eraser), int(mode)
+        return b
+
+    def brush_stamps(self, target, brush: Brush, points, selection=None):
+        t = _u8(target).copy()
+        h, w = t.shape[:2]
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        sel = None if selection is None else _u8(selection)
+        self._check(self._lib.pfx_brush_stamps(self._h, _p(t), C.c_uint32(w), C.c_uint32(h), C.byref(brush), _p(pts),
+                                               C.c_uint32(len(pts)), _p(sel)))
+        return t
+
+    def brush_line(self, target, brush: Brush, p0, p1, selection=None):
+        t = _u8(target).copy()
+        h, w = t.shape[:2]
+        sel = None if selection is None else _u8(selection)
+        self._check(self._lib.pfx_brush_line(self._h, _p(t), C.c_uint32(w), C.c_uint32(h), C.byref(brush), C.c_float(p0[0]),
+                                             C.c_float(p0[1]), C.c_float(p1[0]), C.c_float(p1[1]), _p(sel)))
+        return t
+
+    def brush_commit(self, layer, preview, blend_mode: int, is_eraser=False, selection=None):
+        l = _u8(layer).copy()
+        h, w = l.shape[:2]
+        p = _u8(preview)
+        sel = None if selection is None else _u8(selection)
+        self._check(self._lib.pfx_brush_commit(self._h, _p(l), _p(p), C.c_uint32(w), C.c_uint32(h), C.c_uint8(blend_mode),
+                                               C.c_int(int(is_eraser)), _p(sel)))
+        return l
+
+    # ------------------------------------------------------------------ script front-end
+    def execute_script_sync(self, source: str, pixels, mask=None):
+        px = _u8(pixels).copy()
+        h, w = px.shape[:2]
+        m = None if mask is None else _u8(mask)
+        res = ScriptResult()
+        st = self._lib.pfx_script_run(self._h, source.encode(), _p(px), C.c_uint32(w), C.c_uint32(h), _p(m), C.byref(res))
+        console = [s for s in res.console.decode(errors="replace").split("\n") if s]
+        if st != _lib.OK:
+            msg = res.error.decode(errors="replace") or self._lib.pfx_last_error(self._h).decode()
+            err = PfxError(st, msg)
+            err.line, err.col = res.error_line, res.error_col
+            raise err
+        return px, console
+
+    # ------------------------------------------------------------------ device tier (raw device pointers as ints)
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.pfx_dev_alloc(self._h, C.c_size_t(nbytes), C.byref(p)))
+        return int(p.value)
+
+    def dev_free(self, ptr: int):
+        self._check(self._lib.pfx_dev_free(self._h, C.c_void_p(ptr)))
+
+    def dev_upload(self, ptr: int, host: np.ndarray):
+        a = np.ascontiguousarray(host)
+        self._check(self._lib.pfx_dev_upload(self._h, C.c_void_p(ptr), _p(a), C.c_size_t(a.nbytes)))
+
+    def dev_download(self, ptr: int, shape, dtype=np.uint8) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        self._check(self._lib.pfx_dev_download(self._h, _p(out), C.c_void_p(ptr), C.c_size_t(out.nbytes)))
+        return out
+
+    def flatten_dev(self, layer_ptrs: Sequence[int], layer_info: Iterable, w: int, h: int, dst_ptr: int, mask_ptrs=None):
+        arr, n = self._infos(layer_info)
+        lp = (C.c_void_p * max(n, 1))(*[C.c_void_p(p) for p in layer_ptrs])
+        mp = None
+        if mask_ptrs is not None:
+            mp = (C.c_void_p * max(n, 1))(*[C.c_void_p(p or 0) for p in mask_ptrs])
+        self._check(self._lib.pfx_flatten_dev(self._h, lp, mp, arr, C.c_uint32(n), C.c_uint32(w), C.c_uint32(h),
+                                              C.c_void_p(dst_ptr)))
+
+    def gaussian_blur_dev(self, src_ptr: int, dst_ptr: int, w: int, h: int, sigma: float, tmp_ptr: int = 0):
+        self._check(self._lib.pfx_gaussian_blur_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w),
+                                                    C.c_uint32(h), C.c_float(sigma), C.c_void_p(tmp_ptr or None)))
+
+    def adjust_dev(self, src_ptr, dst_ptr, w, h, op, params=(), lut=None, mask_ptr=0, sparse=DENSE):
+        opi = ADJUST_OPS.index(op) if isinstance(op, str) else int(op)
+        arr, n = _fparams(params)
+        l = None if lut is None else _u8(lut)
+        self._check(self._lib.pfx_adjust_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
+                                             C.c_int(opi), arr, n, _p(l), C.c_void_p(mask_ptr or None), C.c_int(sparse)))
+
+    def box_blur_dev(self, src_ptr, dst_ptr, w, h, radius, mask_ptr=0, tmp_ptr=0):
+        self._check(self._lib.pfx_box_blur_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
+                                               C.c_float(radius), C.c_void_p(mask_ptr or None), C.c_void_p(tmp_ptr or None)))
+
+    def median_dev(self, src_ptr, dst_ptr, w, h, radius, mask_ptr=0):
+        self._check(self._lib.pfx_median_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
+                                             C.c_uint32(radius), C.c_void_p(mask_ptr or None)))
+
+    def warp_mesh_catmull_rom_dev(self, src_ptr, orig, deformed, cols, rows, w, h, dst_ptr):
+        o = None if orig is None else np.ascontiguousarray(orig, np.float32)
+        d = np.ascontiguousarray(deformed, np.float32)
+        self._check(self._lib.pfx_warp_mesh_catmull_rom_dev(self._h, C.c_void_p(src_ptr), _p(o), _p(d), C.c_uint32(cols),
+                                                            C.c_uint32(rows), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr)))
+
+    def warp_displacement_dev(self, src_ptr, sw, sh, disp_ptr, w, h, dst_ptr):
+        self._check(self._lib.pfx_warp_displacement_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(sw), C.c_uint32(sh),
+                                                        C.c_void_p(disp_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr)))
+
+    def timing_enable(self, on: bool):
+        self._check(self._lib.pfx_timing_enable(self._h, C.c_int(int(on))))
+
+    def timing_reset(self):
+        self._check(self._lib.pfx_timing_reset(self._h))
+
+    def timing_read(self, name: str):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self._lib.pfx_timing_read(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -66,3 +66,69 @@ class OracleBackend:
     def brush_line(self, target, brush, p0, p1, selection=None):
         t = GC.brush_target(target) if isinstance(target, str) else np.ascontiguousarray(target).copy()
         return O.brush_line(t, O.make_brush(**brush), p0, p1, selection)
+
+
+class GpuBackend:
+    """Same method names, routed through libpfx.so's C ABI (HIP kernels).  No oracle involved."""
+    name = "gpu"
+
+    def __init__(self, device: int = 0):
+        from paintfe_amd import GpuRenderer
+        self.r = GpuRenderer(device)
+
+    def composite(self, layers, w, h):
+        self.r.clear_layers()
+        info = []
+        for i, L in enumerate(layers):
+            kind = L.get("kind", 0)
+            if kind == 0:
+                self.r.ensure_layer_texture(i, L["pixels"], generation=1)
+                if L.get("mask") is not None:
+                    self.r.set_layer_mask(i, L["mask"])
+            info.append((i, L.get("opacity", 1.0), L.get("visible", True), L.get("mode", 0), kind, L.get("adj", ())))
+        return self.r.composite(w, h, info)
+
+    def gaussian_blur(self, img, sigma, mask=None):
+        return self.r.gaussian_blur_core(img, sigma, mask)
+
+    def box_blur(self, img, radius, mask=None):
+        return self.r.box_blur_core(img, radius, mask)
+
+    def median(self, img, radius, mask=None):
+        return self.r.median_core(img, radius, mask)
+
+    def pixelate(self, img, block, mask=None):
+        return self.r.pixelate_core(img, block, mask)
+
+    def rhai_adjust(self, img, op, params=()):
+        return self.r.rhai_adjust(img, op, params)
+
+    def adjust(self, img, op, params=(), lut=None, mask=None, sparse=0):
+        return self.r.adjust(img, op, params, lut, mask, sparse)
+
+    def auto_levels(self, img, mask=None):
+        return self.r.auto_levels(img, mask)
+
+    def levels(self, img, in_black, in_white, gamma, out_black, out_white, mask=None):
+        return self.r.levels(img, in_black, in_white, gamma, out_black, out_white, mask)
+
+    def warp_push(self, img, brushes):
+        h, w = img.shape[:2]
+        d = np.zeros((h, w, 2), np.float32)
+        for (mode, cx, cy, dx, dy, radius, strength) in brushes:
+            self.r.displacement_brush(d, mode, cx, cy, dx, dy, radius, strength)
+        return self.r.warp_displacement(img, d)
+
+    def warp_displacement(self, img, disp):
+        return self.r.warp_displacement(img, disp)
+
+    def warp_mesh(self, img, orig, deformed, cols, rows):
+        return self.r.warp_mesh_catmull_rom(img, orig, deformed, cols, rows)
+
+    def brush_stamps(self, target, brush, points, selection=None):
+        t = GC.brush_target(target) if isinstance(target, str) else target
+        return self.r.brush_stamps(t, self.r.make_brush(**brush), points, selection)
+
+    def brush_line(self, target, brush, p0, p1, selection=None):
+        t = GC.brush_target(target) if isinstance(target, str) else target
+        return self.r.brush_line(t, self.r.make_brush(**brush), p0, p1, selection)

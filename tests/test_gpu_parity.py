@@ -1,0 +1,372 @@
+"""Parity gate 2 (GPU): HIP path (through the C ABI) vs the CPU oracle on seeded random inputs at sizes the oracle
+finishes in seconds, including ragged sizes (not multiples of 4 / 64), masks, empty chunks and the edge cases the
+reference tests.  Bars: bit-exact for the compositor, the integer filters, LUT ops and (as it turns out) every
+float op evaluated in reference order; Gaussian with fused multiply-add is held to the stated ±1 LSB and is
+bit-exact in `exact` mode."""
+import numpy as np
+import pytest
+
+from . import inputs as I
+from . import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from .backends import GpuBackend
+    return GpuBackend(0)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from .backends import OracleBackend
+    return OracleBackend()
+
+
+def assert_same(a, b, tol=0, what=""):
+    assert a.shape == b.shape, what
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    assert d.max() <= tol, f"{what}: max diff {int(d.max())}, {int((d.max(-1) > tol).sum())} px over tolerance {tol}"
+
+
+def sparse_alpha_image(w, h, seed):
+    """random RGBA with fully transparent 64x64 chunks and transparent-but-coloured pixels (chunk rule coverage)"""
+    img = I.random_rgba(w, h, seed)
+    rng = np.random.default_rng(seed + 99)
+    img[..., 3] = np.where(rng.random((h, w)) < 0.3, 0, img[..., 3])
+    for cy in range(0, h, 64):
+        for cx in range(0, w, 64):
+            if rng.random() < 0.35:
+                img[cy:cy + 64, cx:cx + 64, 3] = 0
+    return img
+
+
+# ------------------------------------------------------------------ compositor
+@pytest.mark.parametrize("mode", range(25))
+def test_blend_mode_random_bitexact(gpu, oracle, mode):
+    w, h = 333, 131  # ragged: not a multiple of 4 or 64
+    base = I.random_rgba(w, h, 1000 + mode)
+    top = sparse_alpha_image(w, h, 2000 + mode)
+    for opacity in (1.0, 0.37, 0.0, 1.5):
+        layers = [dict(pixels=base), dict(pixels=top, mode=mode, opacity=opacity)]
+        assert_same(gpu.composite(layers, w, h), oracle.composite(layers, w, h), 0, f"mode {mode} opacity {opacity}")
+
+
+def test_blend_pixels_exhaustive_alpha_lattice(gpu):
+    """every (base alpha, top alpha) pair x a colour sweep, all 25 modes, through pfx_blend_pixels"""
+    ba, ta = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (256 * 256, 4), dtype=np.uint8)
+    top = rng.integers(0, 256, (256 * 256, 4), dtype=np.uint8)
+    base[:, 3] = ba.ravel()
+    top[:, 3] = ta.ravel()
+    for mode in range(25):
+        for opacity in (1.0, 0.5):
+            got = gpu.r.blend_pixels(base, top, mode, opacity)
+            exp = np.stack([O.blend_pixel(base[i], top[i], mode, opacity) for i in range(0, len(base), 97)])
+            assert_same(got[::97], exp, 0, f"mode {mode} opacity {opacity}")
+
+
+def test_flatten_stack_8_layers(gpu):
+    w, h, n = 515, 259, 8
+    stack, modes, opac = I.layer_stack(w, h, n, seed=42)
+    layers = [dict(pixels=stack[k], mode=int(modes[k]), opacity=float(opac[k])) for k in range(n)]
+    assert_same(gpu.composite(layers, w, h), O.flatten_stack(stack, modes, opac), 0, "8-layer stack")
+
+
+def test_flatten_all_modes_32_layers(gpu):
+    w, h, n = 260, 130, 32
+    stack, modes, opac = I.layer_stack(w, h, n, seed=77)
+    layers = [dict(pixels=stack[k], mode=int(modes[k]), opacity=float(opac[k])) for k in range(n)]
+    assert_same(gpu.composite(layers, w, h), O.flatten_stack(stack, modes, opac), 0, "32-layer stack")
+
+
+def test_composite_masks_hidden_and_adjustment_layers(gpu, oracle):
+    w, h = 200, 150
+    rng = np.random.default_rng(3)
+    bg = sparse_alpha_image(w, h, 11)
+    fg = sparse_alpha_image(w, h, 12)
+    mask = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    mask[rng.random((h, w)) < 0.3] = 0
+    layers = [
+        dict(pixels=bg),
+        dict(kind=O.ADJ_INVERT, opacity=0.6),
+        dict(pixels=fg, mode=8, opacity=0.8, mask=mask),
+        dict(pixels=I.random_rgba(w, h, 13), visible=False, mode=3),
+        dict(kind=O.ADJ_EXPOSURE, adj=[0.7], opacity=1.0),
+        dict(kind=O.ADJ_BC, adj=[12.0, 30.0], opacity=0.5),
+        dict(kind=O.ADJ_MIXER, adj=[0.5, 0.3, 0.2, 0.0, 0.1, 0.8, 0.1, 0.0, 0.0, 0.2, 0.8, 0.0, 0.0, 0.0, 0.0, 1.0], opacity=0.9),
+    ]
+    assert_same(gpu.composite(layers, w, h), oracle.composite(layers, w, h), 0, "masks + adjustment layers")
+
+
+def test_composite_empty_and_single_hidden(gpu, oracle):
+    w, h = 70, 66
+    img = I.random_rgba(w, h, 1)
+    assert_same(gpu.composite([dict(pixels=img, visible=False)], w, h), np.zeros((h, w, 4), np.uint8), 0, "all hidden")
+    assert_same(gpu.composite([dict(pixels=img)], w, h), oracle.composite([dict(pixels=img)], w, h), 0, "single")
+
+
+def test_layer_store_generation_and_dirty_rect(gpu):
+    r = gpu.r
+    r.clear_layers()
+    w, h = 128, 96
+    a = I.random_rgba(w, h, 21)
+    b = I.random_rgba(w, h, 22)
+    r.ensure_layer_texture(0, a, generation=5)
+    r.ensure_layer_texture(0, b, generation=5)  # same generation: upload skipped (ref: renderer.rs:336-342)
+    assert_same(r.composite(w, h, [(0, 1.0, True, 0)]), O.composite([dict(pixels=a)], w, h), 0, "generation skip")
+    r.ensure_layer_texture(0, b, generation=6)
+    patch = I.random_rgba(40, 20, 23)
+    r.update_layer_rect(0, 64, 10, patch)
+    b2 = b.copy()
+    b2[10:30, 64:104] = patch
+    assert_same(r.composite(w, h, [(0, 1.0, True, 0)]), O.composite([dict(pixels=b2)], w, h), 0, "update_rect")
+    reg = r.composite_dirty_readback(w, h, [(0, 0.5, True, 0)], (8, 4, 64, 32))
+    assert_same(reg, O.composite([dict(pixels=b2, opacity=0.5)], w, h)[4:36, 8:72], 0, "dirty readback")
+    assert r.active_texture_count() == 1 and r.active_texture_memory() == w * h * 4
+    r.remove_layer(0)
+    assert r.active_texture_count() == 0
+
+
+# ------------------------------------------------------------------ stencils
+@pytest.mark.parametrize("sigma", [0.0, 0.3, 1.0, 2.5, 5.0, 16.0])
+@pytest.mark.parametrize("size", [(64, 64), (301, 97), (1100, 150)])
+def test_gaussian_vs_oracle(gpu, sigma, size):
+    w, h = size
+    img = I.random_rgba(w, h, int(sigma * 10) + w)
+    ref = O.gaussian_blur(img, sigma)
+    gpu.r.set_exact(False)
+    assert_same(gpu.gaussian_blur(img, sigma), ref, 1, f"fma sigma={sigma} {w}x{h}")  # stated tolerance: ±1 LSB
+    gpu.r.set_exact(True)
+    assert_same(gpu.gaussian_blur(img, sigma), ref, 0, f"exact sigma={sigma} {w}x{h}")
+    gpu.r.set_exact(False)
+
+
+def test_gaussian_fma_mismatch_rate_is_float_noise(gpu):
+    img = I.random_rgba(1024, 512, 5)
+    ref = O.gaussian_blur(img, 16.0)
+    out = gpu.gaussian_blur(img, 16.0)
+    d = np.abs(out.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1
+    assert (d > 0).mean() < 1e-3, f"{(d > 0).mean():.2e} of channels differ"
+
+
+def test_gaussian_identity_and_selection(gpu, oracle):
+    img = I.random_rgba(200, 120, 9)
+    assert_same(gpu.gaussian_blur(img, 0.0), img, 0, "sigma=0 identity (visual_filters.rs:291)")
+    mask = np.zeros((120, 200), np.uint8)
+    mask[30:70, 50:140] = 255
+    mask[35, 60] = 0
+    mask[100:110, 180:200] = 7  # grey mask values count as selected (mask > 0)
+    gpu.r.set_exact(True)
+    assert_same(gpu.gaussian_blur(img, 3.0, mask), oracle.gaussian_blur(img, 3.0, mask), 0, "blur_with_selection")
+    assert_same(gpu.gaussian_blur(img, 3.0, np.zeros_like(mask)), img, 0, "empty selection")
+    gpu.r.set_exact(False)
+
+
+@pytest.mark.parametrize("radius", [0.2, 0.5, 1.0, 3.0, 7.5, 48.0])
+def test_box_blur_bitexact(gpu, oracle, radius):
+    img = I.random_rgba(2100, 75, int(radius * 7))
+    mask = (np.random.default_rng(1).random((75, 2100)) < 0.7).astype(np.uint8) * 200
+    assert_same(gpu.box_blur(img, radius), oracle.box_blur(img, radius), 0, f"box r={radius}")
+    assert_same(gpu.box_blur(img, radius, mask), oracle.box_blur(img, radius, mask), 0, f"box r={radius} masked")
+
+
+@pytest.mark.parametrize("radius", [0, 1, 2, 3, 7, 12])
+def test_median_bitexact(gpu, oracle, radius):
+    img = I.random_rgba(131, 77, 40 + radius)
+    img[10:30, 10:50] = (img[10:30, 10:50] // 64) * 64  # heavy ties
+    mask = (np.random.default_rng(2).random((77, 131)) < 0.6).astype(np.uint8)
+    assert_same(gpu.median(img, radius), oracle.median(img, radius), 0, f"median r={radius}")
+    assert_same(gpu.median(img, radius, mask), oracle.median(img, radius, mask), 0, f"median r={radius} masked")
+
+
+def test_median_beyond_device_radius_returns_none(gpu):
+    assert gpu.r.median_rgba(I.random_rgba(32, 32, 1), 25) is None  # ref: median_rgba -> None, renderer.rs:945
+
+
+@pytest.mark.parametrize("block", [0, 1, 2, 5, 8, 64, 1000])
+def test_pixelate_bitexact(gpu, oracle, block):
+    img = I.random_rgba(203, 99, block)
+    mask = (np.random.default_rng(3).random((99, 203)) < 0.5).astype(np.uint8)
+    assert_same(gpu.pixelate(img, block), oracle.pixelate(img, block), 0, f"pixelate {block}")
+    assert_same(gpu.pixelate(img, block, mask), oracle.pixelate(img, block, mask), 0, f"pixelate {block} masked")
+
+
+# ------------------------------------------------------------------ pointwise bank
+def _lut_rgba(seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (4, 256), dtype=np.uint8)
+
+
+ADJ_CASES = [
+    ("invert", []), ("invert_alpha", []), ("sepia", []), ("brightness_contrast", [30.0, 20.0]),
+    ("brightness_contrast", [-55.5, -80.0]), ("hsl", [30.0, -20.0, 10.0]), ("hsl", [-170.0, 60.0, -35.0]),
+    ("hsl", [0.0, 0.0, 0.0]), ("exposure", [1.0]), ("exposure", [-2.3]), ("highlights_shadows", [30.0, -20.0]),
+    ("temperature_tint", [30.0, 10.0]), ("threshold", [128.0]), ("posterize", [4.0]), ("posterize", [1.0]),
+    ("color_balance", [10.0, 0.0, -10.0, 5.0, -5.0, 2.0, -10.0, 0.0, 10.0]), ("black_and_white", [30.0, 59.0, 11.0]),
+    ("vibrance", [50.0]), ("vibrance", [-70.0]), ("desaturate", []),
+]
+
+
+@pytest.mark.parametrize("op,params", ADJ_CASES, ids=[f"{o}-{i}" for i, (o, _) in enumerate(ADJ_CASES)])
+@pytest.mark.parametrize("sparse", [0, 1, 2])
+def test_adjust_bank_bitexact(gpu, oracle, op, params, sparse):
+    w, h = 197, 141
+    img = sparse_alpha_image(w, h, 300 + len(params))
+    mask = (np.random.default_rng(4).random((h, w)) < 0.8).astype(np.uint8) * 255
+    assert_same(gpu.adjust(img, op, params, sparse=sparse), oracle.adjust(img, op, params, sparse=sparse), 0, f"{op} sparse={sparse}")
+    assert_same(gpu.adjust(img, op, params, mask=mask, sparse=sparse), oracle.adjust(img, op, params, mask=mask, sparse=sparse), 0,
+                f"{op} masked sparse={sparse}")
+
+
+def test_adjust_all_rgb_triples_hsl(gpu, oracle):
+    """HSL / vibrance over a dense colour lattice (every branch of rgb_to_hsl / hue_to_rgb)"""
+    v = np.arange(0, 256, 3, dtype=np.uint8)
+    r, g, b = np.meshgrid(v, v, v, indexing="ij")
+    n = r.size
+    w = 512
+    h = (n + w - 1) // w
+    img = np.zeros((h * w, 4), np.uint8)
+    img[:n, 0], img[:n, 1], img[:n, 2] = r.ravel(), g.ravel(), b.ravel()
+    img[:, 3] = 255
+    img = img.reshape(h, w, 4)
+    for op, params in (("hsl", [47.0, 35.0, -12.0]), ("hsl", [-90.0, -100.0, 0.0]), ("vibrance", [80.0])):
+        assert_same(gpu.adjust(img, op, params), oracle.adjust(img, op, params), 0, f"{op} lattice")
+    assert_same(gpu.rhai_adjust(img, "hsl", [47.0, 35.0, -12.0]), oracle.rhai_adjust(img, "hsl", [47.0, 35.0, -12.0]), 0, "rhai hsl lattice")
+
+
+def test_lut_ops(gpu, oracle):
+    img = sparse_alpha_image(130, 70, 8)
+    luts = _lut_rgba(1)
+    for sparse in (0, 1, 2):
+        assert_same(gpu.adjust(img, "lut_rgba", lut=luts, sparse=sparse), oracle.adjust(img, "lut_rgba", lut=luts, sparse=sparse), 0, "lut_rgba")
+    gm = np.random.default_rng(2).integers(0, 256, (256, 4), dtype=np.uint8)
+    assert_same(gpu.adjust(img, "gradient_map", lut=gm), oracle.adjust(img, "gradient_map", lut=gm), 0, "gradient_map")
+    assert_same(gpu.auto_levels(img), oracle.auto_levels(img), 0, "auto_levels")
+    narrow = (img // 3 + 40).astype(np.uint8)
+    narrow[..., 3] = img[..., 3]
+    mask = np.zeros((70, 130), np.uint8)
+    mask[10:60, 20:100] = 1
+    assert_same(gpu.auto_levels(narrow, mask), oracle.auto_levels(narrow, mask), 0, "auto_levels masked")
+    assert_same(gpu.levels(img, 20.0, 235.0, 1.2, 10.0, 240.0), oracle.levels(img, 20.0, 235.0, 1.2, 10.0, 240.0), 0, "levels")
+
+
+def test_lut_builders_match_oracle(gpu):
+    r = gpu.r
+    for args in ((20.0, 235.0, 1.2, 0.0, 255.0), (0.0, 255.0, 1.0, 0.0, 255.0), (100.0, 90.0, 0.001, 255.0, 0.0), (5.5, 200.25, 3.7, 12.0, 199.0)):
+        assert np.array_equal(r.build_levels_lut(*args), O.levels_lut(*args)), args
+    for pts in ([(0, 0), (255, 255)], [(0, 0), (64, 40), (128, 160), (255, 255)], [(0, 255), (100, 100), (100.0000001, 50), (255, 0)],
+                [(10, 20)], [(0, 0), (50, 200), (60, 10), (255, 255)]):
+        assert np.array_equal(r.build_curves_lut(pts), O.curves_lut(pts)), pts
+
+
+RHAI_CASES = [("invert", []), ("desaturate", []), ("sepia", []), ("sepia_strength", [0.4]), ("sepia_strength", [7.0]),
+              ("brightness_contrast", [20.0, 10.0]), ("hsl", [30.0, -20.0, 10.0]), ("hsl", [-400.0, 150.0, 90.0]),
+              ("exposure", [0.8]), ("levels", [20.0, 230.0, 0.8])]
+
+
+@pytest.mark.parametrize("op,params", RHAI_CASES, ids=[f"{o}-{i}" for i, (o, _) in enumerate(RHAI_CASES)])
+def test_rhai_flavour_bitexact(gpu, oracle, op, params):
+    img = sparse_alpha_image(150, 70, 17)
+    p = list(params)
+    if op == "sepia_strength":  # the host clamps in f64 before the cast (scripting.rs:923)
+        exp = oracle.rhai_adjust(img, op, [min(max(p[0], 0.0), 1.0)])
+    else:
+        exp = oracle.rhai_adjust(img, op, p)
+    assert_same(gpu.rhai_adjust(img, op, p), exp, 0, f"rhai {op}")
+
+
+# ------------------------------------------------------------------ TiledImage rule
+@pytest.mark.parametrize("size", [(64, 64), (65, 63), (200, 130), (513, 258)])
+def test_tiled_roundtrip_and_chunk_keys(gpu, size):
+    w, h = size
+    img = sparse_alpha_image(w, h, w * 3 + h)
+    assert_same(gpu.r.tiled_roundtrip(img), O.tiled_roundtrip(img), 0, "tiled roundtrip")
+    assert np.array_equal(gpu.r.chunk_populated(img), O.chunk_populated(img))
+
+
+# ------------------------------------------------------------------ warp
+def test_warp_displacement_random_field(gpu, oracle):
+    w, h = 257, 190
+    img = sparse_alpha_image(w, h, 31)
+    rng = np.random.default_rng(6)
+    disp = (rng.random((h, w, 2)).astype(np.float32) - np.float32(0.5)) * np.float32(40.0)
+    disp[5, 5] = [1e9, 0]       # far outside -> transparent
+    disp[6, 6] = [np.nan, 0.0]  # NaN -> `as i32` == 0 path
+    disp[7, 7] = [7.0 + 1.0, 0.0]  # x0 == -1: blends with the transparent left texel (transform.rs:1310)
+    assert_same(gpu.warp_displacement(img, disp), oracle.warp_displacement(img, disp), 0, "random field")
+    zero = np.zeros((h, w, 2), np.float32)
+    assert_same(gpu.warp_displacement(img, zero), img, 0, "identity field (transform_ops.rs:125)")
+
+
+def test_warp_source_size_differs_from_field(gpu, oracle):
+    img = I.random_rgba(90, 60, 4)
+    disp = (np.random.default_rng(7).random((80, 120, 2)).astype(np.float32) - np.float32(0.5)) * np.float32(30.0)
+    assert_same(gpu.warp_displacement(img, disp), oracle.warp_displacement(img, disp), 0, "src != field size")
+
+
+@pytest.mark.parametrize("grid", [(2, 2), (6, 6), (1, 1), (9, 4)])
+def test_mesh_warp_and_field(gpu, grid):
+    cols, rows = grid
+    w, h = 300, 170
+    img = I.random_rgba(w, h, cols * 10 + rows)
+    orig, deformed = I.jittered_mesh(cols, rows, w, h, seed=cols + rows)
+    assert_same(gpu.warp_mesh(img, orig, deformed, cols, rows), O.warp_mesh_catmull_rom(img, orig, deformed, cols, rows), 0, "fused mesh warp")
+    f_gpu = gpu.r.generate_displacement(deformed, cols, rows, w, h, original_points=orig)
+    assert np.array_equal(f_gpu.view(np.uint32), O.mesh_displacement(orig, deformed, cols, rows, w, h).view(np.uint32)), "field bits"
+    f_fast = gpu.r.generate_displacement(deformed, cols, rows, w, h)
+    assert np.array_equal(f_fast.view(np.uint32), O.mesh_displacement_fast(deformed, cols, rows, w, h).view(np.uint32)), "fast field bits"
+
+
+def test_displacement_brushes_host(gpu):
+    for mode in range(5):
+        a = np.zeros((64, 80, 2), np.float32)
+        b = np.zeros((64, 80, 2), np.float32)
+        gpu.r.displacement_brush(a, mode, 30.5, 20.25, 3.0, -2.0, 14.0, 0.7)
+        O.displacement_brush(b, mode, 30.5, 20.25, 3.0, -2.0, 14.0, 0.7)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
+
+
+# ------------------------------------------------------------------ brush
+@pytest.mark.parametrize("mode,eraser,aa", [(0, False, True), (0, False, False), (0, True, True), (1, False, True), (2, False, False), (3, False, True)])
+def test_brush_random_strokes(gpu, oracle, mode, eraser, aa):
+    w, h = 220, 140
+    rng = np.random.default_rng(50 + mode)
+    target = I.random_rgba(w, h, 60) if mode else np.zeros((h, w, 4), np.uint8)
+    sel = (rng.random((h, w)) < 0.9).astype(np.uint8) * 255
+    pts = [(float(x), float(y)) for x, y in zip(rng.random(60) * (w + 40) - 20, rng.random(60) * (h + 40) - 20)]
+    brush = dict(size=17.5, hardness=0.6, anti_aliased=aa, color=(0.9, 0.3, 0.1, 0.8), flow=0.85, is_eraser=eraser, mode=mode)
+    assert_same(gpu.brush_stamps(target, brush, pts), oracle.brush_stamps(target, brush, pts), 0, "stamps")
+    assert_same(gpu.brush_stamps(target, brush, pts, sel), oracle.brush_stamps(target, brush, pts, sel), 0, "stamps + selection")
+    assert_same(gpu.brush_line(target, brush, (-10.0, 5.0), (250.0, 130.0)), oracle.brush_line(target, brush, (-10.0, 5.0), (250.0, 130.0)), 0, "line")
+
+
+def test_brush_commit(gpu):
+    w, h = 100, 80
+    layer = I.random_rgba(w, h, 70)
+    preview = np.zeros((h, w, 4), np.uint8)
+    b = dict(size=30.0, hardness=0.5, anti_aliased=True, color=(0.2, 0.4, 0.9, 1.0))
+    preview = O.brush_stamp(preview, O.make_brush(**b), 50.0, 40.0)
+    sel = np.ones((h, w), np.uint8)
+    sel[:, :40] = 0
+    for mode in (0, 1, 8, 13, 14):
+        assert_same(gpu.r.brush_commit(layer, preview, mode, False, sel), O.brush_commit(layer, preview, mode, sel), 0, f"commit mode {mode}")
+    assert_same(gpu.r.brush_commit(layer, preview, 0, True, None), O.eraser_commit(layer, preview, None), 0, "eraser commit")
+
+
+# ------------------------------------------------------------------ error behaviour (dst untouched, status codes)
+def test_errors_leave_dst_untouched(gpu):
+    import ctypes as C
+    from paintfe_amd import _lib
+    lib = _lib.load()
+    src = I.random_rgba(16, 16, 1)
+    dst = np.full_like(src, 0xAB)
+    st = lib.pfx_median_rgba(gpu.r.handle, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), C.c_uint32(16), C.c_uint32(16), C.c_uint32(1000))
+    assert st == _lib.ERR_UNSUPPORTED and (dst == 0xAB).all()
+    st = lib.pfx_blur_rgba(gpu.r.handle, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), C.c_uint32(0), C.c_uint32(16), C.c_float(2.0))
+    assert st == _lib.ERR_INVALID and (dst == 0xAB).all()
+    st = lib.pfx_blur_rgba(gpu.r.handle, None, dst.ctypes.data_as(C.c_void_p), C.c_uint32(16), C.c_uint32(16), C.c_float(2.0))
+    assert st == _lib.ERR_INVALID and b"null" in lib.pfx_last_error(gpu.r.handle)
