@@ -57,6 +57,26 @@ def synth_stack(torch, device, w, h, n, seed):
     return stack, modes, opac
 
 
+def usable_cores() -> int:
+    """threads the CPU baseline may really use: scheduler affinity, capped by the cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // period))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +87,7 @@ def main() -> int:
     ap.add_argument("--layers", type=int, default=NLAYERS)
     ap.add_argument("--sigma", type=float, default=SIGMA)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="key=value kernel tuning knob (development)")
     ap.add_argument("--exact", action="store_true", help="Gaussian without FMA contraction (bit-exact with the CPU path)")
     args = ap.parse_args()
 
@@ -87,6 +108,9 @@ def main() -> int:
     from paintfe_amd import GpuRenderer
     r = GpuRenderer(local_rank)
     r.set_exact(args.exact)
+    for kv in args.tune:
+        k, v = kv.split('=')
+        r.tune(k, int(v))
     r.set_stream(torch.cuda.current_stream().cuda_stream)  # HIP events + kernels on the stream torch synchronises
 
     w, h, n = args.width, args.height, args.layers
@@ -164,10 +188,10 @@ def main() -> int:
                 out["check"]["mismatching_px"] = int((ref != got).any(-1).sum())
 
         if not args.no_cpu_baseline and world == 1:
-            # bounded sample of the same workload: a 1920x1080 window of the same 32-layer stack
-            sh, sw = min(1080, h), min(1920, w)
+            # bounded sample of the same workload: a 3840x2160 window of the same 32-layer stack
+            sh, sw = min(2160, h), min(3840, w)
             sample = stack[:, :sh, :sw, :].contiguous().cpu().numpy()
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             t1 = time.perf_counter()
             f = O.flatten_stack(sample, modes, opac, threads=cores)
             t2 = time.perf_counter()

@@ -251,6 +251,13 @@ int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h,
                          const float* points_xy, uint32_t n_points, const void* selection_dev);
 int pfx_tiled_roundtrip_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h);
 
+/* device self-test: compares the compositor's shared-reciprocal division with the compiler's IEEE f32 divide on
+ * n_millions*1e6 random operand pairs drawn from the kernel's operand range; *mismatches must come back 0 */
+int pfx_selftest_division(pfx_ctx* ctx, uint64_t seed, uint32_t n_millions, uint64_t* mismatches);
+
+/* development tuning knobs (kernel tile configurations); unknown keys return PFX_ERR_INVALID.  Results never change. */
+int pfx_tune(pfx_ctx* ctx, const char* key, int value);
+
 /* per-launch timing of the most recent `_dev` call family, measured with HIP events on the context stream
  * (used by bench.py for the roofline line).  Enable, run, then read the accumulated milliseconds / launches. */
 int pfx_timing_enable(pfx_ctx* ctx, int on);

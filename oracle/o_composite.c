@@ -214,7 +214,7 @@ void pfxo_composite(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t
     }
 
     o_set_threads(threads);
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 1)
     for (long ci = 0; ci < (long)n_chunks; ++ci) { /* :565 par_iter over active chunks */
         if (!active[ci]) continue;
         uint32_t cx = (uint32_t)ci % cxn, cy = (uint32_t)ci / cxn;

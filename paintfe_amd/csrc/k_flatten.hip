@@ -3,7 +3,7 @@
 // Reference: src/canvas/canvas_state.rs:505-698 (composite_viewport) and :1246-1505 (blend_pixel_static and the
 // per-channel helpers); adjustment layers src/canvas/layers.rs:276-325; live mask :660-665.
 //
-// Design (HBM-bound streaming, no LDS, no MFMA):
+// Design (streaming, no LDS, no MFMA):
 //   * one lane owns 4 consecutive pixels: every layer is read with one 16-byte load per lane (1 KiB per wave
 //     instruction, fully coalesced), the result is written with one 16-byte store;
 //   * the accumulator ("pixels[idx]" in the reference, a u8 RGBA re-quantised after every layer) lives in
@@ -12,7 +12,9 @@
 //   * the blend mode is uniform per layer, so the 25-way dispatch is a scalar branch outside the pixel code and
 //     each mode is its own straight-line specialisation;
 //   * arithmetic is the reference's f32 sequence, operation for operation, without FMA contraction
-//     (this file is compiled with -ffp-contract=off); u8/255 uses the proved 2-op form (k_common.h:div255).
+//     (this file is compiled with -ffp-contract=off); u8/255 uses the proved 2-op form (k_common.h:div255);
+//   * the three `/ out_a` of a pixel share one refined reciprocal (rdiv below): the exact operation sequence
+//     hipcc emits for an IEEE f32 divide, with the per-denominator part hoisted — bit-identical to `/`.
 #include "k_common.h"
 #include "pfx_kernels.h"
 
@@ -26,22 +28,51 @@ enum : uint32_t {
     M_SUBTRACT, M_DIVIDE, M_LINEAR_BURN, M_VIVID_LIGHT, M_LINEAR_LIGHT, M_PIN_LIGHT, M_HARD_MIX
 };
 
+// ---- correctly rounded division with a shared denominator -------------------------------------------------
+// hipcc lowers `n / d` (f32, IEEE) to: div_scale x2, rcp, 2 FMAs refining the reciprocal, mul + 4 FMAs refining the
+// quotient, div_fmas, div_fixup.  div_scale / div_fmas scaling / div_fixup only act when an operand or the quotient
+// is denormal, huge, zero-denominator or NaN.  For this kernel's operands (numerators in [0, ~1], denominators in
+// [2^-48, 1]: guaranteed by the host, which selects the FAST=false instantiation when a layer opacity is a positive
+// value below 2^-40) they are identities, so the sequence below produces the same bits with the reciprocal part
+// computed once per denominator.  tests/test_gpu_parity.py::test_fast_division_matches_ieee checks 2^28 operand
+// pairs against `/` on the device; every golden / oracle parity test runs through this path.
+struct rdiv { float d, y; };
+PFX_DEV rdiv rdiv_prepare(float d)
+{
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y0, 1.0f);
+    return {d, __builtin_fmaf(e, y0, y0)};
+}
+PFX_DEV float rdiv_apply(const rdiv k, float n)
+{
+    const float q0 = n * k.y;
+    const float r0 = __builtin_fmaf(-k.d, q0, n);
+    const float q1 = __builtin_fmaf(r0, k.y, q0);
+    const float r1 = __builtin_fmaf(-k.d, q1, n);
+    return __builtin_fmaf(r1, k.y, q1);
+}
+template <bool FAST> PFX_DEV float fdiv(float n, float d)
+{
+    if constexpr (FAST) return rdiv_apply(rdiv_prepare(d), n);
+    else return n / d;
+}
+
 // ---- canvas_state.rs:1425-1505 ----
 PFX_DEV float overlay_channel(float base, float top)
 {
     return (base < 0.5f) ? 2.0f * base * top : 1.0f - 2.0f * (1.0f - base) * (1.0f - top);
 }
-PFX_DEV float color_burn_channel(float base, float top)
+template <bool F> PFX_DEV float color_burn_channel(float base, float top)
 {
-    return (top == 0.0f) ? 0.0f : __builtin_fmaxf(1.0f - (1.0f - base) / top, 0.0f);
+    return (top == 0.0f) ? 0.0f : __builtin_fmaxf(1.0f - fdiv<F>(1.0f - base, top), 0.0f);
 }
-PFX_DEV float color_dodge_channel(float base, float top)
+template <bool F> PFX_DEV float color_dodge_channel(float base, float top)
 {
-    return (top >= 1.0f) ? 1.0f : __builtin_fminf(base / (1.0f - top), 1.0f);
+    return (top >= 1.0f) ? 1.0f : __builtin_fminf(fdiv<F>(base, 1.0f - top), 1.0f);
 }
-PFX_DEV float reflect_channel(float base, float top)
+template <bool F> PFX_DEV float reflect_channel(float base, float top)
 {
-    return (top >= 1.0f) ? 1.0f : __builtin_fminf(base * base / (1.0f - top), 1.0f);
+    return (top >= 1.0f) ? 1.0f : __builtin_fminf(fdiv<F>(base * base, 1.0f - top), 1.0f);
 }
 PFX_DEV float soft_light_channel(float base, float top)
 {
@@ -49,35 +80,39 @@ PFX_DEV float soft_light_channel(float base, float top)
     float d = (base <= 0.25f) ? ((16.0f * base - 12.0f) * base + 4.0f) * base : __builtin_sqrtf(base);
     return base + (2.0f * top - 1.0f) * (d - base);
 }
-PFX_DEV float divide_channel(float base, float top)
+template <bool F> PFX_DEV float divide_channel(float base, float top)
 {
-    return (top <= 0.0f) ? 1.0f : __builtin_fminf(base / top, 1.0f);
+    return (top <= 0.0f) ? 1.0f : __builtin_fminf(fdiv<F>(base, top), 1.0f);
 }
-PFX_DEV float vivid_light_channel(float base, float top)
+template <bool F> PFX_DEV float vivid_light_channel(float base, float top)
 {
-    if (top <= 0.5f) {
-        float t2 = 2.0f * top;
-        return (t2 <= 0.0f) ? 0.0f : __builtin_fmaxf(1.0f - (1.0f - base) / t2, 0.0f);
-    }
-    float t2 = 2.0f * (top - 0.5f);
-    return (t2 >= 1.0f) ? 1.0f : __builtin_fminf(base / (1.0f - t2), 1.0f);
+    // canvas_state.rs:1479-1497.  Both branches divide; the operands are selected first so that a lane pays for one
+    // division (the branch is per-lane data, so "both sides" is what a divergent wave would execute anyway).
+    const bool lo = (top <= 0.5f);
+    const float t2 = lo ? 2.0f * top : 2.0f * (top - 0.5f);
+    const float n = lo ? 1.0f - base : base;
+    const float d = lo ? t2 : 1.0f - t2;
+    const float q = fdiv<F>(n, d);
+    const float burn = (t2 <= 0.0f) ? 0.0f : __builtin_fmaxf(1.0f - q, 0.0f);
+    const float dodge = (t2 >= 1.0f) ? 1.0f : __builtin_fminf(q, 1.0f);
+    return lo ? burn : dodge;
 }
 PFX_DEV float pin_light_channel(float base, float top)
 {
     return (top <= 0.5f) ? __builtin_fminf(base, 2.0f * top) : __builtin_fmaxf(base, 2.0f * (top - 0.5f));
 }
 
-template <uint32_t M>
+template <uint32_t M, bool F>
 PFX_DEV float blend_fn(float b, float t)
 {
     if constexpr (M == M_NORMAL) return t;
     else if constexpr (M == M_MULTIPLY) return b * t;
     else if constexpr (M == M_SCREEN) return 1.0f - (1.0f - b) * (1.0f - t);
     else if constexpr (M == M_ADDITIVE) return __builtin_fminf(b + t, 1.0f);
-    else if constexpr (M == M_REFLECT) return reflect_channel(b, t);
-    else if constexpr (M == M_GLOW) return reflect_channel(t, b);
-    else if constexpr (M == M_COLOR_BURN) return color_burn_channel(b, t);
-    else if constexpr (M == M_COLOR_DODGE) return color_dodge_channel(b, t);
+    else if constexpr (M == M_REFLECT) return reflect_channel<F>(b, t);
+    else if constexpr (M == M_GLOW) return reflect_channel<F>(t, b);
+    else if constexpr (M == M_COLOR_BURN) return color_burn_channel<F>(b, t);
+    else if constexpr (M == M_COLOR_DODGE) return color_dodge_channel<F>(b, t);
     else if constexpr (M == M_OVERLAY) return overlay_channel(b, t);
     else if constexpr (M == M_DIFFERENCE) return __builtin_fabsf(b - t);
     else if constexpr (M == M_NEGATION) return 1.0f - __builtin_fabsf(1.0f - b - t);
@@ -87,73 +122,96 @@ PFX_DEV float blend_fn(float b, float t)
     else if constexpr (M == M_SOFT_LIGHT) return soft_light_channel(b, t);
     else if constexpr (M == M_EXCLUSION) return b + t - 2.0f * b * t;
     else if constexpr (M == M_SUBTRACT) return __builtin_fmaxf(b - t, 0.0f);
-    else if constexpr (M == M_DIVIDE) return divide_channel(b, t);
+    else if constexpr (M == M_DIVIDE) return divide_channel<F>(b, t);
     else if constexpr (M == M_LINEAR_BURN) return __builtin_fmaxf(b + t - 1.0f, 0.0f);
-    else if constexpr (M == M_VIVID_LIGHT) return vivid_light_channel(b, t);
+    else if constexpr (M == M_VIVID_LIGHT) return vivid_light_channel<F>(b, t);
     else if constexpr (M == M_LINEAR_LIGHT) return rs_clamp(b + 2.0f * t - 1.0f, 0.0f, 1.0f);
     else if constexpr (M == M_PIN_LIGHT) return pin_light_channel(b, t);
     else if constexpr (M == M_HARD_MIX) return (b + t >= 1.0f) ? 1.0f : 0.0f;
     else return t;
 }
 
+// Rust `(v * 255.0).clamp(0.0, 255.0) as u8`, kept as an integer-valued float.  A -0.0 result is harmless: div255(-0.0)
+// is +0.0 and (uint32_t)(-0.0f) is 0.
+// CLAMP=false drops the clamp where it is provably the identity: every quotient q = n/d of blend_pixel_static with
+// d > 0 satisfies 0 <= q <= 1 + 3 ulp (all 23 separable blend functions return values in [0, 1] in f32 — checked
+// function by function in DESIGN.md §flatten — so 0 <= n <= d(1 + 2 ulp)); then 0 <= q*255 < 255.001 and
+// trunc() alone yields the clamped value.  The FAST=false instantiation keeps the clamp.
+template <bool CLAMP>
+PFX_DEV float q255(float v)
+{
+    if constexpr (CLAMP) return __builtin_truncf(__builtin_fminf(__builtin_fmaxf(v * 255.0f, 0.0f), 255.0f));
+    else return __builtin_truncf(v * 255.0f);
+}
+
 // One blend_pixel_static (canvas_state.rs:1246-1422).  `acc` = base as integer-valued floats (r,g,b,a);
 // `top` = packed RGBA8 of the layer pixel (alpha already masked); `opacity_raw` = layer.opacity as stored,
 // `opc` = opacity.clamp(0,1).
-template <uint32_t M>
+// Branch-free on purpose: per-lane early-outs diverge on real data (a wave almost never agrees), so the early
+// returns of the reference become selects at the end; the discarded lanes may hold NaN/Inf (0/0), never stored.
+template <uint32_t M, bool F>
 PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float opc)
 {
     const uint32_t ta8 = top >> 24;
-    if (ta8 == 0u) return;                                             // :1253
-    if (M == M_NORMAL && opacity_raw >= 1.0f && ta8 == 255u) {         // :1258
-        acc[0] = ubyte0(top); acc[1] = ubyte1(top); acc[2] = ubyte2(top); acc[3] = 255.0f;
-        return;
+    const bool skip = (ta8 == 0u);                                     // :1253  -> keep base
+    const float t0 = ubyte0(top), t1 = ubyte1(top), t2 = ubyte2(top), t3 = (float)ta8;
+    const float top_r = div255(t0), top_g = div255(t1), top_b = div255(t2);
+    const float top_a = div255(t3) * opc;                              // :1272
+    float o0, o1, o2, o3;
+    constexpr bool CL = !F; // the FAST instantiation runs only when every layer opacity clamps into [2^-40, 1]
+    if constexpr (M == M_OVERWRITE) {                                  // :1275 (`as u8` without clamp == with clamp)
+        o0 = q255<CL>(top_r); o1 = q255<CL>(top_g); o2 = q255<CL>(top_b); o3 = q255<CL>(top_a);
+    } else {
+        const float base_r = div255(acc[0]), base_g = div255(acc[1]), base_b = div255(acc[2]), base_a = div255(acc[3]);
+        const float ita = 1.0f - top_a;
+        float den, nr, ng, nb;
+        if constexpr (M == M_XOR) {                                    // :1283
+            const float iba = 1.0f - base_a;
+            den = base_a * ita + top_a * iba;
+            nr = base_r * base_a * ita + top_r * top_a * iba;
+            ng = base_g * base_a * ita + top_g * top_a * iba;
+            nb = base_b * base_a * ita + top_b * top_a * iba;
+        } else {
+            const float r = blend_fn<M, F>(base_r, top_r);
+            const float g = blend_fn<M, F>(base_g, top_g);
+            const float b = blend_fn<M, F>(base_b, top_b);
+            den = top_a + base_a * ita;                                // :1407
+            nr = r * top_a + base_r * base_a * ita;                    // :1412
+            ng = g * top_a + base_g * base_a * ita;
+            nb = b * top_a + base_b * base_a * ita;
+        }
+        float qr, qg, qb;
+        if constexpr (F) { const rdiv k = rdiv_prepare(den); qr = rdiv_apply(k, nr); qg = rdiv_apply(k, ng); qb = rdiv_apply(k, nb); }
+        else { qr = nr / den; qg = ng / den; qb = nb / den; }
+        o0 = q255<CL>(qr); o1 = q255<CL>(qg); o2 = q255<CL>(qb); o3 = q255<CL>(den);
+        // :1285 / :1408 `den == 0 -> (0,0,0,0)`.  With opacity > 0 (FAST precondition) a non-skipped pixel has
+        // top_a > 0, hence out_a = top_a + base_a*(1-top_a) > 0: the check can only fire for Xor (both opaque).
+        if constexpr (!F || M == M_XOR) {
+            const bool zero = (den == 0.0f);
+            o0 = zero ? 0.0f : o0; o1 = zero ? 0.0f : o1; o2 = zero ? 0.0f : o2; o3 = zero ? 0.0f : o3;
+        }
     }
-    const float top_r = div255(ubyte0(top)), top_g = div255(ubyte1(top)), top_b = div255(ubyte2(top));
-    const float top_a = div255((float)ta8) * opc;                      // :1272
-
-    if constexpr (M == M_OVERWRITE) {                                  // :1275
-        acc[0] = trunc_u8f(top_r * 255.0f);
-        acc[1] = trunc_u8f(top_g * 255.0f);
-        acc[2] = trunc_u8f(top_b * 255.0f);
-        acc[3] = trunc_u8f(top_a * 255.0f);
-        return;
+    if constexpr (M == M_NORMAL) {
+        if (opacity_raw >= 1.0f) {                                     // uniform; :1258 opaque overwrite
+            const bool opaque = (ta8 == 255u);
+            o0 = opaque ? t0 : o0; o1 = opaque ? t1 : o1; o2 = opaque ? t2 : o2; o3 = opaque ? 255.0f : o3;
+        }
     }
-    const float base_r = div255(acc[0]), base_g = div255(acc[1]), base_b = div255(acc[2]), base_a = div255(acc[3]);
-    if constexpr (M == M_XOR) {                                        // :1283
-        const float ita = 1.0f - top_a, iba = 1.0f - base_a;
-        const float xor_a = base_a * ita + top_a * iba;
-        if (xor_a == 0.0f) { acc[0] = acc[1] = acc[2] = acc[3] = 0.0f; return; }
-        const float xr = (base_r * base_a * ita + top_r * top_a * iba) / xor_a;
-        const float xg = (base_g * base_a * ita + top_g * top_a * iba) / xor_a;
-        const float xb = (base_b * base_a * ita + top_b * top_a * iba) / xor_a;
-        acc[0] = quant255(xr * 255.0f); acc[1] = quant255(xg * 255.0f); acc[2] = quant255(xb * 255.0f);
-        acc[3] = quant255(xor_a * 255.0f);
-        return;
-    }
-    const float r = blend_fn<M>(base_r, top_r);
-    const float g = blend_fn<M>(base_g, top_g);
-    const float b = blend_fn<M>(base_b, top_b);
-    const float ita = 1.0f - top_a;
-    const float out_a = top_a + base_a * ita;                          // :1407
-    if (out_a == 0.0f) { acc[0] = acc[1] = acc[2] = acc[3] = 0.0f; return; }
-    const float out_r = (r * top_a + base_r * base_a * ita) / out_a;   // :1412
-    const float out_g = (g * top_a + base_g * base_a * ita) / out_a;
-    const float out_b = (b * top_a + base_b * base_a * ita) / out_a;
-    acc[0] = quant255(out_r * 255.0f); acc[1] = quant255(out_g * 255.0f); acc[2] = quant255(out_b * 255.0f);
-    acc[3] = quant255(out_a * 255.0f);
+    acc[0] = skip ? acc[0] : o0; acc[1] = skip ? acc[1] : o1; acc[2] = skip ? acc[2] : o2; acc[3] = skip ? acc[3] : o3;
 }
 
-template <uint32_t M>
+template <uint32_t M, bool F>
 PFX_DEV void blend4(float (&acc)[4][4], const uint32_t (&top)[4], float opacity_raw, float opc)
 {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) blend_px<M>(acc[p], top[p], opacity_raw, opc);
+    for (int p = 0; p < 4; ++p) blend_px<M, F>(acc[p], top[p], opacity_raw, opc);
 }
 
+template <bool F>
 PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[4][4], const uint32_t (&top)[4], float opacity_raw, float opc)
 {
     switch (mode) { // wave-uniform: one scalar branch per layer
-#define PFX_CASE(M) case M: blend4<M>(acc, top, opacity_raw, opc); break;
+#define PFX_CASE(M) case M: blend4<M, F>(acc, top, opacity_raw, opc); break;
         PFX_CASE(M_NORMAL) PFX_CASE(M_MULTIPLY) PFX_CASE(M_SCREEN) PFX_CASE(M_ADDITIVE) PFX_CASE(M_REFLECT)
         PFX_CASE(M_GLOW) PFX_CASE(M_COLOR_BURN) PFX_CASE(M_COLOR_DODGE) PFX_CASE(M_OVERLAY) PFX_CASE(M_DIFFERENCE)
         PFX_CASE(M_NEGATION) PFX_CASE(M_LIGHTEN) PFX_CASE(M_DARKEN) PFX_CASE(M_XOR) PFX_CASE(M_OVERWRITE)
@@ -161,7 +219,7 @@ PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[4][4], const uint32_t (
         PFX_CASE(M_LINEAR_BURN) PFX_CASE(M_VIVID_LIGHT) PFX_CASE(M_LINEAR_LIGHT) PFX_CASE(M_PIN_LIGHT)
         PFX_CASE(M_HARD_MIX)
 #undef PFX_CASE
-    default: blend4<M_NORMAL>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
+    default: blend4<M_NORMAL, F>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
     }
 }
 
@@ -203,7 +261,7 @@ PFX_DEV void adjust_px(float (&p)[4], uint32_t kind, const float* __restrict__ a
     for (int c = 0; c < 4; ++c) p[c] = round_u8f(p[c] * inv + o[c] * t); // `.round() as u8`
 }
 
-template <bool GENERAL>
+template <bool GENERAL, bool F>
 __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
                                                       const float* __restrict__ adj_table,
                                                       const uint8_t* __restrict__ chunk_active, uint32_t w, uint32_t h,
@@ -230,6 +288,27 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
             }
         }
 
+        if (!GENERAL && full && n_layers > 0) {
+            // raster-only stack: software-pipelined — layer k+1's descriptor (scalar load) and 16-byte pixel quad
+            // are requested before layer k is blended, so the ~100 VALU ops of a blend cover the HBM latency
+            pfxk_layer_desc L = layers[0];
+            uint4 v = *reinterpret_cast<const uint4*>(L.pixels + p0 * 4);
+            for (uint32_t li = 0; li < n_layers; ++li) {
+                pfxk_layer_desc Ln = L;
+                uint4 vn = v;
+                if (li + 1 < n_layers) {
+                    Ln = layers[li + 1];
+                    vn = *reinterpret_cast<const uint4*>(Ln.pixels + p0 * 4);
+                }
+                const uint32_t top[4] = {v.x, v.y, v.z, v.w};
+                // wave-level early-out: a wave whose 256 pixels are all transparent in this layer (sparse layers of real
+                // documents; the TiledImage analogue is a missing chunk, canvas_state.rs:600) skips the blend entirely
+                if (__any(((v.x | v.y | v.z | v.w) >> 24) != 0u))
+                    blend4_dispatch<F>(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
+                L = Ln;
+                v = vn;
+            }
+        } else
         for (uint32_t li = 0; li < n_layers; ++li) {
             const pfxk_layer_desc L = layers[li]; // uniform -> scalar loads
             if (GENERAL && L.kind != PFXK_LAYER_RASTER) {
@@ -252,7 +331,7 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
                 for (int p = 0; p < 4; ++p)
                     if (p0 + p < n_px) top[p] = apply_conceal(top[p], L.mask[p0 + p]);
             }
-            blend4_dispatch(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
+            blend4_dispatch<F>(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
         }
 
         uint32_t out[4];
@@ -291,6 +370,7 @@ __global__ __launch_bounds__(256) void chunk_active_kernel(const pfxk_layer_desc
 }
 
 // dst[i] = blend_pixel_static(base[i], top[i], mode, opacity) — element-wise form (spot checks)
+template <bool F>
 __global__ __launch_bounds__(256) void blend_arrays_kernel(const uint32_t* __restrict__ base, const uint32_t* __restrict__ top,
                                                            uint32_t* __restrict__ dst, size_t n, uint32_t mode, float opacity)
 {
@@ -301,7 +381,7 @@ __global__ __launch_bounds__(256) void blend_arrays_kernel(const uint32_t* __res
 #pragma unroll
         for (int p = 1; p < 4; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0f;
         const uint32_t t[4] = {top[i], 0u, 0u, 0u};
-        blend4_dispatch(mode, acc, t, opacity, rs_clamp(opacity, 0.0f, 1.0f));
+        blend4_dispatch<F>(mode, acc, t, opacity, rs_clamp(opacity, 0.0f, 1.0f));
         dst[i] = pack_rgba(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
     }
 }
@@ -329,22 +409,50 @@ __global__ __launch_bounds__(256) void brush_commit_kernel(uint32_t* __restrict_
 #pragma unroll
             for (int p = 1; p < 4; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0f;
             const uint32_t t[4] = {pp, 0u, 0u, 0u};
-            blend4_dispatch(mode, acc, t, 1.0f, 1.0f);
+            blend4_dispatch<true>(mode, acc, t, 1.0f, 1.0f);
             layer[i] = pack_rgba(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
         }
     }
 }
 
+// device-side check of rdiv against the compiler's IEEE divide: out[0] += number of mismatching pairs
+__global__ __launch_bounds__(256) void rdiv_check_kernel(uint64_t seed, uint32_t iters, unsigned long long* out)
+{
+    uint64_t s = seed + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned long long bad = 0;
+    for (uint32_t i = 0; i < iters; ++i) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const uint32_t a = (uint32_t)(s >> 33), b = (uint32_t)(s >> 7);
+        // numerator in [0, 2), denominator in [2^-48, 1]: random mantissas, exponents in the kernel's operand range
+        const float n = ((a & 0xC0u) == 0u) ? 0.0f : __builtin_bit_cast(float, ((a >> 8) & 0x007fffffu) | ((127u - (a & 31u)) << 23));
+        const float d = __builtin_bit_cast(float, (b & 0x007fffffu) | ((127u - ((b >> 23) % 49u)) << 23));
+        const float q_ref = n / d;
+        const float q_fast = rdiv_apply(rdiv_prepare(d), n);
+        bad += (__builtin_bit_cast(uint32_t, q_ref) != __builtin_bit_cast(uint32_t, q_fast));
+    }
+    if (bad) atomicAdd(out, bad);
+}
+
 } // namespace
 
+extern "C" hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out)
+{
+    rdiv_check_kernel<<<blocks, 256, 0, s>>>(seed, iters, d_out);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t pfxk_blend_arrays(hipStream_t s, const uint8_t* d_base, const uint8_t* d_top, uint8_t* d_dst,
-                                        size_t n_px, uint32_t mode, float opacity)
+                                        size_t n_px, uint32_t mode, float opacity, int fast_div)
 {
     if (n_px == 0) return hipSuccess;
     size_t blocks = (n_px + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    blend_arrays_kernel<<<(uint32_t)blocks, 256, 0, s>>>((const uint32_t*)d_base, (const uint32_t*)d_top, (uint32_t*)d_dst,
-                                                         n_px, mode, opacity);
+    if (fast_div)
+        blend_arrays_kernel<true><<<(uint32_t)blocks, 256, 0, s>>>((const uint32_t*)d_base, (const uint32_t*)d_top,
+                                                                   (uint32_t*)d_dst, n_px, mode, opacity);
+    else
+        blend_arrays_kernel<false><<<(uint32_t)blocks, 256, 0, s>>>((const uint32_t*)d_base, (const uint32_t*)d_top,
+                                                                    (uint32_t*)d_dst, n_px, mode, opacity);
     return hipGetLastError();
 }
 
@@ -361,8 +469,8 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 }
 
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
-                                   const float* d_adj_table, int general, uint8_t* d_chunk_active, uint32_t w,
-                                   uint32_t h, uint8_t* d_dst)
+                                   const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
+                                   uint32_t w, uint32_t h, uint8_t* d_dst)
 {
     const size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
@@ -374,9 +482,10 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
     size_t blocks = (n_quads + block - 1) / block;
     const size_t cap = 256u * 8u * 4u; // 256 CUs x 8 blocks, x4 waves of grid-stride work granularity
     if (blocks > cap) blocks = cap;
-    if (general)
-        flatten_kernel<true><<<(uint32_t)blocks, block, 0, stream>>>(d_layers, n_layers, d_adj_table, d_chunk_active, w, h, d_dst);
-    else
-        flatten_kernel<false><<<(uint32_t)blocks, block, 0, stream>>>(d_layers, n_layers, nullptr, nullptr, w, h, d_dst);
+    const uint32_t g = (uint32_t)blocks;
+#define PFX_LAUNCH(G, F) flatten_kernel<G, F><<<g, block, 0, stream>>>(d_layers, n_layers, d_adj_table, (G) ? d_chunk_active : nullptr, w, h, d_dst)
+    if (general) { if (fast_div) PFX_LAUNCH(true, true); else PFX_LAUNCH(true, false); }
+    else         { if (fast_div) PFX_LAUNCH(false, true); else PFX_LAUNCH(false, false); }
+#undef PFX_LAUNCH
     return hipGetLastError();
 }

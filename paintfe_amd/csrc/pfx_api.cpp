@@ -20,6 +20,12 @@ namespace {
 
 inline size_t img_bytes(uint32_t w, uint32_t h) { return (size_t)w * h * 4; }
 
+// FAST instantiation of the compositor (k_flatten.hip): requires opacity.clamp(0,1) in [2^-40, 1] for every layer, so
+// that (a) every division operand of blend_pixel_static stays in the normal range where v_div_scale / v_div_fixup
+// are identities and (b) top_a > 0 for every non-skipped pixel (out_a > 0: no zero check, no clamp).  Anything else
+// (zero, negative, tiny or NaN opacity) runs the plain instantiation with IEEE '/', clamps and zero checks.
+inline bool opacity_allows_fast_div(float opacity) { return opacity >= 9.094947017729282e-13f; /* 2^-40 */ }
+
 int check_img(pfx_ctx* ctx, const void* src, const void* dst, uint32_t w, uint32_t h, const char* who)
 {
     if (!ctx) return PFX_ERR_INVALID;
@@ -172,9 +178,11 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
         PFX_TRY(pfx_reserve(ctx, ctx->d_chunks, nchunks));
         d_chunks = (uint8_t*)ctx->d_chunks.p;
     }
+    bool fast_div = true; // k_flatten.hip:rdiv is bit-identical to '/' unless an opacity is a positive value < 2^-40
+    for (uint32_t i = 0; i < n_layers; ++i) fast_div = fast_div && opacity_allows_fast_div(layers[i].opacity);
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
-                              general ? 1 : 0, d_chunks, w, h, (uint8_t*)dst_dev));
+                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, w, h, (uint8_t*)dst_dev));
     return PFX_OK;
 }
 
@@ -223,15 +231,16 @@ int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint
     const int radius = pfx_host_gaussian_kernel(sigma, k);
     if (radius > pfxk_gauss_max_radius())
         return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "gaussian radius %d beyond the device tile limit %d", radius, pfxk_gauss_max_radius());
-    std::vector<float> padded(k.size() + 16, 0.0f);
-    std::copy(k.begin(), k.end(), padded.begin() + 8);
+    const int pad = pfxk_gauss_weight_pad(); // zero taps on both sides: the kernels' register blocking reads past the ends
+    std::vector<float> padded(k.size() + 2 * (size_t)pad, 0.0f);
+    std::copy(k.begin(), k.end(), padded.begin() + pad);
     PFX_TRY(pfx_reserve(ctx, ctx->d_wts, padded.size() * sizeof(float)));
     PFX_TRY(pfx_h2d(ctx, ctx->d_wts.p, padded.data(), padded.size() * sizeof(float)));
     if (!tmp_dev) {
         PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 16));
         tmp_dev = ctx->st_tmp.p;
     }
-    const float* wts = (const float*)ctx->d_wts.p + 8;
+    const float* wts = (const float*)ctx->d_wts.p + pad;
     {
         pfx_timer t(ctx, "gauss_h");
         PFX_HIP(ctx, pfxk_gauss_h(ctx->stream, (const uint8_t*)src_dev, (float*)tmp_dev, wts, radius, w, h, ctx->exact ? 1 : 0));
@@ -436,13 +445,22 @@ int pfx_gaussian_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint3
     PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_gaussian_blur_core"));
     const void* d_mask;
     PFX_TRY(stage_in(ctx, src, mask, w, h, &d_mask));
-    if (!mask) {
-        PFX_TRY(pfx_gaussian_blur_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h, sigma, nullptr));
-    } else {
-        // blur_with_selection (filters.rs:141-207) blurs the selection's bounding box padded by the kernel radius and
-        // copies back where mask > 0.  For selected pixels that equals blurring the whole image (the crop only drops
-        // pixels farther than the radius from every selected pixel... except that clamp-to-edge then happens at the
-        // crop border), so the crop is reproduced exactly: blur the crop rectangle as its own image.
+    PFX_TRY(pfx_int_blur_with_selection_dev(ctx, ctx->st_in.p, ctx->st_out.p, w, h, sigma, mask, d_mask));
+    return finish_out(ctx, dst, w, h);
+}
+
+} // extern "C"
+
+// blur_with_selection (ref: src/ops/filters.rs:141-207) on device-resident images.  The reference blurs the
+// selection's bounding box padded by the kernel radius *as its own image* (clamp-to-edge happens at the crop border)
+// and copies back where mask > 0; the crop is reproduced exactly.  `mask_host` is scanned for the bounding box on the
+// host (like the reference), `d_mask` is the same mask on the device.
+int pfx_int_blur_with_selection_dev(pfx_ctx* ctx, const void* d_src, void* d_dst, uint32_t w, uint32_t h, float sigma,
+                                    const uint8_t* mask, const void* d_mask)
+{
+    if (!mask) return pfx_gaussian_blur_dev(ctx, d_src, d_dst, w, h, sigma, nullptr);
+    struct { void* p; } in{const_cast<void*>(d_src)}, out{d_dst};
+    {
         uint32_t min_x = w, min_y = h, max_x = 0, max_y = 0;
         for (uint32_t y = 0; y < h; ++y)
             for (uint32_t x = 0; x < w; ++x)
@@ -451,7 +469,7 @@ int pfx_gaussian_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint3
                     max_x = std::max(max_x, x); max_y = std::max(max_y, y);
                 }
         if (min_x > max_x || min_y > max_y) { // nothing selected: flat.clone()
-            PFX_HIP(ctx, hipMemcpyAsync(ctx->st_out.p, ctx->st_in.p, img_bytes(w, h), hipMemcpyDeviceToDevice, ctx->stream));
+            PFX_HIP(ctx, hipMemcpyAsync(out.p, in.p, img_bytes(w, h), hipMemcpyDeviceToDevice, ctx->stream));
         } else {
             const float padf = ceilf(sigma * 3.0f);
             const uint32_t pad = !(padf > 0.0f) ? 0u : (padf >= 4294967296.0f ? 0xffffffffu : (uint32_t)padf);
@@ -461,20 +479,22 @@ int pfx_gaussian_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint3
             const uint32_t cw = cx1 - cx0, ch = cy1 - cy0;
             PFX_TRY(pfx_reserve(ctx, ctx->st_aux, img_bytes(cw, ch)));
             PFX_TRY(pfx_reserve(ctx, ctx->st_aux2, img_bytes(w, h)));
-            PFX_HIP(ctx, hipMemcpy2DAsync(ctx->st_aux.p, (size_t)cw * 4, (const uint8_t*)ctx->st_in.p + ((size_t)cy0 * w + cx0) * 4,
+            PFX_HIP(ctx, hipMemcpy2DAsync(ctx->st_aux.p, (size_t)cw * 4, (const uint8_t*)in.p + ((size_t)cy0 * w + cx0) * 4,
                                           (size_t)w * 4, (size_t)cw * 4, ch, hipMemcpyDeviceToDevice, ctx->stream));
-            // blurred crop -> st_aux (in place is not allowed: H pass reads src while V writes dst; use aux2 as dst)
+            // blurred crop -> st_aux2 (the H pass reads its source while the V pass writes the destination)
             PFX_TRY(pfx_gaussian_blur_dev(ctx, ctx->st_aux.p, ctx->st_aux2.p, cw, ch, sigma, nullptr));
             // paste the blurred crop over a copy of the source, then select by mask
-            PFX_HIP(ctx, hipMemcpyAsync(ctx->st_out.p, ctx->st_in.p, img_bytes(w, h), hipMemcpyDeviceToDevice, ctx->stream));
-            PFX_HIP(ctx, hipMemcpy2DAsync((uint8_t*)ctx->st_out.p + ((size_t)cy0 * w + cx0) * 4, (size_t)w * 4, ctx->st_aux2.p,
+            PFX_HIP(ctx, hipMemcpyAsync(out.p, in.p, img_bytes(w, h), hipMemcpyDeviceToDevice, ctx->stream));
+            PFX_HIP(ctx, hipMemcpy2DAsync((uint8_t*)out.p + ((size_t)cy0 * w + cx0) * 4, (size_t)w * 4, ctx->st_aux2.p,
                                           (size_t)cw * 4, (size_t)cw * 4, ch, hipMemcpyDeviceToDevice, ctx->stream));
-            PFX_HIP(ctx, pfxk_select_by_mask(ctx->stream, (const uint8_t*)ctx->st_in.p, (const uint8_t*)ctx->st_out.p,
-                                             (const uint8_t*)d_mask, (uint8_t*)ctx->st_out.p, w, h));
+            PFX_HIP(ctx, pfxk_select_by_mask(ctx->stream, (const uint8_t*)in.p, (const uint8_t*)out.p,
+                                             (const uint8_t*)d_mask, (uint8_t*)out.p, w, h));
         }
     }
-    return finish_out(ctx, dst, w, h);
+    return PFX_OK;
 }
+
+extern "C" {
 
 int pfx_blur_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float sigma)
 {
@@ -601,7 +621,7 @@ int pfx_blend_pixels(pfx_ctx* ctx, const uint8_t* base, const uint8_t* top, uint
     PFX_TRY(pfx_h2d(ctx, ctx->st_in.p, base, n_pixels * 4));
     PFX_TRY(pfx_h2d(ctx, ctx->st_aux.p, top, n_pixels * 4));
     PFX_HIP(ctx, pfxk_blend_arrays(ctx->stream, (const uint8_t*)ctx->st_in.p, (const uint8_t*)ctx->st_aux.p, (uint8_t*)ctx->st_out.p,
-                                   n_pixels, blend_mode > 24 ? 0u : blend_mode, opacity));
+                                   n_pixels, blend_mode > 24 ? 0u : blend_mode, opacity, opacity_allows_fast_div(opacity) ? 1 : 0));
     PFX_TRY(pfx_d2h(ctx, dst, ctx->st_out.p, n_pixels * 4));
     return pfx_sync(ctx);
 }
@@ -696,6 +716,28 @@ int pfx_chunk_populated(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h
     PFX_HIP(ctx, pfxk_chunk_populated(ctx->stream, (const uint8_t*)ctx->st_in.p, w, h, (uint8_t*)ctx->d_chunks.p));
     PFX_TRY(pfx_d2h(ctx, populated, ctx->d_chunks.p, nchunks));
     return pfx_sync(ctx);
+}
+
+int pfx_tune(pfx_ctx* ctx, const char* key, int value)
+{
+    if (!ctx || !key) return PFX_ERR_INVALID;
+    if (std::strcmp(key, "gauss_v_cfg") == 0) { pfxk_gauss_set_v_config(value); return PFX_OK; }
+    return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_tune: unknown key %s", key);
+}
+
+int pfx_selftest_division(pfx_ctx* ctx, uint64_t seed, uint32_t n_millions, uint64_t* mismatches)
+{
+    if (!ctx || !mismatches) return PFX_ERR_INVALID;
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->d_misc, 64));
+    PFX_HIP(ctx, hipMemsetAsync(ctx->d_misc.p, 0, 8, ctx->stream));
+    const uint32_t blocks = 1024, iters = (uint32_t)(((uint64_t)n_millions * 1000000ull + blocks * 256ull - 1) / (blocks * 256ull));
+    PFX_HIP(ctx, pfxk_rdiv_check(ctx->stream, seed, blocks, iters, (unsigned long long*)ctx->d_misc.p));
+    unsigned long long bad = 0;
+    PFX_TRY(pfx_d2h(ctx, &bad, ctx->d_misc.p, 8));
+    PFX_TRY(pfx_sync(ctx));
+    *mismatches = bad;
+    return PFX_OK;
 }
 
 } // extern "C"

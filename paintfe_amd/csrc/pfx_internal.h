@@ -80,6 +80,10 @@ struct pfx_timer {
     ~pfx_timer();
 };
 
+// blur_with_selection on device-resident images (pfx_api.cpp); mask_host may be NULL (= no selection)
+int pfx_int_blur_with_selection_dev(pfx_ctx* ctx, const void* d_src, void* d_dst, uint32_t w, uint32_t h, float sigma,
+                                    const uint8_t* mask_host, const void* d_mask);
+
 // host-side restatements that the reference also runs on the host (pfx_host_math.cpp)
 int  pfx_host_gaussian_kernel(float sigma, std::vector<float>& out);  // ref: src/ops/filters.rs:214-234
 float pfx_host_bc_factor(float contrast);                             // ref: src/ops/adjustments.rs:273

@@ -33,12 +33,17 @@ enum { PFXK_RHAI_INVERT = 0, PFXK_RHAI_DESATURATE, PFXK_RHAI_SEPIA, PFXK_RHAI_SE
        PFXK_RHAI_BRIGHTNESS_CONTRAST, PFXK_RHAI_HSL, PFXK_RHAI_EXPOSURE, PFXK_RHAI_LEVELS, PFXK_RHAI_COUNT };
 
 // ---- k_flatten.hip ----
+// fast_div: 1 = shared-reciprocal division (bit-identical to '/' for opacities that are 0 or >= 2^-40), 0 = plain '/'
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
-                        const float* d_adj_table, int general, uint8_t* d_chunk_active, uint32_t w, uint32_t h,
-                        uint8_t* d_dst);
+                        const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, uint32_t w,
+                        uint32_t h, uint8_t* d_dst);
+// counts (into *d_out) operand pairs for which the shared-reciprocal division differs from the IEEE divide
+hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out);
 
-// ---- k_gauss.hip ---- (d_wts_tap0 points at tap 0 of a device array with 8 zeros of padding on both sides)
+// ---- k_gauss.hip ---- (d_wts_tap0 points at tap 0 of a device array with pfxk_gauss_weight_pad() zeros on both sides)
 int        pfxk_gauss_max_radius(void);
+int        pfxk_gauss_weight_pad(void);
+void       pfxk_gauss_set_v_config(int cfg); // tuning knob, 0 = shipped
 hipError_t pfxk_gauss_h(hipStream_t stream, const uint8_t* d_src, float* d_tmp, const float* d_wts_tap0, int radius,
                         uint32_t w, uint32_t h, int exact);
 hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8_t* d_dst, const float* d_wts_tap0, int radius,
@@ -91,7 +96,7 @@ hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const uint8_t* d_p
                              uint32_t w, uint32_t h, uint32_t mode, int is_eraser);
 // element-wise blend_pixel_static over two pixel arrays (spot checks / stroke commit)
 hipError_t pfxk_blend_arrays(hipStream_t s, const uint8_t* d_base, const uint8_t* d_top, uint8_t* d_dst, size_t n_px,
-                             uint32_t mode, float opacity);
+                             uint32_t mode, float opacity, int fast_div);
 
 #ifdef __cplusplus
 }

@@ -397,6 +397,14 @@ class GpuRenderer:
         self._check(self._lib.pfx_warp_displacement_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(sw), C.c_uint32(sh),
                                                         C.c_void_p(disp_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr)))
 
+    def selftest_division(self, seed: int, n_millions: int) -> int:
+        bad = C.c_uint64(0)
+        self._check(self._lib.pfx_selftest_division(self._h, C.c_uint64(seed), C.c_uint32(n_millions), C.byref(bad)))
+        return int(bad.value)
+
+    def tune(self, key: str, value: int):
+        self._check(self._lib.pfx_tune(self._h, key.encode(), C.c_int(value)))
+
     def timing_enable(self, on: bool):
         self._check(self._lib.pfx_timing_enable(self._h, C.c_int(int(on))))
 

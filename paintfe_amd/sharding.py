@@ -1,0 +1,115 @@
+"""Row-band sharding of one document across ranks (one process per GPU, torch.distributed over RCCL/xGMI).
+
+The reference has no distributed layer at all; its natural unit of independence is the 64x64
+TiledImage chunk (ref: src/canvas/canvas_state.rs:565 parallelises the compositor over chunks), so a document is cut
+into bands of whole chunk rows:
+
+  * flatten and every pointwise op are per-pixel: a band needs nothing from its neighbours;
+  * a separable stencil of radius r needs r rows of the *input of the stencil* from each neighbour before its
+    vertical pass (the horizontal pass is row-local).  For "flatten -> Gaussian" that input is the flattened u8 band:
+    r x w x 4 bytes per neighbour and direction (sigma=16 at 8K: 48 x 7680 x 4 = 1.47 MB), one point-to-point
+    message each way per neighbour pair — the only collective-free exchange the path has;
+  * the final image is the concatenation of the bands (all_gather only if one rank needs the whole picture).
+
+All functions take plain ``torch`` tensors, so the same code runs on CPU tensors over gloo (tests, world_size 2) and
+on device tensors over RCCL (bench.py --shard band).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+CHUNK = 64  # ref: src/canvas/defs.rs:7
+
+
+def band_rows(height: int, world: int, rank: int) -> Tuple[int, int]:
+    """[y0, y1) of rank's band: whole chunk rows, remainder spread over the first ranks.  Empty bands are possible
+    when there are fewer chunk rows than ranks."""
+    chunk_rows = (height + CHUNK - 1) // CHUNK
+    base, rem = divmod(chunk_rows, world)
+    c0 = rank * base + min(rank, rem)
+    c1 = c0 + base + (1 if rank < rem else 0)
+    return min(c0 * CHUNK, height), min(c1 * CHUNK, height)
+
+
+def all_bands(height: int, world: int) -> List[Tuple[int, int]]:
+    return [band_rows(height, world, r) for r in range(world)]
+
+
+def halo_plan(height: int, world: int, rank: int, radius: int):
+    """What rank must receive: list of (src_rank, src_y0, src_y1) row ranges above and below its band, at most
+    `radius` rows each, possibly spanning several (thin) neighbouring bands."""
+    y0, y1 = band_rows(height, world, rank)
+    need = []
+    if y1 > y0:
+        lo0, lo1 = max(0, y0 - radius), y0
+        hi0, hi1 = y1, min(height, y1 + radius)
+        for r, (b0, b1) in enumerate(all_bands(height, world)):
+            if r == rank or b1 <= b0:
+                continue
+            for (a, b) in ((lo0, lo1), (hi0, hi1)):
+                s0, s1 = max(a, b0), min(b, b1)
+                if s1 > s0:
+                    need.append((r, s0, s1))
+    return sorted(need, key=lambda t: t[1])
+
+
+def exchange_halo(band, height: int, radius: int, group=None):
+    """band: (rows, w, C) tensor holding rows [y0, y1) of this rank.  Returns (padded, top, bottom) where padded holds
+    rows [y0 - top, y1 + bottom) of the full image.  Uses batched point-to-point ops (RCCL send/recv on GPUs)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    y0, y1 = band_rows(height, world, rank)
+    my_need = halo_plan(height, world, rank, radius)
+    ops, recv_bufs = [], []
+    for (src, s0, s1) in my_need:
+        buf = torch.empty((s1 - s0,) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
+        recv_bufs.append((s0, s1, buf))
+        ops.append(dist.P2POp(dist.irecv, buf, src, group))
+    keep = []
+    for other in range(world):
+        if other == rank:
+            continue
+        for (src, s0, s1) in halo_plan(height, world, other, radius):
+            if src == rank:
+                piece = band[s0 - y0:s1 - y0].contiguous()
+                keep.append(piece)
+                ops.append(dist.P2POp(dist.isend, piece, other, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    above = [b for (s0, s1, b) in recv_bufs if s1 <= y0]
+    below = [b for (s0, s1, b) in recv_bufs if s0 >= y1]
+    top = sum(int(b.shape[0]) for b in above)
+    bottom = sum(int(b.shape[0]) for b in below)
+    padded = torch.cat(above + [band] + below, dim=0) if (above or below) else band
+    return padded, top, bottom
+
+
+def gather_bands(band, height: int, group=None):
+    """all_gather of the (ragged) bands into the full image on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    bands = all_bands(height, world)
+    max_rows = max(b1 - b0 for b0, b1 in bands)
+    pad = torch.zeros((max_rows,) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
+    pad[:band.shape[0]] = band
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:b1 - b0] for o, (b0, b1) in zip(outs, bands)], dim=0)
+
+
+def max_over_ranks(value: float, device=None, group=None) -> float:
+    """wall time of a step = slowest rank (bench.py contract)"""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

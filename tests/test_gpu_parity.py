@@ -68,6 +68,23 @@ def test_blend_pixels_exhaustive_alpha_lattice(gpu):
             assert_same(got[::97], exp, 0, f"mode {mode} opacity {opacity}")
 
 
+def test_fast_division_matches_ieee(gpu):
+    """k_flatten.hip:rdiv (shared refined reciprocal) vs the compiler's IEEE f32 divide on 2^28 random operand pairs
+    from the compositor's operand range — must be bit-identical."""
+    assert gpu.r.selftest_division(seed=0xD1D1, n_millions=268) == 0
+
+
+def test_tiny_opacity_takes_ieee_division_path(gpu, oracle):
+    """opacity below 2^-40 selects the plain '/' instantiation (operands may leave the normal range)"""
+    w, h = 130, 70
+    base = I.random_rgba(w, h, 91)
+    top = I.random_rgba(w, h, 92)
+    for mode in (0, 1, 6, 13, 19):
+        for opacity in (1e-20, 3e-39, 1e-44):
+            layers = [dict(pixels=base), dict(pixels=top, mode=mode, opacity=opacity)]
+            assert_same(gpu.composite(layers, w, h), oracle.composite(layers, w, h), 0, f"mode {mode} opacity {opacity}")
+
+
 def test_flatten_stack_8_layers(gpu):
     w, h, n = 515, 259, 8
     stack, modes, opac = I.layer_stack(w, h, n, seed=42)

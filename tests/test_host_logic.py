@@ -1,0 +1,116 @@
+"""CPU-side checks of the product's host logic (no GPU, no kernels): the C-ABI library loads and exports every
+symbol include/pfx.h declares, host-side constant builders agree with the oracle bit for bit, error paths that do
+not need a device behave, and the proved arithmetic shortcuts used by the kernels hold exhaustively."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from . import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from paintfe_amd import _lib
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "pfx.h")).read()
+    declared = sorted(set(re.findall(r"\b(pfx_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 60
+    missing = [d for d in declared if not hasattr(lib, d)]
+    assert not missing, missing
+    assert lib.pfx_abi_version() == 1
+
+
+def test_no_device_is_reported_not_hidden(lib):
+    """GpuRenderer::try_new -> None when there is no adapter (ref: src/gpu/renderer.rs:261); never a CPU fallback"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    st = lib.pfx_ctx_create(C.c_int(0), C.byref(h))
+    assert st == -2 and not h.value  # PFX_ERR_NO_DEVICE
+    assert b"no HIP device" in lib.pfx_last_error(None)
+    from paintfe_amd import GpuRenderer, PfxError
+    assert GpuRenderer.try_new(0) is None
+    with pytest.raises(PfxError):
+        GpuRenderer(0)
+
+
+def test_product_package_never_touches_the_oracle():
+    """no source file of the product includes, links, imports or calls anything under oracle/ (comments may name it)"""
+    needles = ("pfx_oracle", "pfxo_", "oracle_lib", "libpfx_oracle", "oracle/", "import oracle", "from oracle", "from tests")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "paintfe_amd")):
+        if "build" in dirpath.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                hits = [n for n in needles if n in txt]
+                assert not hits, f"{f} references the oracle: {hits}"
+
+
+def test_levels_curves_stretch_lut_builders_match_oracle(lib):
+    lut = np.zeros(256, np.uint8)
+    for args in ((20.0, 235.0, 1.2, 0.0, 255.0), (0.0, 255.0, 1.0, 0.0, 255.0), (100.0, 90.0, 0.001, 255.0, 0.0), (5.5, 200.25, 3.7, 12.0, 199.0)):
+        lib.pfx_build_levels_lut(*[C.c_float(a) for a in args], lut.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(lut, O.levels_lut(*args)), args
+    for pts in ([(0, 0), (255, 255)], [(0, 0), (64, 40), (128, 160), (255, 255)], [(0, 255), (100, 100), (100.0000001, 50), (255, 0)],
+                [(10, 20)], [(0, 0), (50, 200), (60, 10), (255, 255)], [(0, 0), (30, 250), (200, 251), (255, 0)]):
+        p = np.asarray(pts, np.float32)
+        lib.pfx_build_curves_lut(p.ctypes.data_as(C.c_void_p), C.c_uint32(len(p)), lut.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(lut, O.curves_lut(pts)), pts
+    for mn, mx in ((0, 255), (10, 200), (50, 50), (200, 10), (254, 255)):
+        lib.pfx_build_stretch_lut(C.c_uint8(mn), C.c_uint8(mx), lut.ctypes.data_as(C.c_void_p))
+        ref = np.zeros(256, np.uint8)
+        O.lib().pfxo_stretch_lut(C.c_uint8(mn), C.c_uint8(mx), ref.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(lut, ref), (mn, mx)
+
+
+def test_displacement_brushes_match_oracle(lib):
+    for mode in range(5):
+        a = np.zeros((64, 80, 2), np.float32)
+        b = np.zeros((64, 80, 2), np.float32)
+        for (cx, cy, dx, dy, r, s) in ((30.5, 20.25, 3.0, -2.0, 14.0, 0.7), (-3.0, 70.0, 1.0, 1.0, 9.0, 0.5), (79.0, 0.0, -5.0, 2.0, 0.3, 1.0)):
+            lib.pfx_displacement_brush(a.ctypes.data_as(C.c_void_p), C.c_uint32(80), C.c_uint32(64), C.c_int(mode), C.c_float(cx), C.c_float(cy),
+                                       C.c_float(dx), C.c_float(dy), C.c_float(r), C.c_float(s))
+            O.displacement_brush(b, mode, cx, cy, dx, dy, r, s)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
+
+
+def test_div255_two_op_form_is_exact():
+    """k_common.h:div255 — RN(x*C_HI + RN(x*C_LO)) == RN(x/255) for all 256 byte values (the FMA is emulated exactly in
+    float64: x*C_HI needs 32 bits, the sum stays below 53)"""
+    c_hi = np.uint32(998277249).view(np.float32)
+    c_lo = np.uint32(2944335615).view(np.float32)
+    x = np.arange(256, dtype=np.float32)
+    lo = (x * c_lo).astype(np.float32)
+    fma = (x.astype(np.float64) * np.float64(c_hi) + lo.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(fma, x / np.float32(255.0))
+    assert (x * c_hi != x / np.float32(255.0)).sum() > 100  # a plain multiply by 1/255 is NOT enough
+
+
+def test_box_blur_reciprocal_division_is_exact():
+    """k_stencil.hip:div_round — umulhi(n, floor(2^32/d)+1) == n // d for every n the box blur can produce"""
+    for d in (3, 5, 7, 15, 97, 255, 1001, 4095):
+        magic = (1 << 32) // d + 1
+        n = np.unique(np.concatenate([np.arange(0, min(255 * d + d // 2, 200000) + 1), np.array([255 * d + d // 2])])).astype(np.uint64)
+        assert np.array_equal((n * np.uint64(magic)) >> np.uint64(32), n // np.uint64(d)), d
+
+
+def test_cli_errors_before_device_creation():
+    exe = os.path.join(ROOT, "paintfe_amd", "pfx")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "-i", "/nonexistent/*.png"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no input files matched" in r.stderr  # ref: src/cli.rs:108-111
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "--input" in r.stderr                 # clap: required argument
+    r = subprocess.run([exe, "-i", __file__, os.path.join(ROOT, "bench.py"), "-o", "/tmp/x.png"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--output-dir" in r.stderr           # ref: src/cli.rs:114-121
