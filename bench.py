@@ -37,24 +37,50 @@ W8K, H8K, NLAYERS, SIGMA = 7680, 4320, 32, 16.0
 def synth_stack(torch, device, w, h, n, seed):
     """S2 generator on the device: uniform RGB; alpha 25% = 0, 25% = 255, 50% uniform 1..254; layer 0 opaque;
     mode k -> k mod 25; opacity 1.0 for even k, 0.25 + 0.75*u for odd k."""
-    g = torch.Generator(device=device)
     stack = torch.empty((n, h, w, 4), dtype=torch.uint8, device=device)
+    for k in range(n):
+        stack[k] = synth_layer(torch, device, w, h, k, seed)
+    modes, opac = synth_params(n, seed)
+    return stack, modes, opac
+
+
+def synth_layer(torch, device, w, h, k, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + k)
+    px = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=device, generator=g)
+    sel = torch.randint(0, 4, (h, w), dtype=torch.uint8, device=device, generator=g)
+    a = torch.randint(1, 255, (h, w), dtype=torch.uint8, device=device, generator=g)
+    a = torch.where(sel == 0, torch.zeros_like(a), torch.where(sel == 1, torch.full_like(a, 255), a))
+    px[..., 3] = 255 if k == 0 else a
+    return px
+
+
+def synth_params(n, seed):
     modes = np.zeros(n, np.uint8)
     opac = np.ones(n, np.float32)
     rng = np.random.default_rng(seed)
     for k in range(n):
-        g.manual_seed(seed + k)
-        px = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=device, generator=g)
-        sel = torch.randint(0, 4, (h, w), dtype=torch.uint8, device=device, generator=g)
-        a = torch.randint(1, 255, (h, w), dtype=torch.uint8, device=device, generator=g)
-        a = torch.where(sel == 0, torch.zeros_like(a), torch.where(sel == 1, torch.full_like(a, 255), a))
-        px[..., 3] = 255 if k == 0 else a
-        stack[k] = px
         modes[k] = k % 25
         if k % 2 == 1:
             opac[k] = np.float32(0.25) + np.float32(0.75) * np.float32(rng.random())
-        del px, sel, a
-    return stack, modes, opac
+    return modes, opac
+
+
+def pmc_traffic(kernel: str, w: int, h: int, n: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json, produced by
+    tools/prof.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled as the gfx950 guide
+    prescribes).  PMC collection cannot run inside this process, so the figure is only reported for the exact
+    configuration it was measured on (8K x 32 layers); otherwise null."""
+    if (w, h, n) != (W8K, H8K, NLAYERS):
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))[kernel]["hbm_bytes"]
+    except Exception:
+        return None
 
 
 def usable_cores() -> int:
@@ -86,6 +112,9 @@ def main() -> int:
     ap.add_argument("--height", type=int, default=H8K)
     ap.add_argument("--layers", type=int, default=NLAYERS)
     ap.add_argument("--sigma", type=float, default=SIGMA)
+    ap.add_argument("--shard", choices=["doc", "band"], default="doc",
+                    help="N>1: 'doc' = one document per GPU, no collective (weak scaling, default); 'band' = ONE document cut "
+                         "into row bands with an RCCL halo exchange before the blur (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], help="key=value kernel tuning knob (development)")
     ap.add_argument("--exact", action="store_true", help="Gaussian without FMA contraction (bit-exact with the CPU path)")
@@ -114,16 +143,41 @@ def main() -> int:
     r.set_stream(torch.cuda.current_stream().cuda_stream)  # HIP events + kernels on the stream torch synchronises
 
     w, h, n = args.width, args.height, args.layers
-    stack, modes, opac = synth_stack(torch, device, w, h, n, seed=0x5EED0002 + 1000 * rank)
-    flat = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
-    blurred = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
-    tmp = torch.empty((h, w, 4), dtype=torch.float32, device=device)  # f32 horizontal-pass intermediate
+    band_mode = args.shard == "band" and world > 1
+    state = {}
+    if band_mode:
+        # ONE document for the whole job, cut into bands of whole chunk rows (paintfe_amd/sharding.py): every rank
+        # generates the same layers (same seeds) and keeps only its rows
+        from paintfe_amd import sharding as S
+        y0, y1 = S.band_rows(h, world, rank)
+        hh = y1 - y0
+        modes, opac = synth_params(n, 0x5EED0002)
+        stack = torch.empty((n, hh, w, 4), dtype=torch.uint8, device=device)
+        for k in range(n):
+            stack[k] = synth_layer(torch, device, w, h, k, 0x5EED0002)[y0:y1]
+    else:
+        stack, modes, opac = synth_stack(torch, device, w, h, n, seed=0x5EED0002 + 1000 * rank)
+        hh = h
+    flat = torch.empty((max(hh, 1), w, 4), dtype=torch.uint8, device=device)
     info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
     ptrs = [stack[k].data_ptr() for k in range(n)]
+    radius = int(np.ceil(np.float32(args.sigma) * np.float32(3.0)))
+    pad_rows = hh + (2 * radius if band_mode else 0)
+    blurred = torch.empty((max(pad_rows, 1), w, 4), dtype=torch.uint8, device=device)
+    tmp = torch.empty((max(pad_rows, 1), w, 4), dtype=torch.float32, device=device)  # f32 horizontal-pass intermediate
 
     def step():
-        r.flatten_dev(ptrs, info, w, h, flat.data_ptr())
-        r.gaussian_blur_dev(flat.data_ptr(), blurred.data_ptr(), w, h, args.sigma, tmp.data_ptr())
+        if hh > 0:
+            r.flatten_dev(ptrs, info, w, hh, flat.data_ptr())
+        if band_mode:
+            # the only exchange of the path: `radius` rows of the flattened u8 band from each neighbour (RCCL send/recv
+            # on the current stream, so it is ordered after the flatten and before the blur without host syncs)
+            padded, top, bottom = S.exchange_halo(flat[:hh], h, radius)
+            if hh > 0:
+                r.gaussian_blur_dev(padded.data_ptr(), blurred.data_ptr(), w, int(padded.shape[0]), args.sigma, tmp.data_ptr())
+                state["result"] = blurred[top:top + hh]
+        else:
+            r.gaussian_blur_dev(flat.data_ptr(), blurred.data_ptr(), w, h, args.sigma, tmp.data_ptr())
 
     def bracket():
         if world > 1:
@@ -147,39 +201,44 @@ def main() -> int:
         elapsed = float(t.item())
 
     px_per_step = w * h
-    value = px_per_step * args.steps * world / elapsed / 1e6  # whole-job Mpx/s
+    docs = 1 if band_mode else world                        # band mode: the whole job is one document per step
+    value = px_per_step * args.steps * docs / elapsed / 1e6  # whole-job Mpx/s
+    px_per_launch = w * hh                                   # pixels one flatten launch on this rank covers
 
     # per-kernel launch durations from HIP events recorded on the launch stream during the timed region
     kern = {}
     for name in ("flatten", "gauss_h", "gauss_v"):
         ms, cnt = r.timing_read(name)
         kern[name] = (ms / max(cnt, 1), cnt)
-    alg_bytes = {"flatten": (4 * n + 4) * px_per_step, "gauss_h": 8 * px_per_step // 2, "gauss_v": 8 * px_per_step // 2}
+    alg_bytes = {"flatten": (4 * n + 4) * px_per_launch, "gauss_h": 4 * px_per_launch, "gauss_v": 4 * px_per_launch}
     dominant = "flatten"  # carries 132 of the 140 algorithmic bytes/px; named in DESIGN.md
     d_ms = kern[dominant][0]
     achieved = alg_bytes[dominant] / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
     pipeline_bytes = (4 * n + 4 + 8) * px_per_step
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant, w, h, n),
                 "kernel_ms": {k: round(v[0], 4) for k, v in kern.items()},
                 "pipeline_achieved_GBs": round(pipeline_bytes * args.steps / elapsed / 1e9, 1),
                 "pipeline_frac": round(pipeline_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
 
     out = {"metric": "Mpixels/sec: 8K 32-layer flatten + Gaussian sigma=16; HBM GB/s vs peak", "value": round(value, 1),
            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "strong" if band_mode else "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{w}x{h} RGBA8 x {n} layers (25 blend modes cycling, S2) flatten -> Gaussian sigma={args.sigma:g}",
                       "width": w, "height": h, "layers": n, "sigma": args.sigma, "gaussian_mode": "exact" if args.exact else "fma",
-                      "sharding": "one document per GPU, no collective" if world > 1 else "single GPU"},
+                      "sharding": ("one document cut into chunk-row bands, RCCL halo exchange before the blur" if band_mode else
+                                   "one document per GPU, no collective") if world > 1 else "single GPU"},
            "roofline": roofline}
 
     if rank == 0:
         # correctness spot check of the timed result against the oracle on a crop (flatten is per-pixel, so a crop
         # of the full-size flatten equals the flatten of the cropped stack)
         from tests import oracle_lib as O
-        cy, cx, ch, cw = 1000, 2000, 256, 512
-        crop_stack = stack[:, cy:cy + ch, cx:cx + cw, :].contiguous().cpu().numpy() if h >= cy + ch and w >= cx + cw else None
+        ch, cw = 256, 512
+        cy, cx = min(1000, max(hh - ch, 0)), min(2000, max(w - cw, 0))
+        crop_stack = stack[:, cy:cy + ch, cx:cx + cw, :].contiguous().cpu().numpy() if hh >= cy + ch and w >= cx + cw else None
         if crop_stack is not None:
             ref = O.flatten_stack(crop_stack, modes, opac)
             got = flat[cy:cy + ch, cx:cx + cw, :].contiguous().cpu().numpy()

@@ -202,6 +202,7 @@ bool parse(const char* src, std::vector<Call>& calls, ScriptErr& err)
             }
             if (!lx.next(t, err)) return false;
             if (t.t == Tok::Comma) { if (!lx.next(t, err)) return false; }
+            else if (t.t == Tok::End) { err = {"Expecting ')' to close the parameters list of function call '" + c.name + "'", t.line, t.col, PFX_ERR_SCRIPT}; return false; }
             else if (t.t != Tok::RParen) { err = {"Expecting ',' to separate the parameters of function call '" + c.name + "'", t.line, t.col, PFX_ERR_SCRIPT}; return false; }
         }
         calls.push_back(c);
