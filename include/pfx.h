@@ -57,7 +57,10 @@ int         pfx_abi_version(void);
  * +-1 LSB class), 1 = reference evaluation order without FMA contraction (bit-exact with the CPU path). */
 int         pfx_ctx_set_exact(pfx_ctx* ctx, int exact);
 void*       pfx_ctx_stream(pfx_ctx* ctx);                 /* hipStream_t of this context */
-int         pfx_ctx_set_stream(pfx_ctx* ctx, void* hip_stream); /* adopt a caller stream (e.g. torch's); NULL restores own */
+/* adopt != 0: run on the caller's hipStream_t (NULL = the device's default stream, which is what torch's default
+ * stream is); adopt == 0: back to the context's own stream.  Lets `_dev` calls interleave in order with a host
+ * framework's kernels and RCCL collectives without host synchronisation. */
+int         pfx_ctx_set_stream(pfx_ctx* ctx, void* hip_stream, int adopt);
 int         pfx_ctx_synchronize(pfx_ctx* ctx);
 
 /* ---- device memory helpers for the `_dev` tier ---- */
@@ -95,6 +98,20 @@ int pfx_median_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, 
 /* pixelate_core (ref: src/ops/effects/distort.rs:333-373) */
 int pfx_pixelate_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t block_size,
                       const uint8_t* mask);
+/* effects that reuse the same kernels.  sharpen / glow run the Gaussian in the context's numeric mode:
+ * bit-exact with the CPU path after pfx_ctx_set_exact(ctx, 1), otherwise the Gaussian's +-1 LSB enters `amount` times. */
+/* sharpen_core(flat, amount, radius, mask) (ref: src/ops/effects/stylize.rs:96-143) */
+int pfx_sharpen_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float amount, float radius,
+                     const uint8_t* mask);
+/* glow_core(flat, radius, intensity, mask) (ref: src/ops/effects/stylize.rs:26-70) */
+int pfx_glow_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float radius, float intensity,
+                  const uint8_t* mask);
+/* bokeh_blur_core(flat, radius, mask) (ref: src/ops/effects/blur.rs:22-115) */
+int pfx_bokeh_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float radius,
+                        const uint8_t* mask);
+/* motion_blur_core(flat, angle_deg, distance, mask) (ref: src/ops/effects/blur.rs:144-210) */
+int pfx_motion_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float angle_deg,
+                         float distance, const uint8_t* mask);
 
 /* ---- the pointwise adjustment bank: one entry point, op id + parameter block ----
  * ops::adjustments flavour (f32, `.round().clamp(0,255) as u8`), ref: src/ops/adjustments.rs:21-108 */
@@ -250,6 +267,14 @@ int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float
 int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush,
                          const float* points_xy, uint32_t n_points, const void* selection_dev);
 int pfx_tiled_roundtrip_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h);
+int pfx_sharpen_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float amount, float radius,
+                    const void* mask_dev);
+int pfx_glow_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius, float intensity,
+                 const void* mask_dev);
+int pfx_bokeh_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius,
+                       const void* mask_dev);
+int pfx_motion_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float angle_deg,
+                        float distance, const void* mask_dev);
 
 /* device self-test: compares the compositor's shared-reciprocal division with the compiler's IEEE f32 divide on
  * n_millions*1e6 random operand pairs drawn from the kernel's operand range; *mismatches must come back 0 */

@@ -76,6 +76,12 @@ void pfxo_box_blur(const uint8_t* src, uint32_t w, uint32_t h, float radius, con
 void pfxo_median(const uint8_t* src, uint32_t w, uint32_t h, uint32_t radius, const uint8_t* mask, uint8_t* dst, int threads);
 void pfxo_pixelate(const uint8_t* src, uint32_t w, uint32_t h, uint32_t block, const uint8_t* mask, uint8_t* dst, int threads);
 
+/* ---- N3: effects that reuse the same kernels (src/ops/effects/stylize.rs:26-143, blur.rs:22-210) ---- */
+void pfxo_glow(const uint8_t* src, uint32_t w, uint32_t h, float radius, float intensity, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_sharpen(const uint8_t* src, uint32_t w, uint32_t h, float amount, float radius, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_bokeh_blur(const uint8_t* src, uint32_t w, uint32_t h, float radius, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_motion_blur(const uint8_t* src, uint32_t w, uint32_t h, float angle_deg, float distance, const uint8_t* mask, uint8_t* dst, int threads);
+
 /* ---- A7/A8: ops::adjustments flavour (f32, .round()) (src/ops/adjustments.rs, src/ops/filters.rs:321) ---- */
 enum {
     PFXO_OP_INVERT = 0, PFXO_OP_INVERT_ALPHA, PFXO_OP_SEPIA, PFXO_OP_BRIGHTNESS_CONTRAST, PFXO_OP_HSL,

@@ -25,6 +25,30 @@ PFX_DEV float div255(float x)
     return __builtin_fmaf(x, C_HI, x * C_LO);
 }
 
+// ---- correctly rounded f32 division, reciprocal part hoistable ------------------------------------------------
+// hipcc lowers an IEEE `n / d` to: v_div_scale x2, v_rcp, 2 FMAs refining the reciprocal, mul + 4 FMAs refining the
+// quotient, v_div_fmas, v_div_fixup.  The scale/fixup steps only act when an operand or the quotient is denormal,
+// huge, zero-denominator or NaN/Inf.  For operands in the normal range (every use in this library: numerators 0 or in
+// [2^-100, 2^20], denominators in [2^-48, 2^20], checked where used) they are identities, so the sequence below yields
+// the same bits as `/`, and the 3-instruction reciprocal part can be shared by all divisions with one denominator.
+// pfx_selftest_division() compares it with `/` on 2.7e8 random operand pairs on the device.
+struct rdiv { float d, y; };
+PFX_DEV rdiv rdiv_prepare(float d)
+{
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y0, 1.0f);
+    return {d, __builtin_fmaf(e, y0, y0)};
+}
+PFX_DEV float rdiv_apply(const rdiv k, float n)
+{
+    const float q0 = n * k.y;
+    const float r0 = __builtin_fmaf(-k.d, q0, n);
+    const float q1 = __builtin_fmaf(r0, k.y, q0);
+    const float r1 = __builtin_fmaf(-k.d, q1, n);
+    return __builtin_fmaf(r1, k.y, q1);
+}
+PFX_DEV float fdiv_fast(float n, float d) { return rdiv_apply(rdiv_prepare(d), n); }
+
 // Rust `v.clamp(0.0, 255.0) as u8` kept as an integer-valued float (0..255), NaN -> 0.
 PFX_DEV float quant255(float v)
 {

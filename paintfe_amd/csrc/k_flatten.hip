@@ -36,21 +36,7 @@ enum : uint32_t {
 // value below 2^-40) they are identities, so the sequence below produces the same bits with the reciprocal part
 // computed once per denominator.  tests/test_gpu_parity.py::test_fast_division_matches_ieee checks 2^28 operand
 // pairs against `/` on the device; every golden / oracle parity test runs through this path.
-struct rdiv { float d, y; };
-PFX_DEV rdiv rdiv_prepare(float d)
-{
-    const float y0 = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, y0, 1.0f);
-    return {d, __builtin_fmaf(e, y0, y0)};
-}
-PFX_DEV float rdiv_apply(const rdiv k, float n)
-{
-    const float q0 = n * k.y;
-    const float r0 = __builtin_fmaf(-k.d, q0, n);
-    const float q1 = __builtin_fmaf(r0, k.y, q0);
-    const float r1 = __builtin_fmaf(-k.d, q1, n);
-    return __builtin_fmaf(r1, k.y, q1);
-}
+// (rdiv / rdiv_prepare / rdiv_apply live in k_common.h)
 template <bool FAST> PFX_DEV float fdiv(float n, float d)
 {
     if constexpr (FAST) return rdiv_apply(rdiv_prepare(d), n);
@@ -200,18 +186,18 @@ PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float op
     acc[0] = skip ? acc[0] : o0; acc[1] = skip ? acc[1] : o1; acc[2] = skip ? acc[2] : o2; acc[3] = skip ? acc[3] : o3;
 }
 
-template <uint32_t M, bool F>
-PFX_DEV void blend4(float (&acc)[4][4], const uint32_t (&top)[4], float opacity_raw, float opc)
+template <uint32_t M, bool F, int PX>
+PFX_DEV void blendN(float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw, float opc)
 {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) blend_px<M, F>(acc[p], top[p], opacity_raw, opc);
+    for (int p = 0; p < PX; ++p) blend_px<M, F>(acc[p], top[p], opacity_raw, opc);
 }
 
-template <bool F>
-PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[4][4], const uint32_t (&top)[4], float opacity_raw, float opc)
+template <bool F, int PX = 4>
+PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw, float opc)
 {
     switch (mode) { // wave-uniform: one scalar branch per layer
-#define PFX_CASE(M) case M: blend4<M, F>(acc, top, opacity_raw, opc); break;
+#define PFX_CASE(M) case M: blendN<M, F, PX>(acc, top, opacity_raw, opc); break;
         PFX_CASE(M_NORMAL) PFX_CASE(M_MULTIPLY) PFX_CASE(M_SCREEN) PFX_CASE(M_ADDITIVE) PFX_CASE(M_REFLECT)
         PFX_CASE(M_GLOW) PFX_CASE(M_COLOR_BURN) PFX_CASE(M_COLOR_DODGE) PFX_CASE(M_OVERLAY) PFX_CASE(M_DIFFERENCE)
         PFX_CASE(M_NEGATION) PFX_CASE(M_LIGHTEN) PFX_CASE(M_DARKEN) PFX_CASE(M_XOR) PFX_CASE(M_OVERWRITE)
@@ -219,7 +205,7 @@ PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[4][4], const uint32_t (
         PFX_CASE(M_LINEAR_BURN) PFX_CASE(M_VIVID_LIGHT) PFX_CASE(M_LINEAR_LIGHT) PFX_CASE(M_PIN_LIGHT)
         PFX_CASE(M_HARD_MIX)
 #undef PFX_CASE
-    default: blend4<M_NORMAL, F>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
+    default: blendN<M_NORMAL, F, PX>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
     }
 }
 
@@ -347,6 +333,53 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
     }
 }
 
+// Raster-only, FAST-precondition stacks whose pixel count is a multiple of PX: the streaming core without the general
+// kernel's tail/mask/adjustment handling.  PX pixels per lane (PX*4-byte loads), MINW = waves/SIMD the register
+// allocator must allow.  Variants are selected with pfx_tune("flatten_variant", v) for measurement; all produce
+// identical results (same blend_px).
+template <int PX> struct px_vec;
+template <> struct px_vec<4> { using type = uint4; };
+template <> struct px_vec<2> { using type = uint2; };
+template <> struct px_vec<1> { using type = uint32_t; };
+
+template <int PX, int MINW>
+__global__ __launch_bounds__(256, MINW) void flatten_fast_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
+                                                                 size_t n_groups, uint8_t* __restrict__ dst)
+{
+    using V = typename px_vec<PX>::type;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_groups; q += (size_t)gridDim.x * blockDim.x) {
+        float acc[PX][4];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0f;
+        pfxk_layer_desc L = layers[0];
+        V v = reinterpret_cast<const V*>(L.pixels)[q];
+        for (uint32_t li = 0; li < n_layers; ++li) {
+            pfxk_layer_desc Ln = L;
+            V vn = v;
+            if (li + 1 < n_layers) { // prefetch layer li+1 before blending layer li
+                Ln = layers[li + 1];
+                vn = reinterpret_cast<const V*>(Ln.pixels)[q];
+            }
+            uint32_t top[PX];
+            __builtin_memcpy(top, &v, sizeof top);
+            uint32_t any_a = 0;
+#pragma unroll
+            for (int p = 0; p < PX; ++p) any_a |= top[p];
+            if (__any((any_a >> 24) != 0u)) blend4_dispatch<true, PX>(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
+            L = Ln;
+            v = vn;
+        }
+        uint32_t out[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) out[p] = pack_rgba(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+        V o;
+        __builtin_memcpy(&o, out, sizeof out);
+        reinterpret_cast<V*>(dst)[q] = o;
+    }
+}
+
+int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant)
+
 // chunk activity = union over visible raster layers of "chunk has any alpha != 0" (canvas_state.rs:529-550)
 __global__ __launch_bounds__(256) void chunk_active_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
                                                            uint32_t w, uint32_t h, uint8_t* __restrict__ chunk_active)
@@ -435,6 +468,8 @@ __global__ __launch_bounds__(256) void rdiv_check_kernel(uint64_t seed, uint32_t
 
 } // namespace
 
+extern "C" void pfxk_flatten_set_variant(int v) { g_flatten_variant = v; }
+
 extern "C" hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out)
 {
     rdiv_check_kernel<<<blocks, 256, 0, s>>>(seed, iters, d_out);
@@ -479,8 +514,21 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
         chunk_active_kernel<<<nchunks, 256, 0, stream>>>(d_layers, n_layers, w, h, d_chunk_active);
     }
     const uint32_t block = 256;
-    size_t blocks = (n_quads + block - 1) / block;
     const size_t cap = 256u * 8u * 4u; // 256 CUs x 8 blocks, x4 waves of grid-stride work granularity
+    const size_t n_px = (size_t)w * h;
+    if (!general && fast_div && n_layers > 0 && (n_px & 3u) == 0 && g_flatten_variant > 0) {
+        auto grid = [&](size_t groups) { size_t b = (groups + block - 1) / block; return (uint32_t)(b > cap ? cap : b); };
+        switch (g_flatten_variant) {
+        case 1: flatten_fast_kernel<4, 1><<<grid(n_px / 4), block, 0, stream>>>(d_layers, n_layers, n_px / 4, d_dst); break;
+        case 2: flatten_fast_kernel<4, 8><<<grid(n_px / 4), block, 0, stream>>>(d_layers, n_layers, n_px / 4, d_dst); break;
+        case 3: flatten_fast_kernel<2, 1><<<grid(n_px / 2), block, 0, stream>>>(d_layers, n_layers, n_px / 2, d_dst); break;
+        case 4: flatten_fast_kernel<2, 8><<<grid(n_px / 2), block, 0, stream>>>(d_layers, n_layers, n_px / 2, d_dst); break;
+        case 5: flatten_fast_kernel<1, 8><<<grid(n_px), block, 0, stream>>>(d_layers, n_layers, n_px, d_dst); break;
+        default: flatten_fast_kernel<4, 4><<<grid(n_px / 4), block, 0, stream>>>(d_layers, n_layers, n_px / 4, d_dst); break;
+        }
+        return hipGetLastError();
+    }
+    size_t blocks = (n_quads + block - 1) / block;
     if (blocks > cap) blocks = cap;
     const uint32_t g = (uint32_t)blocks;
 #define PFX_LAUNCH(G, F) flatten_kernel<G, F><<<g, block, 0, stream>>>(d_layers, n_layers, d_adj_table, (G) ? d_chunk_active : nullptr, w, h, d_dst)

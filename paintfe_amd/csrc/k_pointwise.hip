@@ -28,17 +28,20 @@ PFX_DEV hsl3 rgb_to_hsl(float r, float g, float b)
     const float mn = __builtin_fminf(__builtin_fminf(r, g), b);
     const float l = (mx + mn) / 2.0f;
     if (__builtin_fabsf(mx - mn) < 1e-6f) return {0.0f, 0.0f, l};
+    // Divisions via k_common.h:rdiv (bit-identical to '/'): inputs are k/255, so d = max-min >= 1/255, the saturation
+    // denominators are >= 1/255 and every numerator is 0 or >= 1/255 in magnitude — all in the normal range.
     const float d = mx - mn;
-    const float s = (l > 0.5f) ? d / (2.0f - mx - mn) : d / (mx + mn);
+    const float s = fdiv_fast(d, (l > 0.5f) ? (2.0f - mx - mn) : (mx + mn)); // selecting the operand == selecting the quotient
+    const rdiv kd = rdiv_prepare(d), k6 = rdiv_prepare(6.0f);
     float h;
     if (__builtin_fabsf(mx - r) < 1e-6f) {
-        h = (g - b) / d;
+        h = rdiv_apply(kd, g - b);
         if (h < 0.0f) h += 6.0f;
-        h = h / 6.0f;
+        h = rdiv_apply(k6, h);
     } else if (__builtin_fabsf(mx - g) < 1e-6f) {
-        h = ((b - r) / d + 2.0f) / 6.0f;
+        h = rdiv_apply(k6, rdiv_apply(kd, b - r) + 2.0f);
     } else {
-        h = ((r - g) / d + 4.0f) / 6.0f;
+        h = rdiv_apply(k6, rdiv_apply(kd, r - g) + 4.0f);
     }
     return {h, s, l};
 }
@@ -81,7 +84,7 @@ PFX_DEV void adjust_px(const pfxk_params& P, const uint8_t* __restrict__ lut, fl
         o[1] = P.p[1] * (g + P.p[0] - 128.0f) + 128.0f;
         o[2] = P.p[1] * (b + P.p[0] - 128.0f) + 128.0f;
     } else if constexpr (OP == PFXK_OP_HSL) { // p0 = hue_shift/360, p1 = sat_factor, p2 = light_offset
-        const hsl3 c = rgb_to_hsl(r / 255.0f, g / 255.0f, b / 255.0f);
+        const hsl3 c = rgb_to_hsl(div255(r), div255(g), div255(b)); // r, g, b are byte values: div255 == r / 255.0
         float nh = c.h + P.p[0];
         nh = nh - __builtin_truncf(nh); // f32::fract
         if (nh < 0.0f) nh = nh + 1.0f;
@@ -123,7 +126,7 @@ PFX_DEV void adjust_px(const pfxk_params& P, const uint8_t* __restrict__ lut, fl
         o[0] = v; o[1] = v; o[2] = v;
     } else if constexpr (OP == PFXK_OP_VIBRANCE) { // p0 = amount / 100
         const float v = P.p[0];
-        const hsl3 c = rgb_to_hsl(r / 255.0f, g / 255.0f, b / 255.0f);
+        const hsl3 c = rgb_to_hsl(div255(r), div255(g), div255(b)); // r, g, b are byte values: div255 == r / 255.0
         const float boost = (v >= 0.0f) ? v * ((1.0f - c.s) * (1.0f - c.s)) : v * (c.s * c.s);
         const float ns = rs_clamp(c.s + boost, 0.0f, 1.0f);
         const rgb3 n = hsl_to_rgb<false>(c.h, ns, c.l);
@@ -163,18 +166,19 @@ PFX_DEV void rhai_px(const pfxk_params& P, const uint8_t* __restrict__ lut, uint
         o[1] = quant255(P.p[1] * (g + P.p[0] - 128.0f) + 128.0f);
         o[2] = quant255(P.p[1] * (b + P.p[0] - 128.0f) + 128.0f);
     } else if constexpr (OP == PFXK_RHAI_HSL) { // p0 = hue_shift/360, p1 = sat_factor, p2 = light_offset
-        const float rn = r / 255.0f, gn = g / 255.0f, bn = b / 255.0f;
+        const float rn = div255(r), gn = div255(g), bn = div255(b);
         const float cmax = __builtin_fmaxf(__builtin_fmaxf(rn, gn), bn), cmin = __builtin_fminf(__builtin_fminf(rn, gn), bn);
         const float l = (cmax + cmin) / 2.0f;
         float h = 0.0f, s = 0.0f;
-        if (!(__builtin_fabsf(cmax - cmin) < 1e-10f)) {
+        if (!(__builtin_fabsf(cmax - cmin) < 1e-10f)) { // k/255 inputs: distinct values differ by >= 1/255 (same ranges as rgb_to_hsl)
             const float d = cmax - cmin;
-            s = (l > 0.5f) ? d / (2.0f - cmax - cmin) : d / (cmax + cmin);
+            s = fdiv_fast(d, (l > 0.5f) ? (2.0f - cmax - cmin) : (cmax + cmin));
+            const rdiv kd = rdiv_prepare(d);
             float hh;
-            if (__builtin_fabsf(cmax - rn) < 1e-10f) hh = (gn - bn) / d + ((gn < bn) ? 6.0f : 0.0f);
-            else if (__builtin_fabsf(cmax - gn) < 1e-10f) hh = (bn - rn) / d + 2.0f;
-            else hh = (rn - gn) / d + 4.0f;
-            h = hh / 6.0f;
+            if (__builtin_fabsf(cmax - rn) < 1e-10f) hh = rdiv_apply(kd, gn - bn) + ((gn < bn) ? 6.0f : 0.0f);
+            else if (__builtin_fabsf(cmax - gn) < 1e-10f) hh = rdiv_apply(kd, bn - rn) + 2.0f;
+            else hh = rdiv_apply(kd, rn - gn) + 4.0f;
+            h = fdiv_fast(hh, 6.0f);
         }
         float nh = h + P.p[0];
         { // f32::rem_euclid(1.0)

@@ -94,34 +94,36 @@ PFX_DEV float2 cr_surface(const float2* __restrict__ pts, uint32_t cols, uint32_
 
 constexpr uint32_t MESH_LDS_PTS = 2048; // control points per grid staged in LDS (2 grids x 16 KiB)
 
-// MODE 0: write displacement field; MODE 1: fused field + gather
-template <int MODE>
+// MODE 0: write displacement field; MODE 1: fused field + gather.  IN_LDS: control points staged in LDS (the normal
+// case: a 6x6 grid is 49 points); the pointer's address space is then known at compile time (ds_read, not flat_load).
+template <int MODE, bool IN_LDS>
 __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ g_orig,
                                                    const float2* __restrict__ g_def, uint32_t cols, uint32_t rows,
                                                    uint32_t w, uint32_t h, float2* __restrict__ disp,
                                                    uint32_t* __restrict__ dst)
 {
-    __shared__ float2 s_orig[MESH_LDS_PTS];
-    __shared__ float2 s_def[MESH_LDS_PTS];
-    const uint32_t npts = (cols + 1u) * (rows + 1u);
-    const bool in_lds = npts <= MESH_LDS_PTS;
-    if (in_lds) {
+    __shared__ float2 s_orig[IN_LDS ? MESH_LDS_PTS : 1];
+    __shared__ float2 s_def[IN_LDS ? MESH_LDS_PTS : 1];
+    if constexpr (IN_LDS) {
+        const uint32_t npts = (cols + 1u) * (rows + 1u);
         for (uint32_t i = threadIdx.x; i < npts; i += 256u) {
             if (g_orig) s_orig[i] = g_orig[i];
             s_def[i] = g_def[i];
         }
         __syncthreads();
     }
-    const float2* orig = g_orig ? (in_lds ? s_orig : g_orig) : nullptr;
-    const float2* def = in_lds ? s_def : g_def;
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    const float u = ((float)x + 0.5f) / (float)w * (float)cols; // :1687-1688
-    const float v = ((float)y + 0.5f) / (float)h * (float)rows;
-    const float2 d = cr_surface(def, cols, rows, u, v);
-    float2 o;
-    if (orig) o = cr_surface(orig, cols, rows, u, v);
-    else o = make_float2((float)x + 0.5f, (float)y + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
+    // :1687-1688; operands in [0.5, 2^15]: k_common.h:fdiv_fast is bit-identical to '/'
+    const float u = fdiv_fast((float)x + 0.5f, (float)w) * (float)cols;
+    const float v = fdiv_fast((float)y + 0.5f, (float)h) * (float)rows;
+    float2 d, o;
+    if constexpr (IN_LDS) d = cr_surface(s_def, cols, rows, u, v);
+    else d = cr_surface(g_def, cols, rows, u, v);
+    if (g_orig) {
+        if constexpr (IN_LDS) o = cr_surface(s_orig, cols, rows, u, v);
+        else o = cr_surface(g_orig, cols, rows, u, v);
+    } else o = make_float2((float)x + 0.5f, (float)y + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
     const float ddx = d.x - o.x, ddy = d.y - o.y;
     const size_t i = (size_t)y * w + x;
     if constexpr (MODE == 0) disp[i] = make_float2(ddx, ddy);
@@ -145,8 +147,10 @@ extern "C" hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig,
 {
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 3) / 4);
-    mesh_kernel<0><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h,
-                                     (float2*)d_disp, nullptr);
+    if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
+        mesh_kernel<0, true><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr);
+    else
+        mesh_kernel<0, false><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr);
     return hipGetLastError();
 }
 
@@ -155,7 +159,9 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
 {
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 3) / 4);
-    mesh_kernel<1><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h,
-                                     nullptr, (uint32_t*)d_dst);
+    if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
+        mesh_kernel<1, true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst);
+    else
+        mesh_kernel<1, false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst);
     return hipGetLastError();
 }

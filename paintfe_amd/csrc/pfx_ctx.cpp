@@ -139,12 +139,12 @@ int pfx_ctx_set_exact(pfx_ctx* ctx, int exact)
 
 void* pfx_ctx_stream(pfx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-int pfx_ctx_set_stream(pfx_ctx* ctx, void* hip_stream)
+int pfx_ctx_set_stream(pfx_ctx* ctx, void* hip_stream, int adopt)
 {
     if (!ctx) return PFX_ERR_INVALID;
     PFX_TRY(pfx_use(ctx));
     PFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = adopt ? (hipStream_t)hip_stream : ctx->own_stream;
     return PFX_OK;
 }
 

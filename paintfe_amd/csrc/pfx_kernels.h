@@ -37,6 +37,7 @@ enum { PFXK_RHAI_INVERT = 0, PFXK_RHAI_DESATURATE, PFXK_RHAI_SEPIA, PFXK_RHAI_SE
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                         const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, uint32_t w,
                         uint32_t h, uint8_t* d_dst);
+void       pfxk_flatten_set_variant(int v); // tuning knob: 0 = shipped kernel, 1.. = experimental pixels-per-lane / occupancy variants
 // counts (into *d_out) operand pairs for which the shared-reciprocal division differs from the IEEE divide
 hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out);
 
@@ -72,6 +73,15 @@ hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, cons
                        uint32_t w, uint32_t h);
 hipError_t pfxk_pixelate(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, uint32_t bs,
                          uint32_t w, uint32_t h);
+
+// ---- k_effects.hip ---- sharpen / glow combine pass, bokeh disc blur, motion blur
+enum { PFXK_FX_SHARPEN = 0, PFXK_FX_GLOW = 1 };
+hipError_t pfxk_combine(hipStream_t s, const uint8_t* d_src, const uint8_t* d_blur, const uint8_t* d_mask, uint8_t* d_dst,
+                        uint32_t w, uint32_t h, int op, float p0);
+hipError_t pfxk_bokeh(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, const int32_t* d_spans_dy_hw,
+                      int n_spans, float inv_count, uint32_t w, uint32_t h);
+hipError_t pfxk_motion(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, int steps, float dx, float dy,
+                       float inv_steps, uint32_t w, uint32_t h);
 
 // ---- k_warp.hip ----
 hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, const float* d_disp,

@@ -221,8 +221,8 @@ bool sig(const Call& c, std::initializer_list<Tok> want)
 }
 
 // effect names that exist in the reference but are outside this back-end's scope
-const char* kNotProvided[] = {"apply_motion_blur", "apply_sharpen", "apply_reduce_noise", "apply_noise", "apply_crystallize", "apply_bulge",
-                              "apply_twist", "apply_glow", "apply_vignette", "apply_halftone", "apply_ink", "apply_oil_painting",
+const char* kNotProvided[] = {"apply_reduce_noise", "apply_noise", "apply_crystallize", "apply_bulge",
+                              "apply_twist", "apply_vignette", "apply_halftone", "apply_ink", "apply_oil_painting",
                               "for_each_pixel", "map_channels", "for_region", "get_pixel", "set_pixel", "flip_horizontal", "flip_vertical",
                               "rotate_180", "rotate_canvas_90cw", "rotate_canvas_90ccw", "rotate_canvas_180", "flip_canvas_horizontal",
                               "flip_canvas_vertical", "resize_image", "resize_canvas", "select_rect", "clear_selection", "invert_selection",
@@ -249,6 +249,15 @@ int run_calls(pfx_ctx* ctx, const std::vector<Call>& calls, void* d_img, void* d
             swapped = true;
         } else if (c.name == "apply_pixelate" && sig(c, {Tok::Int})) { // :1096 pixelate_core(img, size.max(1) as u32, mask)
             st = pfx_pixelate_dev(ctx, cur, other, w, h, (uint32_t)std::max<int64_t>(c.args[0].i, 1), d_mask);
+            swapped = true;
+        } else if (c.name == "apply_motion_blur" && sig(c, {Tok::Float, Tok::Float})) { // :839 motion_blur_core(img, angle, distance, mask)
+            st = pfx_motion_blur_dev(ctx, cur, other, w, h, (float)c.args[0].f, (float)c.args[1].f, d_mask);
+            swapped = true;
+        } else if (c.name == "apply_sharpen" && sig(c, {Tok::Float})) { // :847 sharpen_core(img, amount as f32, 1.0, mask)
+            st = pfx_sharpen_dev(ctx, cur, other, w, h, (float)c.args[0].f, 1.0f, d_mask);
+            swapped = true;
+        } else if (c.name == "apply_glow" && sig(c, {Tok::Float, Tok::Float})) { // :1125 glow_core(img, radius, intensity, mask)
+            st = pfx_glow_dev(ctx, cur, other, w, h, (float)c.args[0].f, (float)c.args[1].f, d_mask);
             swapped = true;
         } else if (c.name == "apply_invert" && sig(c, {})) {
             st = pfx_rhai_adjust_dev(ctx, cur, w, h, PFX_RHAI_INVERT, nullptr, 0);

@@ -85,7 +85,12 @@ class GpuRenderer:
         return int(self._lib.pfx_ctx_stream(self._h) or 0)
 
     def set_stream(self, hip_stream: int):
-        self._check(self._lib.pfx_ctx_set_stream(self._h, C.c_void_p(hip_stream)))
+        """hip_stream: an integer hipStream_t (0 = the device's default stream, e.g. torch's default), or None to go
+        back to the context's own stream."""
+        if hip_stream is None:
+            self._check(self._lib.pfx_ctx_set_stream(self._h, None, C.c_int(0)))
+        else:
+            self._check(self._lib.pfx_ctx_set_stream(self._h, C.c_void_p(hip_stream or None), C.c_int(1)))
 
     def set_exact(self, exact: bool):
         self._check(self._lib.pfx_ctx_set_exact(self._h, C.c_int(int(exact))))
@@ -140,6 +145,18 @@ class GpuRenderer:
 
     def pixelate_core(self, img, block_size: int, mask=None):
         return self._img_call(self._lib.pfx_pixelate_core, img, C.c_uint32(block_size), mask=mask)
+
+    def sharpen_core(self, img, amount: float, radius: float, mask=None):      # stylize.rs:96
+        return self._img_call(self._lib.pfx_sharpen_core, img, C.c_float(amount), C.c_float(radius), mask=mask)
+
+    def glow_core(self, img, radius: float, intensity: float, mask=None):      # stylize.rs:26
+        return self._img_call(self._lib.pfx_glow_core, img, C.c_float(radius), C.c_float(intensity), mask=mask)
+
+    def bokeh_blur_core(self, img, radius: float, mask=None):                   # blur.rs:22
+        return self._img_call(self._lib.pfx_bokeh_blur_core, img, C.c_float(radius), mask=mask)
+
+    def motion_blur_core(self, img, angle_deg: float, distance: float, mask=None):  # blur.rs:144
+        return self._img_call(self._lib.pfx_motion_blur_core, img, C.c_float(angle_deg), C.c_float(distance), mask=mask)
 
     def adjust(self, img, op, params: Sequence[float] = (), lut=None, mask=None, sparse: int = DENSE):
         opi = ADJUST_OPS.index(op) if isinstance(op, str) else int(op)

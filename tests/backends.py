@@ -29,6 +29,18 @@ class OracleBackend:
     def pixelate(self, img, block, mask=None):
         return O.pixelate(img, block, mask)
 
+    def sharpen(self, img, amount, radius, mask=None):
+        return O.sharpen(img, amount, radius, mask)
+
+    def glow(self, img, radius, intensity, mask=None):
+        return O.glow(img, radius, intensity, mask)
+
+    def bokeh_blur(self, img, radius, mask=None):
+        return O.bokeh_blur(img, radius, mask)
+
+    def motion_blur(self, img, angle_deg, distance, mask=None):
+        return O.motion_blur(img, angle_deg, distance, mask)
+
     def rhai_adjust(self, img, op, params=()):
         return O.rhai_adjust(img, op, params)
 
@@ -99,6 +111,26 @@ class GpuBackend:
 
     def pixelate(self, img, block, mask=None):
         return self.r.pixelate_core(img, block, mask)
+
+    def sharpen(self, img, amount, radius, mask=None):
+        self.r.set_exact(True)  # composite effects amplify the Gaussian's +-1 LSB; goldens are held at tolerance 0
+        try:
+            return self.r.sharpen_core(img, amount, radius, mask)
+        finally:
+            self.r.set_exact(False)
+
+    def glow(self, img, radius, intensity, mask=None):
+        self.r.set_exact(True)
+        try:
+            return self.r.glow_core(img, radius, intensity, mask)
+        finally:
+            self.r.set_exact(False)
+
+    def bokeh_blur(self, img, radius, mask=None):
+        return self.r.bokeh_blur_core(img, radius, mask)
+
+    def motion_blur(self, img, angle_deg, distance, mask=None):
+        return self.r.motion_blur_core(img, angle_deg, distance, mask)
 
     def rhai_adjust(self, img, op, params=()):
         return self.r.rhai_adjust(img, op, params)

@@ -82,6 +82,11 @@ def filter_cases():
         ("filters/median_r2", "median", dict(img=t, radius=2)),
         ("filters/pixelate_8", "pixelate", dict(img=t, block=8)),
         ("scripting/apply_pixelate", "pixelate", dict(img=t, block=4)),
+        # effects built from the same kernels (tests/visual_filters.rs:43-55,154-165)
+        ("filters/sharpen_a1_r1", "sharpen", dict(img=t, amount=1.0, radius=1.0)),
+        ("filters/glow_r3_i05", "glow", dict(img=t, radius=3.0, intensity=0.5)),
+        ("filters/bokeh_blur_r5", "bokeh_blur", dict(img=t, radius=5.0)),
+        ("filters/motion_blur_45_10", "motion_blur", dict(img=t, angle_deg=45.0, distance=10.0)),
     ]
 
 

@@ -183,6 +183,22 @@ def pixelate(img, block, mask=None, threads=0):
     return _img_op(lib().pfxo_pixelate, img, C.c_uint32(block), mask=mask, threads=threads)
 
 
+def glow(img, radius, intensity, mask=None, threads=0):
+    return _img_op(lib().pfxo_glow, img, C.c_float(radius), C.c_float(intensity), mask=mask, threads=threads)
+
+
+def sharpen(img, amount, radius, mask=None, threads=0):
+    return _img_op(lib().pfxo_sharpen, img, C.c_float(amount), C.c_float(radius), mask=mask, threads=threads)
+
+
+def bokeh_blur(img, radius, mask=None, threads=0):
+    return _img_op(lib().pfxo_bokeh_blur, img, C.c_float(radius), mask=mask, threads=threads)
+
+
+def motion_blur(img, angle_deg, distance, mask=None, threads=0):
+    return _img_op(lib().pfxo_motion_blur, img, C.c_float(angle_deg), C.c_float(distance), mask=mask, threads=threads)
+
+
 def adjust(img, op, params=(), lut=None, mask=None, sparse=DENSE, threads=0):
     h, w = img.shape[:2]
     src, ps = _u8(img)

@@ -325,7 +325,7 @@ def test_warp_source_size_differs_from_field(gpu, oracle):
     assert_same(gpu.warp_displacement(img, disp), oracle.warp_displacement(img, disp), 0, "src != field size")
 
 
-@pytest.mark.parametrize("grid", [(2, 2), (6, 6), (1, 1), (9, 4)])
+@pytest.mark.parametrize("grid", [(2, 2), (6, 6), (1, 1), (9, 4), (63, 40)])  # (63,40): > 2048 points, non-LDS path
 def test_mesh_warp_and_field(gpu, grid):
     cols, rows = grid
     w, h = 300, 170
@@ -387,3 +387,32 @@ def test_errors_leave_dst_untouched(gpu):
     assert st == _lib.ERR_INVALID and (dst == 0xAB).all()
     st = lib.pfx_blur_rgba(gpu.r.handle, None, dst.ctypes.data_as(C.c_void_p), C.c_uint32(16), C.c_uint32(16), C.c_float(2.0))
     assert st == _lib.ERR_INVALID and b"null" in lib.pfx_last_error(gpu.r.handle)
+
+
+# ------------------------------------------------------------------ effects built from the same kernels (N3)
+@pytest.mark.parametrize("amount,radius", [(1.0, 1.0), (2.5, 3.0), (0.0, 2.0), (-0.5, 0.7)])
+def test_sharpen_vs_oracle(gpu, oracle, amount, radius):
+    img = I.random_rgba(211, 97, 5)
+    mask = (np.random.default_rng(8).random((97, 211)) < 0.6).astype(np.uint8)
+    assert_same(gpu.sharpen(img, amount, radius), oracle.sharpen(img, amount, radius), 0, "sharpen")
+    assert_same(gpu.sharpen(img, amount, radius, mask), oracle.sharpen(img, amount, radius, mask), 0, "sharpen masked")
+
+
+@pytest.mark.parametrize("radius,intensity", [(3.0, 0.5), (8.0, 1.7), (0.0, 1.0)])
+def test_glow_vs_oracle(gpu, oracle, radius, intensity):
+    img = I.random_rgba(140, 120, 6)
+    assert_same(gpu.glow(img, radius, intensity), oracle.glow(img, radius, intensity), 0, "glow")
+
+
+@pytest.mark.parametrize("radius", [0.3, 0.5, 1.0, 5.0, 12.7])
+def test_bokeh_bitexact(gpu, oracle, radius):
+    img = I.random_rgba(150, 90, int(radius * 10))
+    mask = (np.random.default_rng(9).random((90, 150)) < 0.5).astype(np.uint8)
+    assert_same(gpu.bokeh_blur(img, radius), oracle.bokeh_blur(img, radius), 0, f"bokeh r={radius}")
+    assert_same(gpu.bokeh_blur(img, radius, mask), oracle.bokeh_blur(img, radius, mask), 0, f"bokeh r={radius} masked")
+
+
+@pytest.mark.parametrize("angle,distance", [(45.0, 10.0), (0.0, 1.0), (90.0, 25.5), (-133.0, 7.2), (30.0, 0.5)])
+def test_motion_blur_bitexact(gpu, oracle, angle, distance):
+    img = I.random_rgba(173, 88, 12)
+    assert_same(gpu.motion_blur(img, angle, distance), oracle.motion_blur(img, angle, distance), 0, f"motion {angle} {distance}")

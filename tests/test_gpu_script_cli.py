@@ -46,7 +46,8 @@ def test_script_chain_comments_and_console(r):
     apply_box_blur(2);
     apply_median(1);
     apply_levels(10.0, 240.0, 1.1);
-    apply_exposure(-0.5); apply_sepia(0.25)
+    apply_exposure(-0.5); apply_sepia(0.25);
+    apply_sharpen(1.5); apply_glow(2.0, 0.4); apply_motion_blur(30.0, 4.0)
     """
     r.set_exact(True)
     out, console = r.execute_script_sync(src, img)
@@ -59,6 +60,9 @@ def test_script_chain_comments_and_console(r):
     ref = O.rhai_adjust(ref, "levels", [10.0, 240.0, 1.1])
     ref = O.rhai_adjust(ref, "exposure", [-0.5])
     ref = O.rhai_adjust(ref, "sepia_strength", [0.25])
+    ref = O.sharpen(ref, 1.5, 1.0)
+    ref = O.glow(ref, 2.0, 0.4)
+    ref = O.motion_blur(ref, 30.0, 4.0)
     assert np.array_equal(out, ref)
     assert console == ["done"]
 
@@ -79,7 +83,7 @@ def test_script_selection_mask(r):
 @pytest.mark.parametrize("src,status,needle", [
     ("apply_blur(2);", -6, "Function not found: apply_blur (i64)"),          # Rhai does not coerce i64 -> f64
     ("apply_frobnicate(1.0);", -6, "Function not found: apply_frobnicate (f64)"),
-    ("apply_glow(3.0, 0.5);", -5, "not provided by the HIP back-end"),
+    ("apply_vignette(0.8, 0.5);", -5, "not provided by the HIP back-end"),
     ("let x = 4.0; apply_blur(x);", -5, "full language runtime"),
     ("map_channels(|r, g, b, a| { [255 - r, g, b, a] });", -5, "literal"),
     ("apply_blur(2.0", -6, "Expecting ')'"),
