@@ -126,16 +126,23 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PFX_BENCH_BACKEND=gloo is a plumbing self-test only: it lets N ranks share the one GPU of a development box
+    # (RCCL refuses two ranks per device).  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("PFX_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     from paintfe_amd import GpuRenderer
-    r = GpuRenderer(local_rank)
+    r = GpuRenderer(dev_index)
     r.set_exact(args.exact)
     for kv in args.tune:
         k, v = kv.split('=')
@@ -196,9 +203,8 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     r.timing_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from paintfe_amd.sharding import max_over_ranks
+        elapsed = max_over_ranks(elapsed, device=device)  # the step time of the job is the slowest rank's
 
     px_per_step = w * h
     docs = 1 if band_mode else world                        # band mode: the whole job is one document per step
@@ -245,6 +251,15 @@ def main() -> int:
             out["check"] = {"flatten_crop_bitexact": bool(np.array_equal(ref, got))}
             if not out["check"]["flatten_crop_bitexact"]:
                 out["check"]["mismatching_px"] = int((ref != got).any(-1).sum())
+
+        if band_mode and w * h <= (1 << 22) and hh > 0:
+            # small documents only: rank 0 rebuilds the whole document and checks ITS band of the sharded result (which
+            # needed rank 1's halo rows) against the single-process oracle pipeline
+            full = torch.stack([synth_layer(torch, device, w, h, k, 0x5EED0002) for k in range(n)]).cpu().numpy()
+            ref_blur = O.gaussian_blur(O.flatten_stack(full, modes, opac), args.sigma)[y0:y1]
+            got_blur = state["result"].contiguous().cpu().numpy()
+            dmax = int(np.abs(ref_blur.astype(np.int16) - got_blur.astype(np.int16)).max())
+            out.setdefault("check", {})["band_blur_max_diff_vs_single_process"] = dmax
 
         if not args.no_cpu_baseline and world == 1:
             # bounded sample of the same workload: a 3840x2160 window of the same 32-layer stack

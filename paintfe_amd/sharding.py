@@ -63,6 +63,9 @@ def exchange_halo(band, height: int, radius: int, group=None):
     rank = dist.get_rank(group)
     y0, y1 = band_rows(height, world, rank)
     my_need = halo_plan(height, world, rank, radius)
+    out_device = band.device
+    if band.device.type == "cuda" and dist.get_backend(group) == "gloo":
+        band = band.cpu()  # plumbing self-test on a single-GPU box: gloo moves host memory; RCCL moves device memory
     ops, recv_bufs = [], []
     for (src, s0, s1) in my_need:
         buf = torch.empty((s1 - s0,) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
@@ -85,7 +88,7 @@ def exchange_halo(band, height: int, radius: int, group=None):
     top = sum(int(b.shape[0]) for b in above)
     bottom = sum(int(b.shape[0]) for b in below)
     padded = torch.cat(above + [band] + below, dim=0) if (above or below) else band
-    return padded, top, bottom
+    return padded.to(out_device), top, bottom
 
 
 def gather_bands(band, height: int, group=None):
@@ -110,6 +113,8 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()):
         return value
+    if dist.get_backend(group) == "gloo":
+        device = None
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())

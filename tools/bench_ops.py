@@ -78,7 +78,18 @@ def main() -> int:
     timed("median r=1", ["median"], lambda: r.median_dev(s, d, w, h, 1), px, 8)
     timed("median r=2", ["median"], lambda: r.median_dev(s, d, w, h, 2), px, 8)
     timed("median r=7", ["median"], lambda: r.median_dev(s, d, w, h, 7), px, 8, "225-element windows")
-    del src, dst, tmp, mask
+    del tmp, mask
+    # ---------------- compositor, one blend mode at a time: 8 layers of the same mode over an opaque background (8K)
+    from paintfe_amd import BLEND_MODES
+    nl = 9
+    layers = [src] + [torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=dev, generator=g) for _ in range(nl - 1)]
+    layers[0][..., 3] = 255
+    ptrs = [t_.data_ptr() for t_ in layers]
+    for m, name in enumerate(BLEND_MODES):
+        info = [(0, 1.0, True, 0)] + [(k, 0.8, True, m) for k in range(1, nl)]
+        timed(f"flatten 9 layers, mode {m} {name}", ["flatten"], lambda: r.flatten_dev(ptrs, info, w, h, d), px, 4 * nl + 4,
+              f"{(nl - 1)} blends/px")
+    del layers, src, dst
 
     # ---------------- 16K (config 4: mesh warp 6x6 Catmull-Rom + liquify displacement)
     w, h = 15360, 8640
