@@ -113,6 +113,69 @@ int pfx_bokeh_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t
 int pfx_motion_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float angle_deg,
                          float distance, const uint8_t* mask);
 
+/* ---- the rest of the effect bank: every remaining `*_core(flat, params.., mask) -> RgbaImage` of src/ops/effects/ ----
+ * Same convention as above (caller-allocated dst, mask = w*h bytes or NULL, 0 leaves the pixel).  Integer / hash based
+ * effects are bit-exact with the CPU path; twist, gaussian noise, reduce_noise and vignette evaluate one libm function
+ * per pixel and are in the +-1 LSB class.  Enumerations mirror the reference enums in declaration order. */
+enum { PFX_NOISE_UNIFORM = 0, PFX_NOISE_GAUSSIAN = 1, PFX_NOISE_PERLIN = 2 };                        /* NoiseType, distort.rs:501-506 */
+enum { PFX_HALFTONE_CIRCLE = 0, PFX_HALFTONE_SQUARE = 1, PFX_HALFTONE_DIAMOND = 2, PFX_HALFTONE_LINE = 3 }; /* HalftoneShape, stylize.rs:195-201 */
+enum { PFX_GRID_LINES = 0, PFX_GRID_CHECKERBOARD = 1 };                                              /* GridStyle, stylize.rs:285-289 */
+enum { PFX_OUTLINE_OUTSIDE = 0, PFX_OUTLINE_INSIDE = 1, PFX_OUTLINE_CENTER = 2 };                    /* OutlineMode, render.rs:353-358 */
+enum { PFX_COLOR_FILTER_MULTIPLY = 0, PFX_COLOR_FILTER_SCREEN = 1, PFX_COLOR_FILTER_OVERLAY = 2, PFX_COLOR_FILTER_SOFT_LIGHT = 3 }; /* artistic.rs:219-225 */
+/* zoom_blur_core (ref: src/ops/effects/blur.rs:322-427); tint_color = RGBA in 0..1, may be NULL (= no tint) */
+int pfx_zoom_blur_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float center_x, float center_y, float strength,
+                       uint32_t samples, const float tint_color[4], float tint_strength, const uint8_t* mask);
+/* crystallize_core (ref: src/ops/effects/distort.rs:26-169) */
+int pfx_crystallize_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float cell_size, uint32_t seed, const uint8_t* mask);
+/* dents_core (ref: src/ops/effects/distort.rs:248-310) */
+int pfx_dents_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float scale, float amount, uint32_t seed,
+                   uint32_t octaves, float roughness, int pinch, int wrap, const uint8_t* mask);
+/* bulge_core_at / twist_core_at (ref: src/ops/effects/distort.rs:400-437, 464-493); bulge_core / twist_core = origin (0.5, 0.5) */
+int pfx_bulge_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float amount, float origin_x, float origin_y,
+                   const uint8_t* mask);
+int pfx_twist_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float angle_deg, float origin_x, float origin_y,
+                   const uint8_t* mask);
+/* add_noise_core (ref: src/ops/effects/noise.rs:73-143) */
+int pfx_add_noise_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float amount, int noise_type, int monochrome,
+                       uint32_t seed, float scale, uint32_t octaves, const uint8_t* mask);
+/* reduce_noise_core (ref: src/ops/effects/noise.rs:172-261) */
+int pfx_reduce_noise_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float strength, uint32_t radius,
+                          const uint8_t* mask);
+/* vignette_core (ref: src/ops/effects/stylize.rs:170-191) */
+int pfx_vignette_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float amount, float softness, const uint8_t* mask);
+/* halftone_core (ref: src/ops/effects/stylize.rs:242-277) */
+int pfx_halftone_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float dot_size, float angle_deg, int shape,
+                      const uint8_t* mask);
+/* grid_core (ref: src/ops/effects/render.rs:52-92) */
+int pfx_grid_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t cell_w, uint32_t cell_h, uint32_t line_width,
+                  const uint8_t color[4], int style, float opacity, const uint8_t* mask);
+/* canvas_border_core (ref: src/ops/effects/render.rs:114-165) */
+int pfx_canvas_border_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t width, const uint8_t color[4],
+                           const uint8_t* mask);
+/* shadow_core (ref: src/ops/effects/render.rs:220-349); the Gaussian inside follows pfx_ctx_set_exact */
+int pfx_shadow_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, int32_t offset_x, int32_t offset_y, float blur_radius,
+                    int widen_radius, const uint8_t color[4], float opacity, const uint8_t* mask);
+/* outline_core (ref: src/ops/effects/render.rs:403-572) */
+int pfx_outline_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t width, const uint8_t color[4], int mode,
+                     int anti_alias, const uint8_t* mask);
+/* pixel_drag_core (ref: src/ops/effects/glitch.rs:44-99) */
+int pfx_pixel_drag_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t seed, float amount, uint32_t distance,
+                        float direction, const uint8_t* mask);
+/* rgb_displace_core(flat, r_off, g_off, b_off, mask) (ref: src/ops/effects/glitch.rs:142-196) */
+int pfx_rgb_displace_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, int32_t r_dx, int32_t r_dy, int32_t g_dx,
+                          int32_t g_dy, int32_t b_dx, int32_t b_dy, const uint8_t* mask);
+/* ink_core (ref: src/ops/effects/artistic.rs:31-99) */
+int pfx_ink_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float edge_strength, float threshold, const uint8_t* mask);
+/* oil_painting_core (ref: src/ops/effects/artistic.rs:123-215) */
+int pfx_oil_painting_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t radius, uint32_t levels,
+                          const uint8_t* mask);
+/* color_filter_core (ref: src/ops/effects/artistic.rs:266-309) */
+int pfx_color_filter_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, const uint8_t filter_color[4], float intensity,
+                          int mode, const uint8_t* mask);
+/* contours_core (ref: src/ops/effects/contours.rs:56-112) */
+int pfx_contours_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float scale, float frequency, float line_width,
+                      const uint8_t line_color[4], uint32_t seed, uint32_t octaves, float blend, const uint8_t* mask);
+
 /* ---- the pointwise adjustment bank: one entry point, op id + parameter block ----
  * ops::adjustments flavour (f32, `.round().clamp(0,255) as u8`), ref: src/ops/adjustments.rs:21-108 */
 typedef enum pfx_adjust_op {
@@ -275,6 +338,43 @@ int pfx_bokeh_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_
                        const void* mask_dev);
 int pfx_motion_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float angle_deg,
                         float distance, const void* mask_dev);
+/* the rest of the effect bank on device-resident images (src_dev != dst_dev except for the purely pointwise ones) */
+int pfx_zoom_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float center_x, float center_y, float strength,
+                      uint32_t samples, const float tint_color[4], float tint_strength, const void* mask_dev);
+int pfx_crystallize_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float cell_size, uint32_t seed,
+                        const void* mask_dev);
+int pfx_dents_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float scale, float amount, uint32_t seed,
+                  uint32_t octaves, float roughness, int pinch, int wrap, const void* mask_dev);
+int pfx_bulge_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float amount, float origin_x, float origin_y,
+                  const void* mask_dev);
+int pfx_twist_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float angle_deg, float origin_x, float origin_y,
+                  const void* mask_dev);
+int pfx_add_noise_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float amount, int noise_type, int monochrome,
+                      uint32_t seed, float scale, uint32_t octaves, const void* mask_dev);
+int pfx_reduce_noise_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float strength, uint32_t radius,
+                         const void* mask_dev);
+int pfx_vignette_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float amount, float softness, const void* mask_dev);
+int pfx_halftone_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float dot_size, float angle_deg, int shape,
+                     const void* mask_dev);
+int pfx_grid_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t cell_w, uint32_t cell_h, uint32_t line_width,
+                 const uint8_t color[4], int style, float opacity, const void* mask_dev);
+int pfx_canvas_border_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t width, const uint8_t color[4],
+                          const void* mask_dev);
+int pfx_shadow_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, int32_t offset_x, int32_t offset_y, float blur_radius,
+                   int widen_radius, const uint8_t color[4], float opacity, const void* mask_dev);
+int pfx_outline_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t width, const uint8_t color[4], int mode,
+                    int anti_alias, const void* mask_dev);
+int pfx_pixel_drag_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t seed, float amount, uint32_t distance,
+                       float direction, const void* mask_dev);
+int pfx_rgb_displace_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, int32_t r_dx, int32_t r_dy, int32_t g_dx,
+                         int32_t g_dy, int32_t b_dx, int32_t b_dy, const void* mask_dev);
+int pfx_ink_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float edge_strength, float threshold, const void* mask_dev);
+int pfx_oil_painting_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius, uint32_t levels,
+                         const void* mask_dev);
+int pfx_color_filter_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, const uint8_t filter_color[4], float intensity,
+                         int mode, const void* mask_dev);
+int pfx_contours_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float scale, float frequency, float line_width,
+                     const uint8_t line_color[4], uint32_t seed, uint32_t octaves, float blend, const void* mask_dev);
 
 /* device self-test: compares the compositor's shared-reciprocal division with the compiler's IEEE f32 divide on
  * n_millions*1e6 random operand pairs drawn from the kernel's operand range; *mismatches must come back 0 */

@@ -82,6 +82,39 @@ void pfxo_sharpen(const uint8_t* src, uint32_t w, uint32_t h, float amount, floa
 void pfxo_bokeh_blur(const uint8_t* src, uint32_t w, uint32_t h, float radius, const uint8_t* mask, uint8_t* dst, int threads);
 void pfxo_motion_blur(const uint8_t* src, uint32_t w, uint32_t h, float angle_deg, float distance, const uint8_t* mask, uint8_t* dst, int threads);
 
+/* the rest of the effect bank (o_effects2.c; src/ops/effects/{blur,distort,noise,stylize,render,glitch,artistic,contours}.rs) */
+float pfxo_hash_f32(uint32_t x, uint32_t y, uint32_t seed);
+float pfxo_turbulence_2d(float x, float y, uint32_t seed, uint32_t octaves, float roughness);
+void pfxo_zoom_blur(const uint8_t* src, uint32_t w, uint32_t h, float center_x, float center_y, float strength, uint32_t samples,
+                    const float tint_color[4], float tint_strength, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_crystallize(const uint8_t* src, uint32_t w, uint32_t h, float cell_size, uint32_t seed, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_dents(const uint8_t* src, uint32_t w, uint32_t h, float scale, float amount, uint32_t seed, uint32_t octaves, float roughness,
+                int pinch, int wrap, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_bulge(const uint8_t* src, uint32_t w, uint32_t h, float amount, float origin_x, float origin_y, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_twist(const uint8_t* src, uint32_t w, uint32_t h, float angle_deg, float origin_x, float origin_y, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_add_noise(const uint8_t* src, uint32_t w, uint32_t h, float amount, int noise_type /* 0 uniform 1 gaussian 2 perlin */, int monochrome,
+                    uint32_t seed, float scale, uint32_t octaves, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_reduce_noise(const uint8_t* src, uint32_t w, uint32_t h, float strength, uint32_t radius, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_vignette(const uint8_t* src, uint32_t w, uint32_t h, float amount, float softness, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_halftone(const uint8_t* src, uint32_t w, uint32_t h, float dot_size, float angle_deg, int shape /* 0 circle 1 square 2 diamond 3 line */,
+                   const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_grid(const uint8_t* src, uint32_t w, uint32_t h, uint32_t cell_w, uint32_t cell_h, uint32_t line_width, const uint8_t color[4],
+               int style /* 0 lines 1 checkerboard */, float opacity, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_canvas_border(const uint8_t* src, uint32_t w, uint32_t h, uint32_t width, const uint8_t color[4], const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_drop_shadow(const uint8_t* src, uint32_t w, uint32_t h, int32_t offset_x, int32_t offset_y, float blur_radius, int widen_radius,
+                      const uint8_t color[4], float opacity, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_outline(const uint8_t* src, uint32_t w, uint32_t h, uint32_t width, const uint8_t color[4], int mode /* 0 outside 1 inside 2 center */,
+                  int anti_alias, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_pixel_drag(const uint8_t* src, uint32_t w, uint32_t h, uint32_t seed, float amount, uint32_t distance, float direction,
+                     const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_rgb_displace(const uint8_t* src, uint32_t w, uint32_t h, const int32_t off_rx_ry_gx_gy_bx_by[6], const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_ink(const uint8_t* src, uint32_t w, uint32_t h, float edge_strength, float threshold, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_oil_painting(const uint8_t* src, uint32_t w, uint32_t h, uint32_t radius, uint32_t levels, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_color_filter(const uint8_t* src, uint32_t w, uint32_t h, const uint8_t filter_color[4], float intensity,
+                       int mode /* 0 multiply 1 screen 2 overlay 3 soft light */, const uint8_t* mask, uint8_t* dst, int threads);
+void pfxo_contours(const uint8_t* src, uint32_t w, uint32_t h, float scale, float frequency, float line_width, const uint8_t line_color[4],
+                   uint32_t seed, uint32_t octaves, float blend, const uint8_t* mask, uint8_t* dst, int threads);
+
 /* ---- A7/A8: ops::adjustments flavour (f32, .round()) (src/ops/adjustments.rs, src/ops/filters.rs:321) ---- */
 enum {
     PFXO_OP_INVERT = 0, PFXO_OP_INVERT_ALPHA, PFXO_OP_SEPIA, PFXO_OP_BRIGHTNESS_CONTRAST, PFXO_OP_HSL,

@@ -83,6 +83,23 @@ hipError_t pfxk_bokeh(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const
 hipError_t pfxk_motion(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, int steps, float dx, float dy,
                        float inv_steps, uint32_t w, uint32_t h);
 
+// ---- k_effects2.hip ---- the rest of the effect bank: one template kernel, parameter block by value (layout per effect
+// documented next to each fx_pixel branch)
+typedef struct pfxk_fx_params { float f[16]; int32_t i[8]; uint32_t u[4]; const void* aux0; } pfxk_fx_params;
+enum { PFXK_FX2_ZOOM = 0, PFXK_FX2_DENTS, PFXK_FX2_BULGE, PFXK_FX2_TWIST, PFXK_FX2_NOISE, PFXK_FX2_REDUCE_NOISE, PFXK_FX2_VIGNETTE,
+       PFXK_FX2_HALFTONE, PFXK_FX2_GRID, PFXK_FX2_BORDER, PFXK_FX2_SHADOW, PFXK_FX2_OUTLINE, PFXK_FX2_PIXEL_DRAG, PFXK_FX2_RGB_DISPLACE,
+       PFXK_FX2_INK, PFXK_FX2_COLOR_FILTER, PFXK_FX2_CONTOURS };
+hipError_t pfxk_fx(hipStream_t s, int fx, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, const pfxk_fx_params* P,
+                   uint32_t w, uint32_t h);
+hipError_t pfxk_crystallize(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, const float* d_seeds_xy,
+                            unsigned long long* d_acc /* cells*5 */, uint32_t* d_avg /* cells */, int cells_x, int cells_y, float cs,
+                            uint32_t w, uint32_t h);
+hipError_t pfxk_oil_painting(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, int radius, int levels,
+                             uint32_t w, uint32_t h);
+// offset alpha plane -> optional separable max of radius `spread` -> aaaa RGBA image (input of the shadow's Gaussian)
+hipError_t pfxk_shadow_alpha(hipStream_t s, const uint8_t* d_src, uint8_t* d_plane_a, uint8_t* d_plane_b, uint8_t* d_rgba, int ox, int oy,
+                             int spread, uint32_t w, uint32_t h);
+
 // ---- k_warp.hip ----
 hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, const float* d_disp,
                                   uint32_t w, uint32_t h, uint8_t* d_dst);

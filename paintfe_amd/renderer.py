@@ -41,6 +41,76 @@ def _fparams(params: Sequence[float]):
     return arr, C.c_uint32(len(params))
 
 
+NOISE_TYPES = ["uniform", "gaussian", "perlin"]                       # NoiseType
+HALFTONE_SHAPES = ["circle", "square", "diamond", "line"]             # HalftoneShape
+GRID_STYLES = ["lines", "checkerboard"]                               # GridStyle
+OUTLINE_MODES = ["outside", "inside", "center"]                       # OutlineMode
+COLOR_FILTER_MODES = ["multiply", "screen", "overlay", "soft_light"]  # ColorFilterMode
+
+
+def _enum(names, v):
+    return C.c_int(names.index(v) if isinstance(v, str) else int(v))
+
+
+def _c4(color):
+    return (C.c_uint8 * 4)(*[int(v) for v in color])
+
+
+def _f4(color):
+    return None if color is None else (C.c_float * 4)(*[float(v) for v in color])
+
+
+# The rest of the effect bank (ref: src/ops/effects/*.rs `*_core`): name -> marshaller of the reference's parameters, in the
+# reference's order.  GpuRenderer grows `<name>_core(img, ..., mask=None)` and `<name>_dev(src_ptr, dst_ptr, w, h, ..., mask_ptr=0)`.
+_EFFECTS = {
+    "zoom_blur": lambda center_x, center_y, strength, samples, tint_color=None, tint_strength=0.0: [
+        C.c_float(center_x), C.c_float(center_y), C.c_float(strength), C.c_uint32(samples), _f4(tint_color), C.c_float(tint_strength)],
+    "crystallize": lambda cell_size, seed: [C.c_float(cell_size), C.c_uint32(seed)],
+    "dents": lambda scale, amount, seed, octaves, roughness, pinch=False, wrap=False: [
+        C.c_float(scale), C.c_float(amount), C.c_uint32(seed), C.c_uint32(octaves), C.c_float(roughness), C.c_int(int(pinch)), C.c_int(int(wrap))],
+    "bulge": lambda amount, origin=(0.5, 0.5): [C.c_float(amount), C.c_float(origin[0]), C.c_float(origin[1])],
+    "twist": lambda angle_deg, origin=(0.5, 0.5): [C.c_float(angle_deg), C.c_float(origin[0]), C.c_float(origin[1])],
+    "add_noise": lambda amount, noise_type, monochrome, seed, scale, octaves: [
+        C.c_float(amount), _enum(NOISE_TYPES, noise_type), C.c_int(int(monochrome)), C.c_uint32(seed), C.c_float(scale), C.c_uint32(octaves)],
+    "reduce_noise": lambda strength, radius: [C.c_float(strength), C.c_uint32(radius)],
+    "vignette": lambda amount, softness: [C.c_float(amount), C.c_float(softness)],
+    "halftone": lambda dot_size, angle_deg, shape="circle": [C.c_float(dot_size), C.c_float(angle_deg), _enum(HALFTONE_SHAPES, shape)],
+    "grid": lambda cell_w, cell_h, line_width, color, style="lines", opacity=1.0: [
+        C.c_uint32(cell_w), C.c_uint32(cell_h), C.c_uint32(line_width), _c4(color), _enum(GRID_STYLES, style), C.c_float(opacity)],
+    "canvas_border": lambda width, color: [C.c_uint32(width), _c4(color)],
+    "shadow": lambda offset_x, offset_y, blur_radius, widen_radius, color, opacity: [
+        C.c_int32(offset_x), C.c_int32(offset_y), C.c_float(blur_radius), C.c_int(int(widen_radius)), _c4(color), C.c_float(opacity)],
+    "outline": lambda width, color, mode="outside", anti_alias=True: [
+        C.c_uint32(width), _c4(color), _enum(OUTLINE_MODES, mode), C.c_int(int(anti_alias))],
+    "pixel_drag": lambda seed, amount, distance, direction: [C.c_uint32(seed), C.c_float(amount), C.c_uint32(distance), C.c_float(direction)],
+    "rgb_displace": lambda r_off, g_off, b_off: [C.c_int32(r_off[0]), C.c_int32(r_off[1]), C.c_int32(g_off[0]), C.c_int32(g_off[1]),
+                                                 C.c_int32(b_off[0]), C.c_int32(b_off[1])],
+    "ink": lambda edge_strength, threshold: [C.c_float(edge_strength), C.c_float(threshold)],
+    "oil_painting": lambda radius, levels: [C.c_uint32(radius), C.c_uint32(levels)],
+    "color_filter": lambda filter_color, intensity, mode="multiply": [_c4(filter_color), C.c_float(intensity), _enum(COLOR_FILTER_MODES, mode)],
+    "contours": lambda scale, frequency, line_width, line_color, seed, octaves, blend: [
+        C.c_float(scale), C.c_float(frequency), C.c_float(line_width), _c4(line_color), C.c_uint32(seed), C.c_uint32(octaves), C.c_float(blend)],
+}
+
+
+def _install_effects(cls):
+    def make(name, marshal):
+        def core(self, img, *a, mask=None, **kw):
+            return self._img_call(getattr(self._lib, f"pfx_{name}_core"), img, *marshal(*a, **kw), mask=mask)
+
+        def dev(self, src_ptr, dst_ptr, w, h, *a, mask_ptr=0, **kw):
+            self._check(getattr(self._lib, f"pfx_{name}_dev")(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
+                                                              *marshal(*a, **kw), C.c_void_p(mask_ptr or None)))
+        core.__name__, dev.__name__ = f"{name}_core", f"{name}_dev"
+        core.__doc__ = dev.__doc__ = f"{name}_core of src/ops/effects/ (see include/pfx.h: pfx_{name}_core / pfx_{name}_dev)"
+        setattr(cls, f"{name}_core", core)
+        setattr(cls, f"{name}_dev", dev)
+    for name, marshal in _EFFECTS.items():
+        make(name, marshal)
+    return cls
+
+
+@_install_effects
 class GpuRenderer:
     """One HIP device + stream (ref: GpuRenderer::try_new, src/gpu/renderer.rs:261)."""
 

@@ -41,6 +41,10 @@ class OracleBackend:
     def motion_blur(self, img, angle_deg, distance, mask=None):
         return O.motion_blur(img, angle_deg, distance, mask)
 
+    def effect(self, name, img, **kw):
+        """the rest of the effect bank (golden_cases.effect_cases): same keyword names on both back-ends"""
+        return getattr(O, name)(img, **kw)
+
     def rhai_adjust(self, img, op, params=()):
         return O.rhai_adjust(img, op, params)
 
@@ -131,6 +135,14 @@ class GpuBackend:
 
     def motion_blur(self, img, angle_deg, distance, mask=None):
         return self.r.motion_blur_core(img, angle_deg, distance, mask)
+
+    def effect(self, name, img, **kw):
+        if name == "shadow":  # Gaussian inside: goldens are held at tolerance 0
+            self.r.set_exact(True)
+        try:
+            return getattr(self.r, name + "_core")(img, **kw)
+        finally:
+            self.r.set_exact(False)
 
     def rhai_adjust(self, img, op, params=()):
         return self.r.rhai_adjust(img, op, params)

@@ -204,5 +204,40 @@ def brush_target(kind: str) -> np.ndarray:
     raise ValueError(kind)
 
 
+def _square(color):
+    img = np.zeros((64, 64, 4), np.uint8)
+    img[16:48, 16:48] = color
+    return img
+
+
+def effect_cases():
+    """tests/visual_filters.rs:64-284: the rest of the effect bank, one golden each"""
+    t = _grad()
+    E = lambda key, name, img=t, **kw: (f"filters/{key}", "effect", dict(name=name, img=img, **kw))
+    return [
+        E("zoom_blur", "zoom_blur", center_x=0.5, center_y=0.5, strength=0.3, samples=8, tint_color=(0.0, 0.0, 0.0, 0.0), tint_strength=0.0),
+        E("crystallize_s16", "crystallize", cell_size=16.0, seed=42),
+        E("dents", "dents", scale=20.0, amount=10.0, seed=42, octaves=2, roughness=0.5, pinch=False, wrap=False),
+        E("bulge_05", "bulge", amount=0.5),
+        E("twist_45", "twist", angle_deg=45.0),
+        E("add_noise_uniform", "add_noise", amount=30.0, noise_type="uniform", monochrome=False, seed=42, scale=1.0, octaves=1),
+        E("add_noise_gaussian_mono", "add_noise", amount=30.0, noise_type="gaussian", monochrome=True, seed=42, scale=1.0, octaves=1),
+        E("add_noise_perlin", "add_noise", amount=50.0, noise_type="perlin", monochrome=False, seed=42, scale=5.0, octaves=3),
+        E("reduce_noise", "reduce_noise", strength=0.5, radius=2),
+        E("vignette_08_05", "vignette", amount=0.8, softness=0.5),
+        E("halftone_circle", "halftone", dot_size=4.0, angle_deg=45.0, shape="circle"),
+        E("grid_lines_16", "grid", cell_w=16, cell_h=16, line_width=1, color=(0, 0, 0, 255), style="lines", opacity=1.0),
+        E("drop_shadow", "shadow", img=_square((255, 255, 255, 255)), offset_x=5, offset_y=5, blur_radius=3.0, widen_radius=False,
+          color=(0, 0, 0, 255), opacity=0.8),
+        E("outline_outside", "outline", img=_square((255, 0, 0, 255)), width=2, color=(0, 0, 255, 255), mode="outside", anti_alias=True),
+        E("contours", "contours", scale=10.0, frequency=5.0, line_width=1.0, line_color=(0, 0, 0, 255), seed=42, octaves=2, blend=0.5),
+        E("pixel_drag", "pixel_drag", seed=42, amount=50.0, distance=20, direction=0.0),
+        E("rgb_displace", "rgb_displace", r_off=(5, 0), g_off=(0, 0), b_off=(-5, 0)),
+        E("ink", "ink", edge_strength=1.0, threshold=0.5),
+        E("oil_painting", "oil_painting", radius=3, levels=20),
+        E("color_filter_multiply", "color_filter", filter_color=(255, 128, 0, 255), intensity=0.5, mode="multiply"),
+    ]
+
+
 def all_cases():
-    return (blend_cases() + filter_cases() + rhai_cases() + adjustment_cases() + warp_cases() + brush_cases())
+    return (blend_cases() + filter_cases() + rhai_cases() + adjustment_cases() + warp_cases() + brush_cases() + effect_cases())

@@ -199,6 +199,107 @@ def motion_blur(img, angle_deg, distance, mask=None, threads=0):
     return _img_op(lib().pfxo_motion_blur, img, C.c_float(angle_deg), C.c_float(distance), mask=mask, threads=threads)
 
 
+def _c4(color):
+    return (C.c_uint8 * 4)(*[int(v) for v in color])
+
+
+NOISE_TYPES = {"uniform": 0, "gaussian": 1, "perlin": 2}
+HALFTONE_SHAPES = {"circle": 0, "square": 1, "diamond": 2, "line": 3}
+GRID_STYLES = {"lines": 0, "checkerboard": 1}
+OUTLINE_MODES = {"outside": 0, "inside": 1, "center": 2}
+COLOR_FILTER_MODES = {"multiply": 0, "screen": 1, "overlay": 2, "soft_light": 3}
+
+
+def zoom_blur(img, center_x, center_y, strength, samples, tint_color=(0.0, 0.0, 0.0, 0.0), tint_strength=0.0, mask=None, threads=0):
+    tint = (C.c_float * 4)(*tint_color)
+    return _img_op(lib().pfxo_zoom_blur, img, C.c_float(center_x), C.c_float(center_y), C.c_float(strength), C.c_uint32(samples),
+                   tint, C.c_float(tint_strength), mask=mask, threads=threads)
+
+
+def crystallize(img, cell_size, seed, mask=None, threads=0):
+    return _img_op(lib().pfxo_crystallize, img, C.c_float(cell_size), C.c_uint32(seed), mask=mask, threads=threads)
+
+
+def dents(img, scale, amount, seed, octaves, roughness, pinch=False, wrap=False, mask=None, threads=0):
+    return _img_op(lib().pfxo_dents, img, C.c_float(scale), C.c_float(amount), C.c_uint32(seed), C.c_uint32(octaves),
+                   C.c_float(roughness), C.c_int(int(pinch)), C.c_int(int(wrap)), mask=mask, threads=threads)
+
+
+def bulge(img, amount, origin=(0.5, 0.5), mask=None, threads=0):
+    return _img_op(lib().pfxo_bulge, img, C.c_float(amount), C.c_float(origin[0]), C.c_float(origin[1]), mask=mask, threads=threads)
+
+
+def twist(img, angle_deg, origin=(0.5, 0.5), mask=None, threads=0):
+    return _img_op(lib().pfxo_twist, img, C.c_float(angle_deg), C.c_float(origin[0]), C.c_float(origin[1]), mask=mask, threads=threads)
+
+
+def add_noise(img, amount, noise_type, monochrome, seed, scale, octaves, mask=None, threads=0):
+    return _img_op(lib().pfxo_add_noise, img, C.c_float(amount), C.c_int(NOISE_TYPES[noise_type]), C.c_int(int(monochrome)),
+                   C.c_uint32(seed), C.c_float(scale), C.c_uint32(octaves), mask=mask, threads=threads)
+
+
+def reduce_noise(img, strength, radius, mask=None, threads=0):
+    return _img_op(lib().pfxo_reduce_noise, img, C.c_float(strength), C.c_uint32(radius), mask=mask, threads=threads)
+
+
+def vignette(img, amount, softness, mask=None, threads=0):
+    return _img_op(lib().pfxo_vignette, img, C.c_float(amount), C.c_float(softness), mask=mask, threads=threads)
+
+
+def halftone(img, dot_size, angle_deg, shape="circle", mask=None, threads=0):
+    return _img_op(lib().pfxo_halftone, img, C.c_float(dot_size), C.c_float(angle_deg), C.c_int(HALFTONE_SHAPES[shape]), mask=mask, threads=threads)
+
+
+def grid(img, cell_w, cell_h, line_width, color, style="lines", opacity=1.0, mask=None, threads=0):
+    return _img_op(lib().pfxo_grid, img, C.c_uint32(cell_w), C.c_uint32(cell_h), C.c_uint32(line_width), _c4(color),
+                   C.c_int(GRID_STYLES[style]), C.c_float(opacity), mask=mask, threads=threads)
+
+
+def canvas_border(img, width, color, mask=None, threads=0):
+    return _img_op(lib().pfxo_canvas_border, img, C.c_uint32(width), _c4(color), mask=mask, threads=threads)
+
+
+def drop_shadow(img, offset_x, offset_y, blur_radius, widen_radius, color, opacity, mask=None, threads=0):
+    return _img_op(lib().pfxo_drop_shadow, img, C.c_int32(offset_x), C.c_int32(offset_y), C.c_float(blur_radius), C.c_int(int(widen_radius)),
+                   _c4(color), C.c_float(opacity), mask=mask, threads=threads)
+
+
+shadow = drop_shadow  # the reference calls it shadow_core (render.rs:220)
+
+
+def outline(img, width, color, mode="outside", anti_alias=True, mask=None, threads=0):
+    return _img_op(lib().pfxo_outline, img, C.c_uint32(width), _c4(color), C.c_int(OUTLINE_MODES[mode]), C.c_int(int(anti_alias)),
+                   mask=mask, threads=threads)
+
+
+def pixel_drag(img, seed, amount, distance, direction, mask=None, threads=0):
+    return _img_op(lib().pfxo_pixel_drag, img, C.c_uint32(seed), C.c_float(amount), C.c_uint32(distance), C.c_float(direction),
+                   mask=mask, threads=threads)
+
+
+def rgb_displace(img, r_off, g_off, b_off, mask=None, threads=0):
+    off = (C.c_int32 * 6)(r_off[0], r_off[1], g_off[0], g_off[1], b_off[0], b_off[1])
+    return _img_op(lib().pfxo_rgb_displace, img, off, mask=mask, threads=threads)
+
+
+def ink(img, edge_strength, threshold, mask=None, threads=0):
+    return _img_op(lib().pfxo_ink, img, C.c_float(edge_strength), C.c_float(threshold), mask=mask, threads=threads)
+
+
+def oil_painting(img, radius, levels, mask=None, threads=0):
+    return _img_op(lib().pfxo_oil_painting, img, C.c_uint32(radius), C.c_uint32(levels), mask=mask, threads=threads)
+
+
+def color_filter(img, filter_color, intensity, mode="multiply", mask=None, threads=0):
+    return _img_op(lib().pfxo_color_filter, img, _c4(filter_color), C.c_float(intensity), C.c_int(COLOR_FILTER_MODES[mode]),
+                   mask=mask, threads=threads)
+
+
+def contours(img, scale, frequency, line_width, line_color, seed, octaves, blend, mask=None, threads=0):
+    return _img_op(lib().pfxo_contours, img, C.c_float(scale), C.c_float(frequency), C.c_float(line_width), _c4(line_color),
+                   C.c_uint32(seed), C.c_uint32(octaves), C.c_float(blend), mask=mask, threads=threads)
+
+
 def adjust(img, op, params=(), lut=None, mask=None, sparse=DENSE, threads=0):
     h, w = img.shape[:2]
     src, ps = _u8(img)

@@ -23,7 +23,7 @@ def test_golden_coverage(golden):
     """Every golden of the hot-path categories we claim is exercised (names listed explicitly so a
     missing case is visible)."""
     covered = {c[0] for c in CASES}
-    for cat in ("blend", "tools", "scripting"):
+    for cat in ("blend", "tools", "scripting", "filters", "adjustments"):
         missing = {k for k in golden.files if k.startswith(cat + "/")} - covered
         # flips are image-crate transforms (out of scope, SURVEY §8c)
         missing -= {"scripting/flip_horizontal", "scripting/flip_vertical"}
