@@ -397,10 +397,36 @@ typedef struct pfx_script_result {
     uint32_t ops_executed;
     char     console[2048];   /* print_line output, '\n' separated (truncated) */
 } pfx_script_result;
-/* execute_script_sync(source, pixels, w, h, mask): runs the Effect-API call statements of a Rhai script against
- * `pixels_inout`.  Names, arity and numeric flavour per registered function follow scripting.rs:822-1165. */
+/* execute_script_sync(source, pixels, w, h, mask) (ref: scripting.rs:1733-1821).  The script language is the Rhai subset of
+ * paintfe_amd/csrc/pfx_rhai.h (let / if / loops / fn / closures, strict i64-f64 typing, checked integer arithmetic); the
+ * registered host API keeps the reference's names, arity and numeric flavour (scripting.rs:323-1482).  Bulk work runs on
+ * the device: effects through the kernels above, per-pixel closures (map_channels / for_each_pixel / for_region) compiled
+ * to a bytecode kernel; get_pixel / set_pixel touch a host mirror of the image.  Constructs outside the subset and
+ * resize_image (image-crate resampling) return PFX_ERR_UNSUPPORTED.  Pixels are untouched on error. */
+/* fixed-size form: the script must leave the image size unchanged (PFX_ERR_UNSUPPORTED otherwise) */
 int pfx_script_run(pfx_ctx* ctx, const char* source, uint8_t* pixels_inout, uint32_t w, uint32_t h,
                    const uint8_t* mask, pfx_script_result* result);
+/* CanvasOpRequest (ref: scripting.rs:41-58): canvas-wide transforms the caller replays on its other layers */
+enum { PFX_CANVAS_FLIP_HORIZONTAL = 0, PFX_CANVAS_FLIP_VERTICAL = 1, PFX_CANVAS_ROTATE_90CW = 2, PFX_CANVAS_ROTATE_90CCW = 3,
+       PFX_CANVAS_ROTATE_180 = 4, PFX_CANVAS_RESIZE_IMAGE = 5, PFX_CANVAS_RESIZE_CANVAS = 6 };
+typedef struct pfx_canvas_op {
+    int32_t  kind;           /* PFX_CANVAS_* */
+    uint32_t w, h;           /* RESIZE_IMAGE / RESIZE_CANVAS: new size */
+    uint32_t anchor_x, anchor_y; /* RESIZE_CANVAS: 0 / 1 / 2 per axis (parse_anchor, scripting.rs:69-82) */
+} pfx_canvas_op;
+/* full form: returns (result_pixels, final_w, final_h, console_output, canvas_ops) like the reference.  *out is an opaque
+ * result owned by the library until pfx_script_output_free; NULL on error. */
+typedef struct pfx_script_output pfx_script_output;
+int pfx_script_execute(pfx_ctx* ctx, const char* source, const uint8_t* pixels, uint32_t w, uint32_t h, const uint8_t* mask,
+                       pfx_script_output** out, pfx_script_result* result);
+const uint8_t* pfx_script_output_pixels(const pfx_script_output* out, uint32_t* w, uint32_t* h);
+uint32_t    pfx_script_output_console_lines(const pfx_script_output* out);
+const char* pfx_script_output_console_line(const pfx_script_output* out, uint32_t index);
+uint32_t    pfx_script_output_canvas_ops(const pfx_script_output* out, pfx_canvas_op* ops, uint32_t capacity); /* returns the count */
+void        pfx_script_output_free(pfx_script_output* out);
+/* language-only evaluation (no device, no image functions): syntax / typing / console checks, e.g. from an editor's
+ * "compile" button (ref: compile_script, scripting.rs:1489-1508).  ctx may be NULL. */
+int pfx_script_check(const char* source, uint32_t w, uint32_t h, pfx_script_result* result);
 /* the `pfx` batch CLI main (same flags as src/cli.rs:43-89); returns the process exit code */
 int pfx_cli_main(int argc, char** argv);
 

@@ -38,6 +38,10 @@ class ScriptResult(C.Structure):
                 ("ops_executed", C.c_uint32), ("console", C.c_char * 2048)]
 
 
+class CanvasOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("w", C.c_uint32), ("h", C.c_uint32), ("anchor_x", C.c_uint32), ("anchor_y", C.c_uint32)]
+
+
 _lib = None
 
 

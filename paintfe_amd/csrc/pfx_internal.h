@@ -85,6 +85,11 @@ struct pfx_timer {
 int pfx_int_blur_with_selection_dev(pfx_ctx* ctx, const void* d_src, void* d_dst, uint32_t w, uint32_t h, float sigma,
                                     const uint8_t* mask_host, const void* d_mask);
 
+// script front-end on the device image held in ctx->st_in (pfx_script_host.cpp).  On success the result is in ctx->st_in and
+// *w / *h hold the final size; console / ops may be NULL.
+int pfx_int_script_run_dev(pfx_ctx* ctx, const char* source, uint32_t* w, uint32_t* h, const uint8_t* mask, pfx_script_result* result,
+                           std::vector<std::string>* console, std::vector<pfx_canvas_op>* ops);
+
 // host-side restatements that the reference also runs on the host (pfx_host_math.cpp)
 int  pfx_host_gaussian_kernel(float sigma, std::vector<float>& out);  // ref: src/ops/filters.rs:214-234
 float pfx_host_bc_factor(float contrast);                             // ref: src/ops/adjustments.rs:273

@@ -100,6 +100,27 @@ hipError_t pfxk_oil_painting(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst
 hipError_t pfxk_shadow_alpha(hipStream_t s, const uint8_t* d_src, uint8_t* d_plane_a, uint8_t* d_plane_b, uint8_t* d_rgba, int ox, int oy,
                              int spread, uint32_t w, uint32_t h);
 
+// ---- k_script.hip ---- per-pixel closure VM + the pixel-moving functions of the script transform / selection API
+typedef struct pfxk_vm_args {
+    const uint32_t* src;      // pre-call image (what the closure's parameters, get_pixel and get_r..a see)
+    uint32_t* dst;            // result image (must not alias src)
+    const uint8_t* mask;      // selection for is_selected(), or NULL
+    const void* code;         // rhai::BcIns[n_code]
+    const uint64_t* consts;
+    unsigned long long* err;  // initialised to ~0: min over failing pixels of (row-major index << 24 | code << 16 | line)
+    int n_code, n_regs, n_params;
+    int w, h;
+    int x0, y0, x1, y1;       // region processed (for_region); the rest of dst must already equal src
+} pfxk_vm_args;
+hipError_t pfxk_vm_run(hipStream_t s, const pfxk_vm_args* A);
+// mode: 0 flip_horizontal, 1 flip_vertical, 2 rotate180, 3 rotate90 (cw), 4 rotate270 (ccw); (w, h) = source size
+hipError_t pfxk_permute(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, int mode, uint32_t w, uint32_t h);
+hipError_t pfxk_recanvas(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, uint32_t ow, uint32_t oh, uint32_t nw, uint32_t nh, int off_x, int off_y);
+// op: 0 rect [x0,x1)x[y0,y1), 1 ellipse (centre cx,cy; squared radii), 2 invert, 3 clear
+hipError_t pfxk_mask_op(hipStream_t s, uint8_t* d_mask, int op, int x0, int y0, int x1, int y1, double cx, double cy, double rx2, double ry2,
+                        uint32_t w, uint32_t h);
+hipError_t pfxk_fill_masked(hipStream_t s, uint8_t* d_img, const uint8_t* d_mask, uint32_t rgba, uint32_t w, uint32_t h);
+
 // ---- k_warp.hip ----
 hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, const float* d_disp,
                                   uint32_t w, uint32_t h, uint8_t* d_dst);

@@ -93,6 +93,19 @@ _EFFECTS = {
 }
 
 
+def script_check(source: str, w: int = 64, h: int = 64):
+    """Language-only evaluation of a script (no device, no image functions; ref: compile_script, scripting.rs:1489): returns
+    the console lines or raises PfxError with .line / .col."""
+    lib = _lib.load()
+    res = ScriptResult()
+    st = lib.pfx_script_check(source.encode(), C.c_uint32(w), C.c_uint32(h), C.byref(res))
+    if st != _lib.OK:
+        err = PfxError(st, res.error.decode(errors="replace"))
+        err.line, err.col = res.error_line, res.error_col
+        raise err
+    return [s for s in res.console.decode(errors="replace").split("\n") if s]
+
+
 def _install_effects(cls):
     def make(name, marshal):
         def core(self, img, *a, mask=None, **kw):
@@ -414,19 +427,39 @@ class GpuRenderer:
         return l
 
     # ------------------------------------------------------------------ script front-end
-    def execute_script_sync(self, source: str, pixels, mask=None):
-        px = _u8(pixels).copy()
+    def execute_script_sync(self, source: str, pixels, mask=None, with_ops: bool = False):
+        """execute_script_sync (ref: src/ops/scripting.rs:1733): returns (result_pixels, console_output) — the result may have
+        another size than the input (rotate_canvas_90*, resize_canvas) — plus the CanvasOpRequest list with with_ops=True, as
+        (kind, w, h, anchor_x, anchor_y) tuples."""
+        px = _u8(pixels)
         h, w = px.shape[:2]
         m = None if mask is None else _u8(mask)
         res = ScriptResult()
-        st = self._lib.pfx_script_run(self._h, source.encode(), _p(px), C.c_uint32(w), C.c_uint32(h), _p(m), C.byref(res))
-        console = [s for s in res.console.decode(errors="replace").split("\n") if s]
+        out = C.c_void_p()
+        st = self._lib.pfx_script_execute(self._h, source.encode(), _p(px), C.c_uint32(w), C.c_uint32(h), _p(m), C.byref(out), C.byref(res))
         if st != _lib.OK:
             msg = res.error.decode(errors="replace") or self._lib.pfx_last_error(self._h).decode()
             err = PfxError(st, msg)
             err.line, err.col = res.error_line, res.error_col
             raise err
-        return px, console
+        try:
+            ow, oh = C.c_uint32(), C.c_uint32()
+            self._lib.pfx_script_output_pixels.restype = C.POINTER(C.c_uint8)
+            self._lib.pfx_script_output_console_line.restype = C.c_char_p
+            p = self._lib.pfx_script_output_pixels(out, C.byref(ow), C.byref(oh))
+            result = np.ctypeslib.as_array(p, shape=(oh.value, ow.value, 4)).copy()
+            console = [self._lib.pfx_script_output_console_line(out, C.c_uint32(k)).decode(errors="replace")
+                       for k in range(self._lib.pfx_script_output_console_lines(out))]
+            n_ops = self._lib.pfx_script_output_canvas_ops(out, None, C.c_uint32(0))
+            ops_arr = (_lib.CanvasOp * max(n_ops, 1))()
+            self._lib.pfx_script_output_canvas_ops(out, ops_arr, C.c_uint32(n_ops))
+            ops = [(o.kind, o.w, o.h, o.anchor_x, o.anchor_y) for o in ops_arr[:n_ops]]
+        finally:
+            self._lib.pfx_script_output_free(out)
+        return (result, console, ops) if with_ops else (result, console)
+
+    def script_check(self, source: str, w: int = 64, h: int = 64):
+        return script_check(source, w, h)
 
     # ------------------------------------------------------------------ device tier (raw device pointers as ints)
     def dev_alloc(self, nbytes: int) -> int:
