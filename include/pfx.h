@@ -389,6 +389,15 @@ int pfx_timing_enable(pfx_ctx* ctx, int on);
 int pfx_timing_read(pfx_ctx* ctx, const char* kernel_name, double* total_ms, uint64_t* launches);
 int pfx_timing_reset(pfx_ctx* ctx);
 
+/* ---- resize_image: imageops::resize(&flat, new_w, new_h, filter) per layer (ref: src/ops/transform.rs:347-359; script
+ * function resize_image src/ops/scripting.rs:749-770).  Filters = ScriptFilterType (scripting.rs:22-37): Nearest, Bilinear
+ * (Triangle), Bicubic (CatmullRom), Lanczos (Lanczos3).  The resampling algorithm is the `image` crate's (0.25.9), restated;
+ * nearest / bilinear / lanczos3 are pinned by the reference's goldens, bicubic is unpinned.  Bit-exact class. */
+enum { PFX_RESIZE_NEAREST = 0, PFX_RESIZE_BILINEAR = 1, PFX_RESIZE_BICUBIC = 2, PFX_RESIZE_LANCZOS3 = 3 };
+int pfx_resize_image(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst /* new_w*new_h*4 */, uint32_t new_w, uint32_t new_h,
+                     int filter);
+int pfx_resize_image_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t h, void* dst_dev, uint32_t new_w, uint32_t new_h, int filter);
+
 /* ================= B5/B6: script front-end and CLI (ref: src/ops/scripting.rs:1733-1821, src/cli.rs) ================= */
 typedef struct pfx_script_result {
     char     error[512];      /* ScriptError::friendly_message-style text, empty on success */
@@ -401,8 +410,8 @@ typedef struct pfx_script_result {
  * paintfe_amd/csrc/pfx_rhai.h (let / if / loops / fn / closures, strict i64-f64 typing, checked integer arithmetic); the
  * registered host API keeps the reference's names, arity and numeric flavour (scripting.rs:323-1482).  Bulk work runs on
  * the device: effects through the kernels above, per-pixel closures (map_channels / for_each_pixel / for_region) compiled
- * to a bytecode kernel; get_pixel / set_pixel touch a host mirror of the image.  Constructs outside the subset and
- * resize_image (image-crate resampling) return PFX_ERR_UNSUPPORTED.  Pixels are untouched on error. */
+ * to a bytecode kernel; get_pixel / set_pixel touch a host mirror of the image.  Constructs outside the subset
+ * return PFX_ERR_UNSUPPORTED.  Pixels are untouched on error. */
 /* fixed-size form: the script must leave the image size unchanged (PFX_ERR_UNSUPPORTED otherwise) */
 int pfx_script_run(pfx_ctx* ctx, const char* source, uint8_t* pixels_inout, uint32_t w, uint32_t h,
                    const uint8_t* mask, pfx_script_result* result);
@@ -412,7 +421,7 @@ enum { PFX_CANVAS_FLIP_HORIZONTAL = 0, PFX_CANVAS_FLIP_VERTICAL = 1, PFX_CANVAS_
 typedef struct pfx_canvas_op {
     int32_t  kind;           /* PFX_CANVAS_* */
     uint32_t w, h;           /* RESIZE_IMAGE / RESIZE_CANVAS: new size */
-    uint32_t anchor_x, anchor_y; /* RESIZE_CANVAS: 0 / 1 / 2 per axis (parse_anchor, scripting.rs:69-82) */
+    uint32_t anchor_x, anchor_y; /* RESIZE_CANVAS: 0 / 1 / 2 per axis (parse_anchor, scripting.rs:69-82); RESIZE_IMAGE: anchor_x = PFX_RESIZE_* filter */
 } pfx_canvas_op;
 /* full form: returns (result_pixels, final_w, final_h, console_output, canvas_ops) like the reference.  *out is an opaque
  * result owned by the library until pfx_script_output_free; NULL on error. */

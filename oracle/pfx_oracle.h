@@ -115,6 +115,11 @@ void pfxo_color_filter(const uint8_t* src, uint32_t w, uint32_t h, const uint8_t
 void pfxo_contours(const uint8_t* src, uint32_t w, uint32_t h, float scale, float frequency, float line_width, const uint8_t line_color[4],
                    uint32_t seed, uint32_t octaves, float blend, const uint8_t* mask, uint8_t* dst, int threads);
 
+/* imageops::resize of the `image` crate 0.25.9 as called by resize_image (o_resize.c; src/ops/transform.rs:347-359) */
+enum { PFXO_RESIZE_NEAREST = 0, PFXO_RESIZE_BILINEAR = 1, PFXO_RESIZE_BICUBIC = 2, PFXO_RESIZE_LANCZOS3 = 3 };
+size_t pfxo_resize_weights(uint32_t n_in, uint32_t n_out, int filter, uint32_t* left, uint32_t* count, size_t* off, float* wts);
+void pfxo_resize(const uint8_t* src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, int filter, uint8_t* dst, int threads);
+
 /* ---- A7/A8: ops::adjustments flavour (f32, .round()) (src/ops/adjustments.rs, src/ops/filters.rs:321) ---- */
 enum {
     PFXO_OP_INVERT = 0, PFXO_OP_INVERT_ALPHA, PFXO_OP_SEPIA, PFXO_OP_BRIGHTNESS_CONTRAST, PFXO_OP_HSL,

@@ -121,6 +121,11 @@ hipError_t pfxk_mask_op(hipStream_t s, uint8_t* d_mask, int op, int x0, int y0, 
                         uint32_t w, uint32_t h);
 hipError_t pfxk_fill_masked(hipStream_t s, uint8_t* d_img, const uint8_t* d_mask, uint32_t rgba, uint32_t w, uint32_t h);
 
+// ---- k_resize.hip ---- separable resampling with per-axis window / weight tables (v_*: per output row, h_*: per output column)
+hipError_t pfxk_resize(hipStream_t s, const uint8_t* d_src, float* d_tmp /* w*nh*4 f32 */, uint8_t* d_dst, const uint32_t* v_left, const uint32_t* v_count,
+                       const uint32_t* v_off, const float* v_wts, const uint32_t* h_left, const uint32_t* h_count, const uint32_t* h_off, const float* h_wts,
+                       uint32_t w, uint32_t h, uint32_t nw, uint32_t nh);
+
 // ---- k_warp.hip ----
 hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, const float* d_disp,
                                   uint32_t w, uint32_t h, uint8_t* d_dst);

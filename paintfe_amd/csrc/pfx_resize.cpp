@@ -1,0 +1,131 @@
+// pfx_resize.cpp — C ABI of resize_image: `imageops::resize(&flat, new_w, new_h, filter)` (ref: src/ops/transform.rs:347-359,
+// resize_image script function src/ops/scripting.rs:749-770, filter mapping :29-37,60-67).
+//
+// The sampling algorithm is the `image` crate's (0.25.9 per Cargo.lock; not part of the reference tree): per output sample a
+// window of source samples around (o + 0.5) * ratio, kernel weights normalised by their f32 sum, vertical pass into f32 then
+// horizontal pass with clamp and round-to-nearest.  The per-axis weight tables are built here on the host (sinf for
+// Lanczos3 from glibc, as the crate's f32::sin resolves to on Linux) and the two passes run in k_resize.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pfx_internal.h"
+
+namespace {
+
+float k_box(float) { return 1.0f; }
+float k_triangle(float x) { const float a = fabsf(x); return a < 1.0f ? 1.0f - a : 0.0f; }
+float sinc(float t)
+{
+    const float a = t * 3.14159265358979323846f;
+    return t == 0.0f ? 1.0f : sinf(a) / a;
+}
+float k_lanczos3(float x) { return fabsf(x) < 3.0f ? sinc(x) * sinc(x / 3.0f) : 0.0f; }
+float k_catmullrom(float x) // bc_cubic_spline(x, 0.0, 0.5)
+{
+    const float b = 0.0f, c = 0.5f, a = fabsf(x);
+    float k;
+    if (a < 1.0f) k = (12.0f - 9.0f * b - 6.0f * c) * (a * a * a) + (-18.0f + 12.0f * b + 6.0f * c) * (a * a) + (6.0f - 2.0f * b);
+    else if (a < 2.0f) k = (-b - 6.0f * c) * (a * a * a) + (6.0f * b + 30.0f * c) * (a * a) + (-12.0f * b - 48.0f * c) * a + (8.0f * b + 24.0f * c);
+    else k = 0.0f;
+    return k / 6.0f;
+}
+
+struct AxisTable {
+    std::vector<uint32_t> left, count, off;
+    std::vector<float> wts;
+};
+
+void build_axis(uint32_t n_in, uint32_t n_out, int filter, AxisTable& t)
+{
+    float (*kernel)(float) = k_triangle;
+    float support = 1.0f;
+    switch (filter) {
+    case PFX_RESIZE_NEAREST: kernel = k_box; support = 0.0f; break;
+    case PFX_RESIZE_BICUBIC: kernel = k_catmullrom; support = 2.0f; break;
+    case PFX_RESIZE_LANCZOS3: kernel = k_lanczos3; support = 3.0f; break;
+    default: break;
+    }
+    const float ratio = (float)n_in / (float)n_out;
+    const float sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float src_support = support * sratio;
+    t.left.resize(n_out);
+    t.count.resize(n_out);
+    t.off.resize(n_out);
+    t.wts.clear();
+    for (uint32_t o = 0; o < n_out; ++o) {
+        float input = ((float)o + 0.5f) * ratio;
+        int64_t l = (int64_t)floorf(input - src_support);
+        l = std::min<int64_t>(std::max<int64_t>(l, 0), (int64_t)n_in - 1);
+        int64_t r = (int64_t)ceilf(input + src_support);
+        r = std::min<int64_t>(std::max<int64_t>(r, l + 1), (int64_t)n_in);
+        input = input - 0.5f;
+        t.left[o] = (uint32_t)l;
+        t.count[o] = (uint32_t)(r - l);
+        t.off[o] = (uint32_t)t.wts.size();
+        float sum = 0.0f;
+        const size_t base = t.wts.size();
+        for (int64_t i = l; i < r; ++i) {
+            const float w = kernel(((float)i - input) / sratio);
+            t.wts.push_back(w);
+            sum += w;
+        }
+        for (size_t k = base; k < t.wts.size(); ++k) t.wts[k] /= sum;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int pfx_resize_image_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t h, void* dst_dev, uint32_t new_w, uint32_t new_h, int filter)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src_dev && dst_dev && src_dev != dst_dev, "pfx_resize_image_dev: bad image pointers");
+    PFX_REQUIRE(ctx, w && h && new_w && new_h && (uint64_t)w * h <= 256000000ull && (uint64_t)new_w * new_h <= 256000000ull, "pfx_resize_image_dev: bad size");
+    PFX_REQUIRE(ctx, filter >= PFX_RESIZE_NEAREST && filter <= PFX_RESIZE_LANCZOS3, "pfx_resize_image_dev: unknown filter");
+    PFX_TRY(pfx_use(ctx));
+    if (new_w == w && new_h == h) { // the crate copies instead of resampling
+        PFX_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, (size_t)w * h * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return PFX_OK;
+    }
+    AxisTable v, hz;
+    build_axis(h, new_h, filter, v);
+    build_axis(w, new_w, filter, hz);
+    PFX_REQUIRE(ctx, v.wts.size() < 0xffffffffull && hz.wts.size() < 0xffffffffull, "pfx_resize_image_dev: weight table too large");
+    // one parameter blob: [v.left | v.count | v.off | h.left | h.count | h.off | v.wts | h.wts]
+    const size_t n_u32 = 3 * (size_t)new_h + 3 * (size_t)new_w;
+    std::vector<uint32_t> blob(n_u32 + v.wts.size() + hz.wts.size());
+    uint32_t* p = blob.data();
+    auto put = [&](const std::vector<uint32_t>& a) { std::copy(a.begin(), a.end(), p); p += a.size(); };
+    put(v.left); put(v.count); put(v.off); put(hz.left); put(hz.count); put(hz.off);
+    std::memcpy(p, v.wts.data(), v.wts.size() * 4);
+    std::memcpy(p + v.wts.size(), hz.wts.data(), hz.wts.size() * 4);
+    PFX_TRY(pfx_reserve(ctx, ctx->fx_a, blob.size() * 4));
+    PFX_TRY(pfx_h2d(ctx, ctx->fx_a.p, blob.data(), blob.size() * 4));
+    PFX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `blob` is pageable host memory about to go out of scope
+    PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * new_h * 16));
+    const uint32_t* d = (const uint32_t*)ctx->fx_a.p;
+    const float* dw = (const float*)(d + n_u32);
+    pfx_timer t(ctx, "resize");
+    PFX_HIP(ctx, pfxk_resize(ctx->stream, (const uint8_t*)src_dev, (float*)ctx->st_tmp.p, (uint8_t*)dst_dev, d, d + new_h, d + 2 * (size_t)new_h,
+                             dw, d + 3 * (size_t)new_h, d + 3 * (size_t)new_h + new_w, d + 3 * (size_t)new_h + 2 * (size_t)new_w, dw + v.wts.size(), w, h,
+                             new_w, new_h));
+    return PFX_OK;
+}
+
+int pfx_resize_image(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst, uint32_t new_w, uint32_t new_h, int filter)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src && dst && w && h && new_w && new_h, "pfx_resize_image: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_in, (size_t)w * h * 4));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, (size_t)new_w * new_h * 4));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_in.p, src, (size_t)w * h * 4));
+    PFX_TRY(pfx_resize_image_dev(ctx, ctx->st_in.p, w, h, ctx->st_out.p, new_w, new_h, filter));
+    PFX_TRY(pfx_d2h(ctx, dst, ctx->st_out.p, (size_t)new_w * new_h * 4));
+    return pfx_sync(ctx);
+}
+
+} // extern "C"

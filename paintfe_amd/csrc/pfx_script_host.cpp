@@ -4,7 +4,7 @@
 //   canvas info   :323-349    width height is_selected
 //   pixel access  :355-435    get_pixel set_pixel get_r/g/b/a set_r/g/b/a           (host mirror of the image, synced lazily)
 //   bulk iterators:437-609    for_each_pixel for_region map_channels                  (closure -> bytecode -> one GPU kernel)
-//   transforms    :640-819    flip_* rotate_* resize_canvas (resize_image: image-crate resampling, PFX_ERR_UNSUPPORTED)
+//   transforms    :640-819    flip_* rotate_* resize_canvas resize_image
 //   effects       :822-1165   apply_* — `_core` flavour through the effect kernels, inline flavour through pfx_rhai_adjust
 //   utility       :1171-1350  print_line sleep progress rand_* clamp lerp distance abs min max floor ... rgb_to_hsl hsl_to_rgb
 //   selection     :1356-1481  select_rect select_ellipse clear_selection has_selection invert_selection fill_selected delete_selected
@@ -311,10 +311,19 @@ int ScriptHost::call(rhai::Interp& in, const std::string& name, std::vector<Valu
     FN("resize_image") if (sig({VT::Int, VT::Int, VT::Str})) { // scripting.rs:749-770
         if (need_image()) return 2;
         const uint32_t nw = std::min(i64_as_u32(std::max<int64_t>(a[0].i, 1)), 32768u), nh = std::min(i64_as_u32(std::max<int64_t>(a[1].i, 1)), 32768u);
+        const std::string m = lower(*a[2].s); // parse_script_filter, scripting.rs:60-67
+        const int filter = (m == "nearest" || m == "nn") ? PFX_RESIZE_NEAREST
+                         : (m == "bicubic" || m == "catmull" || m == "catmullrom") ? PFX_RESIZE_BICUBIC
+                         : (m == "lanczos" || m == "lanczos3") ? PFX_RESIZE_LANCZOS3 : PFX_RESIZE_BILINEAR;
         if (nw == w && nh == h) return 2;
-        err.msg = "resize_image resamples with the image crate's filters (image 0.25.9, outside this back-end); use the CPU path";
-        err.status = PFX_ERR_UNSUPPORTED;
-        return 2;
+        const uint32_t ow = w, oh = h;
+        const int st = pingpong([&](const void* s, void* d) { return pfx_resize_image_dev(ctx, s, ow, oh, d, nw, nh, filter); }, nw, nh);
+        if (st == PFX_OK) {
+            ops.push_back({PFX_CANVAS_RESIZE_IMAGE, nw, nh, (uint32_t)filter, 0});
+            has_mask = false; // a mask of the old size no longer applies
+            host_mask_valid = false;
+        }
+        return dev(st);
     }
     // ---------------------------------------------------------------- effects: `_core` flavour, selection aware
 #define FX(NAME, SIG, CALL)                                                                              \

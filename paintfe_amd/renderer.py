@@ -46,6 +46,7 @@ HALFTONE_SHAPES = ["circle", "square", "diamond", "line"]             # Halftone
 GRID_STYLES = ["lines", "checkerboard"]                               # GridStyle
 OUTLINE_MODES = ["outside", "inside", "center"]                       # OutlineMode
 COLOR_FILTER_MODES = ["multiply", "screen", "overlay", "soft_light"]  # ColorFilterMode
+RESIZE_FILTERS = ["nearest", "bilinear", "bicubic", "lanczos3"]       # ScriptFilterType / Interpolation
 
 
 def _enum(names, v):
@@ -427,6 +428,18 @@ class GpuRenderer:
         return l
 
     # ------------------------------------------------------------------ script front-end
+    def resize_image(self, img, new_w: int, new_h: int, filter="bilinear"):   # transform.rs:347 (imageops::resize)
+        src = _u8(img)
+        h, w = src.shape[:2]
+        dst = np.empty((new_h, new_w, 4), np.uint8)
+        self._check(self._lib.pfx_resize_image(self._h, _p(src), C.c_uint32(w), C.c_uint32(h), _p(dst), C.c_uint32(new_w), C.c_uint32(new_h),
+                                               _enum(RESIZE_FILTERS, filter)))
+        return dst
+
+    def resize_image_dev(self, src_ptr, w, h, dst_ptr, new_w, new_h, filter="bilinear"):
+        self._check(self._lib.pfx_resize_image_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr), C.c_uint32(new_w),
+                                                   C.c_uint32(new_h), _enum(RESIZE_FILTERS, filter)))
+
     def execute_script_sync(self, source: str, pixels, mask=None, with_ops: bool = False):
         """execute_script_sync (ref: src/ops/scripting.rs:1733): returns (result_pixels, console_output) — the result may have
         another size than the input (rotate_canvas_90*, resize_canvas) — plus the CanvasOpRequest list with with_ops=True, as

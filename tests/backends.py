@@ -45,6 +45,9 @@ class OracleBackend:
         """the rest of the effect bank (golden_cases.effect_cases): same keyword names on both back-ends"""
         return getattr(O, name)(img, **kw)
 
+    def resize(self, img, new_w, new_h, filter):
+        return O.resize(img, new_w, new_h, filter)
+
     def rhai_adjust(self, img, op, params=()):
         return O.rhai_adjust(img, op, params)
 
@@ -135,6 +138,9 @@ class GpuBackend:
 
     def motion_blur(self, img, angle_deg, distance, mask=None):
         return self.r.motion_blur_core(img, angle_deg, distance, mask)
+
+    def resize(self, img, new_w, new_h, filter):
+        return self.r.resize_image(img, new_w, new_h, filter)
 
     def effect(self, name, img, **kw):
         if name == "shadow":  # Gaussian inside: goldens are held at tolerance 0

@@ -239,5 +239,15 @@ def effect_cases():
     ]
 
 
+def resize_cases():
+    """tests/visual_transforms.rs:134-164: imageops::resize on the asymmetric 64x48 gradient"""
+    t = I.create_test_gradient(64, 48)
+    return [
+        ("transforms/resize_2x_nearest", "resize", dict(img=t, new_w=128, new_h=96, filter="nearest")),
+        ("transforms/resize_half_bilinear", "resize", dict(img=t, new_w=32, new_h=24, filter="bilinear")),
+        ("transforms/resize_half_lanczos", "resize", dict(img=t, new_w=32, new_h=24, filter="lanczos3")),
+    ]
+
+
 def all_cases():
-    return (blend_cases() + filter_cases() + rhai_cases() + adjustment_cases() + warp_cases() + brush_cases() + effect_cases())
+    return (blend_cases() + filter_cases() + rhai_cases() + adjustment_cases() + warp_cases() + brush_cases() + effect_cases() + resize_cases())

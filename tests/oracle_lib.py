@@ -300,6 +300,18 @@ def contours(img, scale, frequency, line_width, line_color, seed, octaves, blend
                    C.c_uint32(seed), C.c_uint32(octaves), C.c_float(blend), mask=mask, threads=threads)
 
 
+RESIZE_FILTERS = {"nearest": 0, "bilinear": 1, "bicubic": 2, "lanczos3": 3}
+
+
+def resize(img, nw, nh, filter="bilinear", threads=0):
+    h, w = img.shape[:2]
+    src, ps = _u8(img)
+    out = np.zeros((nh, nw, 4), np.uint8)
+    lib().pfxo_resize(ps, C.c_uint32(w), C.c_uint32(h), C.c_uint32(nw), C.c_uint32(nh), C.c_int(RESIZE_FILTERS[filter]),
+                      out.ctypes.data_as(C.c_void_p), C.c_int(threads))
+    return out
+
+
 def adjust(img, op, params=(), lut=None, mask=None, sparse=DENSE, threads=0):
     h, w = img.shape[:2]
     src, ps = _u8(img)

@@ -167,6 +167,23 @@ def test_effects_small_and_wide_images(gpu, oracle):
             check(gpu.effect(name, img, **kw), oracle.effect(name, img, **kw), cls, f"{name} {w}x{h}")
 
 
+@pytest.mark.parametrize("filter", ["nearest", "bilinear", "bicubic", "lanczos3"])
+@pytest.mark.parametrize("size,new", [((64, 48), (128, 96)), ((203, 117), (50, 30)), ((203, 117), (640, 11)), ((37, 90), (1, 1)), ((5, 3), (333, 222)),
+                                      ((120, 80), (120, 40)), ((120, 80), (120, 80))])
+def test_resize_image_bitexact(gpu, oracle, filter, size, new):
+    img = I.random_rgba(size[0], size[1], 17)
+    check(gpu.resize(img, new[0], new[1], filter), oracle.resize(img, new[0], new[1], filter), EXACT, f"resize {size}->{new} {filter}")
+
+
+def test_resize_in_scripts(gpu):
+    img = I.random_rgba(90, 60, 4)
+    out, _, ops = gpu.r.execute_script_sync('resize_image(45, 30, "lanczos"); resize_image(45, 30, "nearest"); resize_image(200, 10, "whatever");', img, with_ops=True)
+    from . import oracle_lib as O
+    ref = O.resize(O.resize(img, 45, 30, "lanczos3"), 200, 10, "bilinear")   # unknown method names mean bilinear; same-size calls are no-ops
+    assert np.array_equal(out, ref)
+    assert ops == [(5, 45, 30, 3, 0), (5, 200, 10, 1, 0)]
+
+
 def test_effect_argument_errors(gpu):
     from paintfe_amd import PfxError
     img = I.random_rgba(32, 32, 1)

@@ -83,7 +83,6 @@ def test_script_selection_mask(r):
 @pytest.mark.parametrize("src,status,needle", [
     ("apply_blur(2);", -6, "Function not found: apply_blur (i64)"),          # Rhai does not coerce i64 -> f64
     ("apply_frobnicate(1.0);", -6, "Function not found: apply_frobnicate (f64)"),
-    ("resize_image(32, 32, \"bilinear\");", -5, "image crate"),                 # third-party resampling: outside this back-end
     ("let x = 4; apply_blur(x);", -6, "Function not found: apply_blur (i64)"),  # typing is checked on values, not literals
     ("map_channels(|r, g, b, a| { print(r); [r, g, b, a] });", -5, "cannot be compiled for the GPU"),
     ("switch 1 { 1 => 2 }", -5, "outside the supported subset"),
