@@ -397,6 +397,13 @@ enum { PFX_RESIZE_NEAREST = 0, PFX_RESIZE_BILINEAR = 1, PFX_RESIZE_BICUBIC = 2, 
 int pfx_resize_image(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst /* new_w*new_h*4 */, uint32_t new_w, uint32_t new_h,
                      int filter);
 int pfx_resize_image_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t h, void* dst_dev, uint32_t new_w, uint32_t new_h, int filter);
+/* apply_affine / affine_transform_layer(state, idx, rotation_z, rotation_x, rotation_y, scale, offset) (ref: src/ops/transform.rs:750-946):
+ * Rz*Ry*Rx homography about the canvas centre (angles in degrees), inverse-mapped; PFX_RESIZE_BILINEAR (the layer transform's
+ * mode, against a transparent outside) or PFX_RESIZE_NEAREST.  dst is canvas_w x canvas_h; unmapped pixels are (0,0,0,0). */
+int pfx_affine_transform(pfx_ctx* ctx, const uint8_t* src, uint32_t src_w, uint32_t src_h, uint8_t* dst, uint32_t canvas_w, uint32_t canvas_h,
+                         float rotation_z, float rotation_x, float rotation_y, float scale, float offset_x, float offset_y, int interpolation);
+int pfx_affine_transform_dev(pfx_ctx* ctx, const void* src_dev, uint32_t src_w, uint32_t src_h, void* dst_dev, uint32_t canvas_w, uint32_t canvas_h,
+                             float rotation_z, float rotation_x, float rotation_y, float scale, float offset_x, float offset_y, int interpolation);
 
 /* ================= B5/B6: script front-end and CLI (ref: src/ops/scripting.rs:1733-1821, src/cli.rs) ================= */
 typedef struct pfx_script_result {

@@ -120,6 +120,11 @@ enum { PFXO_RESIZE_NEAREST = 0, PFXO_RESIZE_BILINEAR = 1, PFXO_RESIZE_BICUBIC = 
 size_t pfxo_resize_weights(uint32_t n_in, uint32_t n_out, int filter, uint32_t* left, uint32_t* count, size_t* off, float* wts);
 void pfxo_resize(const uint8_t* src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, int filter, uint8_t* dst, int threads);
 
+/* layer affine / perspective resampler (o_affine.c; src/ops/transform.rs:750-976); interpolation: 0 nearest, else bilinear */
+void pfxo_affine_matrix(uint32_t canvas_w, uint32_t canvas_h, float rotation_z, float rotation_x, float rotation_y, float hi_out[9]);
+void pfxo_affine(const uint8_t* src, uint32_t sw, uint32_t sh, uint32_t canvas_w, uint32_t canvas_h, float rotation_z, float rotation_x, float rotation_y,
+                 float scale, float offset_x, float offset_y, int interpolation, uint8_t* dst, int threads);
+
 /* ---- A7/A8: ops::adjustments flavour (f32, .round()) (src/ops/adjustments.rs, src/ops/filters.rs:321) ---- */
 enum {
     PFXO_OP_INVERT = 0, PFXO_OP_INVERT_ALPHA, PFXO_OP_SEPIA, PFXO_OP_BRIGHTNESS_CONTRAST, PFXO_OP_HSL,

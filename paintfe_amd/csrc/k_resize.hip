@@ -50,7 +50,63 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const float4* __restrict_
     dst[(size_t)oy * nw + ox] = pack_rgba(round_u8f(t0), round_u8f(t1), round_u8f(t2), round_u8f(t3));
 }
 
+// ---- layer affine / perspective resampler (apply_affine, src/ops/transform.rs:826-946) --------------------------------------
+// Inverse homography hi[9] from the host; per pixel: u, v in canvas-centred coordinates, projective divide, bilinear against a
+// transparent outside (lerp form a + (b - a) * t, `.round().clamp(0,255) as u8`) or nearest.  Pixels that map outside stay 0.
+PFX_DEV int rs_i32(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+__global__ __launch_bounds__(256) void affine_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const pfxk_affine_params P, int src_w,
+                                                     int src_h, int cw, int ch)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= cw || dy >= ch) return;
+    uint32_t out = 0u;
+    const float v = ((float)dy - P.cy - P.off_y) * P.inv_scale;
+    const float base_sx = P.hi[1] * v + P.hi[2], base_sy = P.hi[4] * v + P.hi[5], base_sw = P.hi[7] * v + P.hi[8];
+    const float u = ((float)dx - P.cx - P.off_x) * P.inv_scale;
+    const float w = P.hi[6] * u + base_sw;
+    if (!(__builtin_fabsf(w) < 1e-8f)) {
+        const float inv_w = 1.0f / w;
+        const float sx = (P.hi[0] * u + base_sx) * inv_w + P.cx;
+        const float sy = (P.hi[3] * u + base_sy) * inv_w + P.cy;
+        if (P.nearest) {
+            const int nx = rs_i32(__builtin_roundf(sx)), ny = rs_i32(__builtin_roundf(sy));
+            if (nx >= 0 && ny >= 0 && nx < src_w && ny < src_h) out = src[(size_t)ny * src_w + nx];
+        } else {
+            const int x0 = rs_i32(__builtin_floorf(sx)), y0 = rs_i32(__builtin_floorf(sy));
+            if (!(x0 < -1 || y0 < -1 || x0 >= src_w || y0 >= src_h)) {
+                const float fx = sx - (float)x0, fy = sy - (float)y0;
+                auto sample = [&](int px, int py) -> uint32_t { return (px < 0 || py < 0 || px >= src_w || py >= src_h) ? 0u : src[(size_t)py * src_w + px]; };
+                const uint32_t tl = sample(x0, y0), tr = sample(x0 + 1, y0), bl = sample(x0, y0 + 1), br = sample(x0 + 1, y0 + 1);
+                float o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float a = (float)((tl >> (8 * c)) & 0xffu), b = (float)((tr >> (8 * c)) & 0xffu);
+                    const float cc = (float)((bl >> (8 * c)) & 0xffu), d = (float)((br >> (8 * c)) & 0xffu);
+                    const float top = a + (b - a) * fx, bot = cc + (d - cc) * fx;
+                    o[c] = round_u8f(top + (bot - top) * fy);
+                }
+                out = pack_rgba(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    dst[(size_t)dy * cw + dx] = out;
+}
+
 } // namespace
+
+extern "C" hipError_t pfxk_affine(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, uint8_t* d_dst, uint32_t cw, uint32_t ch,
+                                  const pfxk_affine_params* P)
+{
+    if (cw == 0 || ch == 0) return hipSuccess;
+    affine_kernel<<<dim3((cw + 63) / 64, (ch + 3) / 4), 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, *P, (int)sw, (int)sh, (int)cw, (int)ch);
+    return hipGetLastError();
+}
 
 // tables: v_* index by output row (nh entries), h_* by output column (nw entries)
 extern "C" hipError_t pfxk_resize(hipStream_t s, const uint8_t* d_src, float* d_tmp, uint8_t* d_dst, const uint32_t* v_left, const uint32_t* v_count,

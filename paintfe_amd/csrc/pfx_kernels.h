@@ -126,6 +126,10 @@ hipError_t pfxk_resize(hipStream_t s, const uint8_t* d_src, float* d_tmp /* w*nh
                        const uint32_t* v_off, const float* v_wts, const uint32_t* h_left, const uint32_t* h_count, const uint32_t* h_off, const float* h_wts,
                        uint32_t w, uint32_t h, uint32_t nw, uint32_t nh);
 
+typedef struct pfxk_affine_params { float hi[9]; float cx, cy, off_x, off_y, inv_scale; int32_t nearest; } pfxk_affine_params;
+hipError_t pfxk_affine(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, uint8_t* d_dst, uint32_t canvas_w, uint32_t canvas_h,
+                       const pfxk_affine_params* P);
+
 // ---- k_warp.hip ----
 hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, const float* d_disp,
                                   uint32_t w, uint32_t h, uint8_t* d_dst);

@@ -115,6 +115,59 @@ int pfx_resize_image_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t
     return PFX_OK;
 }
 
+// apply_affine (ref: src/ops/transform.rs:826-946): the homography is built and inverted on the host exactly as the reference does
+int pfx_affine_transform_dev(pfx_ctx* ctx, const void* src_dev, uint32_t src_w, uint32_t src_h, void* dst_dev, uint32_t canvas_w, uint32_t canvas_h,
+                             float rotation_z, float rotation_x, float rotation_y, float scale, float offset_x, float offset_y, int interpolation)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src_dev && dst_dev && src_dev != dst_dev, "pfx_affine_transform_dev: bad image pointers");
+    PFX_REQUIRE(ctx, canvas_w && canvas_h && (uint64_t)canvas_w * canvas_h <= 256000000ull && (uint64_t)src_w * src_h <= 256000000ull,
+                "pfx_affine_transform_dev: bad size");
+    PFX_REQUIRE(ctx, interpolation == PFX_RESIZE_NEAREST || interpolation == PFX_RESIZE_BILINEAR, "pfx_affine_transform_dev: nearest or bilinear only");
+    PFX_TRY(pfx_use(ctx));
+    pfxk_affine_params P{};
+    P.cx = (float)canvas_w * 0.5f;
+    P.cy = (float)canvas_h * 0.5f;
+    P.off_x = offset_x;
+    P.off_y = offset_y;
+    P.inv_scale = fabsf(scale) > 1e-6f ? 1.0f / scale : 1.0f;
+    P.nearest = interpolation == PFX_RESIZE_NEAREST;
+    const float focal = (float)std::max(canvas_w, canvas_h) * 1.5f;
+    const float rad = 3.14159265358979323846f / 180.0f; // f32::to_radians
+    const float az = rotation_z * rad, ax = rotation_x * rad, ay = rotation_y * rad;
+    const float sz = sinf(az), cz = cosf(az), sxr = sinf(ax), cxr = cosf(ax), syr = sinf(ay), cyr = cosf(ay);
+    const float r00 = cz * cyr, r01 = cz * syr * sxr - sz * cxr, r10 = sz * cyr, r11 = sz * syr * sxr + cz * cxr, r20 = -syr, r21 = cyr * sxr;
+    const float a = focal * r00, b = focal * r01, c = 0.0f, d = focal * r10, e = focal * r11, f = 0.0f, g = r20, h = r21, i = focal;
+    const float det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g); // invert_3x3, transform.rs:949-976
+    if (fabsf(det) < 1e-12f) {
+        const float id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::memcpy(P.hi, id, sizeof id);
+    } else {
+        const float inv = 1.0f / det;
+        P.hi[0] = (e * i - f * h) * inv; P.hi[1] = (c * h - b * i) * inv; P.hi[2] = (b * f - c * e) * inv;
+        P.hi[3] = (f * g - d * i) * inv; P.hi[4] = (a * i - c * g) * inv; P.hi[5] = (c * d - a * f) * inv;
+        P.hi[6] = (d * h - e * g) * inv; P.hi[7] = (b * g - a * h) * inv; P.hi[8] = (a * e - b * d) * inv;
+    }
+    pfx_timer t(ctx, "affine");
+    PFX_HIP(ctx, pfxk_affine(ctx->stream, (const uint8_t*)src_dev, src_w, src_h, (uint8_t*)dst_dev, canvas_w, canvas_h, &P));
+    return PFX_OK;
+}
+
+int pfx_affine_transform(pfx_ctx* ctx, const uint8_t* src, uint32_t src_w, uint32_t src_h, uint8_t* dst, uint32_t canvas_w, uint32_t canvas_h,
+                         float rotation_z, float rotation_x, float rotation_y, float scale, float offset_x, float offset_y, int interpolation)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src && dst && src_w && src_h && canvas_w && canvas_h, "pfx_affine_transform: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_in, (size_t)src_w * src_h * 4));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, (size_t)canvas_w * canvas_h * 4));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_in.p, src, (size_t)src_w * src_h * 4));
+    PFX_TRY(pfx_affine_transform_dev(ctx, ctx->st_in.p, src_w, src_h, ctx->st_out.p, canvas_w, canvas_h, rotation_z, rotation_x, rotation_y, scale, offset_x,
+                                     offset_y, interpolation));
+    PFX_TRY(pfx_d2h(ctx, dst, ctx->st_out.p, (size_t)canvas_w * canvas_h * 4));
+    return pfx_sync(ctx);
+}
+
 int pfx_resize_image(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst, uint32_t new_w, uint32_t new_h, int filter)
 {
     if (!ctx) return PFX_ERR_INVALID;

@@ -436,6 +436,16 @@ class GpuRenderer:
                                                _enum(RESIZE_FILTERS, filter)))
         return dst
 
+    def affine_transform(self, img, canvas_w: int, canvas_h: int, rotation_z=0.0, rotation_x=0.0, rotation_y=0.0, scale=1.0, offset=(0.0, 0.0),
+                         interpolation="bilinear"):                            # transform.rs:826 apply_affine
+        src = _u8(img)
+        h, w = src.shape[:2]
+        dst = np.empty((canvas_h, canvas_w, 4), np.uint8)
+        self._check(self._lib.pfx_affine_transform(self._h, _p(src), C.c_uint32(w), C.c_uint32(h), _p(dst), C.c_uint32(canvas_w), C.c_uint32(canvas_h),
+                                                   C.c_float(rotation_z), C.c_float(rotation_x), C.c_float(rotation_y), C.c_float(scale),
+                                                   C.c_float(offset[0]), C.c_float(offset[1]), _enum(RESIZE_FILTERS, interpolation)))
+        return dst
+
     def resize_image_dev(self, src_ptr, w, h, dst_ptr, new_w, new_h, filter="bilinear"):
         self._check(self._lib.pfx_resize_image_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr), C.c_uint32(new_w),
                                                    C.c_uint32(new_h), _enum(RESIZE_FILTERS, filter)))

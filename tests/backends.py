@@ -48,6 +48,12 @@ class OracleBackend:
     def resize(self, img, new_w, new_h, filter):
         return O.resize(img, new_w, new_h, filter)
 
+    def affine_layer(self, img, composite=False, **kw):
+        """affine_transform_layer on a one-layer document, then extract_layer (TiledImage round trip) or state.composite()"""
+        h, w = img.shape[:2]
+        layer = O.tiled_roundtrip(O.affine(img, w, h, **kw))
+        return O.composite([dict(pixels=layer)], w, h) if composite else layer
+
     def rhai_adjust(self, img, op, params=()):
         return O.rhai_adjust(img, op, params)
 
@@ -141,6 +147,11 @@ class GpuBackend:
 
     def resize(self, img, new_w, new_h, filter):
         return self.r.resize_image(img, new_w, new_h, filter)
+
+    def affine_layer(self, img, composite=False, **kw):
+        h, w = img.shape[:2]
+        layer = self.r.tiled_roundtrip(self.r.affine_transform(img, w, h, **kw))
+        return self.composite([dict(pixels=layer)], w, h) if composite else layer
 
     def effect(self, name, img, **kw):
         if name == "shadow":  # Gaussian inside: goldens are held at tolerance 0

@@ -249,5 +249,16 @@ def resize_cases():
     ]
 
 
+def affine_cases():
+    """tests/visual_transforms.rs:234-249 (note: passes radians where the function expects degrees) and tests/transform_ops.rs:279-303"""
+    deg = lambda v: float(f32(v))
+    return [
+        ("transforms/affine_rotate_45", "affine_layer", dict(img=I.create_test_gradient(64, 48), rotation_z=deg(f32(45.0) * (f32(np.pi) / f32(180.0))))),
+        ("transform/affine_rotate_90", "affine_layer", dict(img=I.create_test_gradient(32, 32), composite=True, rotation_z=deg(f32(np.pi) / f32(2.0)))),
+        ("transform/affine_scale_half", "affine_layer", dict(img=I.create_test_gradient(32, 32), composite=True, scale=0.5)),
+    ]
+
+
 def all_cases():
-    return (blend_cases() + filter_cases() + rhai_cases() + adjustment_cases() + warp_cases() + brush_cases() + effect_cases() + resize_cases())
+    return (blend_cases() + filter_cases() + rhai_cases() + adjustment_cases() + warp_cases() + brush_cases() + effect_cases() + resize_cases() +
+            affine_cases())

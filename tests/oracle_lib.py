@@ -300,6 +300,16 @@ def contours(img, scale, frequency, line_width, line_color, seed, octaves, blend
                    C.c_uint32(seed), C.c_uint32(octaves), C.c_float(blend), mask=mask, threads=threads)
 
 
+def affine(img, canvas_w, canvas_h, rotation_z=0.0, rotation_x=0.0, rotation_y=0.0, scale=1.0, offset=(0.0, 0.0), interpolation="bilinear", threads=0):
+    h, w = img.shape[:2]
+    src, ps = _u8(img)
+    out = np.zeros((canvas_h, canvas_w, 4), np.uint8)
+    lib().pfxo_affine(ps, C.c_uint32(w), C.c_uint32(h), C.c_uint32(canvas_w), C.c_uint32(canvas_h), C.c_float(rotation_z), C.c_float(rotation_x),
+                      C.c_float(rotation_y), C.c_float(scale), C.c_float(offset[0]), C.c_float(offset[1]), C.c_int(0 if interpolation == "nearest" else 1),
+                      out.ctypes.data_as(C.c_void_p), C.c_int(threads))
+    return out
+
+
 RESIZE_FILTERS = {"nearest": 0, "bilinear": 1, "bicubic": 2, "lanczos3": 3}
 
 

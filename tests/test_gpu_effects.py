@@ -175,6 +175,23 @@ def test_resize_image_bitexact(gpu, oracle, filter, size, new):
     check(gpu.resize(img, new[0], new[1], filter), oracle.resize(img, new[0], new[1], filter), EXACT, f"resize {size}->{new} {filter}")
 
 
+AFFINE = [
+    dict(rotation_z=33.0), dict(rotation_z=-170.0, scale=1.7, offset=(12.5, -8.25)), dict(rotation_x=35.0, rotation_y=-20.0, rotation_z=10.0),
+    dict(scale=0.0), dict(scale=-0.4, rotation_y=80.0), dict(rotation_x=90.0), dict(rotation_z=90.0, interpolation="nearest"),
+    dict(scale=3.0, offset=(-40.0, 15.0), interpolation="nearest"), dict(),
+]
+
+
+@pytest.mark.parametrize("kw", AFFINE, ids=[str(i) for i in range(len(AFFINE))])
+def test_affine_transform_bitexact(gpu, kw):
+    from . import oracle_lib as O
+    img = I.random_rgba(131, 77, 21)
+    img[:20, :30, 3] = 0
+    check(gpu.r.affine_transform(img, 131, 77, **kw), O.affine(img, 131, 77, **kw), EXACT, f"affine {kw}")
+    # canvas larger / smaller than the layer image
+    check(gpu.r.affine_transform(img, 200, 40, **kw), O.affine(img, 200, 40, **kw), EXACT, f"affine {kw} on a 200x40 canvas")
+
+
 def test_resize_in_scripts(gpu):
     img = I.random_rgba(90, 60, 4)
     out, _, ops = gpu.r.execute_script_sync('resize_image(45, 30, "lanczos"); resize_image(45, 30, "nearest"); resize_image(200, 10, "whatever");', img, with_ops=True)
