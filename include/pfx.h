@@ -430,6 +430,16 @@ typedef struct pfx_canvas_op {
     uint32_t w, h;           /* RESIZE_IMAGE / RESIZE_CANVAS: new size */
     uint32_t anchor_x, anchor_y; /* RESIZE_CANVAS: 0 / 1 / 2 per axis (parse_anchor, scripting.rs:69-82); RESIZE_IMAGE: anchor_x = PFX_RESIZE_* filter */
 } pfx_canvas_op;
+/* the same canvas-wide transforms applied to one layer image, for replaying a pfx_canvas_op list on the other layers
+ * (ref: apply_canvas_ops, scripting.rs:1640-1723; ops::transform::flip_canvas_* / rotate_canvas_* / resize_canvas, transform.rs:382-424).
+ * op = PFX_CANVAS_FLIP_HORIZONTAL .. PFX_CANVAS_ROTATE_180; 90-degree rotations swap the output's width and height. */
+int pfx_flip_rotate(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst, int op);
+int pfx_flip_rotate_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t h, void* dst_dev, int op);
+/* anchor 0 / 1 / 2 per axis; fill = colour of the new area (NULL = transparent) */
+int pfx_resize_canvas(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst /* new_w*new_h*4 */, uint32_t new_w, uint32_t new_h,
+                      uint32_t anchor_x, uint32_t anchor_y, const uint8_t fill[4]);
+int pfx_resize_canvas_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t h, void* dst_dev, uint32_t new_w, uint32_t new_h, uint32_t anchor_x,
+                          uint32_t anchor_y, const uint8_t fill[4]);
 /* full form: returns (result_pixels, final_w, final_h, console_output, canvas_ops) like the reference.  *out is an opaque
  * result owned by the library until pfx_script_output_free; NULL on error. */
 typedef struct pfx_script_output pfx_script_output;

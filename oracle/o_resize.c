@@ -77,6 +77,37 @@ size_t pfxo_resize_weights(uint32_t n_in, uint32_t n_out, int filter, uint32_t* 
     return total;
 }
 
+/* imageops::flip_horizontal / flip_vertical / rotate90 / rotate270 / rotate180 (pure permutations); op = CanvasOpRequest order:
+ * 0 flip h, 1 flip v, 2 rotate 90 cw, 3 rotate 90 ccw, 4 rotate 180.  dst is h x w for the 90-degree rotations. */
+void pfxo_flip_rotate(const uint8_t* src, uint32_t w, uint32_t h, int op, uint8_t* dst)
+{
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            uint32_t ox, oy, ow = w;
+            switch (op) {
+            case 0: ox = w - 1 - x; oy = y; break;
+            case 1: ox = x; oy = h - 1 - y; break;
+            case 2: ox = h - 1 - y; oy = x; ow = h; break;  /* rotate90: out.put_pixel(height - 1 - y, x, p) */
+            case 3: ox = y; oy = w - 1 - x; ow = h; break;  /* rotate270: out.put_pixel(y, width - 1 - x, p) */
+            default: ox = w - 1 - x; oy = h - 1 - y; break;
+            }
+            memcpy(dst + ((size_t)oy * ow + ox) * 4, src + ((size_t)y * w + x) * 4, 4);
+        }
+}
+
+/* resize_canvas (src/ops/transform.rs:382-424; script flavour src/ops/scripting.rs:781-818 = transparent fill) */
+void pfxo_resize_canvas(const uint8_t* src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint32_t ax, uint32_t ay, const uint8_t fill[4], uint8_t* dst)
+{
+    int32_t off_x = ax == 0 ? 0 : (ax == 1 ? ((int32_t)nw - (int32_t)w) / 2 : (int32_t)nw - (int32_t)w);
+    int32_t off_y = ay == 0 ? 0 : (ay == 1 ? ((int32_t)nh - (int32_t)h) / 2 : (int32_t)nh - (int32_t)h);
+    for (size_t i = 0; i < (size_t)nw * nh; ++i) memcpy(dst + i * 4, fill, 4);
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            int32_t nx = (int32_t)x + off_x, ny = (int32_t)y + off_y;
+            if (nx >= 0 && ny >= 0 && (uint32_t)nx < nw && (uint32_t)ny < nh) memcpy(dst + ((size_t)ny * nw + nx) * 4, src + ((size_t)y * w + x) * 4, 4);
+        }
+}
+
 void pfxo_resize(const uint8_t* src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, int filter, uint8_t* dst, int threads)
 {
     if (nw == 0 || nh == 0) return;

@@ -119,6 +119,9 @@ void pfxo_contours(const uint8_t* src, uint32_t w, uint32_t h, float scale, floa
 enum { PFXO_RESIZE_NEAREST = 0, PFXO_RESIZE_BILINEAR = 1, PFXO_RESIZE_BICUBIC = 2, PFXO_RESIZE_LANCZOS3 = 3 };
 size_t pfxo_resize_weights(uint32_t n_in, uint32_t n_out, int filter, uint32_t* left, uint32_t* count, size_t* off, float* wts);
 void pfxo_resize(const uint8_t* src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, int filter, uint8_t* dst, int threads);
+void pfxo_flip_rotate(const uint8_t* src, uint32_t w, uint32_t h, int op /* 0 flip h, 1 flip v, 2 90cw, 3 90ccw, 4 180 */, uint8_t* dst);
+void pfxo_resize_canvas(const uint8_t* src, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint32_t anchor_x, uint32_t anchor_y, const uint8_t fill[4],
+                        uint8_t* dst);
 
 /* layer affine / perspective resampler (o_affine.c; src/ops/transform.rs:750-976); interpolation: 0 nearest, else bilinear */
 void pfxo_affine_matrix(uint32_t canvas_w, uint32_t canvas_h, float rotation_z, float rotation_x, float rotation_y, float hi_out[9]);

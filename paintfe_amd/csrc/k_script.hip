@@ -203,12 +203,12 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint32_t* __restrict
 
 // resize_canvas (scripting.rs:798-812): zeroed new image, old pixels copied at (offset_x, offset_y)
 __global__ __launch_bounds__(256) void recanvas_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int ow, int oh, int nw, int nh,
-                                                       int off_x, int off_y)
+                                                       int off_x, int off_y, uint32_t fill)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= nw || y >= nh) return;
     const int sx = x - off_x, sy = y - off_y;
-    dst[(size_t)y * nw + x] = (sx >= 0 && sy >= 0 && sx < ow && sy < oh) ? src[(size_t)sy * ow + sx] : 0u;
+    dst[(size_t)y * nw + x] = (sx >= 0 && sy >= 0 && sx < ow && sy < oh) ? src[(size_t)sy * ow + sx] : fill;
 }
 
 // selection masks (scripting.rs:1359-1431).  op: 0 rect [x0,x1)x[y0,y1), 1 ellipse (f64 like the reference), 2 invert, 3 clear to 0
@@ -258,10 +258,11 @@ extern "C" hipError_t pfxk_permute(hipStream_t s, const uint8_t* d_src, uint8_t*
 }
 
 extern "C" hipError_t pfxk_recanvas(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, uint32_t ow, uint32_t oh, uint32_t nw, uint32_t nh, int off_x,
-                                    int off_y)
+                                    int off_y, uint32_t fill_rgba)
 {
     if (nw == 0 || nh == 0) return hipSuccess;
-    recanvas_kernel<<<tile_grid((int)nw, (int)nh), 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, (int)ow, (int)oh, (int)nw, (int)nh, off_x, off_y);
+    recanvas_kernel<<<tile_grid((int)nw, (int)nh), 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, (int)ow, (int)oh, (int)nw, (int)nh, off_x, off_y,
+                                                                fill_rgba);
     return hipGetLastError();
 }
 

@@ -115,7 +115,8 @@ typedef struct pfxk_vm_args {
 hipError_t pfxk_vm_run(hipStream_t s, const pfxk_vm_args* A);
 // mode: 0 flip_horizontal, 1 flip_vertical, 2 rotate180, 3 rotate90 (cw), 4 rotate270 (ccw); (w, h) = source size
 hipError_t pfxk_permute(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, int mode, uint32_t w, uint32_t h);
-hipError_t pfxk_recanvas(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, uint32_t ow, uint32_t oh, uint32_t nw, uint32_t nh, int off_x, int off_y);
+hipError_t pfxk_recanvas(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, uint32_t ow, uint32_t oh, uint32_t nw, uint32_t nh, int off_x, int off_y,
+                         uint32_t fill_rgba);
 // op: 0 rect [x0,x1)x[y0,y1), 1 ellipse (centre cx,cy; squared radii), 2 invert, 3 clear
 hipError_t pfxk_mask_op(hipStream_t s, uint8_t* d_mask, int op, int x0, int y0, int x1, int y1, double cx, double cy, double rx2, double ry2,
                         uint32_t w, uint32_t h);

@@ -168,6 +168,63 @@ int pfx_affine_transform(pfx_ctx* ctx, const uint8_t* src, uint32_t src_w, uint3
     return pfx_sync(ctx);
 }
 
+// flip / rotate one layer image (ref: src/ops/transform.rs flip_canvas_* / rotate_canvas_* = imageops::flip_* / rotate*)
+int pfx_flip_rotate_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t h, void* dst_dev, int op)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src_dev && dst_dev && src_dev != dst_dev && w && h && (uint64_t)w * h <= 256000000ull, "pfx_flip_rotate_dev: bad arguments");
+    PFX_REQUIRE(ctx, op >= PFX_CANVAS_FLIP_HORIZONTAL && op <= PFX_CANVAS_ROTATE_180, "pfx_flip_rotate_dev: unknown operation");
+    PFX_TRY(pfx_use(ctx));
+    static const int mode_of[5] = {0, 1, 3, 4, 2}; // FLIP_H, FLIP_V, ROTATE_90CW, ROTATE_90CCW, ROTATE_180 -> k_script.hip permutation modes
+    pfx_timer t(ctx, "permute");
+    PFX_HIP(ctx, pfxk_permute(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, mode_of[op], w, h));
+    return PFX_OK;
+}
+
+int pfx_flip_rotate(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst, int op)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src && dst && w && h, "pfx_flip_rotate: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    const size_t bytes = (size_t)w * h * 4;
+    PFX_TRY(pfx_reserve(ctx, ctx->st_in, bytes));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, bytes));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_in.p, src, bytes));
+    PFX_TRY(pfx_flip_rotate_dev(ctx, ctx->st_in.p, w, h, ctx->st_out.p, op));
+    PFX_TRY(pfx_d2h(ctx, dst, ctx->st_out.p, bytes));
+    return pfx_sync(ctx);
+}
+
+// resize_canvas(state, new_w, new_h, anchor, fill) for one layer image (ref: src/ops/transform.rs:382-424)
+int pfx_resize_canvas_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t h, void* dst_dev, uint32_t new_w, uint32_t new_h, uint32_t anchor_x,
+                          uint32_t anchor_y, const uint8_t fill[4])
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src_dev && dst_dev && src_dev != dst_dev && w && h && new_w && new_h && (uint64_t)new_w * new_h <= 256000000ull,
+                "pfx_resize_canvas_dev: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    const int32_t off_x = anchor_x == 0 ? 0 : (anchor_x == 1 ? ((int32_t)new_w - (int32_t)w) / 2 : (int32_t)new_w - (int32_t)w);
+    const int32_t off_y = anchor_y == 0 ? 0 : (anchor_y == 1 ? ((int32_t)new_h - (int32_t)h) / 2 : (int32_t)new_h - (int32_t)h);
+    const uint32_t rgba = fill ? ((uint32_t)fill[0] | ((uint32_t)fill[1] << 8) | ((uint32_t)fill[2] << 16) | ((uint32_t)fill[3] << 24)) : 0u;
+    pfx_timer t(ctx, "resize_canvas");
+    PFX_HIP(ctx, pfxk_recanvas(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, w, h, new_w, new_h, off_x, off_y, rgba));
+    return PFX_OK;
+}
+
+int pfx_resize_canvas(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst, uint32_t new_w, uint32_t new_h, uint32_t anchor_x,
+                      uint32_t anchor_y, const uint8_t fill[4])
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src && dst && w && h && new_w && new_h, "pfx_resize_canvas: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_in, (size_t)w * h * 4));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, (size_t)new_w * new_h * 4));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_in.p, src, (size_t)w * h * 4));
+    PFX_TRY(pfx_resize_canvas_dev(ctx, ctx->st_in.p, w, h, ctx->st_out.p, new_w, new_h, anchor_x, anchor_y, fill));
+    PFX_TRY(pfx_d2h(ctx, dst, ctx->st_out.p, (size_t)new_w * new_h * 4));
+    return pfx_sync(ctx);
+}
+
 int pfx_resize_image(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst, uint32_t new_w, uint32_t new_h, int filter)
 {
     if (!ctx) return PFX_ERR_INVALID;

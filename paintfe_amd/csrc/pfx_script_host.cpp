@@ -299,7 +299,7 @@ int ScriptHost::call(rhai::Interp& in, const std::string& name, std::vector<Valu
         const int32_t off_y = ay == 0 ? 0 : (ay == 1 ? ((int32_t)nh - (int32_t)oh) / 2 : (int32_t)nh - (int32_t)oh);
         const int st = pingpong([&](const void* s, void* d) {
             pfx_timer t(ctx, "resize_canvas");
-            PFX_HIP(ctx, pfxk_recanvas(ctx->stream, (const uint8_t*)s, (uint8_t*)d, ow, oh, nw, nh, off_x, off_y));
+            PFX_HIP(ctx, pfxk_recanvas(ctx->stream, (const uint8_t*)s, (uint8_t*)d, ow, oh, nw, nh, off_x, off_y, 0u)); // RgbaImage::new: transparent
             return (int)PFX_OK;
         }, nw, nh);
         if (st == PFX_OK) {

@@ -47,6 +47,7 @@ GRID_STYLES = ["lines", "checkerboard"]                               # GridStyl
 OUTLINE_MODES = ["outside", "inside", "center"]                       # OutlineMode
 COLOR_FILTER_MODES = ["multiply", "screen", "overlay", "soft_light"]  # ColorFilterMode
 RESIZE_FILTERS = ["nearest", "bilinear", "bicubic", "lanczos3"]       # ScriptFilterType / Interpolation
+CANVAS_OPS = ["flip_horizontal", "flip_vertical", "rotate_90cw", "rotate_90ccw", "rotate_180", "resize_image", "resize_canvas"]  # CanvasOpRequest
 
 
 def _enum(names, v):
@@ -444,6 +445,22 @@ class GpuRenderer:
         self._check(self._lib.pfx_affine_transform(self._h, _p(src), C.c_uint32(w), C.c_uint32(h), _p(dst), C.c_uint32(canvas_w), C.c_uint32(canvas_h),
                                                    C.c_float(rotation_z), C.c_float(rotation_x), C.c_float(rotation_y), C.c_float(scale),
                                                    C.c_float(offset[0]), C.c_float(offset[1]), _enum(RESIZE_FILTERS, interpolation)))
+        return dst
+
+    def flip_rotate(self, img, op):                                            # transform.rs flip_canvas_* / rotate_canvas_*
+        src = _u8(img)
+        h, w = src.shape[:2]
+        opi = _enum(CANVAS_OPS, op)
+        dst = np.empty((w, h, 4) if opi.value in (2, 3) else (h, w, 4), np.uint8)
+        self._check(self._lib.pfx_flip_rotate(self._h, _p(src), C.c_uint32(w), C.c_uint32(h), _p(dst), opi))
+        return dst
+
+    def resize_canvas(self, img, new_w: int, new_h: int, anchor=(0, 0), fill=(0, 0, 0, 0)):   # transform.rs:382
+        src = _u8(img)
+        h, w = src.shape[:2]
+        dst = np.empty((new_h, new_w, 4), np.uint8)
+        self._check(self._lib.pfx_resize_canvas(self._h, _p(src), C.c_uint32(w), C.c_uint32(h), _p(dst), C.c_uint32(new_w), C.c_uint32(new_h),
+                                                C.c_uint32(anchor[0]), C.c_uint32(anchor[1]), _c4(fill)))
         return dst
 
     def resize_image_dev(self, src_ptr, w, h, dst_ptr, new_w, new_h, filter="bilinear"):

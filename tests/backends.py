@@ -48,6 +48,12 @@ class OracleBackend:
     def resize(self, img, new_w, new_h, filter):
         return O.resize(img, new_w, new_h, filter)
 
+    def flip_rotate(self, img, op):
+        return O.flip_rotate(img, op)
+
+    def resize_canvas(self, img, new_w, new_h, anchor, fill):
+        return O.resize_canvas(img, new_w, new_h, anchor, fill)
+
     def affine_layer(self, img, composite=False, **kw):
         """affine_transform_layer on a one-layer document, then extract_layer (TiledImage round trip) or state.composite()"""
         h, w = img.shape[:2]
@@ -147,6 +153,12 @@ class GpuBackend:
 
     def resize(self, img, new_w, new_h, filter):
         return self.r.resize_image(img, new_w, new_h, filter)
+
+    def flip_rotate(self, img, op):
+        return self.r.flip_rotate(img, op)
+
+    def resize_canvas(self, img, new_w, new_h, anchor, fill):
+        return self.r.resize_canvas(img, new_w, new_h, anchor, fill)
 
     def affine_layer(self, img, composite=False, **kw):
         h, w = img.shape[:2]

@@ -249,6 +249,26 @@ def resize_cases():
     ]
 
 
+def canvas_transform_cases():
+    """tests/visual_transforms.rs:25-96,170-228 (64x48 gradient) and tests/scripting.rs:158-168 (64x64 gradient)"""
+    t, s = I.create_test_gradient(64, 48), _grad()
+    T = "transforms/"
+    return [
+        (T + "flip_canvas_h", "flip_rotate", dict(img=t, op="flip_horizontal")),
+        (T + "flip_canvas_v", "flip_rotate", dict(img=t, op="flip_vertical")),
+        (T + "flip_layer_h", "flip_rotate", dict(img=t, op="flip_horizontal")),
+        (T + "flip_layer_v", "flip_rotate", dict(img=t, op="flip_vertical")),
+        (T + "rotate_90cw", "flip_rotate", dict(img=t, op="rotate_90cw")),
+        (T + "rotate_90ccw", "flip_rotate", dict(img=t, op="rotate_90ccw")),
+        (T + "rotate_180", "flip_rotate", dict(img=t, op="rotate_180")),
+        ("scripting/flip_horizontal", "flip_rotate", dict(img=s, op="flip_horizontal")),
+        ("scripting/flip_vertical", "flip_rotate", dict(img=s, op="flip_vertical")),
+        (T + "resize_canvas_center", "resize_canvas", dict(img=t, new_w=96, new_h=80, anchor=(1, 1), fill=(0, 0, 0, 0))),
+        (T + "resize_canvas_topleft", "resize_canvas", dict(img=t, new_w=80, new_h=64, anchor=(0, 0), fill=(255, 0, 0, 255))),
+        (T + "flatten_single", "composite", dict(layers=[dict(pixels=t)], w=64, h=48)),
+    ]
+
+
 def affine_cases():
     """tests/visual_transforms.rs:234-249 (note: passes radians where the function expects degrees) and tests/transform_ops.rs:279-303"""
     deg = lambda v: float(f32(v))
@@ -261,4 +281,4 @@ def affine_cases():
 
 def all_cases():
     return (blend_cases() + filter_cases() + rhai_cases() + adjustment_cases() + warp_cases() + brush_cases() + effect_cases() + resize_cases() +
-            affine_cases())
+            canvas_transform_cases() + affine_cases())

@@ -310,6 +310,27 @@ def affine(img, canvas_w, canvas_h, rotation_z=0.0, rotation_x=0.0, rotation_y=0
     return out
 
 
+CANVAS_OPS = {"flip_horizontal": 0, "flip_vertical": 1, "rotate_90cw": 2, "rotate_90ccw": 3, "rotate_180": 4}
+
+
+def flip_rotate(img, op):
+    h, w = img.shape[:2]
+    src, ps = _u8(img)
+    k = CANVAS_OPS[op]
+    out = np.zeros((w, h, 4) if k in (2, 3) else (h, w, 4), np.uint8)
+    lib().pfxo_flip_rotate(ps, C.c_uint32(w), C.c_uint32(h), C.c_int(k), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def resize_canvas(img, new_w, new_h, anchor=(0, 0), fill=(0, 0, 0, 0)):
+    h, w = img.shape[:2]
+    src, ps = _u8(img)
+    out = np.zeros((new_h, new_w, 4), np.uint8)
+    lib().pfxo_resize_canvas(ps, C.c_uint32(w), C.c_uint32(h), C.c_uint32(new_w), C.c_uint32(new_h), C.c_uint32(anchor[0]), C.c_uint32(anchor[1]),
+                             _c4(fill), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 RESIZE_FILTERS = {"nearest": 0, "bilinear": 1, "bicubic": 2, "lanczos3": 3}
 
 

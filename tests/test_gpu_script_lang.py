@@ -52,6 +52,24 @@ def test_script_goldens(r, golden, key, src, size):
     assert np.array_equal(out, golden[key])
 
 
+def test_layer_transform_entry_points_match_the_goldens(r, golden):
+    """the same transforms through the direct C entry points a caller uses to replay canvas ops on its other layers"""
+    img = I.create_test_gradient(64, 48)
+    for op, key in (("flip_horizontal", "flip_canvas_h"), ("flip_vertical", "flip_canvas_v"), ("rotate_90cw", "rotate_90cw"), ("rotate_90ccw", "rotate_90ccw"),
+                    ("rotate_180", "rotate_180")):
+        assert np.array_equal(r.flip_rotate(img, op), golden["transforms/" + key]), op
+    assert np.array_equal(r.resize_canvas(img, 96, 80, (1, 1), (0, 0, 0, 0)), golden["transforms/resize_canvas_center"])
+    assert np.array_equal(r.resize_canvas(img, 80, 64, (0, 0), (255, 0, 0, 255)), golden["transforms/resize_canvas_topleft"])
+    # shrinking crops; anchors pick the kept corner (transform.rs:393-402)
+    big = I.random_rgba(50, 40, 3)
+    assert np.array_equal(r.resize_canvas(big, 20, 10, (2, 2), (9, 9, 9, 9)), big[30:, 30:])
+    assert np.array_equal(r.resize_canvas(big, 20, 10, (1, 1), None if False else (9, 9, 9, 9)), big[15:25, 15:35])
+    # flatten_image of a one-layer document (tests/visual_transforms.rs:221-228) is the compositor on that layer
+    r.clear_layers()
+    r.ensure_layer_texture(0, img, generation=1)
+    assert np.array_equal(r.composite(64, 48, [(0, 1.0, True, 0)]), golden["transforms/flatten_single"])
+
+
 # ------------------------------------------------------------------ the reference's scripting tests (tests/scripting.rs)
 def test_width_height_and_interpolation(r):
     _, console = run(r, "let w = width();\nlet h = height();\nprint_line(`${w}x${h}`);")
