@@ -257,6 +257,23 @@ int pfx_composite(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* la
 /* composite_dirty_readback: composite, read back only (x, y, rw, rh) into the tight `dst_region` */
 int pfx_composite_region(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* layers, uint32_t n_layers,
                          uint32_t x, uint32_t y, uint32_t rw, uint32_t rh, uint8_t* dst_region);
+/* The tool preview layer (CanvasState::preview_layer + preview_blend_mode / preview_is_eraser / preview_replaces_layer,
+ * ref: src/canvas/canvas_state.rs:541-548,556-560,593-658): while a stroke is in flight its pixels are folded into the ACTIVE
+ * layer's pixel before that layer's mask, blend mode and opacity apply — replaced outright, used as an eraser mask, lerped by
+ * coverage for Overwrite / Xor, or blended with the tool's mode.  The reference's wgpu compositor does not handle it (only
+ * the CPU one does); here it rides on the same kernel.  `preview_pixels` is the preview flattened to w*h RGBA8;
+ * `preview_chunk_present` (one byte per 64x64 chunk, row-major) tells which chunks the preview TiledImage holds — NULL means
+ * "every chunk with a non-zero alpha", TiledImage::from_rgba_image's rule. */
+typedef struct pfx_preview {
+    uint32_t active_layer;   /* index into the pfx_layer_info array of the call (CanvasState::active_layer_index) */
+    uint8_t  blend_mode;     /* BlendMode::to_u8 */
+    uint8_t  is_eraser;
+    uint8_t  replaces_layer;
+    uint8_t  _pad;
+} pfx_preview;
+int pfx_composite_preview(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* layers, uint32_t n_layers,
+                          const uint8_t* preview_pixels, const uint8_t* preview_chunk_present /* may be NULL */,
+                          const pfx_preview* preview, uint8_t* dst);
 /* one blend_pixel_static on the host-visible side of the ABI (kept for spot checks; runs a 1-pixel launch) */
 int pfx_blend_pixels(pfx_ctx* ctx, const uint8_t* base, const uint8_t* top, uint8_t* dst, size_t n_pixels,
                      uint8_t blend_mode, float opacity);
@@ -307,6 +324,9 @@ int pfx_chunk_populated(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h
 /* ================= device-resident tier (`_dev`): same kernels, caller-owned device memory, asynchronous ========= */
 int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev /* may be NULL */,
                     const pfx_layer_info* layers, uint32_t n_layers, uint32_t w, uint32_t h, void* dst_dev);
+int pfx_flatten_preview_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev, const pfx_layer_info* layers,
+                            uint32_t n_layers, uint32_t w, uint32_t h, const void* preview_dev, const void* preview_chunk_present_dev /* may be NULL */,
+                            const pfx_preview* preview, void* dst_dev);
 /* `tmp_dev` = w*h*16 bytes of scratch for the f32 horizontal pass (ref: filters.rs:255 buf_h); NULL = context scratch */
 int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma,
                           void* tmp_dev);

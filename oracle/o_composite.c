@@ -198,19 +198,55 @@ static void adj_apply_with_opacity(const pfxo_layer* L, uint8_t p[4])
 /* canvas_state.rs:505-698 with viewport=None and preview_layer=None */
 void pfxo_composite(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t h, uint8_t* dst, int threads)
 {
+    pfxo_composite_preview(layers, n_layers, w, h, NULL, dst, threads);
+}
+
+/* :621-658: the tool preview is folded into the active layer's pixel before masking and compositing */
+static void apply_preview(uint8_t top[4], const uint8_t pp[4], const pfxo_preview* pv)
+{
+    if (pv->replaces_layer) { memcpy(top, pp, 4); return; }
+    if (pp[3] == 0) return;
+    int mode = pv->blend_mode > 24 ? 0 : pv->blend_mode;
+    if (pv->is_eraser) {
+        float mask_strength = (float)pp[3] / 255.0f, current_a = (float)top[3] / 255.0f;
+        float new_a = fmaxf(current_a * (1.0f - mask_strength), 0.0f);
+        top[3] = rs_f32_as_u8(new_a * 255.0f);
+    } else if (mode == 14 /* Overwrite */ || mode == 13 /* Xor */) {
+        uint8_t ow[4];
+        pfxo_blend_pixel(top, pp, mode, 1.0f, ow);
+        float cov = (float)pp[3] / 255.0f, inv = 1.0f - cov;
+        for (int c = 0; c < 4; ++c) top[c] = rs_f32_as_u8((float)top[c] * inv + (float)ow[c] * cov + 0.5f);
+    } else {
+        uint8_t o[4];
+        pfxo_blend_pixel(top, pp, mode, 1.0f, o);
+        memcpy(top, o, 4);
+    }
+}
+
+/* canvas_state.rs:505-698 with viewport=None */
+void pfxo_composite_preview(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t h, const pfxo_preview* pv, uint8_t* dst, int threads)
+{
     const uint32_t cxn = (w + PFXO_CHUNK - 1) / PFXO_CHUNK, cyn = (h + PFXO_CHUNK - 1) / PFXO_CHUNK;
     const size_t n_chunks = (size_t)cxn * cyn;
     memset(dst, 0, (size_t)w * h * 4); /* :506 RgbaImage::new -> zeroed */
+    if (pv && !pv->pixels) pv = NULL;
 
     /* per-layer chunk population = TiledImage::from_rgba_image's has_content (tiled_image.rs:81-95) */
     uint8_t** pop = (uint8_t**)calloc((size_t)n_layers, sizeof(uint8_t*));
     uint8_t* active = (uint8_t*)calloc(n_chunks, 1);
+    uint8_t* pv_pop = NULL;
     for (int li = 0; li < n_layers; ++li) {
         if (!layers[li].pixels) continue;
         pop[li] = (uint8_t*)malloc(n_chunks);
         pfxo_chunk_populated(layers[li].pixels, w, h, pop[li]);
         if (layers[li].visible) /* :530-540 active_chunks = union over visible layers */
             for (size_t i = 0; i < n_chunks; ++i) active[i] |= pop[li][i];
+    }
+    if (pv) { /* :541-548 the preview's chunk keys join the active set */
+        pv_pop = (uint8_t*)malloc(n_chunks);
+        if (pv->chunk_present) memcpy(pv_pop, pv->chunk_present, n_chunks);
+        else pfxo_chunk_populated(pv->pixels, w, h, pv_pop);
+        for (size_t i = 0; i < n_chunks; ++i) active[i] |= (uint8_t)(pv_pop[i] != 0);
     }
 
     o_set_threads(threads);
@@ -231,14 +267,17 @@ void pfxo_composite(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t
                 for (uint32_t i = 0; i < cw * ch; ++i) adj_apply_with_opacity(L, &acc[i * 4]);
                 continue;
             }
-            if (!L->pixels || !pop[li][ci]) continue; /* :600 */
+            int has_preview = pv && li == pv->active_layer && pv_pop[ci]; /* :593-597 */
+            int has_layer = L->pixels && pop[li][ci];
+            if (!has_layer && !has_preview) continue; /* :600 */
             int mode = L->blend_mode > 24 ? 0 : L->blend_mode;
-            int opaque_overwrite = (mode == 0) && (L->opacity >= 1.0f); /* :605 */
+            int opaque_overwrite = (mode == 0) && (L->opacity >= 1.0f) && !has_preview; /* :605 */
             for (uint32_t ly = 0; ly < ch; ++ly) {
                 for (uint32_t lx = 0; lx < cw; ++lx) {
                     size_t gi = (size_t)(by + ly) * w + (bx + lx);
-                    uint8_t top[4];
-                    memcpy(top, &L->pixels[gi * 4], 4);
+                    uint8_t top[4] = {0, 0, 0, 0};
+                    if (has_layer) memcpy(top, &L->pixels[gi * 4], 4);
+                    if (has_preview) apply_preview(top, &pv->pixels[gi * 4], pv);
                     if (L->mask) { /* :660-665 */
                         uint32_t conceal = L->mask[gi];
                         if (conceal > 0) top[3] = (uint8_t)(((uint32_t)top[3] * (255u - conceal)) / 255u);
@@ -261,6 +300,7 @@ void pfxo_composite(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t
     for (int li = 0; li < n_layers; ++li) free(pop[li]);
     free(pop);
     free(active);
+    free(pv_pop);
 }
 
 void pfxo_flatten_stack(const uint8_t* stack, int n_layers, const uint8_t* modes, const float* opacities,

@@ -60,6 +60,17 @@ typedef struct pfxo_layer {
 void pfxo_blend_pixel(const uint8_t base[4], const uint8_t top[4], int mode, float opacity, uint8_t out[4]);
 /* CanvasState::composite(): flatten bottom->top.  threads<=0 -> all cores (chunk-parallel like rayon). */
 void pfxo_composite(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t h, uint8_t* dst, int threads);
+/* the same with a tool preview layer folded into the active layer (src/canvas/canvas_state.rs:541-548,593-658) */
+typedef struct pfxo_preview {
+    const uint8_t* pixels;        /* w*h*4, the preview TiledImage flattened */
+    const uint8_t* chunk_present; /* one byte per 64x64 chunk (row-major), or NULL = chunks with any alpha != 0 */
+    int32_t active_layer;         /* index into layers[] */
+    uint8_t blend_mode;           /* preview_blend_mode */
+    uint8_t is_eraser;            /* preview_is_eraser */
+    uint8_t replaces_layer;       /* preview_replaces_layer */
+    uint8_t _pad;
+} pfxo_preview;
+void pfxo_composite_preview(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t h, const pfxo_preview* preview, uint8_t* dst, int threads);
 /* dense flavour used by the benchmark baseline: n layers stored back to back (layer stride w*h*4) */
 void pfxo_flatten_stack(const uint8_t* stack, int n_layers, const uint8_t* modes, const float* opacities,
                         uint32_t w, uint32_t h, uint8_t* dst, int threads);

@@ -38,6 +38,10 @@ class ScriptResult(C.Structure):
                 ("ops_executed", C.c_uint32), ("console", C.c_char * 2048)]
 
 
+class Preview(C.Structure):
+    _fields_ = [("active_layer", C.c_uint32), ("blend_mode", C.c_uint8), ("is_eraser", C.c_uint8), ("replaces_layer", C.c_uint8), ("_pad", C.c_uint8)]
+
+
 class CanvasOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("w", C.c_uint32), ("h", C.c_uint32), ("anchor_x", C.c_uint32), ("anchor_y", C.c_uint32)]
 

@@ -247,11 +247,33 @@ PFX_DEV void adjust_px(float (&p)[4], uint32_t kind, const float* __restrict__ a
     for (int c = 0; c < 4; ++c) p[c] = round_u8f(p[c] * inv + o[c] * t); // `.round() as u8`
 }
 
+// Tool preview folded into the active layer's pixel before masking / compositing (canvas_state.rs:621-658): `top` is the layer
+// pixel, `pp` the preview pixel.  Uses the plain-divide instantiation: this path is interactive-only and tiny.
+PFX_DEV uint32_t preview_apply(uint32_t top, uint32_t pp, const pfxk_preview& PV)
+{
+    if (PV.replaces) return pp;                                        // :623
+    if ((pp >> 24) == 0u) return top;                                  // :625
+    if (PV.is_eraser) {                                                // :626-631
+        const float mask_strength = div255(ubyte3(pp)), current_a = div255(ubyte3(top));
+        const float new_a = __builtin_fmaxf(current_a * (1.0f - mask_strength), 0.0f);
+        return (top & 0x00ffffffu) | ((uint32_t)quant255(new_a * 255.0f) << 24);
+    }
+    float b[1][4] = {{ubyte0(top), ubyte1(top), ubyte2(top), ubyte3(top)}};
+    const uint32_t t1[1] = {pp};
+    blend4_dispatch<false, 1>(PV.mode, b, t1, 1.0f, 1.0f);             // blend_pixel_static(top, pp, preview_blend, 1.0)
+    if (PV.mode == M_OVERWRITE || PV.mode == M_XOR) {                  // :632-653 coverage-weighted lerp
+        const float cov = div255(ubyte3(pp)), inv = 1.0f - cov;
+        return pack_rgba(quant255(ubyte0(top) * inv + b[0][0] * cov + 0.5f), quant255(ubyte1(top) * inv + b[0][1] * cov + 0.5f),
+                         quant255(ubyte2(top) * inv + b[0][2] * cov + 0.5f), quant255(ubyte3(top) * inv + b[0][3] * cov + 0.5f));
+    }
+    return pack_rgba(b[0][0], b[0][1], b[0][2], b[0][3]);
+}
+
 template <bool GENERAL, bool F>
 __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
                                                       const float* __restrict__ adj_table,
                                                       const uint8_t* __restrict__ chunk_active, uint32_t w, uint32_t h,
-                                                      uint8_t* __restrict__ dst)
+                                                      uint8_t* __restrict__ dst, const pfxk_preview PV)
 {
     const size_t n_px = (size_t)w * h;
     const size_t n_quads = (n_px + 3) / 4;
@@ -311,6 +333,22 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
                     top[p] = (p0 + p < n_px) ? reinterpret_cast<const uint32_t*>(L.pixels)[p0 + p] : 0u;
+            }
+            if (GENERAL && PV.pixels && li == PV.active_pos) { // :593-597,621-658
+                const uint32_t cxn = (w + 63u) / 64u;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const size_t pi = p0 + p;
+                    if (pi < n_px) {
+                        const uint32_t y = (uint32_t)(pi / w), x = (uint32_t)(pi - (size_t)y * w);
+                        const uint32_t ci = (y >> 6) * cxn + (x >> 6);
+                        if (PV.chunk_present[ci]) {
+                            // a layer chunk that does not exist reads as (0,0,0,0), colour included (:613-617)
+                            const uint32_t lp = PV.layer_chunk_present[ci] ? top[p] : 0u;
+                            top[p] = preview_apply(lp, reinterpret_cast<const uint32_t*>(PV.pixels)[pi], PV);
+                        }
+                    }
+                }
             }
             if (GENERAL && L.mask) {
 #pragma unroll
@@ -382,13 +420,14 @@ int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant)
 
 // chunk activity = union over visible raster layers of "chunk has any alpha != 0" (canvas_state.rs:529-550)
 __global__ __launch_bounds__(256) void chunk_active_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
-                                                           uint32_t w, uint32_t h, uint8_t* __restrict__ chunk_active)
+                                                           uint32_t w, uint32_t h, uint8_t* __restrict__ chunk_active,
+                                                           const uint8_t* __restrict__ preview_present)
 {
     const uint32_t cxn = (w + 63u) / 64u;
     const uint32_t cx = blockIdx.x % cxn, cy = blockIdx.x / cxn;
     const uint32_t bx = cx * 64u, by = cy * 64u;
     const uint32_t cw = min(64u, w - bx), ch = min(64u, h - by);
-    int any = 0;
+    int any = preview_present ? (preview_present[blockIdx.x] != 0) : 0; // the preview's chunk keys join the set (:541-548)
     for (uint32_t li = 0; li < n_layers && !any; ++li) {
         const pfxk_layer_desc L = layers[li];
         if (L.kind != PFXK_LAYER_RASTER || !L.pixels) continue;
@@ -505,13 +544,15 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                                    const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
-                                   uint32_t w, uint32_t h, uint8_t* d_dst)
+                                   uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview)
 {
     const size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
+    pfxk_preview PV{};
+    if (preview && preview->pixels) { PV = *preview; general = 1; }
     if (general && d_chunk_active) {
         const uint32_t nchunks = ((w + 63u) / 64u) * ((h + 63u) / 64u);
-        chunk_active_kernel<<<nchunks, 256, 0, stream>>>(d_layers, n_layers, w, h, d_chunk_active);
+        chunk_active_kernel<<<nchunks, 256, 0, stream>>>(d_layers, n_layers, w, h, d_chunk_active, PV.pixels ? PV.chunk_present : nullptr);
     }
     const uint32_t block = 256;
     const size_t cap = 256u * 8u * 4u; // 256 CUs x 8 blocks, x4 waves of grid-stride work granularity
@@ -531,7 +572,7 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
     size_t blocks = (n_quads + block - 1) / block;
     if (blocks > cap) blocks = cap;
     const uint32_t g = (uint32_t)blocks;
-#define PFX_LAUNCH(G, F) flatten_kernel<G, F><<<g, block, 0, stream>>>(d_layers, n_layers, d_adj_table, (G) ? d_chunk_active : nullptr, w, h, d_dst)
+#define PFX_LAUNCH(G, F) flatten_kernel<G, F><<<g, block, 0, stream>>>(d_layers, n_layers, d_adj_table, (G) ? d_chunk_active : nullptr, w, h, d_dst, PV)
     if (general) { if (fast_div) PFX_LAUNCH(true, true); else PFX_LAUNCH(true, false); }
     else         { if (fast_div) PFX_LAUNCH(false, true); else PFX_LAUNCH(false, false); }
 #undef PFX_LAUNCH

@@ -115,14 +115,23 @@ int upload_lut(pfx_ctx* ctx, const uint8_t* lut_host, size_t bytes)
 }
 
 // layer stack -> device descriptors
+// preview layer of a composite call (device pointers; see pfx_preview in include/pfx.h)
+struct preview_arg {
+    const void* d_pixels = nullptr;
+    const void* d_chunk_present = nullptr; // NULL: derive with the from_rgba_image rule
+    pfx_preview info{};
+};
+
 int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
-                uint32_t n, uint32_t w, uint32_t h, bool from_store, uint32_t* n_desc, bool* general, bool* has_adj)
+                uint32_t n, uint32_t w, uint32_t h, bool from_store, uint32_t* n_desc, bool* general, bool* has_adj,
+                uint32_t track_info = 0xFFFFFFFFu, uint32_t* track_pos = nullptr, const uint8_t** track_pixels = nullptr)
 {
     std::vector<pfxk_layer_desc> desc;
     std::vector<float> adj;
     desc.reserve(n);
     *general = false;
     *has_adj = false;
+    if (track_pos) *track_pos = 0xFFFFFFFFu;
     for (uint32_t i = 0; i < n; ++i) {
         const pfx_layer_info& L = layers[i];
         if (!L.visible) continue; // layer_effectively_visible == false: skipped entirely (canvas_state.rs:576)
@@ -152,6 +161,7 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
             if (!d.pixels) return pfx_fail(ctx, PFX_ERR_INVALID, "layer %u: null device pointer", i);
             if (mask_ptrs && mask_ptrs[i]) { d.mask = (const uint8_t*)mask_ptrs[i]; *general = true; }
         }
+        if (i == track_info && track_pos && d.kind == PFX_LAYER_RASTER) { *track_pos = (uint32_t)desc.size(); *track_pixels = d.pixels; }
         desc.push_back(d);
     }
     *n_desc = (uint32_t)desc.size();
@@ -165,24 +175,41 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
 }
 
 int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
-                   uint32_t n_layers, uint32_t w, uint32_t h, bool from_store, void* dst_dev)
+                   uint32_t n_layers, uint32_t w, uint32_t h, bool from_store, void* dst_dev, const preview_arg* pv = nullptr)
 {
     PFX_REQUIRE(ctx, n_layers <= PFX_MAX_LAYERS, "too many layers");
     PFX_REQUIRE(ctx, n_layers == 0 || layers, "null layer list");
-    uint32_t n_desc = 0;
+    uint32_t n_desc = 0, active_pos = 0xFFFFFFFFu;
+    const uint8_t* active_pixels = nullptr;
     bool general = false, has_adj = false;
-    PFX_TRY(build_stack(ctx, layer_ptrs, mask_ptrs, layers, n_layers, w, h, from_store, &n_desc, &general, &has_adj));
+    PFX_TRY(build_stack(ctx, layer_ptrs, mask_ptrs, layers, n_layers, w, h, from_store, &n_desc, &general, &has_adj,
+                        pv ? pv->info.active_layer : 0xFFFFFFFFu, &active_pos, &active_pixels));
+    const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
     uint8_t* d_chunks = nullptr;
     if (has_adj) { // adjustment layers only run on chunks populated in some visible layer (canvas_state.rs:529-550)
-        const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
         PFX_TRY(pfx_reserve(ctx, ctx->d_chunks, nchunks));
         d_chunks = (uint8_t*)ctx->d_chunks.p;
+    }
+    pfxk_preview PV{};
+    if (pv && pv->d_pixels) { // chunk flags: [preview present | active layer present] (canvas_state.rs:541-548,587,593-597)
+        PFX_TRY(pfx_reserve(ctx, ctx->fx_a, 2 * nchunks));
+        uint8_t* flags = (uint8_t*)ctx->fx_a.p;
+        if (pv->d_chunk_present) PFX_HIP(ctx, hipMemcpyAsync(flags, pv->d_chunk_present, nchunks, hipMemcpyDeviceToDevice, ctx->stream));
+        else PFX_HIP(ctx, pfxk_chunk_populated(ctx->stream, (const uint8_t*)pv->d_pixels, w, h, flags));
+        if (active_pixels) PFX_HIP(ctx, pfxk_chunk_populated(ctx->stream, active_pixels, w, h, flags + nchunks));
+        PV.pixels = (const uint8_t*)pv->d_pixels;
+        PV.chunk_present = flags;
+        PV.layer_chunk_present = flags + nchunks;
+        PV.active_pos = active_pos; // 0xFFFFFFFF when the active layer is hidden: only its chunk keys count
+        PV.mode = pv->info.blend_mode > 24 ? 0u : pv->info.blend_mode;
+        PV.is_eraser = pv->info.is_eraser != 0;
+        PV.replaces = pv->info.replaces_layer != 0;
     }
     bool fast_div = true; // k_flatten.hip:rdiv is bit-identical to '/' unless an opacity is a positive value < 2^-40
     for (uint32_t i = 0; i < n_layers; ++i) fast_div = fast_div && opacity_allows_fast_div(layers[i].opacity);
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
-                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, w, h, (uint8_t*)dst_dev));
+                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr));
     return PFX_OK;
 }
 
@@ -608,6 +635,44 @@ int pfx_composite_region(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_i
 int pfx_composite(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* layers, uint32_t n_layers, uint8_t* dst)
 {
     return pfx_composite_region(ctx, w, h, layers, n_layers, 0, 0, w, h, dst);
+}
+
+// composite with the tool preview layer folded into the active layer (canvas_state.rs:541-548,593-658)
+int pfx_composite_preview(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_info* layers, uint32_t n_layers, const uint8_t* preview_pixels,
+                          const uint8_t* preview_chunk_present, const pfx_preview* preview, uint8_t* dst)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, dst && w && h, "pfx_composite_preview: bad arguments");
+    if (!preview_pixels) return pfx_composite(ctx, w, h, layers, n_layers, dst);
+    PFX_REQUIRE(ctx, preview != nullptr, "pfx_composite_preview: null preview description");
+    PFX_TRY(pfx_use(ctx));
+    const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
+    PFX_TRY(pfx_reserve(ctx, ctx->fx_b, img_bytes(w, h) + nchunks));
+    PFX_TRY(pfx_h2d(ctx, ctx->fx_b.p, preview_pixels, img_bytes(w, h)));
+    preview_arg pv;
+    pv.d_pixels = ctx->fx_b.p;
+    if (preview_chunk_present) {
+        PFX_TRY(pfx_h2d(ctx, (uint8_t*)ctx->fx_b.p + img_bytes(w, h), preview_chunk_present, nchunks));
+        pv.d_chunk_present = (const uint8_t*)ctx->fx_b.p + img_bytes(w, h);
+    }
+    pv.info = *preview;
+    PFX_TRY(flatten_common(ctx, nullptr, nullptr, layers, n_layers, w, h, true, ctx->st_out.p, &pv));
+    return finish_out(ctx, dst, w, h);
+}
+
+int pfx_flatten_preview_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev, const pfx_layer_info* layers,
+                            uint32_t n_layers, uint32_t w, uint32_t h, const void* preview_dev, const void* preview_chunk_present_dev,
+                            const pfx_preview* preview, void* dst_dev)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, dst_dev && w && h && (n_layers == 0 || layer_ptrs_dev) && (!preview_dev || preview), "pfx_flatten_preview_dev: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    preview_arg pv;
+    pv.d_pixels = preview_dev;
+    pv.d_chunk_present = preview_chunk_present_dev;
+    if (preview) pv.info = *preview;
+    return flatten_common(ctx, layer_ptrs_dev, mask_ptrs_dev, layers, n_layers, w, h, false, dst_dev, preview_dev ? &pv : nullptr);
 }
 
 int pfx_blend_pixels(pfx_ctx* ctx, const uint8_t* base, const uint8_t* top, uint8_t* dst, size_t n_pixels, uint8_t blend_mode, float opacity)

@@ -34,9 +34,17 @@ enum { PFXK_RHAI_INVERT = 0, PFXK_RHAI_DESATURATE, PFXK_RHAI_SEPIA, PFXK_RHAI_SE
 
 // ---- k_flatten.hip ----
 // fast_div: 1 = shared-reciprocal division (bit-identical to '/' for opacities that are 0 or >= 2^-40), 0 = plain '/'
+// tool preview layer folded into the active layer (canvas_state.rs:541-548,593-658); all pointers are device memory
+typedef struct pfxk_preview {
+    const uint8_t* pixels;              // w*h*4, NULL = no preview
+    const uint8_t* chunk_present;       // per 64x64 chunk: the preview TiledImage has this chunk
+    const uint8_t* layer_chunk_present; // per chunk: the ACTIVE LAYER has this chunk (a missing chunk reads as (0,0,0,0))
+    uint32_t active_pos;                // position of the active layer in d_layers, 0xFFFFFFFF = not in the stack (hidden)
+    uint32_t mode, is_eraser, replaces; // preview_blend_mode (normalised 0..24), preview_is_eraser, preview_replaces_layer
+} pfxk_preview;
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                         const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, uint32_t w,
-                        uint32_t h, uint8_t* d_dst);
+                        uint32_t h, uint8_t* d_dst, const pfxk_preview* preview /* may be NULL */);
 void       pfxk_flatten_set_variant(int v); // tuning knob: 0 = shipped kernel, 1.. = experimental pixels-per-lane / occupancy variants
 // counts (into *d_out) operand pairs for which the shared-reciprocal division differs from the IEEE divide
 hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out);

@@ -341,6 +341,18 @@ class GpuRenderer:
         self._check(self._lib.pfx_composite(self._h, C.c_uint32(canvas_w), C.c_uint32(canvas_h), arr, C.c_uint32(n), _p(dst)))
         return dst
 
+    def composite_preview(self, canvas_w: int, canvas_h: int, layer_info: Iterable, preview_pixels, active_layer: int, blend_mode: int = 0,
+                          is_eraser: bool = False, replaces_layer: bool = False, chunk_present=None):
+        """composite with the tool preview layer folded into layer_info[active_layer] (ref: canvas_state.rs:593-658)"""
+        arr, n = self._infos(layer_info)
+        dst = np.empty((canvas_h, canvas_w, 4), np.uint8)
+        pv = _lib.Preview(active_layer, blend_mode, int(is_eraser), int(replaces_layer), 0)
+        px = _u8(preview_pixels)
+        cp = None if chunk_present is None else _u8(chunk_present)
+        self._check(self._lib.pfx_composite_preview(self._h, C.c_uint32(canvas_w), C.c_uint32(canvas_h), arr, C.c_uint32(n), _p(px), _p(cp),
+                                                    C.byref(pv), _p(dst)))
+        return dst
+
     def composite_dirty_readback(self, canvas_w, canvas_h, layer_info, rect):
         x, y, rw, rh = rect
         arr, n = self._infos(layer_info)

@@ -107,8 +107,14 @@ def blend_pixel(base, top, mode, opacity):
     return o
 
 
-def composite(layers, w, h, threads=0):
-    """layers: list of dicts {pixels, mask, opacity, mode, visible, kind, adj}."""
+class Preview(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("chunk_present", C.c_void_p), ("active_layer", C.c_int32), ("blend_mode", C.c_uint8),
+                ("is_eraser", C.c_uint8), ("replaces_layer", C.c_uint8), ("_pad", C.c_uint8)]
+
+
+def composite(layers, w, h, threads=0, preview=None):
+    """layers: list of dicts {pixels, mask, opacity, mode, visible, kind, adj}.
+    preview: dict {pixels, active_layer, blend_mode, is_eraser, replaces_layer, chunk_present} or None."""
     arr = (Layer * len(layers))()
     keep = []
     for i, L in enumerate(layers):
@@ -129,6 +135,14 @@ def composite(layers, w, h, threads=0):
         for j, v in enumerate(L.get("adj", [])):
             arr[i].adj[j] = v
     out = np.zeros((h, w, 4), np.uint8)
+    if preview is not None:
+        ppx, pp = _u8(preview["pixels"])
+        pcp, pc = _opt_u8(preview.get("chunk_present"))
+        pv = Preview(pp.value, pc.value if pc is not None else None, preview["active_layer"], preview.get("blend_mode", 0),
+                     int(preview.get("is_eraser", False)), int(preview.get("replaces_layer", False)), 0)
+        lib().pfxo_composite_preview(arr, C.c_int(len(layers)), C.c_uint32(w), C.c_uint32(h), C.byref(pv),
+                                     out.ctypes.data_as(C.c_void_p), C.c_int(threads))
+        return out
     lib().pfxo_composite(arr, C.c_int(len(layers)), C.c_uint32(w), C.c_uint32(h),
                          out.ctypes.data_as(C.c_void_p), C.c_int(threads))
     return out

@@ -389,6 +389,58 @@ def test_errors_leave_dst_untouched(gpu):
     assert st == _lib.ERR_INVALID and b"null" in lib.pfx_last_error(gpu.r.handle)
 
 
+# ------------------------------------------------------------------ tool preview layer in the compositor (canvas_state.rs:593-658)
+def _preview_stack(w, h):
+    bg = I.random_rgba(w, h, 71)
+    bg[..., 3] = 255
+    active = sparse_alpha_image(w, h, 72)           # transparent chunks and transparent-but-coloured pixels
+    above = sparse_alpha_image(w, h, 73)
+    mask = (np.random.default_rng(74).random((h, w)) < 0.3).astype(np.uint8) * 200
+    layers = [dict(pixels=bg), dict(pixels=active, mode=8, opacity=0.8, mask=mask), dict(kind=1, adj=[0.4], opacity=0.5),
+              dict(pixels=above, mode=2, opacity=0.6)]  # kind 1 = exposure adjustment layer (+0.4 EV at half strength)
+    preview = sparse_alpha_image(w, h, 75)
+    preview[h // 2:, :, 3] = 255                    # opaque region too
+    return layers, preview
+
+
+def _gpu_composite_preview(gpu, layers, w, h, pv):
+    gpu.r.clear_layers()
+    info = []
+    for i, L in enumerate(layers):
+        kind = L.get("kind", 0)
+        if kind == 0:
+            gpu.r.ensure_layer_texture(i, L["pixels"], generation=1)
+            if L.get("mask") is not None:
+                gpu.r.set_layer_mask(i, L["mask"])
+        info.append((i, L.get("opacity", 1.0), L.get("visible", True), L.get("mode", 0), kind, L.get("adj", ())))
+    return gpu.r.composite_preview(w, h, info, pv["pixels"], pv["active_layer"], pv.get("blend_mode", 0), pv.get("is_eraser", False),
+                                   pv.get("replaces_layer", False), pv.get("chunk_present"))
+
+
+@pytest.mark.parametrize("kind", ["normal", "multiply", "overwrite", "xor", "soft_light", "eraser", "replace", "replace_all_chunks", "hidden_active",
+                                  "active_is_bottom"])
+def test_composite_with_preview_layer(gpu, kind):
+    w, h = 200, 150
+    layers, preview = _preview_stack(w, h)
+    modes = {"normal": 0, "multiply": 1, "overwrite": 14, "xor": 13, "soft_light": 16}
+    pv = dict(pixels=preview, active_layer=1, blend_mode=modes.get(kind, 0))
+    if kind == "eraser":
+        pv["is_eraser"] = True
+    if kind.startswith("replace"):
+        pv["replaces_layer"] = True
+    if kind == "replace_all_chunks":  # the caller's TiledImage may hold fully transparent chunks: there the layer is hidden by the preview
+        pv["chunk_present"] = np.ones(((h + 63) // 64, (w + 63) // 64), np.uint8)
+    if kind == "hidden_active":
+        layers[1]["visible"] = False
+    if kind == "active_is_bottom":
+        pv["active_layer"] = 0
+    ref = O.composite(layers, w, h, preview=pv)
+    out = _gpu_composite_preview(gpu, layers, w, h, pv)
+    assert_same(out, ref, 0, f"preview {kind}")
+    if kind in ("normal", "eraser", "replace"):
+        assert not np.array_equal(ref, O.composite(layers, w, h)), "the preview must change the picture"
+
+
 # ------------------------------------------------------------------ effects built from the same kernels (N3)
 @pytest.mark.parametrize("amount,radius", [(1.0, 1.0), (2.5, 3.0), (0.0, 2.0), (-0.5, 0.7)])
 def test_sharpen_vs_oracle(gpu, oracle, amount, radius):

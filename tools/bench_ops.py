@@ -78,6 +78,38 @@ def main() -> int:
     timed("median r=1", ["median"], lambda: r.median_dev(s, d, w, h, 1), px, 8)
     timed("median r=2", ["median"], lambda: r.median_dev(s, d, w, h, 2), px, 8)
     timed("median r=7", ["median"], lambda: r.median_dev(s, d, w, h, 7), px, 8, "225-element windows")
+    # ---------------- the rest of the effect bank (k_effects2.hip), script VM, resamplers
+    timed("vignette", ["vignette"], lambda: r.vignette_dev(s, d, w, h, 0.8, 0.5), px, 8)
+    timed("add_noise gaussian mono", ["add_noise"], lambda: r.add_noise_dev(s, d, w, h, 30.0, "gaussian", True, 42, 1.0, 1), px, 8, "f64 ln + cos per pixel")
+    timed("add_noise perlin 3 octaves", ["add_noise"], lambda: r.add_noise_dev(s, d, w, h, 50.0, "perlin", False, 42, 5.0, 3), px, 8)
+    timed("reduce_noise r=2", ["reduce_noise"], lambda: r.reduce_noise_dev(s, d, w, h, 10.0, 2), px, 8, "25 f64 exp per pixel")
+    timed("halftone", ["halftone"], lambda: r.halftone_dev(s, d, w, h, 4.0, 45.0, "circle"), px, 8)
+    timed("ink (sobel)", ["ink"], lambda: r.ink_dev(s, d, w, h, 1.0, 0.5), px, 8)
+    timed("oil_painting r=3 levels=20", ["oil_painting"], lambda: r.oil_painting_dev(s, d, w, h, 3, 20), px, 8, "per-lane LDS histogram")
+    timed("crystallize cell=16", ["crystallize"], lambda: r.crystallize_dev(s, d, w, h, 16.0, 42), px, 8, "global u64 atomics + assign")
+    timed("bulge", ["bulge"], lambda: r.bulge_dev(s, d, w, h, 0.5), px, 8)
+    timed("twist 45", ["twist"], lambda: r.twist_dev(s, d, w, h, 45.0), px, 8, "f64 sin + cos per pixel")
+    timed("zoom_blur 16 samples", ["zoom_blur"], lambda: r.zoom_blur_dev(s, d, w, h, 0.5, 0.5, 0.3, 16), px, 8)
+    timed("outline width=2", ["outline"], lambda: r.outline_dev(s, d, w, h, 2, (0, 0, 255, 255)), px, 8, "7x7 window search")
+    timed("drop shadow blur=3", ["shadow_alpha", "gauss_h", "gauss_v", "shadow_composite"], lambda: r.shadow_dev(s, d, w, h, 5, 5, 3.0, False, (0, 0, 0, 255), 0.8), px, 8)
+    half = torch.empty((h // 2, w // 2, 4), dtype=torch.uint8, device=dev)
+    timed("resize 8K -> 4K bilinear", ["resize"], lambda: r.resize_image_dev(s, w, h, half.data_ptr(), w // 2, h // 2, "bilinear"), px, 5, "4 B read + 1 B/px (quarter-size) written")
+    timed("resize 8K -> 4K lanczos3", ["resize"], lambda: r.resize_image_dev(s, w, h, half.data_ptr(), w // 2, h // 2, "lanczos3"), px, 5)
+    del half
+    src_h = src.cpu().numpy()
+    import time
+    r.timing_reset()
+    r.timing_enable(True)
+    t0 = time.perf_counter()
+    r.execute_script_sync("map_channels(|r, g, b, a| [255 - r, g / 2, (b * 3 + a) / 4, a]);", src_h)
+    wall = (time.perf_counter() - t0) * 1e3
+    r.timing_enable(False)
+    vm_ms = r.timing_read("script_vm")[0]
+    rows.append({"op": "script: map_channels closure at 8K (bytecode VM kernel)", "ms": round(vm_ms, 4), "Mpx_s": round(px / vm_ms / 1e3, 1), "alg_bytes_px": 8,
+                 "achieved_GBs": round(8 * px / (vm_ms * 1e-3) / 1e9, 1), "hbm_frac": round(8 * px / (vm_ms * 1e-3) / 1e9 / HBM_PEAK, 4),
+                 "note": f"pfx_script_execute wall clock incl. H2D/D2H of 133 MB each way and closure compile: {wall:.0f} ms"})
+    print(rows[-1], flush=True)
+    del src_h
     del tmp, mask
     # ---------------- compositor, one blend mode at a time: 8 layers of the same mode over an opaque background (8K)
     from paintfe_amd import BLEND_MODES
