@@ -388,19 +388,41 @@ PFX_DEV int nearest_seed(const float2* __restrict__ seeds, int cells_x, int cell
 }
 
 // acc: per cell 5 x u64 {sum r, g, b, a, count}.  Integer sums == the reference's f64 sums of integers (exact below 2^53).
+// A 64x4 tile touches a handful of cells: the block first accumulates per cell in an LDS hash table (u32 sums: <= 256 px * 255),
+// then flushes one set of global u64 atomics per (block, cell) instead of five per pixel.
 __global__ __launch_bounds__(256) void crystal_accum_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ seeds,
                                                             unsigned long long* __restrict__ acc, int cells_x, int cells_y, float cs,
                                                             int w, int h)
 {
+    constexpr int SLOTS = 512; // >= 2 x the 256 keys a block can insert: open addressing always finds a slot
+    __shared__ int keys[SLOTS];
+    __shared__ uint32_t vals[SLOTS][5];
+    for (int i = threadIdx.x; i < SLOTS; i += 256) { keys[i] = -1; vals[i][0] = vals[i][1] = vals[i][2] = vals[i][3] = vals[i][4] = 0u; }
+    __syncthreads();
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const uint32_t p = src[(size_t)y * w + x];
-    unsigned long long* a = acc + (size_t)nearest_seed(seeds, cells_x, cells_y, cs, x, y) * 5;
-    atomicAdd(a + 0, (unsigned long long)(p & 0xffu));
-    atomicAdd(a + 1, (unsigned long long)((p >> 8) & 0xffu));
-    atomicAdd(a + 2, (unsigned long long)((p >> 16) & 0xffu));
-    atomicAdd(a + 3, (unsigned long long)(p >> 24));
-    atomicAdd(a + 4, 1ull);
+    if (x < w && y < h) {
+        const uint32_t p = src[(size_t)y * w + x];
+        const int cell = nearest_seed(seeds, cells_x, cells_y, cs, x, y);
+        int slot = (int)(((uint32_t)cell * 2654435761u) >> 23); // 9 bits
+        for (;;) {
+            const int prev = atomicCAS(&keys[slot], -1, cell);
+            if (prev == -1 || prev == cell) break;
+            slot = (slot + 1) & (SLOTS - 1);
+        }
+        atomicAdd(&vals[slot][0], p & 0xffu);
+        atomicAdd(&vals[slot][1], (p >> 8) & 0xffu);
+        atomicAdd(&vals[slot][2], (p >> 16) & 0xffu);
+        atomicAdd(&vals[slot][3], p >> 24);
+        atomicAdd(&vals[slot][4], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SLOTS; i += 256) {
+        const int cell = keys[i];
+        if (cell < 0) continue;
+        unsigned long long* a = acc + (size_t)cell * 5;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) atomicAdd(a + c, (unsigned long long)vals[i][c]);
+    }
 }
 
 __global__ __launch_bounds__(256) void crystal_avg_kernel(const unsigned long long* __restrict__ acc, uint32_t* __restrict__ avg, int n)
