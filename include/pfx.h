@@ -295,6 +295,12 @@ int pfx_warp_mesh_catmull_rom(pfx_ctx* ctx, const uint8_t* src, const float* ori
  * exactly as in the reference (serial, glibc expf). mode: 0 push, 1 expand, 2 contract, 3 twirl cw, 4 twirl ccw */
 void pfx_displacement_brush(float* disp_xy, uint32_t w, uint32_t h, int mode, float cx, float cy,
                             float delta_x, float delta_y, float radius, float strength);
+/* the same brushes on a DEVICE-resident field (the Liquify interactive loop: dabs accumulate into the field that
+ * pfx_warp_displacement_dev then samples; no field traffic over PCIe).  A dab list is applied in order.  The Gaussian
+ * falloff's exp() is evaluated on the device: weights may differ from the CPU path in the last ulp (+-1 LSB class after
+ * the warp). */
+typedef struct pfx_disp_dab { int32_t mode; float cx, cy, delta_x, delta_y, radius, strength; } pfx_disp_dab;
+int pfx_displacement_brushes_dev(pfx_ctx* ctx, void* disp_dev /* w*h*2 f32 */, uint32_t w, uint32_t h, const pfx_disp_dab* dabs, uint32_t n_dabs);
 
 /* ================= brush stamp loop (ref: src/ui/panels/tools/behavior/raster/brush_render.rs) ================= */
 typedef enum pfx_brush_mode { PFX_BRUSH_NORMAL = 0, PFX_BRUSH_DODGE = 1, PFX_BRUSH_BURN = 2, PFX_BRUSH_SPONGE = 3 } pfx_brush_mode;

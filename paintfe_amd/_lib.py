@@ -38,6 +38,11 @@ class ScriptResult(C.Structure):
                 ("ops_executed", C.c_uint32), ("console", C.c_char * 2048)]
 
 
+class DispDab(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("cx", C.c_float), ("cy", C.c_float), ("delta_x", C.c_float), ("delta_y", C.c_float), ("radius", C.c_float),
+                ("strength", C.c_float)]
+
+
 class Preview(C.Structure):
     _fields_ = [("active_layer", C.c_uint32), ("blend_mode", C.c_uint8), ("is_eraser", C.c_uint8), ("replaces_layer", C.c_uint8), ("_pad", C.c_uint8)]
 

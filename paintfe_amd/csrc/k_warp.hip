@@ -142,6 +142,58 @@ extern "C" hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src
     return hipGetLastError();
 }
 
+// ---- DisplacementField brushes on a device-resident field (apply_push / expand / contract / twirl, transform.rs:1051-1200) ----
+// The reference stamps dabs one after another; here one lane owns a pixel of the stroke's bounding box and walks the dab list in
+// order, accumulating in registers (same per-pixel order of the `+=`), one read and one write of the field per launch.
+// exp() is evaluated in f64 and rounded once (see k_effects2.hip's header): the field may differ from the CPU path in the last
+// ulp of a weight, which stays far below the warp's +-1 LSB.
+__global__ __launch_bounds__(256) void disp_brush_kernel(float2* __restrict__ disp, uint32_t w, const pfxk_disp_dab* __restrict__ dabs, uint32_t n,
+                                                         int bx0, int by0, int bx1, int by1)
+{
+    const int px = bx0 + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)), py = by0 + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= bx1 || py >= by1) return;
+    float2* p = disp + (size_t)py * w + (size_t)px;
+    float2 d = *p;
+    for (uint32_t k = 0; k < n; ++k) {
+        const pfxk_disp_dab D = dabs[k]; // uniform -> scalar loads
+        if (px < D.x0 || px >= D.x1 || py < D.y0 || py >= D.y1) continue; // the reference's loop bounds (:1066-1069)
+        const float dx = (float)px - D.cx, dy = (float)py - D.cy;
+        const float dist_sq = dx * dx + dy * dy;
+        if (dist_sq > D.r * D.r) continue;
+        if (D.mode == 0) {        // push :1051-1085
+            const float weight = (float)exp((double)(-dist_sq / D.sigma_sq_2)) * D.strength;
+            d.x += D.delta_x * weight;
+            d.y += D.delta_y * weight;
+        } else if (D.mode == 1) { // expand :1087-1120
+            const float dist = __builtin_fmaxf(__builtin_sqrtf(dist_sq), 0.001f);
+            const float t = dist / D.r;
+            const float weight = (1.0f - t) * (1.0f - t) * D.strength * 3.0f;
+            d.x += dx / dist * weight;
+            d.y += dy / dist * weight;
+        } else if (D.mode == 2) { // contract :1122-1155
+            const float dist = __builtin_fmaxf(__builtin_sqrtf(dist_sq), 0.001f);
+            const float weight = (float)exp((double)(-dist_sq / D.sigma_sq_2)) * D.strength;
+            d.x += -dx / dist * weight * 2.0f;
+            d.y += -dy / dist * weight * 2.0f;
+        } else {                  // twirl cw (3) / ccw (4) :1157-1200
+            const float weight = (float)exp((double)(-dist_sq / D.sigma_sq_2)) * D.strength * (D.mode == 3 ? 1.0f : -1.0f);
+            d.x += -dy * weight * 0.1f;
+            d.y += dx * weight * 0.1f;
+        }
+    }
+    *p = d;
+}
+
+extern "C" hipError_t pfxk_disp_brushes(hipStream_t s, float* d_disp, uint32_t w, uint32_t h, const pfxk_disp_dab* d_dabs, uint32_t n, int bx0, int by0,
+                                        int bx1, int by1)
+{
+    (void)h;
+    if (n == 0 || bx1 <= bx0 || by1 <= by0) return hipSuccess;
+    dim3 g((uint32_t)(bx1 - bx0 + 63) / 64, (uint32_t)(by1 - by0 + 3) / 4);
+    disp_brush_kernel<<<g, 256, 0, s>>>((float2*)d_disp, w, d_dabs, n, bx0, by0, bx1, by1);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig, const float* d_def, uint32_t cols,
                                              uint32_t rows, uint32_t w, uint32_t h, float* d_disp)
 {

@@ -382,6 +382,41 @@ int pfx_warp_displacement_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, ui
     return PFX_OK;
 }
 
+// DisplacementField::apply_* on a device-resident field: per-dab prologue (radius clamp, sigma, loop bounds) on the host exactly as
+// the reference computes it (transform.rs:1056-1069), accumulation in k_warp.hip
+int pfx_displacement_brushes_dev(pfx_ctx* ctx, void* disp_dev, uint32_t w, uint32_t h, const pfx_disp_dab* dabs, uint32_t n_dabs)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, disp_dev && w && h && (uint64_t)w * h <= 256000000ull && (n_dabs == 0 || dabs), "pfx_displacement_brushes_dev: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    if (n_dabs == 0) return PFX_OK;
+    auto f2i = [](float v) -> int32_t { return v != v ? 0 : (v >= 2147483648.0f ? 2147483647 : (v <= -2147483648.0f ? (-2147483647 - 1) : (int32_t)v)); };
+    std::vector<pfxk_disp_dab> k(n_dabs);
+    int bx0 = (int)w, by0 = (int)h, bx1 = 0, by1 = 0;
+    for (uint32_t i = 0; i < n_dabs; ++i) {
+        const pfx_disp_dab& D = dabs[i];
+        PFX_REQUIRE(ctx, D.mode >= 0 && D.mode <= 4, "pfx_displacement_brushes_dev: unknown brush mode");
+        pfxk_disp_dab& K = k[i];
+        K.mode = D.mode;
+        K.cx = D.cx; K.cy = D.cy; K.delta_x = D.delta_x; K.delta_y = D.delta_y; K.strength = D.strength;
+        K.r = fmaxf(D.radius, 1.0f);
+        const float sigma = K.r / 3.0f;
+        K.sigma_sq_2 = 2.0f * sigma * sigma;
+        K.x0 = std::max(f2i(floorf(D.cx - K.r)), 0);
+        K.y0 = std::max(f2i(floorf(D.cy - K.r)), 0);
+        K.x1 = std::min(f2i(ceilf(D.cx + K.r)), (int32_t)w);
+        K.y1 = std::min(f2i(ceilf(D.cy + K.r)), (int32_t)h);
+        if (K.x1 > K.x0 && K.y1 > K.y0) { bx0 = std::min(bx0, K.x0); by0 = std::min(by0, K.y0); bx1 = std::max(bx1, K.x1); by1 = std::max(by1, K.y1); }
+    }
+    if (bx1 <= bx0 || by1 <= by0) return PFX_OK; // every dab is off-canvas
+    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, k.size() * sizeof(pfxk_disp_dab)));
+    PFX_TRY(pfx_h2d(ctx, ctx->d_pts.p, k.data(), k.size() * sizeof(pfxk_disp_dab)));
+    PFX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `k` is pageable host memory about to go out of scope
+    pfx_timer t(ctx, "displacement_brush");
+    PFX_HIP(ctx, pfxk_disp_brushes(ctx->stream, (float*)disp_dev, w, h, (const pfxk_disp_dab*)ctx->d_pts.p, n_dabs, bx0, by0, bx1, by1));
+    return PFX_OK;
+}
+
 static int upload_points(pfx_ctx* ctx, const float* orig, const float* def, uint32_t cols, uint32_t rows, const float** d_orig,
                          const float** d_def)
 {

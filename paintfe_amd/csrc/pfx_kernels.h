@@ -148,6 +148,11 @@ hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig, const floa
 hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const float* d_orig, const float* d_def, uint32_t cols,
                           uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst);
 
+// DisplacementField dabs (k_warp.hip): bounds and Gaussian constants are prepared on the host like the reference's prologue
+typedef struct pfxk_disp_dab { int32_t mode, x0, y0, x1, y1; float cx, cy, delta_x, delta_y, r, sigma_sq_2, strength; } pfxk_disp_dab;
+hipError_t pfxk_disp_brushes(hipStream_t s, float* d_disp, uint32_t w, uint32_t h, const pfxk_disp_dab* d_dabs, uint32_t n, int bx0, int by0, int bx1,
+                             int by1);
+
 // ---- k_brush.hip ----
 typedef struct pfxk_brush {
     float radius, radius_sq, draw_radius, draw_radius_sq, inv_radius_sq, hardness, flow;

@@ -475,6 +475,11 @@ class GpuRenderer:
                                                 C.c_uint32(anchor[0]), C.c_uint32(anchor[1]), _c4(fill)))
         return dst
 
+    def displacement_brushes_dev(self, disp_ptr: int, w: int, h: int, dabs):
+        """DisplacementField::apply_* on a device-resident w*h*2 f32 field; dabs = [(mode, cx, cy, delta_x, delta_y, radius, strength), ...]"""
+        arr = (_lib.DispDab * max(len(dabs), 1))(*[_lib.DispDab(int(d[0]), *[float(v) for v in d[1:]]) for d in dabs])
+        self._check(self._lib.pfx_displacement_brushes_dev(self._h, C.c_void_p(disp_ptr), C.c_uint32(w), C.c_uint32(h), arr, C.c_uint32(len(dabs))))
+
     def resize_image_dev(self, src_ptr, w, h, dst_ptr, new_w, new_h, filter="bilinear"):
         self._check(self._lib.pfx_resize_image_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr), C.c_uint32(new_w),
                                                    C.c_uint32(new_h), _enum(RESIZE_FILTERS, filter)))

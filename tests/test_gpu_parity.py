@@ -347,6 +347,41 @@ def test_displacement_brushes_host(gpu):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
 
 
+def test_displacement_brushes_on_a_device_field(gpu):
+    """a Liquify stroke (mixed dabs, overlapping, partly off-canvas, integer-radius edge) accumulated on the device, then warped"""
+    w, h = 300, 200
+    rng = np.random.default_rng(12)
+    dabs = [(int(rng.integers(0, 5)), float(rng.uniform(-20, w + 20)), float(rng.uniform(-20, h + 20)), float(rng.uniform(-8, 8)), float(rng.uniform(-8, 8)),
+             float(rng.uniform(0.2, 60)), float(rng.uniform(0.1, 1.0))) for _ in range(40)]
+    dabs += [(0, 16.0, 16.0, 3.0, 0.0, 10.0, 0.8), (1, 100.0, 100.0, 0.0, 0.0, 25.0, 1.0), (0, 5000.0, 5000.0, 1.0, 1.0, 10.0, 1.0)]
+    ref = np.zeros((h, w, 2), np.float32)
+    for d in dabs:
+        O.displacement_brush(ref, *d)
+    dev = gpu.r.dev_alloc(w * h * 8)
+    try:
+        gpu.r.dev_upload(dev, np.zeros((h, w, 2), np.float32))
+        gpu.r.displacement_brushes_dev(dev, w, h, dabs[:17])      # two calls: the field persists between dab batches
+        gpu.r.displacement_brushes_dev(dev, w, h, dabs[17:])
+        got = gpu.r.dev_download(dev, (h, w, 2), np.float32)
+        # weights use a device exp(): last-ulp differences per dab, accumulated over up to 43 overlapping dabs
+        assert np.allclose(got, ref, rtol=2e-6, atol=2e-6), float(np.abs(got - ref).max())
+        assert (got.view(np.uint32) == ref.view(np.uint32)).mean() > 0.98
+        img = I.random_rgba(w, h, 5)
+        src = gpu.r.dev_alloc(w * h * 4)
+        dst = gpu.r.dev_alloc(w * h * 4)
+        try:
+            gpu.r.dev_upload(src, img)
+            gpu.r.warp_displacement_dev(src, w, h, dev, w, h, dst)
+            out = gpu.r.dev_download(dst, (h, w, 4), np.uint8)
+        finally:
+            gpu.r.dev_free(src)
+            gpu.r.dev_free(dst)
+        d = np.abs(out.astype(int) - O.warp_displacement(img, ref).astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    finally:
+        gpu.r.dev_free(dev)
+
+
 # ------------------------------------------------------------------ brush
 @pytest.mark.parametrize("mode,eraser,aa", [(0, False, True), (0, False, False), (0, True, True), (1, False, True), (2, False, False), (3, False, True)])
 def test_brush_random_strokes(gpu, oracle, mode, eraser, aa):
