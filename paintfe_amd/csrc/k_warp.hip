@@ -47,6 +47,61 @@ PFX_DEV uint32_t sample_bilinear(const uint32_t* __restrict__ src, int32_t src_w
     return pack_rgba(o[0], o[1], o[2], o[3]);
 }
 
+// The same sampler split at the memory boundary, so that a lane can have the taps of several pixels in flight at once, and
+// trimmed where the hardware or the value range makes a step free:
+//  * v_cvt_i32_f32 saturates and maps NaN to 0 — exactly Rust's `as i32` — so the explicit range tests go (inline asm keeps
+//    the compiler from treating an out-of-range conversion as undefined);
+//  * when every lane of the wave samples strictly inside the source, the four per-tap bounds tests (and their exec-mask
+//    branches) are skipped: one wave-uniform branch instead;
+//  * the lerp of bytes with weights in [0, 1) stays within [-eps, 255 + eps], so `.round().clamp(0, 255) as u8` needs no clamp.
+PFX_DEV int32_t cvt_i32_sat(float v)
+{
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+struct bilinear_taps { uint32_t tl, tr, bl, br; float fx, fy; bool ok; };
+PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t src_w, int32_t src_h, float x, float y, float ddx, float ddy)
+{
+    bilinear_taps T;
+    const float sx = x - ddx, sy = y - ddy;
+    const int32_t x0 = cvt_i32_sat(__builtin_floorf(sx)), y0 = cvt_i32_sat(__builtin_floorf(sy));
+    T.fx = sx - (float)x0;
+    T.fy = sy - (float)y0;
+    // :1310; a NaN coordinate converts to texel 0 with NaN weights: every channel is `NaN as u8` = 0, the same as "outside"
+    T.ok = !(x0 < -1 || y0 < -1 || x0 >= src_w || y0 >= src_h) && T.fx == T.fx && T.fy == T.fy;
+    const bool interior = x0 >= 0 && y0 >= 0 && x0 < src_w - 1 && y0 < src_h - 1;
+    if (__all(interior)) {
+        const uint32_t* p = src + ((size_t)(uint32_t)y0 * (uint32_t)src_w + (uint32_t)x0);
+        T.tl = p[0]; T.tr = p[1]; T.bl = p[src_w]; T.br = p[src_w + 1];
+    } else {
+        auto tap = [&](int32_t tx, int32_t ty) -> uint32_t {
+            return (!T.ok || tx < 0 || ty < 0 || tx >= src_w || ty >= src_h) ? 0u : src[(size_t)ty * src_w + tx];
+        };
+        T.tl = tap(x0, y0); T.tr = tap(x0 + 1, y0); T.bl = tap(x0, y0 + 1); T.br = tap(x0 + 1, y0 + 1);
+    }
+    return T;
+}
+PFX_DEV float round_byte_noclamp(float v) // round half away from zero for v in (-0.5, 255.5): result is an integer in [0, 255]
+{
+    const float t = __builtin_truncf(v);
+    return (v - t >= 0.5f) ? t + 1.0f : __builtin_fabsf(t); // fabs: -0.0 -> +0.0
+}
+PFX_DEV uint32_t bilinear_finish(const bilinear_taps& T)
+{
+    if (!T.ok) return 0u;
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float ftl = (float)((T.tl >> (8 * c)) & 0xffu), ftr = (float)((T.tr >> (8 * c)) & 0xffu);
+        const float fbl = (float)((T.bl >> (8 * c)) & 0xffu), fbr = (float)((T.br >> (8 * c)) & 0xffu);
+        const float top = ftl + (ftr - ftl) * T.fx; // :1337-1339
+        const float bot = fbl + (fbr - fbl) * T.fx;
+        o[c] = round_byte_noclamp(top + (bot - top) * T.fy);
+    }
+    return pack_rgba(o[0], o[1], o[2], o[3]);
+}
+
 __global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restrict__ src, int32_t sw, int32_t sh,
                                                         const float2* __restrict__ disp, uint32_t w, uint32_t h,
                                                         uint32_t* __restrict__ dst)
@@ -55,7 +110,7 @@ __global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restri
     if (x >= w || y >= h) return;
     const size_t i = (size_t)y * w + x;
     const float2 d = disp[i];
-    dst[i] = sample_bilinear(src, sw, sh, (float)x, (float)y, d.x, d.y);
+    dst[i] = bilinear_finish(bilinear_fetch(src, sw, sh, (float)x, (float)y, d.x, d.y));
 }
 
 PFX_DEV void cr_weights(float t, float (&wt)[4]) // :1558-1567
@@ -92,7 +147,56 @@ PFX_DEV float2 cr_surface(const float2* __restrict__ pts, uint32_t cols, uint32_
                        wv[0] * ry[0] + wv[1] * ry[1] + wv[2] * ry[2] + wv[3] * ry[3]);
 }
 
+// The same surface with its u-dependent half cached: a lane walks down a column (u fixed), so the per-control-row partial sums
+// rx[j], ry[j] (56 of the ~107 operations of an evaluation) only change when the pixel row enters another mesh cell row — a
+// wave-uniform event, since a wave shares y.  Same operations in the same order per result: bit-identical to cr_surface.
+struct cr_column {
+    float wu[4];
+    uint32_t cu[4];
+    float rx[4], ry[4];
+    uint32_t ri_cached;
+};
+PFX_DEV void cr_column_init(cr_column& C, uint32_t cols, float u_global)
+{
+    const uint32_t ppr = cols + 1u;
+    const float col_f = rs_clamp(u_global, 0.0f, (float)cols - 0.0001f);
+    const uint32_t ci = min((uint32_t)col_f, cols - 1u);
+    cr_weights(col_f - (float)ci, C.wu);
+    C.cu[0] = ci == 0u ? 0u : ci - 1u; C.cu[1] = ci; C.cu[2] = min(ci + 1u, ppr - 1u); C.cu[3] = min(ci + 2u, ppr - 1u);
+    C.ri_cached = 0xffffffffu;
+}
+// the v-dependent half of an evaluation (shared by both surfaces of a pixel, and by all 64 pixels of a wave's row)
+struct cr_row { uint32_t ri; float wv[4]; };
+PFX_DEV cr_row cr_row_of(uint32_t rows, float v_global)
+{
+    cr_row R;
+    const float row_f = rs_clamp(v_global, 0.0f, (float)rows - 0.0001f);
+    R.ri = min((uint32_t)row_f, rows - 1u);
+    cr_weights(row_f - (float)R.ri, R.wv);
+    return R;
+}
+PFX_DEV float2 cr_column_eval(cr_column& C, const float2* __restrict__ pts, uint32_t cols, uint32_t rows, const cr_row& R)
+{
+    const uint32_t ppr = cols + 1u, num_rows = rows + 1u;
+    const uint32_t ri = R.ri;
+    const float (&wv)[4] = R.wv;
+    if (ri != C.ri_cached) { // uniform across the wave
+        C.ri_cached = ri;
+        const uint32_t rv[4] = {ri == 0u ? 0u : ri - 1u, ri, min(ri + 1u, num_rows - 1u), min(ri + 2u, num_rows - 1u)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2* base = pts + rv[j] * ppr;
+            const float2 p0 = base[C.cu[0]], p1 = base[C.cu[1]], p2 = base[C.cu[2]], p3 = base[C.cu[3]];
+            C.rx[j] = C.wu[0] * p0.x + C.wu[1] * p1.x + C.wu[2] * p2.x + C.wu[3] * p3.x;
+            C.ry[j] = C.wu[0] * p0.y + C.wu[1] * p1.y + C.wu[2] * p2.y + C.wu[3] * p3.y;
+        }
+    }
+    return make_float2(wv[0] * C.rx[0] + wv[1] * C.rx[1] + wv[2] * C.rx[2] + wv[3] * C.rx[3],
+                       wv[0] * C.ry[0] + wv[1] * C.ry[1] + wv[2] * C.ry[2] + wv[3] * C.ry[3]);
+}
+
 constexpr uint32_t MESH_LDS_PTS = 2048; // control points per grid staged in LDS (2 grids x 16 KiB)
+constexpr uint32_t MESH_YR = 8;         // rows walked by one lane (a block covers 64 x 32 pixels)
 
 // MODE 0: write displacement field; MODE 1: fused field + gather.  IN_LDS: control points staged in LDS (the normal
 // case: a 6x6 grid is 49 points); the pointer's address space is then known at compile time (ds_read, not flat_load).
@@ -112,22 +216,48 @@ __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ 
         }
         __syncthreads();
     }
-    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    const uint32_t x_lane = blockIdx.x * 64u + (threadIdx.x & 63u), y_first = (blockIdx.y * 4u + (threadIdx.x >> 6)) * MESH_YR;
+    if (y_first >= h) return;              // whole wave
+    const bool x_valid = x_lane < w;       // lanes past the right edge stay alive: the row halves below are exchanged by lane index
+    const uint32_t x = x_valid ? x_lane : w - 1u;
     // :1687-1688; operands in [0.5, 2^15]: k_common.h:fdiv_fast is bit-identical to '/'
     const float u = fdiv_fast((float)x + 0.5f, (float)w) * (float)cols;
-    const float v = fdiv_fast((float)y + 0.5f, (float)h) * (float)rows;
-    float2 d, o;
-    if constexpr (IN_LDS) d = cr_surface(s_def, cols, rows, u, v);
-    else d = cr_surface(g_def, cols, rows, u, v);
-    if (g_orig) {
-        if constexpr (IN_LDS) o = cr_surface(s_orig, cols, rows, u, v);
-        else o = cr_surface(g_orig, cols, rows, u, v);
-    } else o = make_float2((float)x + 0.5f, (float)y + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
-    const float ddx = d.x - o.x, ddy = d.y - o.y;
-    const size_t i = (size_t)y * w + x;
-    if constexpr (MODE == 0) disp[i] = make_float2(ddx, ddy);
-    else dst[i] = sample_bilinear(src, (int32_t)w, (int32_t)h, (float)x, (float)y, ddx, ddy);
+    cr_column cd, co;
+    cr_column_init(cd, cols, u);
+    if (g_orig) cr_column_init(co, cols, u);
+    // a wave shares its rows: lane k (< MESH_YR) evaluates row k's v-dependent half once, everyone reads it back through
+    // v_readlane (scalar operands from then on) instead of recomputing ~30 operations per pixel
+    const uint32_t lane = threadIdx.x & 63u;
+    cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_first + (lane & (MESH_YR - 1u))) + 0.5f, (float)h) * (float)rows);
+    const uint32_t y_end = min(y_first + MESH_YR, h);
+    bilinear_taps taps[MESH_YR]; // MODE 1: every row's four taps are requested before any is consumed (latency-bound otherwise)
+#pragma unroll
+    for (uint32_t k = 0; k < MESH_YR; ++k) {
+        const uint32_t y = y_first + k;
+        if (y >= y_end) { taps[k].ok = false; taps[k].tl = taps[k].tr = taps[k].bl = taps[k].br = 0u; taps[k].fx = taps[k].fy = 0.0f; continue; } // uniform
+        cr_row R;
+        R.ri = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, (int)k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R.wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.wv[j]), (int)k));
+        float2 d, o;
+        if constexpr (IN_LDS) d = cr_column_eval(cd, s_def, cols, rows, R);
+        else d = cr_column_eval(cd, g_def, cols, rows, R);
+        if (g_orig) {
+            if constexpr (IN_LDS) o = cr_column_eval(co, s_orig, cols, rows, R);
+            else o = cr_column_eval(co, g_orig, cols, rows, R);
+        } else o = make_float2((float)x + 0.5f, (float)y + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
+        const float ddx = d.x - o.x, ddy = d.y - o.y;
+        const size_t i = (size_t)y * w + x;
+        if constexpr (MODE == 0) { if (x_valid) disp[i] = make_float2(ddx, ddy); }
+        else taps[k] = bilinear_fetch(src, (int32_t)w, (int32_t)h, (float)x, (float)y, ddx, ddy);
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (uint32_t k = 0; k < MESH_YR; ++k) {
+            const uint32_t y = y_first + k;
+            if (y < y_end && x_valid) dst[(size_t)y * w + x] = bilinear_finish(taps[k]);
+        }
+    }
 }
 
 } // namespace
@@ -198,7 +328,7 @@ extern "C" hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig,
                                              uint32_t rows, uint32_t w, uint32_t h, float* d_disp)
 {
     if (w == 0 || h == 0) return hipSuccess;
-    dim3 g((w + 63) / 64, (h + 3) / 4);
+    dim3 g((w + 63) / 64, (h + 4 * MESH_YR - 1) / (4 * MESH_YR));
     if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
         mesh_kernel<0, true><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr);
     else
@@ -210,7 +340,7 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
                                      uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst)
 {
     if (w == 0 || h == 0) return hipSuccess;
-    dim3 g((w + 63) / 64, (h + 3) / 4);
+    dim3 g((w + 63) / 64, (h + 4 * MESH_YR - 1) / (4 * MESH_YR));
     if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
         mesh_kernel<1, true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst);
     else

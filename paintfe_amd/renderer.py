@@ -570,6 +570,12 @@ class GpuRenderer:
         self._check(self._lib.pfx_warp_mesh_catmull_rom_dev(self._h, C.c_void_p(src_ptr), _p(o), _p(d), C.c_uint32(cols),
                                                             C.c_uint32(rows), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr)))
 
+    def mesh_displacement_dev(self, orig, deformed, cols, rows, w, h, disp_ptr):
+        o = None if orig is None else np.ascontiguousarray(orig, np.float32)
+        d = np.ascontiguousarray(deformed, np.float32)
+        self._check(self._lib.pfx_mesh_displacement_dev(self._h, _p(o), _p(d), C.c_uint32(cols), C.c_uint32(rows), C.c_uint32(w), C.c_uint32(h),
+                                                        C.c_void_p(disp_ptr)))
+
     def warp_displacement_dev(self, src_ptr, sw, sh, disp_ptr, w, h, dst_ptr):
         self._check(self._lib.pfx_warp_displacement_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(sw), C.c_uint32(sh),
                                                         C.c_void_p(disp_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr)))
