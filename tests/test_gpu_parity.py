@@ -200,6 +200,18 @@ def test_median_bitexact(gpu, oracle, radius):
     assert_same(gpu.median(img, radius, mask), oracle.median(img, radius, mask), 0, f"median r={radius} masked")
 
 
+@pytest.mark.parametrize("size", [(4, 1), (4, 5), (8, 3), (256, 9), (260, 64), (1024, 33), (1, 1), (3, 7), (255, 6)])
+def test_median_3x3_network_paths(gpu, oracle, size):
+    """r <= 1 takes the min3/med3/max3 network: widths that are multiples of 4 use the 16-byte load + lane-exchange path
+    (wave and image edges included), the others the scalar path"""
+    w, h = size
+    img = I.random_rgba(w, h, 900 + w + h)
+    img[:, : w // 2] = (img[:, : w // 2] // 32) * 32  # ties
+    mask = (np.random.default_rng(3).random((h, w)) < 0.5).astype(np.uint8)
+    assert_same(gpu.median(img, 1), oracle.median(img, 1), 0, f"median3 {size}")
+    assert_same(gpu.median(img, 1, mask), oracle.median(img, 1, mask), 0, f"median3 {size} masked")
+
+
 def test_median_beyond_device_radius_returns_none(gpu):
     assert gpu.r.median_rgba(I.random_rgba(32, 32, 1), 25) is None  # ref: median_rgba -> None, renderer.rs:945
 
