@@ -436,6 +436,41 @@ def test_errors_leave_dst_untouched(gpu):
     assert st == _lib.ERR_INVALID and b"null" in lib.pfx_last_error(gpu.r.handle)
 
 
+# ------------------------------------------------------------------ degenerate image sizes through every kernel family
+@pytest.mark.parametrize("size", [(1, 1), (1, 37), (41, 1), (3, 2), (65, 1), (1, 130)])
+def test_degenerate_sizes(gpu, oracle, size):
+    w, h = size
+    img = I.random_rgba(w, h, 500 + w * 3 + h)
+    top = I.random_rgba(w, h, 600 + w * 3 + h)
+    mask = (np.random.default_rng(w * 7 + h).random((h, w)) < 0.5).astype(np.uint8) * 255
+    layers = [dict(pixels=img), dict(pixels=top, mode=8, opacity=0.6, mask=mask), dict(kind=2, adj=[10.0, 20.0], opacity=0.7)]
+    assert_same(gpu.composite(layers, w, h), oracle.composite(layers, w, h), 0, f"composite {size}")
+    gpu.r.set_exact(True)
+    try:
+        for sigma in (0.4, 3.0, 20.0):
+            assert_same(gpu.gaussian_blur(img, sigma), oracle.gaussian_blur(img, sigma), 0, f"gaussian {size} sigma {sigma}")
+            assert_same(gpu.gaussian_blur(img, sigma, mask), oracle.gaussian_blur(img, sigma, mask), 0, f"gaussian {size} sigma {sigma} masked")
+        assert_same(gpu.sharpen(img, 1.5, 2.0), oracle.sharpen(img, 1.5, 2.0), 0, f"sharpen {size}")
+    finally:
+        gpu.r.set_exact(False)
+    for radius in (1.0, 6.0):
+        assert_same(gpu.box_blur(img, radius, mask), oracle.box_blur(img, radius, mask), 0, f"box {size}")
+    for radius in (1, 2, 3):
+        assert_same(gpu.median(img, radius), oracle.median(img, radius), 0, f"median {size} r={radius}")
+    assert_same(gpu.pixelate(img, 3), oracle.pixelate(img, 3), 0, f"pixelate {size}")
+    assert_same(gpu.bokeh_blur(img, 2.5), oracle.bokeh_blur(img, 2.5), 0, f"bokeh {size}")
+    assert_same(gpu.motion_blur(img, 30.0, 5.0), oracle.motion_blur(img, 30.0, 5.0), 0, f"motion {size}")
+    for sparse in (0, 1, 2):
+        assert_same(gpu.adjust(img, "hsl", [30.0, -20.0, 10.0], None, mask, sparse), oracle.adjust(img, "hsl", [30.0, -20.0, 10.0], None, mask, sparse), 0, f"hsl {size}")
+    assert_same(gpu.rhai_adjust(img, "sepia"), oracle.rhai_adjust(img, "sepia"), 0, f"rhai sepia {size}")
+    disp = (np.random.default_rng(5).random((h, w, 2)).astype(np.float32) - 0.5) * 6
+    assert_same(gpu.warp_displacement(img, disp), oracle.warp_displacement(img, disp), 0, f"warp {size}")
+    orig, deformed = I.jittered_mesh(2, 2, w, h)
+    assert_same(gpu.warp_mesh(img, orig, deformed, 2, 2), oracle.warp_mesh(img, orig, deformed, 2, 2), 0, f"mesh {size}")
+    assert_same(gpu.resize(img, 7, 5, "lanczos3"), oracle.resize(img, 7, 5, "lanczos3"), 0, f"resize {size}")
+    assert_same(gpu.r.tiled_roundtrip(img), O.tiled_roundtrip(img), 0, f"tiled {size}")
+
+
 # ------------------------------------------------------------------ tool preview layer in the compositor (canvas_state.rs:593-658)
 def _preview_stack(w, h):
     bg = I.random_rgba(w, h, 71)
