@@ -273,13 +273,22 @@ template <bool GENERAL, bool F>
 __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
                                                       const float* __restrict__ adj_table,
                                                       const uint8_t* __restrict__ chunk_active, uint32_t w, uint32_t h,
-                                                      uint8_t* __restrict__ dst, const pfxk_preview PV)
+                                                      uint8_t* __restrict__ dst, const pfxk_preview PV, const pfxk_region RG)
 {
-    const size_t n_px = (size_t)w * h;
-    const size_t n_quads = (n_px + 3) / 4;
+    // GENERAL + RG.rw: only the dirty rectangle is composited, into a compact rw x rh destination (composite_dirty_readback,
+    // src/gpu/renderer.rs:588); quads then run along the rectangle's rows
+    const bool region = GENERAL && RG.rw != 0u;
+    const uint32_t qpr = region ? (RG.rw + 3u) / 4u : 0u;
+    const size_t n_quads = region ? (size_t)qpr * RG.rh : ((size_t)w * h + 3) / 4;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (size_t)gridDim.x * blockDim.x) {
-        const size_t p0 = q * 4;
-        const bool full = p0 + 4 <= n_px;
+        size_t p0 = q * 4, n_px = (size_t)w * h, o0 = q * 4; // n_px: exclusive bound of valid pixel indices for this quad
+        if (region) {
+            const uint32_t ry = (uint32_t)(q / qpr), qx = (uint32_t)(q - (size_t)ry * qpr);
+            p0 = (size_t)(RG.y0 + ry) * w + RG.x0 + qx * 4u;
+            n_px = (size_t)(RG.y0 + ry) * w + RG.x0 + RG.rw;
+            o0 = (size_t)ry * RG.rw + qx * 4u;
+        }
+        const bool full = p0 + 4 <= n_px && !(region && (((p0 | o0) & 3u) != 0u)); // 16-byte loads / stores need aligned quads
         float acc[4][4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0f; // :573
@@ -362,11 +371,11 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
 #pragma unroll
         for (int p = 0; p < 4; ++p) out[p] = pack_rgba(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
         if (full) {
-            *reinterpret_cast<uint4*>(dst + p0 * 4) = make_uint4(out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<uint4*>(dst + o0 * 4) = make_uint4(out[0], out[1], out[2], out[3]);
         } else {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                if (p0 + p < n_px) reinterpret_cast<uint32_t*>(dst)[p0 + p] = out[p];
+                if (p0 + p < n_px) reinterpret_cast<uint32_t*>(dst)[o0 + p] = out[p];
         }
     }
 }
@@ -544,12 +553,14 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                                    const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
-                                   uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview)
+                                   uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region)
 {
-    const size_t n_quads = ((size_t)w * h + 3) / 4;
+    size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
     pfxk_preview PV{};
     if (preview && preview->pixels) { PV = *preview; general = 1; }
+    pfxk_region RG{};
+    if (region && region->rw && region->rh) { RG = *region; general = 1; n_quads = (size_t)((RG.rw + 3u) / 4u) * RG.rh; }
     if (general && d_chunk_active) {
         const uint32_t nchunks = ((w + 63u) / 64u) * ((h + 63u) / 64u);
         chunk_active_kernel<<<nchunks, 256, 0, stream>>>(d_layers, n_layers, w, h, d_chunk_active, PV.pixels ? PV.chunk_present : nullptr);
@@ -572,7 +583,7 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
     size_t blocks = (n_quads + block - 1) / block;
     if (blocks > cap) blocks = cap;
     const uint32_t g = (uint32_t)blocks;
-#define PFX_LAUNCH(G, F) flatten_kernel<G, F><<<g, block, 0, stream>>>(d_layers, n_layers, d_adj_table, (G) ? d_chunk_active : nullptr, w, h, d_dst, PV)
+#define PFX_LAUNCH(G, F) flatten_kernel<G, F><<<g, block, 0, stream>>>(d_layers, n_layers, d_adj_table, (G) ? d_chunk_active : nullptr, w, h, d_dst, PV, RG)
     if (general) { if (fast_div) PFX_LAUNCH(true, true); else PFX_LAUNCH(true, false); }
     else         { if (fast_div) PFX_LAUNCH(false, true); else PFX_LAUNCH(false, false); }
 #undef PFX_LAUNCH

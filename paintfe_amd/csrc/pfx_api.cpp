@@ -175,7 +175,8 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
 }
 
 int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
-                   uint32_t n_layers, uint32_t w, uint32_t h, bool from_store, void* dst_dev, const preview_arg* pv = nullptr)
+                   uint32_t n_layers, uint32_t w, uint32_t h, bool from_store, void* dst_dev, const preview_arg* pv = nullptr,
+                   const pfxk_region* region = nullptr)
 {
     PFX_REQUIRE(ctx, n_layers <= PFX_MAX_LAYERS, "too many layers");
     PFX_REQUIRE(ctx, n_layers == 0 || layers, "null layer list");
@@ -209,7 +210,7 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
     for (uint32_t i = 0; i < n_layers; ++i) fast_div = fast_div && opacity_allows_fast_div(layers[i].opacity);
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
-                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr));
+                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region));
     return PFX_OK;
 }
 
@@ -660,10 +661,14 @@ int pfx_composite_region(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_i
     PFX_REQUIRE(ctx, dst_region && w && h && rw && rh && x + rw <= w && y + rh <= h, "pfx_composite: bad arguments");
     PFX_TRY(pfx_use(ctx));
     PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
-    PFX_TRY(flatten_common(ctx, nullptr, nullptr, layers, n_layers, w, h, true, ctx->st_out.p));
-    if (rw == w && rh == h) return finish_out(ctx, dst_region, w, h);
-    PFX_HIP(ctx, hipMemcpy2DAsync(dst_region, (size_t)rw * 4, (const uint8_t*)ctx->st_out.p + ((size_t)y * w + x) * 4, (size_t)w * 4,
-                                  (size_t)rw * 4, rh, hipMemcpyDeviceToHost, ctx->stream));
+    if (rw == w && rh == h) {
+        PFX_TRY(flatten_common(ctx, nullptr, nullptr, layers, n_layers, w, h, true, ctx->st_out.p));
+        return finish_out(ctx, dst_region, w, h);
+    }
+    // dirty rectangle (composite_dirty_readback, renderer.rs:588): only its pixels are composited, into a compact rw x rh image
+    const pfxk_region rg{x, y, rw, rh};
+    PFX_TRY(flatten_common(ctx, nullptr, nullptr, layers, n_layers, w, h, true, ctx->st_out.p, nullptr, &rg));
+    PFX_TRY(pfx_d2h(ctx, dst_region, ctx->st_out.p, (size_t)rw * rh * 4));
     return pfx_sync(ctx);
 }
 

@@ -42,9 +42,12 @@ typedef struct pfxk_preview {
     uint32_t active_pos;                // position of the active layer in d_layers, 0xFFFFFFFF = not in the stack (hidden)
     uint32_t mode, is_eraser, replaces; // preview_blend_mode (normalised 0..24), preview_is_eraser, preview_replaces_layer
 } pfxk_preview;
+// dirty rectangle: composite only [x0, x0+rw) x [y0, y0+rh) into a compact rw x rh destination (rw == 0: whole canvas)
+typedef struct pfxk_region { uint32_t x0, y0, rw, rh; } pfxk_region;
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                         const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, uint32_t w,
-                        uint32_t h, uint8_t* d_dst, const pfxk_preview* preview /* may be NULL */);
+                        uint32_t h, uint8_t* d_dst, const pfxk_preview* preview /* may be NULL */,
+                        const pfxk_region* region /* may be NULL */);
 void       pfxk_flatten_set_variant(int v); // tuning knob: 0 = shipped kernel, 1.. = experimental pixels-per-lane / occupancy variants
 // counts (into *d_out) operand pairs for which the shared-reciprocal division differs from the IEEE divide
 hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out);

@@ -147,6 +147,23 @@ def test_layer_store_generation_and_dirty_rect(gpu):
     assert r.active_texture_count() == 0
 
 
+@pytest.mark.parametrize("canvas", [(256, 192), (203, 117)])
+def test_composite_dirty_rectangles(gpu, canvas):
+    """composite_dirty_readback composites only the rectangle (renderer.rs:588): aligned and ragged rectangles, edge-touching ones,
+    1-pixel ones, on a stack with a mask and an adjustment layer — each must equal the crop of the full composite"""
+    w, h = canvas
+    layers = [dict(pixels=I.random_rgba(w, h, 31)), dict(pixels=sparse_alpha_image(w, h, 32), mode=6, opacity=0.7,
+                                                          mask=(np.random.default_rng(3).random((h, w)) < 0.4).astype(np.uint8) * 180),
+              dict(kind=2, adj=[15.0, 30.0], opacity=0.6), dict(pixels=sparse_alpha_image(w, h, 33), mode=21, opacity=1.0)]
+    full = O.composite(layers, w, h)
+    gpu.composite(layers, w, h)  # uploads the stack
+    info = [(i, L.get("opacity", 1.0), True, L.get("mode", 0), L.get("kind", 0), L.get("adj", ())) for i, L in enumerate(layers)]
+    for (x, y, rw, rh) in ((64, 32, 64, 64), (0, 0, w, 1), (0, 0, 1, h), (w - 1, h - 1, 1, 1), (5, 7, 50, 33), (128, 0, w - 128, h), (3, 100, 13, 2),
+                           (0, 0, w, h)):
+        reg = gpu.r.composite_dirty_readback(w, h, info, (x, y, rw, rh))
+        assert_same(reg, full[y:y + rh, x:x + rw], 0, f"dirty rect {(x, y, rw, rh)}")
+
+
 # ------------------------------------------------------------------ stencils
 @pytest.mark.parametrize("sigma", [0.0, 0.3, 1.0, 2.5, 5.0, 16.0])
 @pytest.mark.parametrize("size", [(64, 64), (301, 97), (1100, 150)])
