@@ -126,6 +126,26 @@ def main() -> int:
               f"{(nl - 1)} blends/px")
     del layers, src, dst
 
+    # ---------------- 4K per-image pipeline of config 5 / S4: Gaussian sigma=4 -> HSL -> 4-layer flatten (image + 3 overlays)
+    w, h = 3840, 2160
+    px = w * h
+    img = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=dev, generator=g)
+    overlays = [torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=dev, generator=g) for _ in range(3)]
+    a = torch.empty_like(img)
+    b = torch.empty_like(img)
+    tmp4 = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    info4 = [(0, 1.0, True, 0), (1, 0.8, True, 1), (2, 0.8, True, 2), (3, 0.8, True, 8)]  # Normal, Multiply, Screen, Overlay
+
+    def pipeline():
+        r.gaussian_blur_dev(img.data_ptr(), a.data_ptr(), w, h, 4.0, tmp4.data_ptr())
+        r.adjust_dev(a.data_ptr(), b.data_ptr(), w, h, "hsl", [30.0, -20.0, 10.0])
+        r.flatten_dev([b.data_ptr()] + [o.data_ptr() for o in overlays], info4, w, h, a.data_ptr())
+    timed("config-5 per-image pipeline at 4K (blur s=4 + HSL + 4-layer flatten)", ["gauss_h", "gauss_v", "adjust", "flatten"], pipeline, px, 36,
+          "8 + 8 + 20 algorithmic B/px; images/s = 1000 / ms")
+    for name in ("gauss_h", "gauss_v", "adjust", "flatten"):
+        print("   ", name, round(r.timing_read(name)[0] / args.reps, 4), "ms", flush=True)
+    del img, overlays, a, b, tmp4
+
     # ---------------- 16K (config 4: mesh warp 6x6 Catmull-Rom + liquify displacement)
     w, h = 15360, 8640
     px = w * h
