@@ -317,6 +317,27 @@ int pfx_brush_stamps(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h
 /* draw_line_no_dirty (ref: brush_render.rs:762-835): dense 1-px stepping, then the stamp loop */
 int pfx_brush_line(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush,
                    float x0, float y0, float x1, float y1, const uint8_t* selection);
+/* Brush dynamics — the remaining ToolProperties fields draw_circle_no_dirty reads (ref: state.rs:112-128, brush_render.rs:148-256,
+ * 533-760) plus ToolsPanel::stamp_counter: per-stamp scatter, hue / brightness jitter (hashed from the stamp position), and image
+ * brush tips with fixed or random rotation.  `tip_mask` is brush_tip_mask: the tip's coverage image already rescaled to the
+ * brush size (pfx_brush_tip_rescale does what rebuild_tip_mask does, brush_render.rs:404-528); NULL = the round tip.
+ * Image tips stamp with max-alpha or erase only (the reference ignores brush->mode for them). */
+typedef struct pfx_brush_dynamics {
+    float    scatter, hue_jitter, brightness_jitter;
+    uint32_t stamp_counter;
+    const uint8_t* tip_mask;      /* tip_mask_size^2 bytes (host memory), or NULL */
+    uint32_t tip_mask_size;
+    float    tip_rotation;        /* degrees */
+    int32_t  tip_random_rotation;
+    float    tip_rotation_lo, tip_rotation_hi; /* tip_rotation_range */
+} pfx_brush_dynamics;
+int pfx_brush_stamps_ex(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, const pfx_brush_dynamics* dyn /* may be NULL */,
+                        const float* points_xy, uint32_t n_points, const uint8_t* selection);
+int pfx_brush_line_ex(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, const pfx_brush_dynamics* dyn,
+                      float x0, float y0, float x1, float y1, const uint8_t* selection);
+/* rebuild_tip_mask (host side, like the reference): bilinear rescale of a square source mask to ceil(brush_size), hardness contrast,
+ * anti-alias box passes.  `out` needs ceil(brush_size)^2 bytes; returns that side length (0 = no source). */
+uint32_t pfx_brush_tip_rescale(const uint8_t* src_mask, uint32_t src_size, float brush_size, float hardness, uint8_t* out);
 /* commit_bezier_to_layer / commit_eraser_to_layer (ref: bezier_commit.rs:103-225) */
 int pfx_brush_commit(pfx_ctx* ctx, uint8_t* layer_inout, const uint8_t* preview, uint32_t w, uint32_t h,
                      uint8_t blend_mode, int is_eraser, const uint8_t* selection);
@@ -355,6 +376,8 @@ int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float
                                   void* dst_dev);
 int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush,
                          const float* points_xy, uint32_t n_points, const void* selection_dev);
+int pfx_brush_stamps_ex_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush, const pfx_brush_dynamics* dyn,
+                            const float* points_xy, uint32_t n_points, const void* selection_dev);
 int pfx_tiled_roundtrip_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h);
 int pfx_sharpen_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float amount, float radius,
                     const void* mask_dev);

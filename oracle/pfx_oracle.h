@@ -196,6 +196,19 @@ typedef struct pfxo_brush {
     int   is_eraser;
     int   mode;          /* PFXO_BRUSH_* (BrushMode) */
 } pfxo_brush;
+/* brush dynamics: the ToolProperties fields draw_circle_no_dirty also reads (state.rs:112-128) + ToolsPanel::stamp_counter */
+typedef struct pfxo_brush_dyn {
+    float scatter, hue_jitter, brightness_jitter;
+    uint32_t stamp_counter;
+    const uint8_t* tip_mask;     /* brush_tip_mask rescaled to the brush size (pfxo_brush_tip_rescale); NULL = circle tip */
+    uint32_t tip_mask_size;
+    float tip_rotation;          /* degrees */
+    int32_t tip_random_rotation;
+    float tip_rotation_lo, tip_rotation_hi;
+} pfxo_brush_dyn;
+void pfxo_brush_stamp_ex(uint8_t* target, uint32_t w, uint32_t h, const pfxo_brush* b, const pfxo_brush_dyn* d, float px, float py,
+                         const uint8_t* selection);
+uint32_t pfxo_brush_tip_rescale(const uint8_t* src_mask, uint32_t src_size, float brush_size, float hardness, uint8_t* out);
 float pfxo_brush_alpha(float dist, float radius, float hardness, int anti_aliased);
 void pfxo_brush_lut(float size, float hardness, int anti_aliased, uint8_t lut[256]);
 void pfxo_brush_stamp(uint8_t* target, uint32_t w, uint32_t h, const pfxo_brush* b, float cx, float cy,

@@ -38,6 +38,12 @@ class ScriptResult(C.Structure):
                 ("ops_executed", C.c_uint32), ("console", C.c_char * 2048)]
 
 
+class BrushDynamics(C.Structure):
+    _fields_ = [("scatter", C.c_float), ("hue_jitter", C.c_float), ("brightness_jitter", C.c_float), ("stamp_counter", C.c_uint32),
+                ("tip_mask", C.c_void_p), ("tip_mask_size", C.c_uint32), ("tip_rotation", C.c_float), ("tip_random_rotation", C.c_int32),
+                ("tip_rotation_lo", C.c_float), ("tip_rotation_hi", C.c_float)]
+
+
 class DispDab(C.Structure):
     _fields_ = [("mode", C.c_int32), ("cx", C.c_float), ("cy", C.c_float), ("delta_x", C.c_float), ("delta_y", C.c_float), ("radius", C.c_float),
                 ("strength", C.c_float)]

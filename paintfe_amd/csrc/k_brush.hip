@@ -1,7 +1,9 @@
-// k_brush.hip — the round-tip brush stamp loop over a preview image.
+// k_brush.hip — the brush stamp loop over a preview image: round tip and image tips.
 //
-// Reference: draw_circle_no_dirty src/ui/panels/tools/behavior/raster/brush_render.rs:135-400 (circle tip, no
-// scatter / colour jitter), rebuild_brush_lut :27-50, compute_brush_alpha :54-82.
+// Reference: draw_circle_no_dirty src/ui/panels/tools/behavior/raster/brush_render.rs:135-400, draw_image_tip_no_dirty
+// :533-760, rebuild_brush_lut :27-50, compute_brush_alpha :54-82.  Scatter, colour jitter and tip rotation are per-stamp
+// quantities the reference computes on the CPU before touching pixels; here the host prologue (pfx_api.cpp) does the same and
+// hands the kernel a list of prepared stamps (centre, colour bytes, inverse-rotation cos / sin).
 // The reference stamps serially, stamp after stamp, each stamp looping over its bounding box.  Stamps only ever
 // read and write the pixel they are positioned on, so the loop nest is interchanged: one lane per pixel of the
 // stroke's bounding box walks the stamp list IN ORDER.  That keeps every order-dependent mode (max-alpha Normal
@@ -41,10 +43,48 @@ PFX_DEV float hue_to_rgb(float p, float q, float t)
 }
 PFX_DEV uint32_t rs_f32_as_u32(float v) { return (v > 0.0f) ? ((v >= 4294967296.0f) ? 0xffffffffu : (uint32_t)v) : 0u; }
 
+PFX_DEV int32_t rs_f32_as_i32(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)v;
+}
+
+// geometry of one image-tip stamp at pixel (gx, gy): draw_image_tip_no_dirty :584-727.  Returns false when the stamp does not
+// touch the pixel; otherwise geom_u8 = the tip mask's coverage there (nearest texel, or bilinear under inverse rotation).
+PFX_DEV bool tip_coverage(const pfxk_brush& B, const pfxk_stamp& S, const uint8_t* __restrict__ mask, int gx, int gy, uint32_t wm1, uint32_t hm1,
+                          uint32_t& geom_u8)
+{
+    const uint32_t ms = B.tip_size;
+    const float half = (float)ms / 2.0f;
+    const float eh = S.rotated ? half * 1.41421356237309504880f : half;
+    const uint32_t min_x = rs_f32_as_u32(__builtin_fmaxf(S.cx - eh, 0.0f)), min_y = rs_f32_as_u32(__builtin_fmaxf(S.cy - eh, 0.0f));
+    const uint32_t max_x = min(rs_f32_as_u32(S.cx + eh), wm1), max_y = min(rs_f32_as_u32(S.cy + eh), hm1);
+    if ((uint32_t)gx < min_x || (uint32_t)gx > max_x || (uint32_t)gy < min_y || (uint32_t)gy > max_y) return false;
+    const float rel_x = (float)gx - S.cx, rel_y = (float)gy - S.cy;
+    if (S.rotated) {
+        const float rot_x = rel_x * S.cos_a - rel_y * S.sin_a + half, rot_y = rel_x * S.sin_a + rel_y * S.cos_a + half;
+        if (rot_x < -0.5f || rot_y < -0.5f || rot_x >= (float)ms - 0.5f || rot_y >= (float)ms - 0.5f) return false;
+        const float sx = __builtin_fmaxf(rot_x, 0.0f), sy = __builtin_fmaxf(rot_y, 0.0f);
+        const uint32_t sx0 = rs_f32_as_u32(__builtin_floorf(sx)), sy0 = rs_f32_as_u32(__builtin_floorf(sy));
+        const uint32_t sx1 = min(sx0 + 1u, ms - 1u), sy1 = min(sy0 + 1u, ms - 1u);
+        const float fx = sx - (float)sx0, fy = sy - (float)sy0;
+        const float v00 = (float)mask[sy0 * ms + sx0], v10 = (float)mask[sy0 * ms + sx1], v01 = (float)mask[sy1 * ms + sx0], v11 = (float)mask[sy1 * ms + sx1];
+        const float top = v00 * (1.0f - fx) + v10 * fx, bot = v01 * (1.0f - fx) + v11 * fx;
+        geom_u8 = (uint32_t)__builtin_fminf(__builtin_roundf(top * (1.0f - fy) + bot * fy), 255.0f);
+    } else {
+        const int32_t mx = rs_f32_as_i32(__builtin_roundf(rel_x + half)), my = rs_f32_as_i32(__builtin_roundf(rel_y + half));
+        if (mx < 0 || my < 0 || mx >= (int32_t)ms || my >= (int32_t)ms) return false;
+        geom_u8 = mask[(uint32_t)my * ms + (uint32_t)mx];
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ target, uint32_t w, uint32_t h, pfxk_brush B,
-                                                    const float2* __restrict__ pts, uint32_t n_pts,
-                                                    const uint8_t* __restrict__ lut, const uint8_t* __restrict__ selection,
-                                                    int bx0, int by0, int bx1, int by1)
+                                                    const pfxk_stamp* __restrict__ stamps, uint32_t n_pts,
+                                                    const uint8_t* __restrict__ lut, const uint8_t* __restrict__ tip_mask,
+                                                    const uint8_t* __restrict__ selection, int bx0, int by0, int bx1, int by1)
 {
     const int gx = bx0 + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int gy = by0 + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
@@ -55,7 +95,22 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
     const uint32_t px_in = px;
     const uint32_t wm1 = w ? w - 1u : 0u, hm1 = h ? h - 1u : 0u;
     for (uint32_t k = 0; k < n_pts; ++k) {
-        const float2 c = pts[k];
+        const pfxk_stamp S = stamps[k]; // uniform -> scalar loads
+        if (B.tip_size) { // image tip (:533-760): max-alpha stamping or eraser only, no brush modes, no 0.01 cut-off for paint
+            uint32_t g8;
+            if (!tip_coverage(B, S, tip_mask, gx, gy, wm1, hm1, g8) || g8 == 0u) continue;
+            const float geom_alpha = div255((float)g8);
+            if (B.is_eraser) {
+                const float erase_strength = geom_alpha * B.src_a * B.flow;
+                if (erase_strength < 0.01f) continue;
+                if (erase_strength > div255((float)(px >> 24))) px = (uint32_t)trunc_u8f(erase_strength * 255.0f) << 24;
+            } else {
+                const uint32_t a8 = (uint32_t)trunc_u8f(geom_alpha * B.src_a * B.flow * 255.0f);
+                if (a8 >= (px >> 24)) px = S.rgb8 | (a8 << 24);
+            }
+            continue;
+        }
+        const float2 c = make_float2(S.cx, S.cy);
         // stamp bounding box exactly as the reference computes it (:209-215)
         const uint32_t min_x = rs_f32_as_u32(__builtin_fmaxf(__builtin_floorf(c.x - B.draw_radius), 0.0f));
         const uint32_t max_x = min(rs_f32_as_u32(__builtin_ceilf(c.x + B.draw_radius)), wm1);
@@ -84,7 +139,7 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
             if (brush_alpha < 0.01f) continue;
             if (B.mode == 0) { // Normal: max-alpha stamping, ties overwrite (:363-373)
                 const uint32_t a8 = (uint32_t)trunc_u8f(brush_alpha * 255.0f);
-                if (a8 >= (px >> 24)) px = B.rgb8 | (a8 << 24);
+                if (a8 >= (px >> 24)) px = S.rgb8 | (a8 << 24);
             } else { // Dodge / Burn / Sponge (:374-393)
                 hsl3 c3 = rgb_to_hsl(div255(ubyte0(px)), div255(ubyte1(px)), div255(ubyte2(px)));
                 const float strength = brush_alpha * 0.5f;
@@ -111,12 +166,11 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
 } // namespace
 
 extern "C" hipError_t pfxk_brush_stamps(hipStream_t s, uint8_t* d_target, uint32_t w, uint32_t h, const pfxk_brush* B,
-                                        const float* d_points_xy, uint32_t n_points, const uint8_t* d_lut256,
+                                        const pfxk_stamp* d_stamps, uint32_t n_points, const uint8_t* d_lut256, const uint8_t* d_tip_mask,
                                         const uint8_t* d_selection, int bx0, int by0, int bx1, int by1)
 {
     if (n_points == 0 || bx1 < bx0 || by1 < by0) return hipSuccess;
     dim3 g((uint32_t)(bx1 - bx0 + 64) / 64u, (uint32_t)(by1 - by0 + 4) / 4u);
-    brush_kernel<<<g, 256, 0, s>>>((uint32_t*)d_target, w, h, *B, (const float2*)d_points_xy, n_points, d_lut256,
-                                   d_selection, bx0, by0, bx1, by1);
+    brush_kernel<<<g, 256, 0, s>>>((uint32_t*)d_target, w, h, *B, d_stamps, n_points, d_lut256, d_tip_mask, d_selection, bx0, by0, bx1, by1);
     return hipGetLastError();
 }

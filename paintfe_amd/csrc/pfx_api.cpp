@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 
+#include "k_brush_math.h"
 #include "pfx_internal.h"
 
 void pfx_host_brush_lut(float size, float hardness, bool anti_aliased, uint8_t lut[256]);
@@ -459,39 +460,143 @@ int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float
     return PFX_OK;
 }
 
-int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush, const float* points_xy,
-                         uint32_t n_points, const void* selection_dev)
+// Per-stamp host prologue of draw_circle_no_dirty / draw_image_tip_no_dirty (brush_render.rs:148-256, 552-632): the reference
+// computes scatter, colour jitter and tip rotation on the CPU once per stamp; so does this, then the stamp list goes to the kernel.
+static uint32_t stamp_hash(float x, float y, uint32_t counter) // :846-857
+{
+    auto u = [](float v) -> uint32_t { return !(v > 0.0f) ? 0u : (v >= 4294967296.0f ? 0xffffffffu : (uint32_t)v); };
+    uint32_t hsh = u(x * 100.0f) * 374761393u + u(y * 100.0f) * 668265263u + counter * 1013904223u;
+    hsh ^= hsh >> 13;
+    hsh *= 1274126177u;
+    hsh ^= hsh >> 16;
+    return hsh;
+}
+static void host_rgb_to_hsl(float r, float g, float b, float& hh, float& s, float& l) // adjustments.rs:944-974
+{
+    const float mx = fmaxf(fmaxf(r, g), b), mn = fminf(fminf(r, g), b);
+    l = (mx + mn) / 2.0f;
+    if (fabsf(mx - mn) < 1e-6f) { hh = 0.0f; s = 0.0f; return; }
+    const float d = mx - mn;
+    s = l > 0.5f ? d / (2.0f - mx - mn) : d / (mx + mn);
+    if (fabsf(mx - r) < 1e-6f) { float t = (g - b) / d; if (t < 0.0f) t += 6.0f; hh = t / 6.0f; }
+    else if (fabsf(mx - g) < 1e-6f) hh = ((b - r) / d + 2.0f) / 6.0f;
+    else hh = ((r - g) / d + 4.0f) / 6.0f;
+}
+static float host_hue_to_rgb(float p, float q, float t) // adjustments.rs:995-1012
+{
+    if (t < 0.0f) t += 1.0f;
+    if (t > 1.0f) t -= 1.0f;
+    if (t < 1.0f / 6.0f) return p + (q - p) * 6.0f * t;
+    if (t < 1.0f / 2.0f) return q;
+    if (t < 2.0f / 3.0f) return p + (q - p) * (2.0f / 3.0f - t) * 6.0f;
+    return p;
+}
+static void host_hsl_to_rgb(float hh, float s, float l, float& r, float& g, float& b) // adjustments.rs:976-993
+{
+    if (fabsf(s) < 1e-6f) { r = g = b = l; return; }
+    const float q = l < 0.5f ? l * (1.0f + s) : l + s - l * s;
+    const float p = 2.0f * l - q;
+    r = host_hue_to_rgb(p, q, hh + 1.0f / 3.0f);
+    g = host_hue_to_rgb(p, q, hh);
+    b = host_hue_to_rgb(p, q, hh - 1.0f / 3.0f);
+}
+
+int pfx_brush_stamps_ex_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush, const pfx_brush_dynamics* dyn,
+                            const float* points_xy, uint32_t n_points, const void* selection_dev)
 {
     PFX_TRY(check_img(ctx, target_dev, target_dev, w, h, "pfx_brush_stamps_dev"));
     if (n_points == 0) return PFX_OK;
     PFX_REQUIRE(ctx, points_xy != nullptr, "null stamp list");
+    const bool image_tip = dyn && dyn->tip_mask;
     pfxk_brush B;
     bool skip;
     PFX_TRY(brush_prepare(ctx, brush, B, skip));
-    if (skip) return PFX_OK; // radius_sq < 0.001 (brush_render.rs:198)
-    // bounding box of the whole stroke (union of the per-stamp boxes, brush_render.rs:209-215)
-    float minx = points_xy[0], maxx = minx, miny = points_xy[1], maxy = miny;
-    for (uint32_t i = 1; i < n_points; ++i) {
-        minx = std::min(minx, points_xy[2 * i]); maxx = std::max(maxx, points_xy[2 * i]);
-        miny = std::min(miny, points_xy[2 * i + 1]); maxy = std::max(maxy, points_xy[2 * i + 1]);
+    if (image_tip) {
+        if (dyn->tip_mask_size == 0) return PFX_OK; // :546-549
+        PFX_REQUIRE(ctx, dyn->tip_mask_size <= 8192, "brush tip mask too large");
+        B.tip_size = dyn->tip_mask_size;
+    } else if (skip) return PFX_OK; // radius_sq < 0.001 (brush_render.rs:198)
+
+    auto u8 = [](float v) -> uint32_t { return !(v > 0.0f) ? 0u : (v >= 255.0f ? 255u : (uint32_t)(int)v); };
+    std::vector<pfxk_stamp> st(n_points);
+    const float half = image_tip ? (float)dyn->tip_mask_size / 2.0f : 0.0f;
+    float reach = image_tip ? half : B.draw_radius;
+    float minx = 0, maxx = 0, miny = 0, maxy = 0;
+    for (uint32_t i = 0; i < n_points; ++i) {
+        const float px = points_xy[2 * i], py = points_xy[2 * i + 1];
+        pfxk_stamp& S = st[i];
+        S.cx = px; S.cy = py; S.cos_a = 1.0f; S.sin_a = 0.0f; S.rotated = 0;
+        if (dyn && dyn->scatter > 0.01f) { // :179-193 / :552-565
+            const float diam = brush->size; // pressure_size() without pen pressure
+            const float h1 = (float)stamp_hash(px, py, dyn->stamp_counter) / 4294967295.0f;
+            const float h2 = (float)stamp_hash(py, px, dyn->stamp_counter + 99991u) / 4294967295.0f;
+            S.cx = px + (h1 * 2.0f - 1.0f) * dyn->scatter * diam;
+            S.cy = py + (h2 * 2.0f - 1.0f) * dyn->scatter * diam;
+        }
+        S.rgb8 = B.rgb8;
+        if (dyn && (dyn->hue_jitter > 0.01f || dyn->brightness_jitter > 0.01f)) { // :226-256 / :602-632
+            float hh, s, l, nr, ng, nb;
+            host_rgb_to_hsl(brush->color[0], brush->color[1], brush->color[2], hh, s, l);
+            if (dyn->hue_jitter > 0.01f) {
+                const float hv = (float)stamp_hash(px + 0.1f, py + 0.2f, dyn->stamp_counter + 777u) / 4294967295.0f;
+                const float v = hh + (hv * 2.0f - 1.0f) * dyn->hue_jitter * 0.5f;
+                hh = v - truncf(v);
+                if (hh < 0.0f) hh += 1.0f;
+            }
+            if (dyn->brightness_jitter > 0.01f) {
+                const float bv = (float)stamp_hash(px + 0.3f, py + 0.4f, dyn->stamp_counter + 555u) / 4294967295.0f;
+                l = pfx_clampf(l + (bv * 2.0f - 1.0f) * dyn->brightness_jitter * 0.5f, 0.0f, 1.0f);
+            }
+            host_hsl_to_rgb(hh, s, l, nr, ng, nb);
+            S.rgb8 = u8(nr * 255.0f) | (u8(ng * 255.0f) << 8) | (u8(nb * 255.0f) << 16);
+        }
+        if (image_tip) { // :148-163, :570-581
+            float rotation_deg = dyn->tip_rotation;
+            if (dyn->tip_random_rotation) {
+                const float lo = dyn->tip_rotation_lo, range = dyn->tip_rotation_hi - lo;
+                rotation_deg = fabsf(range) < 0.01f ? lo : lo + (float)(stamp_hash(px, py, dyn->stamp_counter) % 10000u) / 10000.0f * range;
+            }
+            if (fabsf(rotation_deg) > 0.01f) {
+                const float rad = -(rotation_deg * (3.14159265358979323846f / 180.0f)); // negative: inverse rotation for sampling
+                S.cos_a = cosf(rad); S.sin_a = sinf(rad); S.rotated = 1;
+                reach = std::max(reach, half * 1.41421356237309504880f);
+            }
+        }
+        if (i == 0) { minx = maxx = S.cx; miny = maxy = S.cy; }
+        else { minx = std::min(minx, S.cx); maxx = std::max(maxx, S.cx); miny = std::min(miny, S.cy); maxy = std::max(maxy, S.cy); }
     }
-    const float pad = B.draw_radius + 2.0f;
-    const int bx0 = (int)std::max(0.0f, floorf(minx - pad)), by0 = (int)std::max(0.0f, floorf(miny - pad));
-    const int bx1 = (int)std::min((float)(w - 1), ceilf(maxx + pad)), by1 = (int)std::min((float)(h - 1), ceilf(maxy + pad));
+    // bounding box of the whole stroke: union of the per-stamp boxes (brush_render.rs:209-215, 584-587) plus slack
+    const float pad = reach + 2.0f;
+    if (!(minx == minx && maxx == maxx && miny == miny && maxy == maxy)) return pfx_fail(ctx, PFX_ERR_INVALID, "stamp positions must be finite");
+    const int bx0 = (int)std::max(0.0f, floorf(std::max(minx - pad, -1.0e9f))), by0 = (int)std::max(0.0f, floorf(std::max(miny - pad, -1.0e9f)));
+    const int bx1 = (int)std::min((float)(w - 1), ceilf(std::min(maxx + pad, 1.0e9f))), by1 = (int)std::min((float)(h - 1), ceilf(std::min(maxy + pad, 1.0e9f)));
     if (bx1 < bx0 || by1 < by0) return PFX_OK;
-    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, (size_t)n_points * 2 * sizeof(float) + 512));
-    PFX_TRY(pfx_h2d(ctx, ctx->d_pts.p, points_xy, (size_t)n_points * 2 * sizeof(float)));
+    const size_t stamp_bytes = st.size() * sizeof(pfxk_stamp), tip_bytes = image_tip ? (size_t)dyn->tip_mask_size * dyn->tip_mask_size : 0;
+    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, stamp_bytes + tip_bytes + 512));
+    PFX_TRY(pfx_h2d(ctx, ctx->d_pts.p, st.data(), stamp_bytes));
+    const uint8_t* d_tip = nullptr;
+    if (image_tip) {
+        PFX_TRY(pfx_h2d(ctx, (uint8_t*)ctx->d_pts.p + stamp_bytes, dyn->tip_mask, tip_bytes));
+        d_tip = (const uint8_t*)ctx->d_pts.p + stamp_bytes;
+    }
+    PFX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `st` is pageable host memory about to go out of scope
     const uint8_t* d_lut = nullptr;
-    if (!B.use_direct_alpha) { // LUT path only when AA is off (brush_render.rs:329-337)
+    if (!image_tip && !B.use_direct_alpha) { // LUT path only when AA is off (brush_render.rs:329-337)
         uint8_t lut[256];
         pfx_host_brush_lut(brush->size, brush->hardness, brush->anti_aliased != 0, lut);
         PFX_TRY(upload_lut(ctx, lut, 256));
         d_lut = (const uint8_t*)ctx->d_lut.p;
     }
     pfx_timer t(ctx, "brush_stamps");
-    PFX_HIP(ctx, pfxk_brush_stamps(ctx->stream, (uint8_t*)target_dev, w, h, &B, (const float*)ctx->d_pts.p, n_points, d_lut,
+    PFX_HIP(ctx, pfxk_brush_stamps(ctx->stream, (uint8_t*)target_dev, w, h, &B, (const pfxk_stamp*)ctx->d_pts.p, n_points, d_lut, d_tip,
                                    (const uint8_t*)selection_dev, bx0, by0, bx1, by1));
     return PFX_OK;
+}
+
+int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush, const float* points_xy,
+                         uint32_t n_points, const void* selection_dev)
+{
+    return pfx_brush_stamps_ex_dev(ctx, target_dev, w, h, brush, nullptr, points_xy, n_points, selection_dev);
 }
 
 int pfx_tiled_roundtrip_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h)
@@ -767,25 +872,84 @@ int pfx_warp_mesh_catmull_rom(pfx_ctx* ctx, const uint8_t* src, const float* ori
     return finish_out(ctx, dst, w, h);
 }
 
-int pfx_brush_stamps(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, const float* points_xy,
-                     uint32_t n_points, const uint8_t* selection)
+int pfx_brush_stamps_ex(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, const pfx_brush_dynamics* dyn,
+                        const float* points_xy, uint32_t n_points, const uint8_t* selection)
 {
     PFX_TRY(check_img(ctx, target_inout, target_inout, w, h, "pfx_brush_stamps"));
     const void* d_sel;
     PFX_TRY(stage_in(ctx, target_inout, selection, w, h, &d_sel));
-    PFX_TRY(pfx_brush_stamps_dev(ctx, ctx->st_in.p, w, h, brush, points_xy, n_points, d_sel));
+    PFX_TRY(pfx_brush_stamps_ex_dev(ctx, ctx->st_in.p, w, h, brush, dyn, points_xy, n_points, d_sel));
     PFX_TRY(pfx_d2h(ctx, target_inout, ctx->st_in.p, img_bytes(w, h)));
     return pfx_sync(ctx);
 }
 
-int pfx_brush_line(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, float x0, float y0,
-                   float x1, float y1, const uint8_t* selection)
+int pfx_brush_stamps(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, const float* points_xy,
+                     uint32_t n_points, const uint8_t* selection)
+{
+    return pfx_brush_stamps_ex(ctx, target_inout, w, h, brush, nullptr, points_xy, n_points, selection);
+}
+
+int pfx_brush_line_ex(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, const pfx_brush_dynamics* dyn, float x0,
+                      float y0, float x1, float y1, const uint8_t* selection)
 {
     if (!ctx) return PFX_ERR_INVALID;
     std::vector<float> pts;
     pfx_host_line_points(x0, y0, x1, y1, w, h, pts);
     if (pts.empty()) return PFX_OK;
-    return pfx_brush_stamps(ctx, target_inout, w, h, brush, pts.data(), (uint32_t)(pts.size() / 2), selection);
+    return pfx_brush_stamps_ex(ctx, target_inout, w, h, brush, dyn, pts.data(), (uint32_t)(pts.size() / 2), selection);
+}
+
+int pfx_brush_line(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, float x0, float y0,
+                   float x1, float y1, const uint8_t* selection)
+{
+    return pfx_brush_line_ex(ctx, target_inout, w, h, brush, nullptr, x0, y0, x1, y1, selection);
+}
+
+// rebuild_tip_mask (brush_render.rs:404-528), host side like the reference
+uint32_t pfx_brush_tip_rescale(const uint8_t* src, uint32_t src_size, float brush_size, float hardness, uint8_t* out)
+{
+    if (!src || !out || src_size == 0) return 0;
+    auto u32 = [](float v) -> uint32_t { return !(v > 0.0f) ? 0u : (v >= 4294967296.0f ? 0xffffffffu : (uint32_t)v); };
+    auto u8 = [](float v) -> uint8_t { return !(v > 0.0f) ? 0 : (v >= 255.0f ? 255 : (uint8_t)(int)v); };
+    const uint32_t dst = std::max(u32(ceilf(brush_size)), 1u);
+    const float scale = (float)src_size / (float)dst;
+    for (uint32_t dy = 0; dy < dst; ++dy)
+        for (uint32_t dx = 0; dx < dst; ++dx) {
+            const float sx = (float)dx * scale, sy = (float)dy * scale;
+            const uint32_t sx0 = u32(floorf(sx)), sy0 = u32(floorf(sy));
+            const uint32_t sx1 = std::min(sx0 + 1, src_size - 1), sy1 = std::min(sy0 + 1, src_size - 1);
+            const float fx = sx - (float)sx0, fy = sy - (float)sy0;
+            const float v00 = src[sy0 * src_size + sx0], v10 = src[sy0 * src_size + sx1], v01 = src[sy1 * src_size + sx0], v11 = src[sy1 * src_size + sx1];
+            const float top = v00 * (1.0f - fx) + v10 * fx, bot = v01 * (1.0f - fx) + v11 * fx;
+            out[dy * dst + dx] = u8(fminf(roundf(top * (1.0f - fy) + bot * fy), 255.0f));
+        }
+    if (hardness < 0.99f) { // hardness as a contrast modifier
+        const float threshold = (1.0f - hardness) * 0.6f, range = 1.0f - threshold;
+        for (uint32_t i = 0; i < dst * dst; ++i)
+            out[i] = u8(roundf(pfx_clampf(((float)out[i] / 255.0f - threshold) / range, 0.0f, 1.0f) * 255.0f));
+    }
+    if (dst < src_size && dst >= 3) { // anti-alias box passes when downscaling
+        const float ratio = (float)src_size / (float)dst;
+        const int passes = ratio > 4.0f ? 2 : (ratio > 1.5f ? 1 : 0);
+        std::vector<uint8_t> tmp((size_t)dst * dst);
+        for (int p = 0; p < passes; ++p) {
+            for (uint32_t y = 0; y < dst; ++y)
+                for (uint32_t x = 0; x < dst; ++x) {
+                    uint32_t sum = out[y * dst + x], count = 1;
+                    if (x > 0) { sum += out[y * dst + x - 1]; ++count; }
+                    if (x + 1 < dst) { sum += out[y * dst + x + 1]; ++count; }
+                    tmp[y * dst + x] = (uint8_t)(sum / count);
+                }
+            for (uint32_t y = 0; y < dst; ++y)
+                for (uint32_t x = 0; x < dst; ++x) {
+                    uint32_t sum = tmp[y * dst + x], count = 1;
+                    if (y > 0) { sum += tmp[(y - 1) * dst + x]; ++count; }
+                    if (y + 1 < dst) { sum += tmp[(y + 1) * dst + x]; ++count; }
+                    out[y * dst + x] = (uint8_t)(sum / count);
+                }
+        }
+    }
+    return dst;
 }
 
 int pfx_brush_commit(pfx_ctx* ctx, uint8_t* layer_inout, const uint8_t* preview, uint32_t w, uint32_t h, uint8_t blend_mode,

@@ -162,9 +162,13 @@ typedef struct pfxk_brush {
     float src_r, src_g, src_b, src_a;
     uint32_t rgb8;          // (c*255) as u8, packed r | g<<8 | b<<16
     int32_t anti_aliased, use_direct_alpha, is_eraser, mode;
+    uint32_t tip_size;      // side of the square image-tip mask, 0 = circle tip
 } pfxk_brush;
+// one stamp after the host prologue of draw_circle_no_dirty / draw_image_tip_no_dirty: scattered centre, jittered colour bytes,
+// inverse-rotation cosine / sine of an image tip
+typedef struct pfxk_stamp { float cx, cy; uint32_t rgb8; float cos_a, sin_a; uint32_t rotated; } pfxk_stamp;
 hipError_t pfxk_brush_stamps(hipStream_t s, uint8_t* d_target, uint32_t w, uint32_t h, const pfxk_brush* B,
-                             const float* d_points_xy, uint32_t n_points, const uint8_t* d_lut256,
+                             const pfxk_stamp* d_stamps, uint32_t n_stamps, const uint8_t* d_lut256, const uint8_t* d_tip_mask,
                              const uint8_t* d_selection, int bx0, int by0, int bx1, int by1);
 hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const uint8_t* d_preview, const uint8_t* d_selection,
                              uint32_t w, uint32_t h, uint32_t mode, int is_eraser);

@@ -414,21 +414,45 @@ class GpuRenderer:
         b.anti_aliased, b.is_eraser, b.mode = int(anti_aliased), int(is_eraser), int(mode)
         return b
 
-    def brush_stamps(self, target, brush: Brush, points, selection=None):
+    @staticmethod
+    def make_dynamics(scatter=0.0, hue_jitter=0.0, brightness_jitter=0.0, stamp_counter=0, tip_mask=None, tip_rotation=0.0,
+                      tip_random_rotation=False, tip_rotation_range=(0.0, 360.0)):
+        """pfx_brush_dynamics (ToolProperties scatter / jitter / image tip; ref: state.rs:112-128).  Returns (struct, keep-alive)."""
+        d = _lib.BrushDynamics(scatter, hue_jitter, brightness_jitter, stamp_counter, None, 0, tip_rotation, int(tip_random_rotation),
+                               tip_rotation_range[0], tip_rotation_range[1])
+        keep = None
+        if tip_mask is not None:
+            keep = _u8(tip_mask)
+            d.tip_mask = keep.ctypes.data
+            d.tip_mask_size = keep.shape[0]
+        return d, keep
+
+    def brush_tip_rescale(self, src_mask, brush_size: float, hardness: float):        # rebuild_tip_mask, brush_render.rs:404
+        src = _u8(src_mask)
+        n = max(int(np.ceil(np.float32(brush_size))), 1)
+        out = np.zeros((n, n), np.uint8)
+        self._lib.pfx_brush_tip_rescale.restype = C.c_uint32
+        got = self._lib.pfx_brush_tip_rescale(_p(src), C.c_uint32(src.shape[0]), C.c_float(brush_size), C.c_float(hardness), _p(out))
+        assert got == n
+        return out
+
+    def brush_stamps(self, target, brush: Brush, points, selection=None, dyn=None):
         t = _u8(target).copy()
         h, w = t.shape[:2]
         pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
         sel = None if selection is None else _u8(selection)
-        self._check(self._lib.pfx_brush_stamps(self._h, _p(t), C.c_uint32(w), C.c_uint32(h), C.byref(brush), _p(pts),
-                                               C.c_uint32(len(pts)), _p(sel)))
+        d, keep = self.make_dynamics(**dyn) if dyn is not None else (None, None)
+        self._check(self._lib.pfx_brush_stamps_ex(self._h, _p(t), C.c_uint32(w), C.c_uint32(h), C.byref(brush), C.byref(d) if d is not None else None,
+                                                  _p(pts), C.c_uint32(len(pts)), _p(sel)))
         return t
 
-    def brush_line(self, target, brush: Brush, p0, p1, selection=None):
+    def brush_line(self, target, brush: Brush, p0, p1, selection=None, dyn=None):
         t = _u8(target).copy()
         h, w = t.shape[:2]
         sel = None if selection is None else _u8(selection)
-        self._check(self._lib.pfx_brush_line(self._h, _p(t), C.c_uint32(w), C.c_uint32(h), C.byref(brush), C.c_float(p0[0]),
-                                             C.c_float(p0[1]), C.c_float(p1[0]), C.c_float(p1[1]), _p(sel)))
+        d, keep = self.make_dynamics(**dyn) if dyn is not None else (None, None)
+        self._check(self._lib.pfx_brush_line_ex(self._h, _p(t), C.c_uint32(w), C.c_uint32(h), C.byref(brush), C.byref(d) if d is not None else None,
+                                                C.c_float(p0[0]), C.c_float(p0[1]), C.c_float(p1[0]), C.c_float(p1[1]), _p(sel)))
         return t
 
     def brush_commit(self, layer, preview, blend_mode: int, is_eraser=False, selection=None):

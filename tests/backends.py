@@ -87,11 +87,11 @@ class OracleBackend:
     def warp_mesh(self, img, orig, deformed, cols, rows):
         return O.warp_mesh_catmull_rom(img, orig, deformed, cols, rows)
 
-    def brush_stamps(self, target, brush, points, selection=None):
+    def brush_stamps(self, target, brush, points, selection=None, dyn=None):
         t = GC.brush_target(target) if isinstance(target, str) else np.ascontiguousarray(target).copy()
         b = O.make_brush(**brush)
         for (x, y) in points:
-            O.brush_stamp(t, b, x, y, selection)
+            O.brush_stamp(t, b, x, y, selection, dyn)
         return t
 
     def brush_line(self, target, brush, p0, p1, selection=None):
@@ -198,9 +198,9 @@ class GpuBackend:
     def warp_mesh(self, img, orig, deformed, cols, rows):
         return self.r.warp_mesh_catmull_rom(img, orig, deformed, cols, rows)
 
-    def brush_stamps(self, target, brush, points, selection=None):
+    def brush_stamps(self, target, brush, points, selection=None, dyn=None):
         t = GC.brush_target(target) if isinstance(target, str) else target
-        return self.r.brush_stamps(t, self.r.make_brush(**brush), points, selection)
+        return self.r.brush_stamps(t, self.r.make_brush(**brush), points, selection, dyn)
 
     def brush_line(self, target, brush, p0, p1, selection=None):
         t = GC.brush_target(target) if isinstance(target, str) else target

@@ -474,10 +474,44 @@ def make_brush(size, hardness, anti_aliased, color=(0, 0, 0, 1), flow=1.0, is_er
     return b
 
 
-def brush_stamp(target, brush, cx, cy, selection=None):
+class BrushDyn(C.Structure):
+    _fields_ = [("scatter", C.c_float), ("hue_jitter", C.c_float), ("brightness_jitter", C.c_float), ("stamp_counter", C.c_uint32),
+                ("tip_mask", C.c_void_p), ("tip_mask_size", C.c_uint32), ("tip_rotation", C.c_float), ("tip_random_rotation", C.c_int32),
+                ("tip_rotation_lo", C.c_float), ("tip_rotation_hi", C.c_float)]
+
+
+def make_dyn(scatter=0.0, hue_jitter=0.0, brightness_jitter=0.0, stamp_counter=0, tip_mask=None, tip_rotation=0.0, tip_random_rotation=False,
+             tip_rotation_range=(0.0, 360.0)):
+    """returns (BrushDyn, keep-alive) — tip_mask: square uint8 array already rescaled to the brush size"""
+    d = BrushDyn(scatter, hue_jitter, brightness_jitter, stamp_counter, None, 0, tip_rotation, int(tip_random_rotation),
+                 tip_rotation_range[0], tip_rotation_range[1])
+    keep = None
+    if tip_mask is not None:
+        keep, p = _u8(tip_mask)
+        d.tip_mask = p.value
+        d.tip_mask_size = keep.shape[0]
+    return d, keep
+
+
+def brush_tip_rescale(src_mask, brush_size, hardness):
+    src, ps = _u8(src_mask)
+    n = max(int(np.ceil(np.float32(brush_size))), 1)
+    out = np.zeros((n, n), np.uint8)
+    lib().pfxo_brush_tip_rescale.restype = C.c_uint32
+    got = lib().pfxo_brush_tip_rescale(ps, C.c_uint32(src.shape[0]), C.c_float(brush_size), C.c_float(hardness), out.ctypes.data_as(C.c_void_p))
+    assert got == n
+    return out
+
+
+def brush_stamp(target, brush, cx, cy, selection=None, dyn=None):
     h, w = target.shape[:2]
     assert target.dtype == np.uint8 and target.flags.c_contiguous
     m, pm = _opt_u8(selection)
+    if dyn is not None:
+        d, keep = make_dyn(**dyn)
+        lib().pfxo_brush_stamp_ex(target.ctypes.data_as(C.c_void_p), C.c_uint32(w), C.c_uint32(h), C.byref(brush), C.byref(d),
+                                  C.c_float(cx), C.c_float(cy), pm)
+        return target
     lib().pfxo_brush_stamp(target.ctypes.data_as(C.c_void_p), C.c_uint32(w), C.c_uint32(h), C.byref(brush),
                            C.c_float(cx), C.c_float(cy), pm)
     return target

@@ -425,6 +425,56 @@ def test_brush_random_strokes(gpu, oracle, mode, eraser, aa):
     assert_same(gpu.brush_line(target, brush, (-10.0, 5.0), (250.0, 130.0)), oracle.brush_line(target, brush, (-10.0, 5.0), (250.0, 130.0)), 0, "line")
 
 
+def _tip_source(n=96):
+    """an asymmetric soft blob with a hole: rotation and hardness are visible"""
+    yy, xx = np.mgrid[0:n, 0:n].astype(np.float32)
+    a = np.clip(1.0 - np.hypot(xx - n * 0.5, (yy - n * 0.35) * 1.6) / (n * 0.42), 0, 1)
+    a *= (np.hypot(xx - n * 0.62, yy - n * 0.3) > n * 0.08)
+    return (a * 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("case", ["scatter", "jitter", "scatter_jitter_eraser", "dodge_scatter", "tip", "tip_rotated", "tip_random_rotation",
+                                  "tip_eraser_scatter", "tip_jitter_selection", "tip_upscaled"])
+def test_brush_dynamics(gpu, oracle, case):
+    """scatter, hue / brightness jitter and image tips (brush_render.rs:148-256, 404-760): host prologue per stamp + the stamp kernel,
+    bit-exact with the oracle for strokes of overlapping stamps, including off-canvas and edge-clipped ones"""
+    w, h = 230, 150
+    rng = np.random.default_rng(sum(map(ord, case)))
+    target = I.random_rgba(w, h, 9) if "dodge" in case else np.zeros((h, w, 4), np.uint8)
+    if "eraser" in case:  # eraser strokes accumulate a strength mask in an initially empty preview (brush_render.rs:345-356)
+        target = np.zeros((h, w, 4), np.uint8)
+        target[:, : w // 2, 3] = 60  # part of it already holds a weaker mask
+    pts = [(float(rng.uniform(-15, w + 15)), float(rng.uniform(-15, h + 15))) for _ in range(60)]
+    pts += [(0.0, 0.0), (w - 1.0, h - 1.0), (w / 2, h / 2), (w / 2 + 0.5, h / 2 + 0.25)]
+    brush = dict(size=26.0, hardness=0.6, anti_aliased=True, color=(0.85, 0.3, 0.1, 0.9), flow=0.8, is_eraser="eraser" in case, mode=1 if "dodge" in case else 0)
+    dyn = dict(stamp_counter=int(rng.integers(0, 2 ** 31)))
+    sel = None
+    if "scatter" in case:
+        dyn["scatter"] = 0.7
+    if "jitter" in case:
+        dyn["hue_jitter"], dyn["brightness_jitter"] = 0.8, 0.5
+    if case.startswith("tip"):
+        size = 41.0 if case == "tip_upscaled" else 26.0
+        brush["size"] = size
+        src = _tip_source(24 if case == "tip_upscaled" else 96)
+        tip_o = O.brush_tip_rescale(src, size, brush["hardness"])
+        tip_g = gpu.r.brush_tip_rescale(src, size, brush["hardness"])
+        assert np.array_equal(tip_o, tip_g), "rebuild_tip_mask"
+        dyn["tip_mask"] = tip_g
+        if case == "tip_rotated":
+            dyn["tip_rotation"] = 33.0
+        if case == "tip_random_rotation":
+            dyn["tip_random_rotation"], dyn["tip_rotation_range"] = True, (-90.0, 250.0)
+        if "selection" in case:
+            sel = (rng.random((h, w)) < 0.7).astype(np.uint8) * 255
+    got = gpu.brush_stamps(target, brush, pts, sel, dyn)
+    ref = oracle.brush_stamps(target, brush, pts, sel, dyn)
+    assert_same(got, ref, 0, f"brush dynamics {case}")
+    assert not np.array_equal(ref, target)
+    if case == "scatter":  # scatter must actually move stamps: differs from the plain stroke
+        assert not np.array_equal(ref, oracle.brush_stamps(target, brush, pts, sel))
+
+
 def test_brush_commit(gpu):
     w, h = 100, 80
     layer = I.random_rgba(w, h, 70)

@@ -343,6 +343,33 @@ def test_closure_runtime_errors_leave_the_image_untouched(r):
     assert "Function not found: sqrt (i64)" in str(e.value)
 
 
+def test_readme_example_script(r):
+    """the script PaintFE's README shows (README.md:52-60), on a photo-sized image"""
+    src = """
+    apply_desaturate();
+    apply_brightness_contrast(10.0, 40.0);
+    apply_vignette(0.5, 0.3);
+
+    map_channels(|r, g, b, a| {
+        [clamp(r + 15, 0, 255), g, clamp(b - 8, 0, 255), a]
+    });
+    """
+    img = I.random_rgba(640, 427, 77)
+    out, _ = run(r, src, img)
+    ref = O.rhai_adjust(img, "desaturate")
+    ref = O.rhai_adjust(ref, "brightness_contrast", [10.0, 40.0])
+    ref = O.vignette(ref, 0.5, 0.3).astype(np.int64)
+    ref[..., 0] = np.clip(ref[..., 0] + 15, 0, 255)
+    ref[..., 2] = np.clip(ref[..., 2] - 8, 0, 255)
+    d = np.abs(out.astype(np.int64) - ref)
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3  # vignette: libm class
+    # the editor's default script (src/components/script_editor.rs:124)
+    out, _ = run(r, "// Write your script here\n// Example: Invert all pixels\nmap_channels(|r, g, b, a| {\n    [255 - r, 255 - g, 255 - b, a]\n});\n", img)
+    ref = img.copy()
+    ref[..., :3] = 255 - ref[..., :3]
+    assert np.array_equal(out, ref)
+
+
 def test_canvas_ops_and_size_changes(r):
     img = I.create_test_gradient(64, 48)
     out, _, ops = run(r, "rotate_canvas_90cw(); flip_canvas_horizontal(); resize_canvas(30, 100, \"bottom-right\"); print(width()); print(height());", img, with_ops=True)
