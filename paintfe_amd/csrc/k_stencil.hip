@@ -188,11 +188,13 @@ __global__ __launch_bounds__(256) void median3_kernel(const uint32_t* __restrict
 // 5x5 median: a 113-comparator selection network (k_median25_net.h, generated and exhaustively verified by
 // tools/gen_median_net.py) on packed 16-bit lanes — R,B in one register pair and G,A in another, so one v_pk_min_u16 /
 // v_pk_max_u16 pair exchanges two channels at once: ~520 VALU ops per pixel against ~2800 for the generic search.
+// 7x7 (R = 3): the same with the 313-comparator median-of-49 network (49 x 2 packed registers per lane).
 typedef unsigned short pfx_us2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(MD_TX* MD_TY) void median5_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
-                                                               const uint8_t* __restrict__ mask, int w, int h)
+template <int R>
+__global__ __launch_bounds__(MD_TX* MD_TY) void median_net_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                                  const uint8_t* __restrict__ mask, int w, int h)
 {
-    constexpr int r = 2, tw = MD_TX + 2 * r, th = MD_TY + 2 * r;
+    constexpr int r = R, side = 2 * R + 1, N = side * side, tw = MD_TX + 2 * r, th = MD_TY + 2 * r;
     __shared__ uint32_t tile[tw * th];
     const int bx = blockIdx.x * MD_TX, by = blockIdx.y * MD_TY;
     for (int i = threadIdx.x; i < tw * th; i += MD_TX * MD_TY) {
@@ -205,21 +207,22 @@ __global__ __launch_bounds__(MD_TX* MD_TY) void median5_kernel(const uint32_t* _
     if (x >= w || y >= h) return;
     const size_t oi = (size_t)y * w + x;
     if (mask && mask[oi] == 0) { dst[oi] = tile[(ly + r) * tw + lx + r]; return; }
-    pfx_us2 e[25], o[25];
+    pfx_us2 e[N], o[N];
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy)
+    for (int dy = 0; dy < side; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
+        for (int dx = 0; dx < side; ++dx) {
             const uint32_t p = tile[(ly + dy) * tw + lx + dx];
-            e[dy * 5 + dx] = __builtin_bit_cast(pfx_us2, p & 0x00ff00ffu);
-            o[dy * 5 + dx] = __builtin_bit_cast(pfx_us2, (p >> 8) & 0x00ff00ffu);
+            e[dy * side + dx] = __builtin_bit_cast(pfx_us2, p & 0x00ff00ffu);
+            o[dy * side + dx] = __builtin_bit_cast(pfx_us2, (p >> 8) & 0x00ff00ffu);
         }
 #define PFX_CE(i, j)                                                                                          \
     { const pfx_us2 a = e[i], b = e[j]; e[i] = __builtin_elementwise_min(a, b); e[j] = __builtin_elementwise_max(a, b); \
       const pfx_us2 c = o[i], d = o[j]; o[i] = __builtin_elementwise_min(c, d); o[j] = __builtin_elementwise_max(c, d); }
-    PFX_MEDIAN25_NET(PFX_CE)
+    if constexpr (R == 2) { PFX_MEDIAN25_NET(PFX_CE) }
+    else { PFX_MEDIAN49_NET(PFX_CE) }
 #undef PFX_CE
-    dst[oi] = __builtin_bit_cast(uint32_t, e[12]) | (__builtin_bit_cast(uint32_t, o[12]) << 8);
+    dst[oi] = __builtin_bit_cast(uint32_t, e[N / 2]) | (__builtin_bit_cast(uint32_t, o[N / 2]) << 8);
 }
 
 // ---------------------------------------------------------------- pixelate
@@ -264,9 +267,10 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         else median3_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         return hipGetLastError();
     }
-    if (radius == 2) { // 5x5: selection network
-        median5_kernel<<<dim3((w + MD_TX - 1) / MD_TX, (h + MD_TY - 1) / MD_TY), MD_TX * MD_TY, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask,
-                                                                                                          (int)w, (int)h);
+    if (radius == 2 || radius == 3) { // 5x5 / 7x7: selection networks
+        const dim3 g((w + MD_TX - 1) / MD_TX, (h + MD_TY - 1) / MD_TY);
+        if (radius == 2) median_net_kernel<2><<<g, MD_TX * MD_TY, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        else median_net_kernel<3><<<g, MD_TX * MD_TY, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(MD_TX + 2 * radius) * (MD_TY + 2 * radius) * 4;
