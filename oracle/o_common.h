@@ -3,6 +3,7 @@
 #define PFX_O_COMMON_H
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -41,8 +42,20 @@ static inline float rs_clampf(float x, float lo, float hi)
 static inline void o_set_threads(int threads)
 {
 #ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(threads);
-    else omp_set_num_threads(omp_get_num_procs());
+    if (threads <= 0) { /* all usable cores: the affinity mask, capped by the cgroup CPU quota (a quota-limited box
+                           with a wide affinity mask would otherwise be oversubscribed and throttled) */
+        threads = omp_get_num_procs();
+        FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+        if (f) {
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+                int q = (int)((quota + period - 1) / period);
+                if (q >= 1 && q < threads) threads = q;
+            }
+            fclose(f);
+        }
+    }
+    omp_set_num_threads(threads);
 #else
     (void)threads;
 #endif
