@@ -505,6 +505,73 @@ int pfx_script_check(const char* source, uint32_t w, uint32_t h, pfx_script_resu
 /* the `pfx` batch CLI main (same flags as src/cli.rs:43-89); returns the process exit code */
 int pfx_cli_main(int argc, char** argv);
 
+/* ================= N2: PFE project files and TiledImage import / export on the device =====================================
+ * A .pfe file is the bincode 1.x (little-endian, fixed-width integers, u64 lengths) image of ProjectFileV0..V3
+ * (ref: src/io.rs:85-208): the layer stack the compositor wants, each raster layer stored as its sparse list of 64x64 chunks.
+ * pfx_project is the host-side document: size, active layer, folders, layers (name, visibility, opacity, blend mode, kind,
+ * chunk list, and every V2/V3 payload kept verbatim so that re-saving loses nothing).  Parity: no .pfe fixture exists in the
+ * reference tree (its tests are save->load round trips), so the byte layout is pinned by an independent Python bincode
+ * restatement under tests/ — "parity unpinned" against real reference output. */
+typedef struct pfx_project pfx_project;
+typedef struct pfx_project_layer {
+    const char* name;                /* owned by the project, valid until it is modified or freed */
+    uint8_t  visible;                /* Layer::visible */
+    uint8_t  effectively_visible;    /* visible and not inside a hidden folder (ref: canvas_state.rs:216-227) */
+    uint8_t  blend_mode;             /* BlendMode::to_u8 as stored */
+    uint8_t  layer_type;             /* 0 raster, 1 text (its rasterised chunks are used), 2 adjustment */
+    float    opacity;
+    int64_t  folder_id;              /* -1 = none */
+    uint32_t n_chunks;               /* stored chunks */
+    uint8_t  kind;                   /* pfx_layer_kind the compositor will use (an adjustment payload that fails to parse
+                                        falls back to raster, io.rs:864-869) */
+    uint8_t  _pad[3];
+    float    adj[16];                /* parameters as in pfx_layer_info.adj */
+} pfx_project_layer;
+
+/* load_pfe_from_bytes (ref: io.rs:477-499; V3 :813, V2 :957, V1 :1110, V0 :1233): NULL + message in err on malformed input,
+ * zero / oversized dimensions (validate_open_dimensions, :505), more than 256 layers, wrong chunk sizes, no layers */
+pfx_project* pfx_project_load(const uint8_t* bytes, size_t n_bytes, char* err, size_t err_cap);
+pfx_project* pfx_project_load_file(const char* path, char* err, size_t err_cap);
+/* CanvasState::new-like empty document (no layers yet) */
+pfx_project* pfx_project_new(uint32_t w, uint32_t h);
+void     pfx_project_free(pfx_project* p);
+uint32_t pfx_project_width(const pfx_project* p);
+uint32_t pfx_project_height(const pfx_project* p);
+uint32_t pfx_project_layer_count(const pfx_project* p);
+uint32_t pfx_project_active_layer(const pfx_project* p);
+int      pfx_project_version(const pfx_project* p);      /* 0..3: the version it was loaded from (new documents: 1) */
+int      pfx_project_layer_get(const pfx_project* p, uint32_t index, pfx_project_layer* out);
+/* Layer::pixels.to_rgba_image(): the layer flattened to w*h*4 on the host (missing chunks = zeros) */
+int      pfx_project_layer_pixels(const pfx_project* p, uint32_t index, uint8_t* dst);
+/* append a layer; rgba (w*h*4) is tiled with from_rgba_image's rule (all-transparent chunks dropped); rgba NULL = empty layer.
+ * kind != PFX_LAYER_RASTER appends an adjustment layer with parameters adj[] (document becomes V3 on save). */
+int      pfx_project_add_layer(pfx_project* p, const char* name, const uint8_t* rgba, float opacity, uint8_t blend_mode, uint8_t visible,
+                               uint8_t kind, const float* adj);
+int      pfx_project_set_active_layer(pfx_project* p, uint32_t index);
+int      pfx_project_set_layer_folder(pfx_project* p, uint32_t index, int64_t folder_id /* -1 = none */);
+int      pfx_project_add_folder(pfx_project* p, uint64_t id, const char* name, uint8_t visible);
+/* replace a layer's pixels (and the document size when new_w/new_h differ is NOT changed: use pfx_project_resize) */
+int      pfx_project_set_layer_pixels(pfx_project* p, uint32_t index, const uint8_t* rgba);
+/* build_pfe + bincode::serialize (ref: io.rs:254-282): V3 if any folder / adjustment layer / experimental payload, V2 if any
+ * text layer, else V1; chunks are written in row-major (cy, cx) order.  *bytes_out is malloc'ed: release with pfx_bytes_free. */
+int      pfx_project_save(const pfx_project* p, uint8_t** bytes_out, size_t* n_out);
+int      pfx_project_save_file(const pfx_project* p, const char* path);
+void     pfx_bytes_free(uint8_t* bytes);
+/* CanvasState::composite() of the document (ref: canvas_state.rs:482-698) on the device: only the stored chunks cross PCIe, a
+ * kernel scatters them into flat layers (TiledImage import), then the compositor runs.  dst = w*h*4 */
+int      pfx_project_composite(pfx_ctx* ctx, const pfx_project* p, uint8_t* dst);
+int      pfx_project_composite_dev(pfx_ctx* ctx, const pfx_project* p, void* dst_dev);
+/* run_one's script step (ref: cli.rs:238-270): the script runs on the active layer, its canvas ops are replayed on every other
+ * layer (apply_canvas_ops, scripting.rs:1640-1723) and the document size follows */
+int      pfx_project_run_script(pfx_ctx* ctx, pfx_project* p, const char* source, pfx_script_result* result);
+
+/* TiledImage <-> flat image on the device.  packed = n stored chunks of 64*64*4 bytes (edge chunks zero-padded), slot[c] for
+ * chunk c = cy * ceil(w/64) + cx is the chunk's index in `packed` or 0xffffffff when the TiledImage has no such chunk.
+ * import = to_rgba_image (ref: tiled_image.rs:271-293), export = from_rgba_image given the populated set (:50-104). */
+#define PFX_NO_CHUNK 0xffffffffu
+int pfx_tiled_import_dev(pfx_ctx* ctx, const void* packed_dev, const uint32_t* slot_host, uint32_t w, uint32_t h, void* flat_dev);
+int pfx_tiled_export_dev(pfx_ctx* ctx, const void* flat_dev, uint32_t w, uint32_t h, const uint32_t* slot_host, void* packed_dev);
+
 #ifdef __cplusplus
 }
 #endif

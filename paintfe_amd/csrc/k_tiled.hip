@@ -61,6 +61,52 @@ __global__ __launch_bounds__(256) void chunk_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// TiledImage <-> flat image.  One workgroup per 64x64 chunk of the canvas; slot[c] = index of the chunk in the packed array
+// (64*64 px each, edge chunks zero-padded) or 0xffffffff = the TiledImage has no such chunk.
+//   IMPORT: to_rgba_image (tiled_image.rs:271-293)  flat <- chunk pixels, zeros where no chunk exists
+//   export: from_rgba_image (:50-104)               chunk <- flat pixels, zero-padded past the canvas edge
+template <bool IMPORT>
+__global__ __launch_bounds__(256) void chunk_copy_kernel(uint32_t* __restrict__ flat, uint32_t* __restrict__ packed,
+                                                         const uint32_t* __restrict__ slot, uint32_t w, uint32_t h)
+{
+    const uint32_t cxn = (w + 63u) / 64u;
+    const uint32_t bx = (blockIdx.x % cxn) * 64u, by = (blockIdx.x / cxn) * 64u;
+    const uint32_t sl = slot[blockIdx.x];
+    if (!IMPORT && sl == 0xffffffffu) return;
+    const uint32_t cg = threadIdx.x & 15u, r0 = threadIdx.x >> 4;
+    const uint32_t x = bx + cg * 4u;
+    const bool vec = (w & 3u) == 0u;
+    uint32_t* chunk = packed + (size_t)sl * 4096u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ly = r0 + 16u * k, y = by + ly;
+        uint4* cp = reinterpret_cast<uint4*>(chunk + ly * 64u + cg * 4u);
+        if constexpr (IMPORT) {
+            if (!(y < h && x < w)) continue;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (sl != 0xffffffffu) v = *cp;
+            const size_t off = (size_t)y * w + x;
+            if (vec) *reinterpret_cast<uint4*>(flat + off) = v;
+            else {
+                const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) if (x + p < w) flat[off + p] = e[p];
+            }
+        } else {
+            uint32_t e[4] = {0u, 0u, 0u, 0u};
+            if (y < h && x < w) {
+                const size_t off = (size_t)y * w + x;
+                if (vec) { const uint4 v = *reinterpret_cast<const uint4*>(flat + off); e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; }
+                else {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) if (x + p < w) e[p] = flat[off + p];
+                }
+            }
+            *cp = make_uint4(e[0], e[1], e[2], e[3]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void select_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ fx,
                                                      const uint8_t* __restrict__ mask, uint32_t* __restrict__ dst, size_t n)
 {
@@ -119,6 +165,22 @@ extern "C" hipError_t pfxk_tiled_roundtrip(hipStream_t s, const uint8_t* d_src, 
     if (w == 0 || h == 0) return hipSuccess;
     const uint32_t nchunks = ((w + 63u) / 64u) * ((h + 63u) / 64u);
     chunk_kernel<true><<<nchunks, 256, 0, s>>>(d_src, d_dst, nullptr, w, h);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_chunks_import(hipStream_t s, const uint8_t* d_packed, const uint32_t* d_slot, uint32_t w, uint32_t h, uint8_t* d_flat)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    const uint32_t nchunks = ((w + 63u) / 64u) * ((h + 63u) / 64u);
+    chunk_copy_kernel<true><<<nchunks, 256, 0, s>>>((uint32_t*)d_flat, (uint32_t*)const_cast<uint8_t*>(d_packed), d_slot, w, h);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_chunks_export(hipStream_t s, const uint8_t* d_flat, const uint32_t* d_slot, uint32_t w, uint32_t h, uint8_t* d_packed)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    const uint32_t nchunks = ((w + 63u) / 64u) * ((h + 63u) / 64u);
+    chunk_copy_kernel<false><<<nchunks, 256, 0, s>>>((uint32_t*)const_cast<uint8_t*>(d_flat), (uint32_t*)d_packed, d_slot, w, h);
     return hipGetLastError();
 }
 

@@ -90,6 +90,9 @@ int pfx_int_blur_with_selection_dev(pfx_ctx* ctx, const void* d_src, void* d_dst
 int pfx_int_script_run_dev(pfx_ctx* ctx, const char* source, uint32_t* w, uint32_t* h, const uint8_t* mask, pfx_script_result* result,
                            std::vector<std::string>* console, std::vector<pfx_canvas_op>* ops);
 
+// run_one's script step on a document (pfx_project.cpp): pfx_project_run_script plus the console lines for --verbose
+int pfx_int_project_run_script(pfx_ctx* ctx, pfx_project* p, const char* source, pfx_script_result* result, std::vector<std::string>* console);
+
 // host-side restatements that the reference also runs on the host (pfx_host_math.cpp)
 int  pfx_host_gaussian_kernel(float sigma, std::vector<float>& out);  // ref: src/ops/filters.rs:214-234
 float pfx_host_bc_factor(float contrast);                             // ref: src/ops/adjustments.rs:273

@@ -70,6 +70,9 @@ hipError_t pfxk_rhai_adjust(hipStream_t s, uint8_t* d_px, const uint8_t* d_lut, 
 // ---- k_tiled.hip ----
 hipError_t pfxk_chunk_populated(hipStream_t s, const uint8_t* d_src, uint32_t w, uint32_t h, uint8_t* d_populated);
 hipError_t pfxk_tiled_roundtrip(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, uint32_t w, uint32_t h);
+// TiledImage <-> flat: packed 64x64 chunks + a slot table per canvas chunk (0xffffffff = no chunk); ref: tiled_image.rs:50-104,271-293
+hipError_t pfxk_chunks_import(hipStream_t s, const uint8_t* d_packed, const uint32_t* d_slot, uint32_t w, uint32_t h, uint8_t* d_flat);
+hipError_t pfxk_chunks_export(hipStream_t s, const uint8_t* d_flat, const uint32_t* d_slot, uint32_t w, uint32_t h, uint8_t* d_packed);
 // dst = mask ? blurred : src   (blur_with_selection's copy-back, ref: src/ops/filters.rs:186-200)
 hipError_t pfxk_select_by_mask(hipStream_t s, const uint8_t* d_src, const uint8_t* d_fx, const uint8_t* d_mask,
                                uint8_t* d_dst, uint32_t w, uint32_t h);

@@ -149,6 +149,11 @@ std::string canonical_format(const std::string& f) // parse_format, src/cli.rs:3
     return "png";
 }
 
+struct doc_guard { // owns the document of one run_one iteration
+    pfx_project* p = nullptr;
+    ~doc_guard() { pfx_project_free(p); }
+};
+
 int mkdir_p(const std::string& dir)
 {
     std::string acc;
@@ -165,7 +170,7 @@ int mkdir_p(const std::string& dir)
 
 extern "C" {
 
-// The `pfx` batch tool: same flags, loop and exit codes as src/cli.rs.  PNG in / PNG out in this build.
+// The `pfx` batch tool: same flags, loop and exit codes as src/cli.rs.  PNG and PFE in / out in this build.
 int pfx_cli_main(int argc, char** argv)
 {
     std::vector<std::string> inputs_raw;
@@ -175,7 +180,7 @@ int pfx_cli_main(int argc, char** argv)
     auto usage = [](int rc) {
         std::printf("pfx — headless batch image processor (HIP back-end of PaintFE's CLI)\n"
                     "  -i, --input <FILE>...   input file(s), glob patterns accepted\n  -s, --script <SCRIPT.rhai>\n  -o, --output <FILE>\n"
-                    "      --output-dir <DIR>\n  -f, --format <FORMAT>   png (other formats are not built in)\n  -q, --quality <1-100>\n"
+                    "      --output-dir <DIR>\n  -f, --format <FORMAT>   png, pfe (other formats are not built in)\n  -q, --quality <1-100>\n"
                     "      --webp-lossy  --tiff-compression <MODE>  --flatten  -v, --verbose  --device <N>\n");
         return rc;
     };
@@ -249,32 +254,47 @@ int pfx_cli_main(int argc, char** argv)
 
         std::string error;
         do { // run_one (cli.rs:222-308)
-            std::vector<uint8_t> file, px;
-            uint32_t w = 0, h = 0;
-            std::string why;
-            if (ext_of(in) != "png") { error = "load failed: only PNG input is built into this back-end"; break; }
-            if (!read_file(in, file) || !png_decode(file, px, w, h, why)) { error = "load failed: " + (why.empty() ? std::string("cannot read file") : why); break; }
-            const size_t bytes = (size_t)w * h * 4;
-            if (pfx_use(ctx) != PFX_OK || pfx_reserve(ctx, ctx->st_in, bytes) != PFX_OK || pfx_reserve(ctx, ctx->st_aux, bytes) != PFX_OK ||
-                pfx_h2d(ctx, ctx->st_aux.p, px.data(), bytes) != PFX_OK) { error = std::string("device error: ") + pfx_last_error(ctx); break; }
-            // load_image_sync stores the image as a TiledImage (all-transparent chunks dropped), the script sees
-            // extract_region_rgba of it, and the result goes back through from_rgba_image (cli.rs:247-260)
-            if (pfx_tiled_roundtrip_dev(ctx, ctx->st_aux.p, ctx->st_in.p, w, h) != PFX_OK) { error = std::string("device error: ") + pfx_last_error(ctx); break; }
+            // Step 1, load_image_sync (io.rs:693-760): a .pfe project keeps its layers, every other format becomes a one-layer
+            // document named after the file; layers are TiledImages (all-transparent chunks dropped)
+            doc_guard doc;
+            const std::string in_ext = ext_of(in);
+            if (in_ext == "pfe") {
+                char why[512] = {0};
+                doc.p = pfx_project_load_file(in.c_str(), why, sizeof why);
+                if (!doc.p) { error = std::string("load failed: ") + why; break; }
+            } else if (in_ext == "png") {
+                std::vector<uint8_t> file, px;
+                uint32_t w = 0, h = 0;
+                std::string why;
+                if (!read_file(in, file) || !png_decode(file, px, w, h, why)) { error = "load failed: " + (why.empty() ? std::string("cannot read file") : why); break; }
+                doc.p = pfx_project_new(w, h);
+                if (!doc.p) { error = "load failed: Image size " + std::to_string(w) + "x" + std::to_string(h) + " is not accepted"; break; }
+                const std::string stem = stem_of(in);
+                if (pfx_project_add_layer(doc.p, stem.empty() ? "Background" : stem.c_str(), px.data(), 1.0f, 0, 1, PFX_LAYER_RASTER, nullptr) != PFX_OK) { error = "load failed: out of memory"; break; }
+            } else { error = "load failed: only PNG and PFE input are built into this back-end"; break; }
+
+            // Step 2, the script runs on the active layer; its canvas-wide ops are replayed on the other layers (cli.rs:238-270)
             if (have_script) {
                 pfx_script_result res;
                 std::vector<std::string> console;
-                // the script may change the canvas size (rotate_canvas_90*, resize_canvas): w, h are updated (cli.rs:262-275)
-                if (pfx_int_script_run_dev(ctx, script_src.c_str(), &w, &h, nullptr, &res, &console, nullptr) != PFX_OK) { error = std::string("script error: ") + res.error; break; }
+                const int st = pfx_int_project_run_script(ctx, doc.p, script_src.c_str(), &res, &console);
+                if (st != PFX_OK) { error = std::string("script error: ") + (res.error[0] ? res.error : pfx_last_error(ctx)); break; }
                 if (verbose)
                     for (const std::string& line : console) std::printf("  [script] %s\n", line.c_str());
-                px.resize((size_t)w * h * 4);
-                if (pfx_reserve(ctx, ctx->st_aux, px.size()) != PFX_OK) { error = std::string("device error: ") + pfx_last_error(ctx); break; }
-                if (pfx_tiled_roundtrip_dev(ctx, ctx->st_in.p, ctx->st_aux.p, w, h) != PFX_OK) { error = std::string("device error: ") + pfx_last_error(ctx); break; }
-                if (pfx_d2h(ctx, px.data(), ctx->st_aux.p, px.size()) != PFX_OK || pfx_sync(ctx) != PFX_OK) { error = std::string("device error: ") + pfx_last_error(ctx); break; }
-            } else {
-                if (pfx_d2h(ctx, px.data(), ctx->st_in.p, bytes) != PFX_OK || pfx_sync(ctx) != PFX_OK) { error = std::string("device error: ") + pfx_last_error(ctx); break; }
             }
-            if (fmt != "png") { error = "save failed: format '" + fmt + "' is not built into this back-end (PNG only)"; break; }
+
+            // Step 3, save (cli.rs:272-306): PFE keeps the layers; raster formats get the composite of a multi-layer document
+            // (--flatten defaults to true) or the active layer of a single-layer one
+            if (fmt == "pfe") {
+                if (pfx_project_save_file(doc.p, out.c_str()) != PFX_OK) { error = "PFE save failed: cannot write '" + out + "'"; break; }
+                break;
+            }
+            if (fmt != "png") { error = "save failed: format '" + fmt + "' is not built into this back-end (PNG and PFE only)"; break; }
+            const uint32_t w = pfx_project_width(doc.p), h = pfx_project_height(doc.p);
+            std::vector<uint8_t> px((size_t)w * h * 4);
+            if (pfx_project_layer_count(doc.p) > 1) {
+                if (pfx_project_composite(ctx, doc.p, px.data()) != PFX_OK) { error = std::string("device error: ") + pfx_last_error(ctx); break; }
+            } else if (pfx_project_layer_pixels(doc.p, pfx_project_active_layer(doc.p), px.data()) != PFX_OK) { error = "internal error: active layer"; break; }
             if (!png_encode(out, px.data(), w, h)) { error = "save failed: cannot write '" + out + "'"; break; }
         } while (false);
 

@@ -1,0 +1,257 @@
+"""PFE project files on the host (no GPU): paintfe_amd/csrc/pfx_project.cpp against the independent layout restatement in
+tests/pfe_format.py, plus the reference's own round-trip tests restated (tests/io_roundtrip.rs:124-330,
+tests/experimental_features.rs:95-160).  Loading / saving never touches the device."""
+import struct
+
+import numpy as np
+import pytest
+
+from . import inputs as I
+from . import pfe_format as F
+from paintfe_amd.project import PfeError, Project
+
+
+def sparse_image(w, h, seed):
+    img = I.random_rgba(w, h, seed)
+    rng = np.random.default_rng(seed + 5)
+    for cy in range(0, h, 64):
+        for cx in range(0, w, 64):
+            if rng.random() < 0.4:
+                img[cy:cy + 64, cx:cx + 64, 3] = 0   # transparent but coloured: the chunk must be dropped, colour and all
+    return img
+
+
+def dropped(img):
+    return F.image_from_tiles(F.tiles_from_image(img), img.shape[1], img.shape[0])
+
+
+# ---------------------------------------------------------------- the reference's round trips
+
+def test_roundtrip_pfe_single_layer():          # io_roundtrip.rs:124-146
+    img = I.create_test_gradient(64, 64)
+    p = Project.new(64, 64)
+    p.add_layer("Background", img)
+    q = Project.load_bytes(p.save_bytes())
+    assert len(q) == 1 and (q.width, q.height) == (64, 64)
+    assert np.array_equal(q.layer_pixels(0), img)
+
+
+def test_roundtrip_pfe_multi_layer():           # io_roundtrip.rs:148-200
+    w = h = 64
+    p = Project.new(w, h)
+    p.add_layer("Background", I.create_solid(w, h, (255, 255, 255, 255)))
+    red = I.create_solid(w, h, (255, 0, 0, 128))
+    p.add_layer("Red", red, opacity=0.75)
+    grad = I.create_test_gradient(w, h)
+    p.add_layer("Gradient", grad)
+    q = Project.load_bytes(p.save_bytes())
+    assert len(q) == 3
+    assert q.layer(1)["opacity"] == 0.75 and q.layer(1)["name"] == "Red" and q.layer(2)["name"] == "Gradient"
+    assert np.array_equal(q.layer_pixels(1), red) and np.array_equal(q.layer_pixels(2), grad)
+
+
+def test_roundtrip_preserves_blend_visibility_active():   # io_roundtrip.rs:202-270
+    p = Project.new(96, 70)
+    for k in range(5):
+        p.add_layer(f"L{k}", I.random_rgba(96, 70, k), opacity=0.2 * k, blend_mode=k * 6, visible=(k % 2 == 0))
+    p.set_active_layer(3)
+    q = Project.load_bytes(p.save_bytes())
+    assert q.active_layer == 3
+    for k in range(5):
+        L = q.layer(k)
+        assert L["blend_mode"] == k * 6 and L["visible"] == (k % 2 == 0) and L["opacity"] == np.float32(0.2 * k)
+
+
+def test_adjustment_layer_roundtrip_is_v3():    # experimental_features.rs:95-115
+    p = Project.new(64, 64)
+    p.add_layer("Background", I.create_test_gradient(64, 64))
+    p.add_layer("Exposure", None, kind="exposure", adj=[1.5], opacity=0.5)
+    p.add_layer("Mixer", None, kind="channel_mixer", adj=[float(i) / 8 for i in range(16)])
+    raw = p.save_bytes()
+    assert raw[8:12] == b"PFE3"
+    q = Project.load_bytes(raw)
+    assert q.layer(1)["layer_type"] == 2 and q.layer(1)["kind"] == 1 and q.layer(1)["adj"][0] == 1.5
+    assert q.layer(2)["kind"] == 4 and q.layer(2)["adj"] == [float(i) / 8 for i in range(16)]
+    d = F.decode(raw)
+    assert d["layers"][1]["content_data"] == F.adjustment_bytes(0, [1.5])
+    assert d["layers"][2]["content_data"] == F.adjustment_bytes(3, [float(i) / 8 for i in range(16)])
+    assert d["layers"][1]["chunks"] == []
+
+
+# ---------------------------------------------------------------- byte layout against the restatement
+
+@pytest.mark.parametrize("size", [(64, 64), (100, 70), (1, 1), (129, 65), (300, 200)])
+def test_save_bytes_equal_the_restatement_v1(size):
+    w, h = size
+    imgs = [sparse_image(w, h, 10 + k) for k in range(3)]
+    p = Project.new(w, h)
+    for k, img in enumerate(imgs):
+        p.add_layer(f"layer {k} é中", img, opacity=1.0 - 0.25 * k, blend_mode=k + 1, visible=k != 1)
+    p.set_active_layer(2)
+    want = F.encode({"version": 1, "width": w, "height": h, "active_layer_index": 2,
+                     "layers": [F.raster_layer(f"layer {k} é中", img, opacity=1.0 - 0.25 * k, blend_mode=k + 1, visible=k != 1)
+                                for k, img in enumerate(imgs)]})
+    assert p.save_bytes() == want
+    q = Project.load_bytes(want)
+    for k, img in enumerate(imgs):
+        assert np.array_equal(q.layer_pixels(k), dropped(img)), "transparent chunks are dropped with their colour"
+        assert q.layer(k)["n_chunks"] == len(F.tiles_from_image(img))
+
+
+def test_save_bytes_equal_the_restatement_v3_with_folder():
+    w, h = 130, 66
+    img = sparse_image(w, h, 3)
+    p = Project.new(w, h)
+    p.add_layer("base", img)
+    p.add_layer("bc", None, kind="brightness_contrast", adj=[10.0, -20.0], opacity=0.8, blend_mode=0)
+    p.add_folder(7, "group", visible=False)
+    p.set_layer_folder(0, 7)
+    want = F.encode({"version": 3, "width": w, "height": h, "active_layer_index": 0,
+                     "folders": [{"id": 7, "name": "group", "visible": False, "collapsed": False}], "next_layer_folder_id": 8,
+                     "layers": [F.raster_layer("base", img, folder_id=7),
+                                {"name": "bc", "visible": True, "opacity": 0.8, "blend_mode": 0, "layer_type": 2, "chunks": [],
+                                 "content_data": F.adjustment_bytes(1, [10.0, -20.0])}]})
+    assert p.save_bytes() == want
+    q = Project.load_bytes(want)
+    assert q.layer(0)["folder_id"] == 7 and q.layer(0)["visible"] and not q.layer(0)["effectively_visible"]
+    assert q.layer(1)["effectively_visible"]
+
+
+def full_v3_document():
+    w, h = 70, 130
+    a, b = sparse_image(w, h, 21), sparse_image(w, h, 22)
+    return {"version": 3, "width": w, "height": h, "active_layer_index": 1,
+            "folders": [{"id": 1, "name": "A", "visible": True, "collapsed": True, "insert_above_layer": 4, "color_index": 9},
+                        {"id": 5, "name": "B", "visible": False, "collapsed": False, "insert_above_layer": None, "color_index": None}],
+            "next_layer_folder_id": 6,
+            "layers": [
+                F.raster_layer("photo", a, folder_id=1, pixel_format=1,
+                               hdr_metadata={"enabled": True, "max_luminance_nits": 1000.0, "reference_white_nits": None, "transfer_function": "pq"},
+                               source_metadata={"source_format": "png", "source_name": "a.png", "color_profile_name": None,
+                                                "png_text_chunks": [("Author", "x"), ("k", "")], "raw_png_chunks": [b"\x00\x01\x02", b""]},
+                               webp_frame_compression=0, deep_pixels=(1, [0, 257, 65535, 1234]), content_data=None),
+                {"name": "text", "visible": True, "folder_id": 5, "opacity": 0.5, "blend_mode": 3, "layer_type": 1, "chunks": F.tiles_from_image(b),
+                 "content_data": b"opaque text payload", "pixel_format": 0, "deep_pixels": (3, [0.5, 1.0])},
+                {"name": "inv", "visible": False, "folder_id": None, "opacity": 1.0, "blend_mode": 0, "layer_type": 2, "chunks": [],
+                 "content_data": F.adjustment_bytes(2), "deep_pixels": (0, [1, 2, 3])},
+                {"name": "f16", "visible": True, "folder_id": None, "opacity": 1.0, "blend_mode": 24, "layer_type": 0, "chunks": [],
+                 "content_data": None, "deep_pixels": (2, [15360, 0])},
+            ]}, (a, b)
+
+
+def test_v3_every_field_survives_load_and_save():
+    doc, (a, b) = full_v3_document()
+    raw = F.encode(doc)
+    p = Project.load_bytes(raw)
+    assert p.version == 3 and len(p) == 4 and p.active_layer == 1
+    assert np.array_equal(p.layer_pixels(0), dropped(a)) and np.array_equal(p.layer_pixels(1), dropped(b))
+    assert p.layer(1)["layer_type"] == 1 and p.layer(1)["kind"] == 0
+    assert not p.layer(1)["effectively_visible"], "folder 5 is hidden"
+    assert p.layer(2)["kind"] == 3 and not p.layer(2)["visible"]
+    assert p.save_bytes() == raw, "re-saving a V3 document is lossless, byte for byte"
+
+
+def test_v2_text_layer_payload_is_kept():
+    w, h = 64, 128
+    img = sparse_image(w, h, 30)
+    doc = {"version": 2, "width": w, "height": h, "active_layer_index": 0,
+           "layers": [F.raster_layer("bg", img, text_data=None),
+                      {"name": "title", "visible": True, "opacity": 1.0, "blend_mode": 0, "layer_type": 1, "chunks": F.tiles_from_image(img),
+                       "text_data": b"\x01\x02 serialized TextLayerData"}]}
+    raw = F.encode(doc)
+    p = Project.load_bytes(raw)
+    assert p.version == 2 and p.layer(1)["layer_type"] == 1
+    assert p.save_bytes() == raw
+
+
+def test_v0_flat_layers_are_tiled_on_load():
+    w, h = 100, 70
+    img = sparse_image(w, h, 40)
+    raw = F.encode({"version": 0, "width": w, "height": h, "active_layer_index": 0,
+                    "layers": [{"name": "legacy", "visible": True, "opacity": 0.5, "blend_mode": 2, "pixels": img.tobytes()}]})
+    p = Project.load_bytes(raw)
+    assert p.version == 0 and np.array_equal(p.layer_pixels(0), dropped(img))
+    d = F.decode(p.save_bytes())
+    assert d["version"] == 1 and d["layers"][0]["chunks"] == F.tiles_from_image(img)
+
+
+def test_active_index_is_clamped_and_trailing_bytes_ignored():
+    img = I.create_test_gradient(64, 64)
+    raw = F.encode({"version": 1, "width": 64, "height": 64, "active_layer_index": 99, "layers": [F.raster_layer("a", img), F.raster_layer("b", img)]})
+    p = Project.load_bytes(raw + b"trailing garbage")
+    assert p.active_layer == 1
+
+
+def test_chunk_index_aliasing_and_duplicates():
+    """set_chunk goes through flat_index = cy * chunks_per_row + cx with no range check on cx (tiled_image.rs:660-662,876-881):
+    (cx = cpr, cy) lands on (0, cy + 1); indices past the table are dropped; a later duplicate wins"""
+    w, h = 128, 128  # 2 x 2 chunks
+    c = [bytes([k]) * F.CHUNK_BYTES for k in range(1, 6)]
+    chunks = [(0, 0, c[0]), (2, 0, c[1]), (5, 7, c[2]), (1, 1, c[3]), (1, 1, c[4])]
+    raw = F.encode({"version": 1, "width": w, "height": h, "active_layer_index": 0,
+                    "layers": [{"name": "x", "visible": True, "opacity": 1.0, "blend_mode": 0, "chunks": chunks}]})
+    p = Project.load_bytes(raw)
+    assert np.array_equal(p.layer_pixels(0), F.image_from_tiles(chunks, w, h))
+    px = p.layer_pixels(0)
+    assert px[0, 0, 0] == 1 and px[64, 0, 0] == 2 and px[64, 64, 0] == 5 and px[0, 64, 0] == 0
+    assert p.layer(0)["n_chunks"] == 3
+
+
+# ---------------------------------------------------------------- errors (io.rs:477-499, 505-516, 819-838, 901-903)
+
+def v1_raw(**over):
+    img = I.create_test_gradient(64, 64)
+    doc = {"version": 1, "width": 64, "height": 64, "active_layer_index": 0, "layers": [F.raster_layer("a", img)]}
+    doc.update(over)
+    return F.encode(doc)
+
+
+@pytest.mark.parametrize("raw, needle", [
+    (b"short", "File too small"),
+    (struct.pack("<Q", 4) + b"PFX9" + b"\0" * 32, "Unknown magic 'PFX9'"),
+    (v1_raw(width=0), "Image dimensions cannot be zero"),
+    (v1_raw(height=25001), "exceeds maximum allowed 25000x25000"),
+    (v1_raw(layers=[]), "Project contains no layers"),
+    (v1_raw(layers=[{"name": "n", "visible": True, "opacity": 1.0, "blend_mode": 0, "chunks": []}] * 257), "exceeds the maximum of 256"),
+    (v1_raw(layers=[{"name": "bad", "visible": True, "opacity": 1.0, "blend_mode": 0, "chunks": [(0, 0, b"\0" * 100)]}]),
+     "Chunk (0,0) in layer 'bad' has 100 bytes, expected 16384"),
+    (v1_raw()[:-1000], "Serialization error"),
+])
+def test_load_errors(raw, needle):
+    with pytest.raises(PfeError) as e:
+        Project.load_bytes(raw)
+    assert needle in str(e.value), str(e.value)
+
+
+def test_invalid_bool_and_option_tags_are_rejected():
+    raw = bytearray(v1_raw())
+    off = 8 + 4 + 4 + 4 + 8 + 8 + 8 + 1      # magic, w, h, active, n_layers, name "a" -> the `visible` byte
+    assert raw[off] == 1
+    raw[off] = 2
+    with pytest.raises(PfeError):
+        Project.load_bytes(bytes(raw))
+    doc, _ = full_v3_document()
+    good = F.encode(doc)
+    assert Project.load_bytes(good) is not None
+    with pytest.raises(PfeError):
+        Project.load_bytes(good[:200])
+
+
+def test_v0_wrong_pixel_count():
+    raw = F.encode({"version": 0, "width": 10, "height": 10, "active_layer_index": 0,
+                    "layers": [{"name": "legacy", "visible": True, "opacity": 1.0, "blend_mode": 0, "pixels": b"\0" * 399}]})
+    with pytest.raises(PfeError) as e:
+        Project.load_bytes(raw)
+    assert "Layer 'legacy' has 399 bytes, expected 400 (10x10x4)" in str(e.value)
+
+
+def test_file_roundtrip(tmp_path):             # io_roundtrip.rs:314-330 (load through a path)
+    img = sparse_image(200, 90, 50)
+    p = Project.new(200, 90)
+    p.add_layer("one", img)
+    path = tmp_path / "doc.pfe"
+    p.save(str(path))
+    q = Project.load(str(path))
+    assert np.array_equal(q.layer_pixels(0), dropped(img))
+    with pytest.raises(PfeError):
+        Project.load(str(tmp_path / "missing.pfe"))
