@@ -77,24 +77,22 @@ __global__ __launch_bounds__(256) void box_v_kernel(const uint32_t* __restrict__
 // ---------------------------------------------------------------- median
 constexpr int MD_TX = 32, MD_TY = 8; // outputs per block: one per lane
 
-// count, per byte lane, of window elements >= candidate; even bytes in lo16/hi16 of `ce`, odd bytes in `co`
-PFX_DEV void count_ge(uint32_t px, uint32_t tce, uint32_t tco, uint32_t& ce, uint32_t& co)
-{
-    // (x + 256 - t) has bit 8 set  <=>  x >= t   (x, t in 0..255), two 16-bit lanes at a time
-    ce += (((px & 0x00ff00ffu) + tce) >> 8) & 0x00010001u;
-    co += ((((px >> 8) & 0x00ff00ffu) + tco) >> 8) & 0x00010001u;
-}
-
+// Radii 4..7: per-channel binary search on the value, MSB first (largest t with count(x >= t) >= need).  The tile is staged in
+// LDS already split into 16-bit lanes — R,B in one word, G,A in the other — so that one packed add tests two channels:
+// (x + 256 - t) has bit 8 set  <=>  x >= t  (x, t in 0..255).  The flags are accumulated where they stand (bit 8 of each
+// lane; a row's <= 49 flags sum to < 2^16, so lanes cannot carry into each other; rows are folded down once each) and two
+// elements share one v_add3.
 __global__ __launch_bounds__(MD_TX* MD_TY) void median_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                               const uint8_t* __restrict__ mask, int r, int w, int h)
 {
-    extern __shared__ uint32_t win_tile[]; // (MD_TY + 2r) x (MD_TX + 2r)
+    extern __shared__ uint2 win_tile[]; // (MD_TY + 2r) x (MD_TX + 2r), {R,B | G,A}
     const int tw = MD_TX + 2 * r, th = MD_TY + 2 * r;
     const int bx = blockIdx.x * MD_TX, by = blockIdx.y * MD_TY;
     for (int i = threadIdx.x; i < tw * th; i += MD_TX * MD_TY) {
         const int ty = i / tw, tx = i - ty * tw;
         const int sx = min(max(bx - r + tx, 0), w - 1), sy = min(max(by - r + ty, 0), h - 1); // noise.rs:389-392
-        win_tile[i] = src[(size_t)sy * w + sx];
+        const uint32_t px = src[(size_t)sy * w + sx];
+        win_tile[i] = make_uint2(px & 0x00ff00ffu, (px >> 8) & 0x00ff00ffu);
     }
     __syncthreads();
     const int lx = threadIdx.x % MD_TX, ly = threadIdx.x / MD_TX;
@@ -105,15 +103,25 @@ __global__ __launch_bounds__(MD_TX* MD_TY) void median_kernel(const uint32_t* __
     const int side = 2 * r + 1;
     const uint32_t n = (uint32_t)(side * side);
     const uint32_t need = n - n / 2; // elements >= the median (element len/2 of the ascending sort)
-    // per-channel binary search, MSB first: largest t with count(x >= t) >= need
     uint32_t te = 0, to = 0; // thresholds: even bytes (R,B) and odd bytes (G,A) in 16-bit lanes
     for (int bit = 7; bit >= 0; --bit) {
         const uint32_t cand_e = te | (0x00010001u << bit), cand_o = to | (0x00010001u << bit);
         const uint32_t tce = 0x01000100u - cand_e, tco = 0x01000100u - cand_o;
         uint32_t ce = 0, co = 0;
         for (int dy = 0; dy < side; ++dy) {
-            const uint32_t* rowp = win_tile + (ly + dy) * tw + lx;
-            for (int dx = 0; dx < side; ++dx) count_ge(rowp[dx], tce, tco, ce, co);
+            const uint2* rowp = win_tile + (ly + dy) * tw + lx;
+            uint32_t re = 0, ro = 0; // one row's flags, left at bit 8 of each lane (<= 49 of them)
+            int dx = 0;
+            for (; dx + 1 < side; dx += 2) {
+                const uint2 a = rowp[dx], b = rowp[dx + 1];
+                re += ((a.x + tce) & 0x01000100u) + ((b.x + tce) & 0x01000100u);
+                ro += ((a.y + tco) & 0x01000100u) + ((b.y + tco) & 0x01000100u);
+            }
+            const uint2 a = rowp[dx]; // side is odd
+            re += (a.x + tce) & 0x01000100u;
+            ro += (a.y + tco) & 0x01000100u;
+            ce += (re >> 8) & 0x00ff00ffu; // window totals up to 49^2 = 2401 per 16-bit lane
+            co += (ro >> 8) & 0x00ff00ffu;
         }
         const uint32_t b = 1u << bit;
         if ((ce & 0xffffu) >= need) te |= b;
@@ -273,7 +281,7 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         else median_net_kernel<3><<<g, MD_TX * MD_TY, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         return hipGetLastError();
     }
-    const size_t lds = (size_t)(MD_TX + 2 * radius) * (MD_TY + 2 * radius) * 4;
+    const size_t lds = (size_t)(MD_TX + 2 * radius) * (MD_TY + 2 * radius) * 8;
     hipError_t e = hipFuncSetAttribute((const void*)median_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e) return e;
     dim3 g((w + MD_TX - 1) / MD_TX, (h + MD_TY - 1) / MD_TY);
