@@ -135,7 +135,12 @@ PFX_DEV float q255(float v)
 // `opc` = opacity.clamp(0,1).
 // Branch-free on purpose: per-lane early-outs diverge on real data (a wave almost never agrees), so the early
 // returns of the reference become selects at the end; the discarded lanes may hold NaN/Inf (0/0), never stored.
-template <uint32_t M, bool F>
+// OB ("opaque base", only with F): the caller has established wave-wide that acc alpha == 255.  Then base_a = 1.0 and
+// out_a = fl(top_a + fl(1 - top_a)) is exactly 1.0 for every f32 top_a in [0, 1] (top_a >= 0.5: 1 - top_a is exact; below,
+// fl(1 - top_a) is off by at most 2^-25, and 1 +- 2^-25 rounds to 1.0, ties to even), base_c * 1.0 = base_c and n / 1.0 = n:
+// the division, the alpha products and the alpha re-quantisation drop out with identical bits.  Typical documents (an opaque
+// background under everything) run this path for every layer.  tests: test_flatten_opaque_base_path_bitexact.
+template <uint32_t M, bool F, bool OB = false>
 PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float opc)
 {
     const uint32_t ta8 = top >> 24;
@@ -148,10 +153,20 @@ PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float op
     if constexpr (M == M_OVERWRITE) {                                  // :1275 (`as u8` without clamp == with clamp)
         o0 = q255<CL>(top_r); o1 = q255<CL>(top_g); o2 = q255<CL>(top_b); o3 = q255<CL>(top_a);
     } else {
-        const float base_r = div255(acc[0]), base_g = div255(acc[1]), base_b = div255(acc[2]), base_a = div255(acc[3]);
+        constexpr bool UNIT = OB && F && M != M_XOR; // out_a == 1.0 exactly, see above
+        const float base_r = div255(acc[0]), base_g = div255(acc[1]), base_b = div255(acc[2]);
+        const float base_a = (OB && F) ? 1.0f : div255(acc[3]);
         const float ita = 1.0f - top_a;
         float den, nr, ng, nb;
-        if constexpr (M == M_XOR) {                                    // :1283
+        if constexpr (UNIT) {
+            const float r = blend_fn<M, F>(base_r, top_r);
+            const float g = blend_fn<M, F>(base_g, top_g);
+            const float b = blend_fn<M, F>(base_b, top_b);
+            den = 1.0f;
+            nr = r * top_a + base_r * ita;
+            ng = g * top_a + base_g * ita;
+            nb = b * top_a + base_b * ita;
+        } else if constexpr (M == M_XOR) {                                    // :1283
             const float iba = 1.0f - base_a;
             den = base_a * ita + top_a * iba;
             nr = base_r * base_a * ita + top_r * top_a * iba;
@@ -167,9 +182,10 @@ PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float op
             nb = b * top_a + base_b * base_a * ita;
         }
         float qr, qg, qb;
-        if constexpr (F) { const rdiv k = rdiv_prepare(den); qr = rdiv_apply(k, nr); qg = rdiv_apply(k, ng); qb = rdiv_apply(k, nb); }
+        if constexpr (UNIT) { qr = nr; qg = ng; qb = nb; }
+        else if constexpr (F) { const rdiv k = rdiv_prepare(den); qr = rdiv_apply(k, nr); qg = rdiv_apply(k, ng); qb = rdiv_apply(k, nb); }
         else { qr = nr / den; qg = ng / den; qb = nb / den; }
-        o0 = q255<CL>(qr); o1 = q255<CL>(qg); o2 = q255<CL>(qb); o3 = q255<CL>(den);
+        o0 = q255<CL>(qr); o1 = q255<CL>(qg); o2 = q255<CL>(qb); o3 = UNIT ? 255.0f : q255<CL>(den);
         // :1285 / :1408 `den == 0 -> (0,0,0,0)`.  With opacity > 0 (FAST precondition) a non-skipped pixel has
         // top_a > 0, hence out_a = top_a + base_a*(1-top_a) > 0: the check can only fire for Xor (both opaque).
         if constexpr (!F || M == M_XOR) {
@@ -186,18 +202,18 @@ PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float op
     acc[0] = skip ? acc[0] : o0; acc[1] = skip ? acc[1] : o1; acc[2] = skip ? acc[2] : o2; acc[3] = skip ? acc[3] : o3;
 }
 
-template <uint32_t M, bool F, int PX>
+template <uint32_t M, bool F, int PX, bool OB>
 PFX_DEV void blendN(float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw, float opc)
 {
 #pragma unroll
-    for (int p = 0; p < PX; ++p) blend_px<M, F>(acc[p], top[p], opacity_raw, opc);
+    for (int p = 0; p < PX; ++p) blend_px<M, F, OB>(acc[p], top[p], opacity_raw, opc);
 }
 
-template <bool F, int PX = 4>
+template <bool F, int PX = 4, bool OB = false>
 PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw, float opc)
 {
     switch (mode) { // wave-uniform: one scalar branch per layer
-#define PFX_CASE(M) case M: blendN<M, F, PX>(acc, top, opacity_raw, opc); break;
+#define PFX_CASE(M) case M: blendN<M, F, PX, OB>(acc, top, opacity_raw, opc); break;
         PFX_CASE(M_NORMAL) PFX_CASE(M_MULTIPLY) PFX_CASE(M_SCREEN) PFX_CASE(M_ADDITIVE) PFX_CASE(M_REFLECT)
         PFX_CASE(M_GLOW) PFX_CASE(M_COLOR_BURN) PFX_CASE(M_COLOR_DODGE) PFX_CASE(M_OVERLAY) PFX_CASE(M_DIFFERENCE)
         PFX_CASE(M_NEGATION) PFX_CASE(M_LIGHTEN) PFX_CASE(M_DARKEN) PFX_CASE(M_XOR) PFX_CASE(M_OVERWRITE)
@@ -205,8 +221,20 @@ PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[PX][4], const uint32_t 
         PFX_CASE(M_LINEAR_BURN) PFX_CASE(M_VIVID_LIGHT) PFX_CASE(M_LINEAR_LIGHT) PFX_CASE(M_PIN_LIGHT)
         PFX_CASE(M_HARD_MIX)
 #undef PFX_CASE
-    default: blendN<M_NORMAL, F, PX>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
+    default: blendN<M_NORMAL, F, PX, OB>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
     }
+}
+
+// the streaming kernels' per-layer entry: picks the opaque-base specialisation when the whole wave's accumulators are opaque
+template <int PX>
+PFX_DEV void blend_layer_fast(uint32_t mode, float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw)
+{
+    const float opc = rs_clamp(opacity_raw, 0.0f, 1.0f);
+    bool ob = true;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) ob = ob && (acc[p][3] == 255.0f);
+    if (__all(ob)) blend4_dispatch<true, PX, true>(mode, acc, top, opacity_raw, opc);
+    else blend4_dispatch<true, PX, false>(mode, acc, top, opacity_raw, opc);
 }
 
 // live layer mask: top.a = (a * (255 - conceal)) / 255, integer (canvas_state.rs:660-665)
@@ -320,8 +348,10 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
                 const uint32_t top[4] = {v.x, v.y, v.z, v.w};
                 // wave-level early-out: a wave whose 256 pixels are all transparent in this layer (sparse layers of real
                 // documents; the TiledImage analogue is a missing chunk, canvas_state.rs:600) skips the blend entirely
-                if (__any(((v.x | v.y | v.z | v.w) >> 24) != 0u))
-                    blend4_dispatch<F>(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
+                if (__any(((v.x | v.y | v.z | v.w) >> 24) != 0u)) {
+                    if constexpr (F) blend_layer_fast<4>(L.mode, acc, top, L.opacity);
+                    else blend4_dispatch<F>(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
+                }
                 L = Ln;
                 v = vn;
             }
@@ -412,7 +442,7 @@ __global__ __launch_bounds__(256, MINW) void flatten_fast_kernel(const pfxk_laye
             uint32_t any_a = 0;
 #pragma unroll
             for (int p = 0; p < PX; ++p) any_a |= top[p];
-            if (__any((any_a >> 24) != 0u)) blend4_dispatch<true, PX>(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
+            if (__any((any_a >> 24) != 0u)) blend_layer_fast<PX>(L.mode, acc, top, L.opacity);
             L = Ln;
             v = vn;
         }

@@ -10,6 +10,8 @@ Bars as everywhere: bit-exact for the compositor, HSL and the warps, +-1 LSB for
 bit-exact in exact mode."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- at collection time, i.e. before any test loads libpfx.so: PyTorch must bring up the HIP runtime
+#                              first (it ships its own copy; loaded second it reports no device), as bench.py does
 
 from . import inputs as I
 from . import oracle_lib as O

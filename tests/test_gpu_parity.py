@@ -99,6 +99,27 @@ def test_flatten_all_modes_32_layers(gpu):
     assert_same(gpu.composite(layers, w, h), O.flatten_stack(stack, modes, opac), 0, "32-layer stack")
 
 
+@pytest.mark.parametrize("mode", range(25))
+def test_flatten_opaque_base_path_bitexact(gpu, mode):
+    """the wave-uniform "accumulator is opaque" specialisation of the compositor (k_flatten.hip, blend_px<.., OB>): an opaque
+    background under a layer of every mode with the full alpha lattice and several opacities, then two more layers so that
+    whatever alpha the mode leaves behind (Xor / Overwrite lower it) is carried through the general path again"""
+    w, h = 512, 64                                   # 128 waves of 256 px, all with an opaque accumulator after layer 0
+    rng = np.random.default_rng(900 + mode)
+    bg = I.random_rgba(w, h, 901 + mode)
+    bg[..., 3] = 255
+    top = I.random_rgba(w, h, 902 + mode)
+    top[..., 3] = np.tile(np.arange(256, dtype=np.uint8), (h, w // 256))   # every alpha value in every row
+    top[:8, :, :3] = rng.integers(0, 2, (8, w, 3), dtype=np.uint8) * 255    # extreme colours: 0/255 hit every branch edge
+    over = I.random_rgba(w, h, 903 + mode)
+    for opacity in (1.0, 0.37, 1e-3, 0.999999):
+        stack = np.stack([bg, top, over, top[::-1].copy()])
+        modes = np.array([0, mode, (mode + 7) % 25, mode], np.uint8)
+        opac = np.array([1.0, opacity, 0.8, 1.0], np.float32)
+        layers = [dict(pixels=stack[k], mode=int(modes[k]), opacity=float(opac[k])) for k in range(4)]
+        assert_same(gpu.composite(layers, w, h), O.flatten_stack(stack, modes, opac), 0, f"mode {mode} opacity {opacity}")
+
+
 def test_composite_masks_hidden_and_adjustment_layers(gpu, oracle):
     w, h = 200, 150
     rng = np.random.default_rng(3)

@@ -97,6 +97,18 @@ def test_div255_two_op_form_is_exact():
     assert (x * c_hi != x / np.float32(255.0)).sum() > 100  # a plain multiply by 1/255 is NOT enough
 
 
+def test_opaque_base_out_alpha_is_exactly_one():
+    """k_flatten.hip blend_px<.., OB>: over an opaque base, out_a = fl(top_a + fl(1 - top_a)) == 1.0 for EVERY f32 top_a in [0, 1]
+    (all 1 065 353 217 of them), so the division by out_a, the base-alpha products and the alpha re-quantisation drop out."""
+    one = np.float32(1.0)
+    top = 0x3F800000  # bit pattern of 1.0f
+    step = 1 << 24
+    for lo in range(0, top + 1, step):
+        ta = np.arange(lo, min(lo + step, top + 1), dtype=np.uint32).view(np.float32)
+        den = ta + (one - ta)
+        assert den.dtype == np.float32 and (den == one).all(), hex(lo)
+
+
 def test_box_blur_reciprocal_division_is_exact():
     """k_stencil.hip:div_round — umulhi(n, floor(2^32/d)+1) == n // d for every n the box blur can produce"""
     for d in (3, 5, 7, 15, 97, 255, 1001, 4095):
