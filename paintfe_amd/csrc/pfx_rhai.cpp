@@ -26,7 +26,7 @@ constexpr uint64_t MAX_OPS = 50000000ull;          // scripting.rs:288
 constexpr int MAX_CALL_LEVELS = 64;                // scripting.rs:289
 constexpr size_t MAX_STRING = 10000, MAX_ARRAY = 10000; // scripting.rs:291-292
 
-struct Throw { Error e; };
+struct Throw { Error e; std::shared_ptr<Value> value; }; // value: what a script's `throw` statement raised
 [[noreturn]] void fail(const std::string& m, int line, int col, int status = ST_SCRIPT) { throw Throw{{m, line, col, status}}; }
 [[noreturn]] void fail(const std::string& m, const Node& n, int status = ST_SCRIPT) { fail(m, n.line, n.col, status); }
 
@@ -357,7 +357,10 @@ private:
         eat();
         return b;
     }
-    static bool block_like(const NodeP& e) { return e->k == NK::If || e->k == NK::While || e->k == NK::Loop || e->k == NK::For || e->k == NK::Block; }
+    static bool block_like(const NodeP& e)
+    {
+        return e->k == NK::If || e->k == NK::While || e->k == NK::Loop || e->k == NK::For || e->k == NK::Block || e->k == NK::Switch || e->k == NK::Try;
+    }
     void end_stmt(const NodeP& st, bool needs_semi)
     {
         if (is_p(";")) { eat(); st->flag = true; return; }
@@ -440,7 +443,44 @@ private:
             st->flag = true;
             return st;
         }
-        for (const char* kw : {"switch", "do", "throw", "try", "import", "export"})
+        if (is_kw("do")) { // do { ... } while cond;  /  do { ... } until cond;
+            eat();
+            auto n = mk(NK::DoWhile, t0);
+            n->kids.push_back(block());
+            if (!is_kw("while") && !is_kw("until")) fail("Expecting 'while' or 'until' after the body of this do loop", cur_.line, cur_.col);
+            n->flag = is_kw("until");
+            eat();
+            n->kids.push_back(expr(0));
+            auto st = wrap_stmt(n, t0);
+            end_stmt(st, true);
+            st->flag = true;
+            return st;
+        }
+        if (is_kw("throw")) {
+            eat();
+            auto n = mk(NK::Throw, t0);
+            if (!is_p(";") && !is_p("}") && cur_.t != TT::End) n->kids.push_back(expr(0));
+            auto st = wrap_stmt(n, t0);
+            end_stmt(st, true);
+            st->flag = true;
+            return st;
+        }
+        if (is_kw("try")) {
+            eat();
+            auto n = mk(NK::Try, t0);
+            n->kids.push_back(block());
+            if (!is_kw("catch")) fail("Expecting 'catch' after the body of this try statement", cur_.line, cur_.col);
+            eat();
+            if (is_p("(")) {
+                eat();
+                n->text = ident("a variable name for the caught error");
+                expect_p(")", "to close the catch variable");
+            }
+            n->kids.push_back(block());
+            if (is_p(";")) eat();
+            return wrap_stmt(n, t0);
+        }
+        for (const char* kw : {"import", "export"})
             if (is_kw(kw)) fail("Rhai statement '" + cur_.text + "' is outside the supported subset", cur_.line, cur_.col, ST_UNSUPPORTED);
         // expression or assignment
         NodeP e = expr(0);
@@ -591,6 +631,48 @@ private:
         }
         return n;
     }
+    // switch value { pattern | pattern if guard => expr-or-block, lo..hi => ..., _ => ... }
+    NodeP switch_expr()
+    {
+        auto n = mk(NK::Switch, cur_);
+        eat();
+        n->kids.push_back(expr(0));
+        expect_p("{", "to start the cases of this switch expression");
+        bool seen_default = false;
+        while (!is_p("}")) {
+            if (cur_.t == TT::End) fail("Expecting '}' to terminate this switch expression", cur_.line, cur_.col);
+            auto arm = mk(NK::Arm, cur_);
+            if (cur_.t == TT::Ident && cur_.text == "_") {
+                if (seen_default) fail("Duplicated default case in this switch expression", cur_.line, cur_.col);
+                seen_default = true;
+                arm->text = "_";
+                eat();
+            } else {
+                if (seen_default) fail("The default case must be the last case of this switch expression", cur_.line, cur_.col);
+                for (;;) {
+                    NodeP pat = expr(35); // above '|' (which separates alternatives here), so ranges and negative literals parse whole
+                    const Node* lit = pat.get();
+                    if (lit->k == NK::Unary && lit->text == "-" && !lit->kids.empty()) lit = lit->kids[0].get();
+                    const bool ok = lit->k == NK::IntLit || lit->k == NK::FloatLit || lit->k == NK::BoolLit || lit->k == NK::StrLit ||
+                                    (pat->k == NK::RangeLit && pat->kids.size() == 2);
+                    if (!ok) fail("A switch case must be a literal value or an integer range", pat->line, pat->col);
+                    arm->kids.push_back(pat);
+                    if (is_p("|")) { eat(); continue; }
+                    break;
+                }
+            }
+            arm->ival = (int64_t)arm->kids.size();
+            if (is_kw("if")) { eat(); arm->flag = true; arm->kids.push_back(expr(0)); }
+            expect_p("=>", "after the case of this switch expression");
+            const bool blk = is_p("{");
+            arm->kids.push_back(blk ? block() : expr(0));
+            n->kids.push_back(arm);
+            if (is_p(",")) eat();
+            else if (!is_p("}") && !blk) fail("Expecting ',' to separate the cases of this switch expression", cur_.line, cur_.col);
+        }
+        eat();
+        return n;
+    }
     NodeP primary()
     {
         const Tok t = cur_;
@@ -610,7 +692,8 @@ private:
         case TT::Ident: {
             if (t.text == "true" || t.text == "false") { eat(); auto n = mk(NK::BoolLit, t); n->ival = t.text == "true"; return n; }
             if (t.text == "if") return if_expr();
-            for (const char* kw : {"switch", "while", "loop", "for", "do", "fn", "let", "const", "return", "break", "continue", "throw", "try", "this"})
+            if (t.text == "switch") return switch_expr();
+            for (const char* kw : {"while", "loop", "for", "do", "fn", "let", "const", "return", "break", "continue", "throw", "try", "this"})
                 if (t.text == kw) fail("'" + t.text + "' is not allowed in this expression position (outside the supported subset)", t.line, t.col, ST_UNSUPPORTED);
             eat();
             if (is_p("(")) {
@@ -1225,6 +1308,56 @@ struct Eval {
         case NK::Return: throw Ret{n.kids.empty() ? Value() : eval(*n.kids[0])};
         case NK::FnDef: return Value();
         case NK::ExprStmt: return eval(*n.kids[0]);
+        case NK::DoWhile: {
+            for (;;) {
+                tick(n);
+                try { block(*n.kids[0]); } catch (Brk&) { break; } catch (Cont&) {}
+                if (truthy(eval(*n.kids[1]), *n.kids[1]) == n.flag) break; // `while`: stop when false; `until`: stop when true
+            }
+            return Value();
+        }
+        case NK::Throw: { // EvalAltResult::ErrorRuntime(value, pos): "Runtime error" / "Runtime error: <value>"
+            Value v = n.kids.empty() ? Value() : eval(*n.kids[0]).copy();
+            const std::string text = v.t == Value::Unit ? std::string() : v.to_string();
+            throw rhai::Throw{{text.empty() ? std::string("Runtime error") : "Runtime error: " + text, n.line, n.col, ST_SCRIPT}, std::make_shared<Value>(v)};
+        }
+        case NK::Try: {
+            try {
+                return block(*n.kids[0]);
+            } catch (rhai::Throw& t) {
+                // not catchable, as in Rhai: the sandbox limits and anything outside the supported subset
+                static const char* fatal[] = {"Too many operations", "Stack overflow", "Length of string too large", "Size of array too large"};
+                for (const char* f : fatal) if (t.e.msg == f) throw;
+                if (t.e.status == ST_UNSUPPORTED) throw;
+                ScopeGuard g(*this);
+                // the thrown value; for a runtime error Rhai binds an object map, here (no maps in the subset) its message
+                if (!n.text.empty()) scopes.back()[n.text] = {t.value ? *t.value : Value::from_str(t.e.msg), false};
+                return block(*n.kids[1], false);
+            }
+        }
+        case NK::Switch: {
+            const Value v = eval(*n.kids[0]);
+            for (size_t k = 1; k < n.kids.size(); ++k) {
+                const Node& arm = *n.kids[k];
+                bool hit = arm.text == "_";
+                for (int64_t pi = 0; pi < arm.ival && !hit; ++pi) {
+                    const Node& pat = *arm.kids[(size_t)pi];
+                    if (pat.k == NK::RangeLit) { // integer ranges match integers only
+                        const Value r = eval(pat);
+                        hit = v.t == Value::Int && r.t == Value::Range && v.i >= r.i && v.i < r.j;
+                    } else {
+                        const Value c = eval(pat);
+                        hit = c.t == v.t && values_equal(c, v); // cases are matched by type and value: 1 does not match 1.0
+                    }
+                }
+                if (!hit) continue;
+                if (arm.flag && !truthy(eval(*arm.kids[(size_t)arm.ival]), *arm.kids[(size_t)arm.ival])) continue;
+                const Node& body = *arm.kids.back();
+                return body.k == NK::Block ? block(body) : eval(body);
+            }
+            return Value();
+        }
+        case NK::Arm: return Value();
         }
         return Value();
     }

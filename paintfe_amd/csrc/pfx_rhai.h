@@ -3,7 +3,9 @@
 // The reference embeds the third-party crate rhai 1.25.1 (Cargo.lock; not vendored under the reference tree) and
 // registers its host API in src/ops/scripting.rs:284-1482.  This runtime restates the part of the published language
 // that effect scripts use — `let`/`const`, i64/f64/bool/string/array values with Rhai's strict typing and checked
-// integer arithmetic, `if`/`while`/`loop`/`for .. in`, `fn` definitions, closures, method-call syntax, back-tick string
+// integer arithmetic, `if`/`while`/`loop`/`do .. while|until`/`for .. in`, `switch` expressions (literal, `|` alternatives,
+// integer ranges, `if` guards, `_`), `throw` / `try .. catch (e)` (a caught runtime error binds its message string — Rhai
+// binds an object map, which this subset does not have), `fn` definitions, closures, method-call syntax, back-tick string
 // interpolation — as a tree-walking interpreter for the *control plane* of a script, plus a compiler that lowers
 // per-pixel closures (`map_channels`, `for_each_pixel`, `for_region`) to a register bytecode executed by one GPU
 // kernel (k_script.hip).  Pixel data never goes through the interpreter except for the scalar get_pixel/set_pixel API.
@@ -51,7 +53,12 @@ struct Closure {
 
 enum class NK : uint8_t {
     IntLit, FloatLit, BoolLit, StrLit, Interp, ArrayLit, Var, Unary, Binary, And, Or, Call, Index, ClosureLit, If, Block, Let, Assign,
-    While, Loop, For, Break, Continue, Return, FnDef, ExprStmt, RangeLit
+    While, Loop, For, Break, Continue, Return, FnDef, ExprStmt, RangeLit,
+    DoWhile,  // kids: body, condition; flag = `until`
+    Throw,    // kids: [value]
+    Try,      // kids: body, handler; text = the catch variable (may be empty)
+    Switch,   // kids: scrutinee, arms...
+    Arm       // kids: patterns (ival of them), [guard if flag], body; text == "_" for the default arm
 };
 
 struct Node {

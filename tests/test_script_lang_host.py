@@ -103,11 +103,63 @@ def test_limits_and_unsupported_constructs():
     assert "Too many operations" in str(err("let i = 0; loop { i += 1; }"))                       # scripting.rs:288
     assert "Size of array too large" in str(err("let a = []; loop { a.push(1); }"))               # :292
     assert "Length of string too large" in str(err('let s = "x"; loop { s += s; }'))              # :291
-    for src in ("switch 1 { 1 => 2 }", "let m = #{a: 1};", "try { } catch { }", "import \"x\";", "let c = 'c';"):
+    for src in ("let m = #{a: 1};", "import \"x\";", "let c = 'c';", "export let x = 1;"):
         assert err(src).status == -5, src
     # image functions need an image
     assert err("apply_invert();").status == -5
     assert err("let p = get_pixel(0, 0);").status == -5
+
+
+def test_switch_expression():
+    src = """
+    fn kind(v) {
+        switch v {
+            0 => "zero",
+            1 | 2 | 3 => "small",
+            4..10 => "medium",
+            10..=99 if v % 2 == 0 => "even tens",
+            10..=99 => "odd tens",
+            -5 => "minus five",
+            "text" => "a string",
+            true => "yes",
+            2.5 => "float",
+            _ => "other"
+        }
+    }
+    for v in [0, 2, 4, 9, 10, 42, 43, 99, 100, -5, "text", true, false, 2.5, 1.0] { print(kind(v)); }
+    """
+    assert out(src) == ["zero", "small", "medium", "medium", "even tens", "even tens", "odd tens", "odd tens", "other", "minus five", "a string", "yes",
+                        "other", "float", "other"]
+    # a switch without a matching case and without a default is (); block bodies; usable as a statement without ';'
+    assert out("let r = switch 5 { 1 => 2 }; print(r == ()); let n = 0; switch 3 { 3 => { n += 10; n += 1; } _ => { n = -1; } } print(n);") == ["true", "11"]
+    assert out("let x = 7; let y = switch x { 7 => { let t = x * 2; t + 1 }, _ => 0 }; print(y);") == ["15"]
+    assert "literal" in str(err("let a = 1; switch 1 { a => 2 }"))
+    assert "default case" in str(err("switch 1 { _ => 1, 2 => 3 }"))
+
+
+def test_do_loops():
+    assert out("let i = 0; do { i += 1; } while i < 5; print(i); do { i -= 2; } until i <= 0; print(i);") == ["5", "-1"]
+    assert out("let i = 0; do { i += 1; if i == 2 { continue; } if i == 4 { break; } } while true; print(i);") == ["4"]
+    assert out("let n = 0; do { n += 1; } while false; print(n);") == ["1"]
+    assert "Too many operations" in str(err("do { } while true;"))
+
+
+def test_throw_and_try_catch():
+    assert out('try { throw "boom"; } catch (e) { print("caught " + e); }') == ["caught boom"]
+    assert out("try { throw 42; } catch (e) { print(e + 1); }") == ["43"]
+    assert out("let x = 0; try { x = 10 / x; } catch { x = -1; } print(x);") == ["-1"]
+    assert out('try { let a = [1]; a[5]; } catch (e) { print(type_of(e)); }') == ["string"]
+    assert out('fn f(n) { if n > 2 { throw `too big: ${n}`; } n } let t = 0; for i in 0..5 { try { t += f(i); } catch (e) { print(e); break; } } print(t);') == \
+        ["too big: 3", "3"]
+    # nested, re-thrown
+    assert out('try { try { throw 1; } catch (e) { throw e + 1; } } catch (e) { print(e); }') == ["2"]
+    e = err('let a = 1;\nthrow "fatal " + a;')
+    assert e.status == -6 and "Runtime error: fatal 1" in str(e) and e.line == 2
+    assert "Runtime error" in str(err("throw;"))
+    # the sandbox limits are not catchable
+    assert "Too many operations" in str(err("try { loop { } } catch { print(1); }"))
+    # break / return pass through a try block
+    assert out("fn g() { try { return 5; } catch { return 6; } } print(g()); for i in 0..3 { try { if i == 1 { break; } } catch { } print(i); }") == ["5", "0"]
 
 
 def test_error_positions():
