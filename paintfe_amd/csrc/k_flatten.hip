@@ -140,9 +140,24 @@ PFX_DEV float q255(float v)
 // fl(1 - top_a) is off by at most 2^-25, and 1 +- 2^-25 rounds to 1.0, ties to even), base_c * 1.0 = base_c and n / 1.0 = n:
 // the division, the alpha products and the alpha re-quantisation drop out with identical bits.  Typical documents (an opaque
 // background under everything) run this path for every layer.  tests: test_flatten_opaque_base_path_bitexact.
-template <uint32_t M, bool F, bool OB = false>
+// OB == 2: in addition the whole wave's top pixels are opaque and the layer opacity is >= 1 (a photo or texture layer with a
+// blend mode at 100 %): top_a = div255(255) * 1.0 = 1.0, 1 - top_a = 0, so n = f * 1.0 + base * 0.0 = f and the pixel is
+// `(f(base, top) * 255) as u8` with alpha 255; Normal is the reference's own early-out (:1258), the top pixel itself.
+template <uint32_t M, bool F, int OB = 0>
 PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float opc)
 {
+    if constexpr (OB == 2 && F && M != M_XOR && M != M_OVERWRITE) {
+        const float t0 = ubyte0(top), t1 = ubyte1(top), t2 = ubyte2(top);
+        if constexpr (M == M_NORMAL) { acc[0] = t0; acc[1] = t1; acc[2] = t2; }
+        else {
+            const float r = blend_fn<M, F>(div255(acc[0]), div255(t0));
+            const float g = blend_fn<M, F>(div255(acc[1]), div255(t1));
+            const float b = blend_fn<M, F>(div255(acc[2]), div255(t2));
+            acc[0] = q255<false>(r); acc[1] = q255<false>(g); acc[2] = q255<false>(b);
+        }
+        acc[3] = 255.0f;
+        return;
+    }
     const uint32_t ta8 = top >> 24;
     const bool skip = (ta8 == 0u);                                     // :1253  -> keep base
     const float t0 = ubyte0(top), t1 = ubyte1(top), t2 = ubyte2(top), t3 = (float)ta8;
@@ -153,9 +168,9 @@ PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float op
     if constexpr (M == M_OVERWRITE) {                                  // :1275 (`as u8` without clamp == with clamp)
         o0 = q255<CL>(top_r); o1 = q255<CL>(top_g); o2 = q255<CL>(top_b); o3 = q255<CL>(top_a);
     } else {
-        constexpr bool UNIT = OB && F && M != M_XOR; // out_a == 1.0 exactly, see above
+        constexpr bool UNIT = OB != 0 && F && M != M_XOR; // out_a == 1.0 exactly, see above
         const float base_r = div255(acc[0]), base_g = div255(acc[1]), base_b = div255(acc[2]);
-        const float base_a = (OB && F) ? 1.0f : div255(acc[3]);
+        const float base_a = (OB != 0 && F) ? 1.0f : div255(acc[3]);
         const float ita = 1.0f - top_a;
         float den, nr, ng, nb;
         if constexpr (UNIT) {
@@ -202,14 +217,14 @@ PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float op
     acc[0] = skip ? acc[0] : o0; acc[1] = skip ? acc[1] : o1; acc[2] = skip ? acc[2] : o2; acc[3] = skip ? acc[3] : o3;
 }
 
-template <uint32_t M, bool F, int PX, bool OB>
+template <uint32_t M, bool F, int PX, int OB>
 PFX_DEV void blendN(float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw, float opc)
 {
 #pragma unroll
     for (int p = 0; p < PX; ++p) blend_px<M, F, OB>(acc[p], top[p], opacity_raw, opc);
 }
 
-template <bool F, int PX = 4, bool OB = false>
+template <bool F, int PX = 4, int OB = 0>
 PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw, float opc)
 {
     switch (mode) { // wave-uniform: one scalar branch per layer
@@ -230,11 +245,13 @@ template <int PX>
 PFX_DEV void blend_layer_fast(uint32_t mode, float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw)
 {
     const float opc = rs_clamp(opacity_raw, 0.0f, 1.0f);
-    bool ob = true;
+    bool ob = true, ot = opacity_raw >= 1.0f;
 #pragma unroll
-    for (int p = 0; p < PX; ++p) ob = ob && (acc[p][3] == 255.0f);
-    if (__all(ob)) blend4_dispatch<true, PX, true>(mode, acc, top, opacity_raw, opc);
-    else blend4_dispatch<true, PX, false>(mode, acc, top, opacity_raw, opc);
+    for (int p = 0; p < PX; ++p) { ob = ob && (acc[p][3] == 255.0f); ot = ot && (top[p] >> 24) == 255u; }
+    if (__all(ob)) {
+        if (__all(ot)) blend4_dispatch<true, PX, 2>(mode, acc, top, opacity_raw, opc);
+        else blend4_dispatch<true, PX, 1>(mode, acc, top, opacity_raw, opc);
+    } else blend4_dispatch<true, PX, 0>(mode, acc, top, opacity_raw, opc);
 }
 
 // live layer mask: top.a = (a * (255 - conceal)) / 255, integer (canvas_state.rs:660-665)
@@ -394,7 +411,8 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
                 for (int p = 0; p < 4; ++p)
                     if (p0 + p < n_px) top[p] = apply_conceal(top[p], L.mask[p0 + p]);
             }
-            blend4_dispatch<F>(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
+            if constexpr (F) blend_layer_fast<4>(L.mode, acc, top, L.opacity); // lanes past the image edge hold alpha 0: they only disable the opaque path
+            else blend4_dispatch<F>(L.mode, acc, top, L.opacity, rs_clamp(L.opacity, 0.0f, 1.0f));
         }
 
         uint32_t out[4];

@@ -118,6 +118,15 @@ def test_flatten_opaque_base_path_bitexact(gpu, mode):
         opac = np.array([1.0, opacity, 0.8, 1.0], np.float32)
         layers = [dict(pixels=stack[k], mode=int(modes[k]), opacity=float(opac[k])) for k in range(4)]
         assert_same(gpu.composite(layers, w, h), O.flatten_stack(stack, modes, opac), 0, f"mode {mode} opacity {opacity}")
+    # second level of the specialisation: the top layer is opaque everywhere and at 100 % (or more) opacity
+    solid = top.copy()
+    solid[..., 3] = 255
+    for opacity in (1.0, 1.5):
+        stack = np.stack([bg, solid, over, solid[:, ::-1].copy()])
+        modes = np.array([0, mode, (mode + 7) % 25, mode], np.uint8)
+        opac = np.array([1.0, opacity, 0.8, 1.0], np.float32)
+        layers = [dict(pixels=stack[k], mode=int(modes[k]), opacity=float(opac[k])) for k in range(4)]
+        assert_same(gpu.composite(layers, w, h), O.flatten_stack(stack, modes, opac), 0, f"mode {mode} opaque top, opacity {opacity}")
 
 
 def test_composite_masks_hidden_and_adjustment_layers(gpu, oracle):
