@@ -14,6 +14,15 @@
 
 namespace pfxk {
 
+// Pins a value in a VGPR at this point.  Used where both sides of a per-pixel choice are computed on purpose and a select
+// picks one: without it LLVM sinks the unchosen side back behind a divergent branch (exec-mask save / restore / s_cbranch per
+// choice, which costs more issue slots than the few VALU ops it skips — the lanes of a wave take both sides anyway).
+PFX_DEV float pin(float v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // x / 255.0f for integer-valued x in [0,255], correctly rounded, in 2 VALU ops instead of an IEEE divide.
 // 1/255 = C_HI + C_LO (C_HI = RN(1/255), C_LO = RN(1/255 - C_HI)); RN(x*C_HI + RN(x*C_LO)) == RN(x/255)
 // for all 256 inputs (exhaustively checked on the host at context creation, pfx_ctx.cpp:selfcheck_div255,

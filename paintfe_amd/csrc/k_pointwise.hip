@@ -27,42 +27,44 @@ PFX_DEV hsl3 rgb_to_hsl(float r, float g, float b)
     const float mx = __builtin_fmaxf(__builtin_fmaxf(r, g), b);
     const float mn = __builtin_fminf(__builtin_fminf(r, g), b);
     const float l = (mx + mn) / 2.0f;
-    if (__builtin_fabsf(mx - mn) < 1e-6f) return {0.0f, 0.0f, l};
+    // Branch-free on purpose (the branches of the reference are per-pixel data: a wave takes all of them, and every divergent
+    // branch costs scalar exec-mask traffic on top): the same operations in the same order, operands selected before each
+    // division, results selected at the end.  Lanes of the grey case divide 0 by 0; that NaN is never selected.
+    const bool gray = __builtin_fabsf(mx - mn) < 1e-6f;
     // Divisions via k_common.h:rdiv (bit-identical to '/'): inputs are k/255, so d = max-min >= 1/255, the saturation
     // denominators are >= 1/255 and every numerator is 0 or >= 1/255 in magnitude — all in the normal range.
     const float d = mx - mn;
     const float s = fdiv_fast(d, (l > 0.5f) ? (2.0f - mx - mn) : (mx + mn)); // selecting the operand == selecting the quotient
     const rdiv kd = rdiv_prepare(d), k6 = rdiv_prepare(6.0f);
-    float h;
-    if (__builtin_fabsf(mx - r) < 1e-6f) {
-        h = rdiv_apply(kd, g - b);
-        if (h < 0.0f) h += 6.0f;
-        h = rdiv_apply(k6, h);
-    } else if (__builtin_fabsf(mx - g) < 1e-6f) {
-        h = rdiv_apply(k6, rdiv_apply(kd, b - r) + 2.0f);
-    } else {
-        h = rdiv_apply(k6, rdiv_apply(kd, r - g) + 4.0f);
-    }
-    return {h, s, l};
+    const bool is_r = __builtin_fabsf(mx - r) < 1e-6f, is_g = __builtin_fabsf(mx - g) < 1e-6f;
+    const float n_rb = pin(is_g ? (b - r) : (r - g));
+    const float sector = rdiv_apply(kd, is_r ? pin(g - b) : n_rb);
+    // red sector: `if h < 0 { h += 6 }` (adding +0.0 otherwise leaves the value as it is); green: + 2; blue: + 4
+    const float offset = is_r ? ((sector < 0.0f) ? 6.0f : 0.0f) : (is_g ? 2.0f : 4.0f);
+    const float h = rdiv_apply(k6, sector + offset);
+    return {gray ? 0.0f : h, gray ? 0.0f : s, l};
 }
-// adjustments.rs:995-1012
+// adjustments.rs:995-1012, branch-free like rgb_to_hsl: both ramps are evaluated, the reference's if-chain becomes the selects
 PFX_DEV float hue_to_rgb(float p, float q, float t)
 {
-    if (t < 0.0f) t += 1.0f;
-    if (t > 1.0f) t -= 1.0f;
-    if (t < 1.0f / 6.0f) return p + (q - p) * 6.0f * t;
-    if (t < 1.0f / 2.0f) return q;
-    if (t < 2.0f / 3.0f) return p + (q - p) * (2.0f / 3.0f - t) * 6.0f;
-    return p;
+    t = (t < 0.0f) ? t + 1.0f : t;
+    t = (t > 1.0f) ? t - 1.0f : t;
+    const float up = pin(p + (q - p) * 6.0f * t);
+    const float down = pin(p + (q - p) * (2.0f / 3.0f - t) * 6.0f);
+    float v = pin((t < 2.0f / 3.0f) ? down : p); // the if-chain read from its last test to its first: three v_cndmask
+    v = pin((t < 1.0f / 2.0f) ? q : v);
+    return (t < 1.0f / 6.0f) ? up : v;
 }
 // adjustments.rs:976-993
 template <bool RHAI>
 PFX_DEV rgb3 hsl_to_rgb(float h, float s, float l)
 {
-    if (__builtin_fabsf(s) < (RHAI ? 1e-10f : 1e-6f)) return {l, l, l};
-    const float q = (l < 0.5f) ? l * (1.0f + s) : l + s - l * s;
+    const bool gray = __builtin_fabsf(s) < (RHAI ? 1e-10f : 1e-6f);
+    const float q_lo = pin(l * (1.0f + s)), q_hi = pin(l + s - l * s);
+    const float q = (l < 0.5f) ? q_lo : q_hi;
     const float p = 2.0f * l - q;
-    return {hue_to_rgb(p, q, h + 1.0f / 3.0f), hue_to_rgb(p, q, h), hue_to_rgb(p, q, h - 1.0f / 3.0f)};
+    const float r = hue_to_rgb(p, q, h + 1.0f / 3.0f), g = hue_to_rgb(p, q, h), b = hue_to_rgb(p, q, h - 1.0f / 3.0f);
+    return {gray ? l : r, gray ? l : g, gray ? l : b};
 }
 PFX_DEV float lum709(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
 

@@ -85,7 +85,8 @@ def test_script_selection_mask(r):
     ("apply_frobnicate(1.0);", -6, "Function not found: apply_frobnicate (f64)"),
     ("let x = 4; apply_blur(x);", -6, "Function not found: apply_blur (i64)"),  # typing is checked on values, not literals
     ("map_channels(|r, g, b, a| { print(r); [r, g, b, a] });", -5, "cannot be compiled for the GPU"),
-    ("switch 1 { 1 => 2 }", -5, "outside the supported subset"),
+    ("import \"effects\";", -5, "outside the supported subset"),
+    ("apply_invert(); throw \"stop here\";", -6, "Runtime error: stop here"),
     ("apply_blur(2.0", -6, "Expecting ')'"),
     ('print_line("unterminated);', -6, "not terminated"),
 ])
