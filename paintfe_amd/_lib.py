@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpfx.so")
+# PFX_LIB_PATH: development override for A/B timing of two builds of the same ABI (never a fallback: the file must exist)
+LIB_PATH = os.environ.get("PFX_LIB_PATH") or os.path.join(_HERE, "libpfx.so")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_SCRIPT = 0, -1, -2, -3, -4, -5, -6
 STATUS_NAMES = {0: "PFX_OK", -1: "PFX_ERR_INVALID", -2: "PFX_ERR_NO_DEVICE", -3: "PFX_ERR_HIP", -4: "PFX_ERR_OOM",
