@@ -19,35 +19,53 @@ namespace {
 PFX_DEV double as_f(uint64_t b) { return __builtin_bit_cast(double, b); }
 PFX_DEV uint64_t f_bits(double d) { return __builtin_bit_cast(uint64_t, d); }
 
+// LCODE: the program (12 bytes per instruction) is staged in LDS behind the register file — instruction fetch is then an LDS
+// read instead of a dependent global load per bytecode instruction, which is what the interpreter's time went into.
+// A workgroup walks over pixels with a grid stride so the staged program serves many pixels.
+// HEAVY: the instantiation that carries the f64 libm routines (fmod, pow, sin, cos, tan, atan2, exp, log: 128 VGPRs and scratch);
+// programs without them run the light instantiation at twice the occupancy.
+template <bool LCODE, bool HEAVY>
 __global__ void vm_kernel(const pfxk_vm_args A)
 {
     extern __shared__ uint64_t regs[];
     const int lanes = blockDim.x, t = threadIdx.x;
+    const BcIns* __restrict__ gcode = (const BcIns*)A.code;
+    BcIns* lcode = reinterpret_cast<BcIns*>(regs + (size_t)lanes * A.n_regs);
+    if constexpr (LCODE) {
+        const int words = A.n_code * 3; // 12-byte instructions
+        for (int i = t; i < words; i += lanes) reinterpret_cast<uint32_t*>(lcode)[i] = reinterpret_cast<const uint32_t*>(gcode)[i];
+        __syncthreads();
+    }
+    auto fetch = [&](int at) -> BcIns {
+        if constexpr (LCODE) return lcode[at];
+        else return gcode[at];
+    };
     const int rw = A.x1 - A.x0;
-    const long long local = (long long)blockIdx.x * lanes + t;
-    if (local >= (long long)rw * (A.y1 - A.y0)) return;
+    const long long total = (long long)rw * (A.y1 - A.y0);
+    const uint64_t* __restrict__ K = A.consts;
+#define R(i) regs[(size_t)(i) * lanes + t]
+  for (long long local = (long long)blockIdx.x * lanes + t; local < total; local += (long long)gridDim.x * lanes) {
+    // a pixel behind an already recorded failure cannot become the first failing pixel: skip it (the result is discarded anyway)
+    if ((unsigned long long)local > (__atomic_load_n(A.err, __ATOMIC_RELAXED) >> 24)) continue;
     const int x = A.x0 + (int)(local % rw), y = A.y0 + (int)(local / rw);
     const size_t pi = (size_t)y * A.w + x;
     const uint32_t px = A.src[pi];
-#define R(i) regs[(size_t)(i) * lanes + t]
     {
         int p = 0;
         if (A.n_params == 6) { R(0) = (uint64_t)(int64_t)x; R(1) = (uint64_t)(int64_t)y; p = 2; }
         R(p) = px & 0xffu; R(p + 1) = (px >> 8) & 0xffu; R(p + 2) = (px >> 16) & 0xffu; R(p + 3) = px >> 24;
     }
-    const BcIns* __restrict__ code = (const BcIns*)A.code;
-    const uint64_t* __restrict__ K = A.consts;
     int pc = 0;
     uint32_t steps = 0;
     int err = 0, err_line = 0;
     uint32_t out = px;
-    for (;;) {
-        if (pc < 0 || pc >= A.n_code) break; // falling off the end = unit
-        const BcIns I = code[pc++];
-        if (++steps > 4000000u) { err = BCE_TOO_MANY_OPS; err_line = I.line; break; }
+    bool done = false;
+    // One bytecode instruction.  Inlined twice below: with a wave-uniform instruction (fields in SGPRs: scalar fetch, scalar
+    // jump table, uniform LDS offsets) and with a per-lane one (lanes of a wave at different program counters).
+    auto step = [&](const BcIns I) {
+        if (++steps > 4000000u) { err = BCE_TOO_MANY_OPS; return; }
         const int64_t ia = (int64_t)R(I.a), ib = (int64_t)R(I.b);
         int64_t ir;
-        bool done = false;
         switch (I.op) {
         case BC_LOADK: R(I.dst) = K[I.a]; break;
         case BC_MOV: R(I.dst) = R(I.a); break;
@@ -102,9 +120,9 @@ __global__ void vm_kernel(const pfxk_vm_args A)
         case BC_FSUB: R(I.dst) = f_bits(as_f(R(I.a)) - as_f(R(I.b))); break;
         case BC_FMUL: R(I.dst) = f_bits(as_f(R(I.a)) * as_f(R(I.b))); break;
         case BC_FDIV: R(I.dst) = f_bits(as_f(R(I.a)) / as_f(R(I.b))); break;
-        case BC_FMOD: R(I.dst) = f_bits(fmod(as_f(R(I.a)), as_f(R(I.b)))); break;
+        case BC_FMOD: if constexpr (HEAVY) { R(I.dst) = f_bits(fmod(as_f(R(I.a)), as_f(R(I.b)))); } else err = 255; break;
         case BC_FNEG: R(I.dst) = R(I.a) ^ 0x8000000000000000ull; break;
-        case BC_FPOW: R(I.dst) = f_bits(pow(as_f(R(I.a)), as_f(R(I.b)))); break;
+        case BC_FPOW: if constexpr (HEAVY) { R(I.dst) = f_bits(pow(as_f(R(I.a)), as_f(R(I.b)))); } else err = 255; break;
         case BC_FABS: R(I.dst) = R(I.a) & 0x7fffffffffffffffull; break;
         case BC_FMIN: R(I.dst) = f_bits(fmin(as_f(R(I.a)), as_f(R(I.b)))); break;
         case BC_FMAX: R(I.dst) = f_bits(fmax(as_f(R(I.a)), as_f(R(I.b)))); break;
@@ -113,12 +131,12 @@ __global__ void vm_kernel(const pfxk_vm_args A)
         case BC_FCEIL: R(I.dst) = f_bits(ceil(as_f(R(I.a)))); break;
         case BC_FROUND: R(I.dst) = f_bits(round(as_f(R(I.a)))); break;
         case BC_FSQRT: R(I.dst) = f_bits(sqrt(as_f(R(I.a)))); break;
-        case BC_FSIN: R(I.dst) = f_bits(sin(as_f(R(I.a)))); break;
-        case BC_FCOS: R(I.dst) = f_bits(cos(as_f(R(I.a)))); break;
-        case BC_FTAN: R(I.dst) = f_bits(tan(as_f(R(I.a)))); break;
-        case BC_FATAN2: R(I.dst) = f_bits(atan2(as_f(R(I.a)), as_f(R(I.b)))); break;
-        case BC_FEXP: R(I.dst) = f_bits(exp(as_f(R(I.a)))); break;
-        case BC_FLN: R(I.dst) = f_bits(log(as_f(R(I.a)))); break;
+        case BC_FSIN: if constexpr (HEAVY) { R(I.dst) = f_bits(sin(as_f(R(I.a)))); } else err = 255; break;
+        case BC_FCOS: if constexpr (HEAVY) { R(I.dst) = f_bits(cos(as_f(R(I.a)))); } else err = 255; break;
+        case BC_FTAN: if constexpr (HEAVY) { R(I.dst) = f_bits(tan(as_f(R(I.a)))); } else err = 255; break;
+        case BC_FATAN2: if constexpr (HEAVY) { R(I.dst) = f_bits(atan2(as_f(R(I.a)), as_f(R(I.b)))); } else err = 255; break;
+        case BC_FEXP: if constexpr (HEAVY) { R(I.dst) = f_bits(exp(as_f(R(I.a)))); } else err = 255; break;
+        case BC_FLN: if constexpr (HEAVY) { R(I.dst) = f_bits(log(as_f(R(I.a)))); } else err = 255; break;
         case BC_FLERP: { const double a = as_f(R(I.a)), b = as_f(R(I.b)), tt = as_f(R(I.c)); R(I.dst) = f_bits(a + (b - a) * tt); break; }
         case BC_FDIST: { // scripting.rs:1266: ((x2-x1)^2 + (y2-y1)^2).sqrt(), operands in 4 consecutive registers
             const double x1 = as_f(R(I.a)), y1 = as_f(R(I.a + 1)), x2 = as_f(R(I.a + 2)), y2 = as_f(R(I.a + 3));
@@ -170,16 +188,36 @@ __global__ void vm_kernel(const pfxk_vm_args A)
         case BC_ERR: err = I.a; break;
         default: err = 255; break;
         }
-        if (err) { err_line = I.line; break; }
+    };
+    BcIns pre{};
+    int pre_pc = -1;
+    for (;;) {
+        if (pc < 0 || pc >= A.n_code) break; // falling off the end = unit
+        const int upc = __builtin_amdgcn_readfirstlane(pc);
+        int line;
+        if (__all(pc == upc)) { // the usual case: straight-line closures and branches every lane takes the same way
+            const BcIns I = (pre_pc == upc) ? pre : fetch(upc);
+            pre_pc = min(upc + 1, A.n_code - 1); // the next instruction in sequence is requested before this one executes
+            pre = fetch(pre_pc);
+            line = I.line;
+            ++pc;
+            step(I);
+        } else {
+            const BcIns I = fetch(pc++);
+            line = I.line;
+            step(I);
+        }
+        if (err) { err_line = line; break; }
         if (done) break;
     }
-#undef R
     if (err) {
         const unsigned long long local_row_major = (unsigned long long)(y - A.y0) * (unsigned long long)rw + (unsigned long long)(x - A.x0);
         atomicMin(A.err, (local_row_major << 24) | ((unsigned long long)(err & 0xff) << 16) | (unsigned long long)(err_line & 0xffff));
-        return;
+        continue;
     }
     A.dst[pi] = out;
+  }
+#undef R
 }
 
 // ---- transforms (imageops::flip_horizontal / flip_vertical / rotate180 / rotate90 / rotate270: pure permutations) ----
@@ -244,8 +282,14 @@ extern "C" hipError_t pfxk_vm_run(hipStream_t s, const pfxk_vm_args* A)
     int lanes = (int)(65536 / ((size_t)A->n_regs * 8));
     lanes = lanes >= 256 ? 256 : (lanes / 64) * 64;
     if (lanes < 64) return hipErrorInvalidValue; // > 128 registers: rejected by the compiler before we get here
-    const size_t lds = (size_t)lanes * A->n_regs * 8;
-    vm_kernel<<<(uint32_t)((n + lanes - 1) / lanes), lanes, lds, s>>>(*A);
+    const size_t lds_regs = (size_t)lanes * A->n_regs * 8, lds_code = ((size_t)A->n_code * 12 + 15) & ~(size_t)15;
+    long long blocks = (n + lanes - 1) / lanes;
+    if (blocks > 256 * 32) blocks = 256 * 32; // grid stride beyond that: the staged program is reused
+    const bool lcode = lds_regs + lds_code <= 65536;
+    const size_t lds = lcode ? lds_regs + lds_code : lds_regs;
+    const uint32_t g = (uint32_t)blocks;
+    if (A->heavy) { if (lcode) vm_kernel<true, true><<<g, lanes, lds, s>>>(*A); else vm_kernel<false, true><<<g, lanes, lds, s>>>(*A); }
+    else          { if (lcode) vm_kernel<true, false><<<g, lanes, lds, s>>>(*A); else vm_kernel<false, false><<<g, lanes, lds, s>>>(*A); }
     return hipGetLastError();
 }
 

@@ -123,6 +123,7 @@ typedef struct pfxk_vm_args {
     const uint64_t* consts;
     unsigned long long* err;  // initialised to ~0: min over failing pixels of (row-major index << 24 | code << 16 | line)
     int n_code, n_regs, n_params;
+    int heavy;                // the program uses fmod / pow / sin / cos / tan / atan2 / exp / ln (selects the kernel that carries them)
     int w, h;
     int x0, y0, x1, y1;       // region processed (for_region); the rest of dst must already equal src
 } pfxk_vm_args;

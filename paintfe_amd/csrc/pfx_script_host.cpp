@@ -131,6 +131,9 @@ struct ScriptHost : rhai::Host {
         A.n_code = (int)prog.code.size();
         A.n_regs = prog.n_regs;
         A.n_params = n_params;
+        for (const rhai::BcIns& ins : prog.code) // f64 libm routines live in the heavier of the two kernel instantiations
+            if (ins.op == rhai::BC_FMOD || ins.op == rhai::BC_FPOW || ins.op == rhai::BC_FSIN || ins.op == rhai::BC_FCOS || ins.op == rhai::BC_FTAN ||
+                ins.op == rhai::BC_FATAN2 || ins.op == rhai::BC_FEXP || ins.op == rhai::BC_FLN) A.heavy = 1;
         A.w = (int)w; A.h = (int)h;
         A.x0 = x0; A.y0 = y0; A.x1 = x1; A.y1 = y1;
         {
