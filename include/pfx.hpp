@@ -8,6 +8,7 @@
 //   pfx::ops::*        <->  the pure `_core` functions           (src/ops/filters.rs:130, effects/*.rs, transform.rs)
 // Header-only; link with -lpfx.  Nothing here does pixel arithmetic.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <optional>
 #include <stdexcept>
@@ -143,6 +144,7 @@ class CanvasState {
 public:
     uint32_t width, height;
     std::vector<Layer> layers;
+    size_t active_layer_index = 0;
     CanvasState(uint32_t w, uint32_t h) : width(w), height(h) { layers.push_back(Layer{"Background", RgbaImage(w, h)}); } // CanvasState::new
     // CanvasState::composite() (canvas_state.rs:482) on the device
     RgbaImage composite(GpuRenderer& gpu) const
@@ -160,6 +162,42 @@ public:
         return out;
     }
 };
+
+// ---- project files: load_pfe / save_pfe (src/io.rs:242-499) over the library's document object ----
+namespace io {
+inline CanvasState load_pfe(const std::string& path) // io.rs:469: layers come back flattened to w*h RGBA8 (to_rgba_image)
+{
+    char why[512] = {0};
+    pfx_project* p = pfx_project_load_file(path.c_str(), why, sizeof why);
+    if (!p) throw Error(PFX_ERR_INVALID, std::string("PfeError: ") + why);
+    CanvasState state(pfx_project_width(p), pfx_project_height(p));
+    state.layers.clear();
+    for (uint32_t i = 0; i < pfx_project_layer_count(p); ++i) {
+        pfx_project_layer L{};
+        pfx_project_layer_get(p, i, &L);
+        Layer out{L.name, RgbaImage(state.width, state.height)};
+        pfx_project_layer_pixels(p, i, out.pixels.data.data());
+        out.opacity = L.opacity;
+        out.blend_mode = (BlendMode)(L.blend_mode > 24 ? 0 : L.blend_mode); // BlendMode::from_u8
+        out.visible = L.effectively_visible != 0;
+        state.layers.push_back(std::move(out));
+    }
+    state.active_layer_index = pfx_project_active_layer(p);
+    pfx_project_free(p);
+    return state;
+}
+inline void save_pfe(const CanvasState& state, const std::string& path) // io.rs:242 (raster layers: a V1 file)
+{
+    pfx_project* p = pfx_project_new(state.width, state.height);
+    if (!p) throw Error(PFX_ERR_INVALID, "save_pfe: bad document size");
+    for (const Layer& L : state.layers)
+        pfx_project_add_layer(p, L.name.c_str(), L.pixels.data.data(), L.opacity, (uint8_t)L.blend_mode, L.visible, PFX_LAYER_RASTER, nullptr);
+    pfx_project_set_active_layer(p, (uint32_t)std::min<size_t>(state.active_layer_index, state.layers.size() - 1));
+    const int st = pfx_project_save_file(p, path.c_str());
+    pfx_project_free(p);
+    if (st != PFX_OK) throw Error(st, "save_pfe: cannot write " + path);
+}
+} // namespace io
 
 // ---- pure `_core` functions ----
 namespace ops {

@@ -154,6 +154,31 @@ int main(int argc, char** argv)
         ++g_run;
         if (!flat || !(RgbaImage(64, 64, *flat) == img)) { std::printf("FAILED single opaque layer composite\n"); ++g_failed; }
     }
+    // ---- io_roundtrip.rs:148-200 roundtrip_pfe_multi_layer, :314-330 load through a path; then composite the loaded document
+    {
+        CanvasState state(64, 64);
+        for (auto& b : state.layers[0].pixels.data) b = 255; // white background
+        RgbaImage red(64, 64);
+        for (size_t i = 0; i < red.data.size(); i += 4) { red.data[i] = 255; red.data[i + 1] = 0; red.data[i + 2] = 0; red.data[i + 3] = 128; }
+        Layer l1{"Red", red};
+        l1.opacity = 0.75f;
+        state.layers.push_back(l1);
+        Layer l2{"Gradient", create_test_gradient(64, 64)};
+        l2.blend_mode = BlendMode::Multiply;
+        state.layers.push_back(l2);
+        state.active_layer_index = 2;
+        const std::string path = std::string(argv[1]) + ".rt_multi.pfe";
+        io::save_pfe(state, path);
+        CanvasState loaded = io::load_pfe(path);
+        ++g_run;
+        if (loaded.layers.size() != 3 || loaded.layers[1].opacity != 0.75f || loaded.layers[1].name != "Red" || loaded.layers[2].name != "Gradient" ||
+            loaded.layers[2].blend_mode != BlendMode::Multiply || loaded.active_layer_index != 2) { std::printf("FAILED pfe metadata round trip\n"); ++g_failed; }
+        for (size_t i = 0; i < 3; ++i) assert_eq(loaded.layers[i].pixels, state.layers[i].pixels, "PFE layers should be pixel-exact");
+        assert_eq(loaded.composite(gpu), state.composite(gpu), "a loaded project composites like the original");
+        std::remove(path.c_str());
+        ++g_run;
+        try { io::load_pfe(path); std::printf("FAILED loading a missing project must fail\n"); ++g_failed; } catch (const Error&) {}
+    }
     std::printf("%d checks, %d failed\n", g_run, g_failed);
     return g_failed ? 1 : 0;
 }
