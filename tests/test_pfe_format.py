@@ -255,3 +255,45 @@ def test_file_roundtrip(tmp_path):             # io_roundtrip.rs:314-330 (load t
     assert np.array_equal(q.layer_pixels(0), dropped(img))
     with pytest.raises(PfeError):
         Project.load(str(tmp_path / "missing.pfe"))
+
+
+def test_mutated_files_never_crash_the_parser():
+    """robustness of the file parser: truncations, bit flips and length-field corruptions of valid V1 / V2 / V3 files must end
+    in a loaded document or a PfeError — never in a crash or a runaway allocation"""
+    doc, _ = full_v3_document()
+    img = sparse_image(100, 70, 77)
+    seeds = [F.encode(doc),
+             F.encode({"version": 1, "width": 100, "height": 70, "active_layer_index": 0, "layers": [F.raster_layer("a", img), F.raster_layer("b", img, opacity=0.5)]}),
+             F.encode({"version": 2, "width": 100, "height": 70, "active_layer_index": 0,
+                       "layers": [dict(F.raster_layer("t", img), layer_type=1, text_data=b"payload")]}),
+             F.encode({"version": 0, "width": 10, "height": 6, "active_layer_index": 0,
+                       "layers": [{"name": "l", "visible": True, "opacity": 1.0, "blend_mode": 0, "pixels": bytes(240)}]})]
+    rng = np.random.default_rng(1234)
+    outcomes = {"ok": 0, "error": 0}
+    for raw in seeds:
+        # the header region (magic, sizes, counts, names, flags) is where the structure lives: mutate it densely
+        hot = min(len(raw), 400)
+        for trial in range(600):
+            b = bytearray(raw)
+            kind = trial % 4
+            if kind == 0:
+                b = b[:int(rng.integers(0, len(b)))]
+            elif kind == 1:
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(0, hot))] = int(rng.integers(0, 256))
+            elif kind == 2:  # a huge or negative-looking length / count somewhere in the header
+                pos = int(rng.integers(8, max(hot - 8, 9)))
+                b[pos:pos + 8] = [0xFFFFFFFFFFFFFFFF, 1 << 40, 1 << 31, 257, 0][int(rng.integers(0, 5))].to_bytes(8, "little")
+            else:
+                pos = int(rng.integers(0, len(b)))
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            try:
+                p = Project.load_bytes(bytes(b))
+                assert 1 <= len(p) <= 256 and 0 < p.width <= 25000 and 0 < p.height <= 25000
+                if p.width * p.height <= 1 << 20:
+                    p.layer_pixels(p.active_layer)
+                    p.save_bytes()
+                outcomes["ok"] += 1
+            except PfeError:
+                outcomes["error"] += 1
+    assert outcomes["ok"] > 100 and outcomes["error"] > 100, outcomes
