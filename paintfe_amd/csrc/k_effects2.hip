@@ -455,20 +455,21 @@ __global__ __launch_bounds__(256) void crystal_assign_kernel(const uint32_t* __r
 }
 
 // ---- oil painting (artistic.rs:123-215): per-lane intensity histogram in LDS ------------------------------------
-// bins[3][levels][lanes] u32: word 0 = count << 17 | sum_r (count <= 441, sum <= 112455 < 2^17), word 1 = sum_g, word 2 = sum_b.
+// bins[levels][lanes] u64, one word per bin: count << 51 | sum_b << 34 | sum_g << 17 | sum_r (count <= 441, each sum <= 112455 < 2^17),
+// so a window element is ONE fire-and-forget ds_add_u64 (no read-modify-write round trip in the dependency chain; the
+// [level][lane] layout keeps a wave's 64 adds on distinct banks whatever the levels are).
 __global__ void oil_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint8_t* __restrict__ mask, int radius,
                            int levels, int w, int h)
 {
-    extern __shared__ uint32_t bins[];
+    extern __shared__ unsigned long long obins[];
     const int lanes = blockDim.x, t = threadIdx.x;
     const int x = blockIdx.x * lanes + t, y = blockIdx.y;
     if (x >= w) return;
     const size_t oi = (size_t)y * w + x;
     const uint32_t s = src[oi];
     if (mask && mask[oi] == 0) { dst[oi] = s; return; }
-    uint32_t* b0 = bins + t;
-    const int plane = levels * lanes;
-    for (int k = 0; k < levels; ++k) { b0[k * lanes] = 0; b0[plane + k * lanes] = 0; b0[2 * plane + k * lanes] = 0; }
+    unsigned long long* b0 = obins + t;
+    for (int k = 0; k < levels; ++k) b0[k * lanes] = 0ull;
     for (int dy = -radius; dy <= radius; ++dy) {
         const uint32_t* row = src + (size_t)clampi(y + dy, 0, h - 1) * w;
         for (int dx = -radius; dx <= radius; ++dx) {
@@ -476,20 +477,19 @@ __global__ void oil_kernel(const uint32_t* __restrict__ src, uint32_t* __restric
             const uint32_t pr = p & 0xffu, pg = (p >> 8) & 0xffu, pb = (p >> 16) & 0xffu;
             uint32_t k = (pr + pg + pb) / 3u * (uint32_t)levels / 256u;
             k = min(k, (uint32_t)levels - 1u);
-            uint32_t* bk = b0 + k * lanes;
-            bk[0] += (1u << 17) + pr;
-            bk[plane] += pg;
-            bk[2 * plane] += pb;
+            atomicAdd(b0 + k * lanes, (1ull << 51) | ((unsigned long long)pb << 34) | ((unsigned long long)pg << 17) | (unsigned long long)pr);
         }
     }
-    uint32_t max_count = 0, max_idx = 0;
+    uint32_t max_count = 0;
+    unsigned long long best = 0ull;
     for (int k = 0; k < levels; ++k) {
-        const uint32_t c = b0[k * lanes] >> 17;
-        if (c > max_count) { max_count = c; max_idx = (uint32_t)k; }
+        const unsigned long long v = b0[k * lanes];
+        const uint32_t c = (uint32_t)(v >> 51);
+        if (c > max_count) { max_count = c; best = v; } // first level with the largest count (artistic.rs:186-195)
     }
     uint32_t out = s & 0xff000000u;
     if (max_count > 0) {
-        const uint32_t sr = b0[max_idx * lanes] & 0x1ffffu, sg = b0[plane + max_idx * lanes], sb = b0[2 * plane + max_idx * lanes];
+        const uint32_t sr = (uint32_t)best & 0x1ffffu, sg = (uint32_t)(best >> 17) & 0x1ffffu, sb = (uint32_t)(best >> 34) & 0x1ffffu;
         out |= (sr / max_count) | ((sg / max_count) << 8) | ((sb / max_count) << 16);
     }
     dst[oi] = out;
@@ -562,8 +562,8 @@ extern "C" hipError_t pfxk_oil_painting(hipStream_t s, const uint8_t* d_src, uin
                                         uint32_t w, uint32_t h)
 {
     if (w == 0 || h == 0) return hipSuccess;
-    const int lanes = levels <= 21 ? 256 : (levels <= 42 ? 128 : 64); // 12 B per level per lane, <= 64 KiB of LDS per block
-    const size_t lds = (size_t)lanes * levels * 12;
+    const int lanes = levels <= 32 ? 256 : (levels <= 64 ? 128 : 64); // 8 B per level per lane, <= 64 KiB of LDS per block
+    const size_t lds = (size_t)lanes * levels * 8;
     oil_kernel<<<dim3((w + lanes - 1) / lanes, h), lanes, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, levels, (int)w, (int)h);
     return hipGetLastError();
 }
