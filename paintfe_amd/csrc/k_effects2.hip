@@ -108,7 +108,39 @@ PFX_DEV float rem_euclid(float a, float b) // f32::rem_euclid
 // glibc's f32 routines evaluated through f64 (see the file header)
 PFX_DEV float libm_cos(float x) { return (float)cos((double)x); }
 PFX_DEV float libm_sin(float x) { return (float)sin((double)x); }
-PFX_DEV float libm_exp(float x) { return (float)exp((double)x); }
+// expf the way glibc >= 2.27 computes it (sysdeps/ieee754/flt-32/e_expf.c, S. Nagy's algorithm): x * 32/ln2 split into an integer
+// k and a remainder r in [-1/2, 1/2], 2^(k/32) from a 32-entry table of doubles with the exponent added into the bit pattern, a
+// degree-3 polynomial in r, everything in f64, one rounding to f32 at the end.  Same table (2^(i/32) correctly rounded, minus
+// i << 47), same coefficients, FMA-contracted like the variant glibc selects on FMA-capable x86 CPUs — so the weights of the
+// bilateral filter are glibc's bits at about a fifth of the instructions of a full-precision f64 exp().
+__device__ const unsigned long long EXP2F_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+PFX_DEV float libm_exp(float x)
+{
+    if (!(x >= -0x1.9fe368p6f)) return (x != x) ? x : 0.0f; // below: the result underflows to +0 (NaN propagates)
+    if (x > 0x1.62e42ep6f) return __builtin_inff();           // above: overflow
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0, C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    const double z = InvLn2N * (double)x;
+    double kd = z + SHIFT; // round to nearest integer, ties to even, in the low mantissa bits
+    const unsigned long long ki = __builtin_bit_cast(unsigned long long, kd);
+    kd -= SHIFT;
+    const double r = z - kd;
+    const unsigned long long t = EXP2F_TAB[ki & 31u] + (ki << 47);
+    const double sc = __builtin_bit_cast(double, t);
+    const double p = __builtin_fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(p, r2, y);
+    return (float)(y * sc);
+}
 PFX_DEV float libm_log(float x) { return (float)log((double)x); }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -195,14 +227,17 @@ PFX_DEV uint32_t fx_pixel(const uint32_t* __restrict__ src, uint32_t s, int x, i
     } else if constexpr (FX == PFXK_FX2_REDUCE_NOISE) { // noise.rs:211-256; f: 2*sigma_s^2, 2*sigma_r^2+0.001; i0: r
         const int rad = P.i[0];
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, wsum = 0.f;
+        // both divisors are per-call constants: the refined reciprocals are shared by all taps (k_common.h:rdiv, bit-identical to
+        // '/' for these operands: divisors >= 0.001, integer-valued numerators <= 195075)
+        const rdiv k_spatial = rdiv_prepare(P.f[0]), k_range = rdiv_prepare(P.f[1]);
         for (int dy = -rad; dy <= rad; ++dy) {
             const uint32_t* row = src + (size_t)clampi(y + dy, 0, h - 1) * w;
             for (int dx = -rad; dx <= rad; ++dx) {
                 const uint32_t p = row[clampi(x + dx, 0, w - 1)];
                 const float pr = ubyte0(p), pg = ubyte1(p), pb = ubyte2(p), pa = ubyte3(p);
-                const float spatial = (float)(dx * dx + dy * dy) / P.f[0];
+                const float spatial = rdiv_apply(k_spatial, (float)(dx * dx + dy * dy));
                 const float dr = r - pr, dg = g - pg, db = b - pb;
-                const float range = (dr * dr + dg * dg + db * db) / P.f[1];
+                const float range = rdiv_apply(k_range, dr * dr + dg * dg + db * db);
                 const float wt = libm_exp(-spatial - range);
                 s0 += pr * wt; s1 += pg * wt; s2 += pb * wt; s3 += pa * wt;
                 wsum += wt;

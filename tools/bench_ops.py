@@ -85,7 +85,7 @@ def main() -> int:
     timed("vignette", ["vignette"], lambda: r.vignette_dev(s, d, w, h, 0.8, 0.5), px, 8)
     timed("add_noise gaussian mono", ["add_noise"], lambda: r.add_noise_dev(s, d, w, h, 30.0, "gaussian", True, 42, 1.0, 1), px, 8, "f64 ln + cos per pixel")
     timed("add_noise perlin 3 octaves", ["add_noise"], lambda: r.add_noise_dev(s, d, w, h, 50.0, "perlin", False, 42, 5.0, 3), px, 8)
-    timed("reduce_noise r=2", ["reduce_noise"], lambda: r.reduce_noise_dev(s, d, w, h, 10.0, 2), px, 8, "25 f64 exp per pixel")
+    timed("reduce_noise r=2", ["reduce_noise"], lambda: r.reduce_noise_dev(s, d, w, h, 10.0, 2), px, 8, "25 exp per pixel (glibc expf algorithm in f64)")
     timed("halftone", ["halftone"], lambda: r.halftone_dev(s, d, w, h, 4.0, 45.0, "circle"), px, 8)
     timed("ink (sobel)", ["ink"], lambda: r.ink_dev(s, d, w, h, 1.0, 0.5), px, 8)
     timed("oil_painting r=3 levels=20", ["oil_painting"], lambda: r.oil_painting_dev(s, d, w, h, 3, 20), px, 8, "per-lane LDS histogram")
