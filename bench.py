@@ -279,7 +279,8 @@ def main() -> int:
             out["cpu_baseline"] = {"value": round(sw * sh / (t3 - t1) / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
                                    "sample": f"{'whole ' + str(sw) + 'x' + str(sh) + ' frame' if whole else str(sw) + 'x' + str(sh) + ' window'} "
                                              f"of the same {n}-layer stack, flatten {t2 - t1:.2f}s + gaussian {t3 - t2:.2f}s, "
-                                             f"OpenMP restatement of PaintFE's rayon CPU path (oracle/)"}
+                                             f"OpenMP restatement of PaintFE's rayon CPU path (oracle/): chunk-parallel compositing with the "
+                                             f"write-back parallel too (serial in the reference), row-parallel Gaussian passes"}
         print(json.dumps(out), flush=True)
 
     if world > 1:
