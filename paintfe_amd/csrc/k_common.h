@@ -35,12 +35,16 @@ PFX_DEV float div255(float x)
 }
 
 // ---- correctly rounded f32 division, reciprocal part hoistable ------------------------------------------------
-// hipcc lowers an IEEE `n / d` to: v_div_scale x2, v_rcp, 2 FMAs refining the reciprocal, mul + 4 FMAs refining the
-// quotient, v_div_fmas, v_div_fixup.  The scale/fixup steps only act when an operand or the quotient is denormal,
-// huge, zero-denominator or NaN/Inf.  For operands in the normal range (every use in this library: numerators 0 or in
-// [2^-100, 2^20], denominators in [2^-48, 2^20], checked where used) they are identities, so the sequence below yields
-// the same bits as `/`, and the 3-instruction reciprocal part can be shared by all divisions with one denominator.
-// pfx_selftest_division() compares it with `/` on 2.7e8 random operand pairs on the device.
+// y = v_rcp_f32(d) refined by one Newton step (2 FMA), then per numerator  q0 = n*y;  r0 = fma(-d, q0, n);
+// q = fma(r0, y, q0): 3 instructions per quotient, the 3-instruction reciprocal shared by every division with the same
+// denominator.  hipcc's own IEEE sequence (v_div_scale x2, rcp, 2 FMA, mul, 4 FMA, v_div_fmas, v_div_fixup) runs one more
+// residual/correction round; on gfx950 that round never changes the result: tools/lab/div_exhaust.hip compares this
+// sequence with `/` for ALL 2^46 pairs of f32 significands (profiles/r02_div_exhaust.json: 0 mismatches of 7.04e13; the
+// same sweep with an unrefined v_rcp finds 47045, which is why the Newton step stays).  Scaling n or d by a power of two
+// scales every intermediate exactly while nothing leaves the normal range and the residual stays representable
+// (exponent(n) >= -100 suffices), which holds for every use in this library: numerators 0 or in [2^-100, 2^20],
+// denominators in [2^-48, 2^20], checked where used.  pfx_selftest_division() re-checks 2.7e8 random pairs of the
+// kernels' operand range against `/` on the device the context runs on.
 struct rdiv { float d, y; };
 PFX_DEV rdiv rdiv_prepare(float d)
 {
@@ -52,11 +56,14 @@ PFX_DEV float rdiv_apply(const rdiv k, float n)
 {
     const float q0 = n * k.y;
     const float r0 = __builtin_fmaf(-k.d, q0, n);
-    const float q1 = __builtin_fmaf(r0, k.y, q0);
-    const float r1 = __builtin_fmaf(-k.d, q1, n);
-    return __builtin_fmaf(r1, k.y, q1);
+    return __builtin_fmaf(r0, k.y, q0);
 }
 PFX_DEV float fdiv_fast(float n, float d) { return rdiv_apply(rdiv_prepare(d), n); }
+
+// x clamped to [0, 1] for an x that is never NaN where the result is used: folds into the `clamp` output modifier of the
+// instruction producing x (no instruction of its own).  Only used where one side of the clamp is provably inactive, i.e.
+// in place of a one-sided fminf(x, 1) with x >= 0 or fmaxf(x, 0) with x <= 1.
+PFX_DEV float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 
 // Rust `v.clamp(0.0, 255.0) as u8` kept as an integer-valued float (0..255), NaN -> 0.
 PFX_DEV float quant255(float v)

@@ -20,239 +20,10 @@
 
 using namespace pfxk;
 
+#include "k_blend.h"
+
 namespace {
 
-enum : uint32_t {
-    M_NORMAL = 0, M_MULTIPLY, M_SCREEN, M_ADDITIVE, M_REFLECT, M_GLOW, M_COLOR_BURN, M_COLOR_DODGE, M_OVERLAY,
-    M_DIFFERENCE, M_NEGATION, M_LIGHTEN, M_DARKEN, M_XOR, M_OVERWRITE, M_HARD_LIGHT, M_SOFT_LIGHT, M_EXCLUSION,
-    M_SUBTRACT, M_DIVIDE, M_LINEAR_BURN, M_VIVID_LIGHT, M_LINEAR_LIGHT, M_PIN_LIGHT, M_HARD_MIX
-};
-
-// ---- correctly rounded division with a shared denominator -------------------------------------------------
-// hipcc lowers `n / d` (f32, IEEE) to: div_scale x2, rcp, 2 FMAs refining the reciprocal, mul + 4 FMAs refining the
-// quotient, div_fmas, div_fixup.  div_scale / div_fmas scaling / div_fixup only act when an operand or the quotient
-// is denormal, huge, zero-denominator or NaN.  For this kernel's operands (numerators in [0, ~1], denominators in
-// [2^-48, 1]: guaranteed by the host, which selects the FAST=false instantiation when a layer opacity is a positive
-// value below 2^-40) they are identities, so the sequence below produces the same bits with the reciprocal part
-// computed once per denominator.  tests/test_gpu_parity.py::test_fast_division_matches_ieee checks 2^28 operand
-// pairs against `/` on the device; every golden / oracle parity test runs through this path.
-// (rdiv / rdiv_prepare / rdiv_apply live in k_common.h)
-template <bool FAST> PFX_DEV float fdiv(float n, float d)
-{
-    if constexpr (FAST) return rdiv_apply(rdiv_prepare(d), n);
-    else return n / d;
-}
-
-// ---- canvas_state.rs:1425-1505 ----
-PFX_DEV float overlay_channel(float base, float top)
-{
-    return (base < 0.5f) ? 2.0f * base * top : 1.0f - 2.0f * (1.0f - base) * (1.0f - top);
-}
-template <bool F> PFX_DEV float color_burn_channel(float base, float top)
-{
-    return (top == 0.0f) ? 0.0f : __builtin_fmaxf(1.0f - fdiv<F>(1.0f - base, top), 0.0f);
-}
-template <bool F> PFX_DEV float color_dodge_channel(float base, float top)
-{
-    return (top >= 1.0f) ? 1.0f : __builtin_fminf(fdiv<F>(base, 1.0f - top), 1.0f);
-}
-template <bool F> PFX_DEV float reflect_channel(float base, float top)
-{
-    return (top >= 1.0f) ? 1.0f : __builtin_fminf(fdiv<F>(base * base, 1.0f - top), 1.0f);
-}
-PFX_DEV float soft_light_channel(float base, float top)
-{
-    if (top <= 0.5f) return base - (1.0f - 2.0f * top) * base * (1.0f - base);
-    float d = (base <= 0.25f) ? ((16.0f * base - 12.0f) * base + 4.0f) * base : __builtin_sqrtf(base);
-    return base + (2.0f * top - 1.0f) * (d - base);
-}
-template <bool F> PFX_DEV float divide_channel(float base, float top)
-{
-    return (top <= 0.0f) ? 1.0f : __builtin_fminf(fdiv<F>(base, top), 1.0f);
-}
-template <bool F> PFX_DEV float vivid_light_channel(float base, float top)
-{
-    // canvas_state.rs:1479-1497.  Both branches divide; the operands are selected first so that a lane pays for one
-    // division (the branch is per-lane data, so "both sides" is what a divergent wave would execute anyway).
-    const bool lo = (top <= 0.5f);
-    const float t2 = lo ? 2.0f * top : 2.0f * (top - 0.5f);
-    const float n = lo ? 1.0f - base : base;
-    const float d = lo ? t2 : 1.0f - t2;
-    const float q = fdiv<F>(n, d);
-    const float burn = (t2 <= 0.0f) ? 0.0f : __builtin_fmaxf(1.0f - q, 0.0f);
-    const float dodge = (t2 >= 1.0f) ? 1.0f : __builtin_fminf(q, 1.0f);
-    return lo ? burn : dodge;
-}
-PFX_DEV float pin_light_channel(float base, float top)
-{
-    return (top <= 0.5f) ? __builtin_fminf(base, 2.0f * top) : __builtin_fmaxf(base, 2.0f * (top - 0.5f));
-}
-
-template <uint32_t M, bool F>
-PFX_DEV float blend_fn(float b, float t)
-{
-    if constexpr (M == M_NORMAL) return t;
-    else if constexpr (M == M_MULTIPLY) return b * t;
-    else if constexpr (M == M_SCREEN) return 1.0f - (1.0f - b) * (1.0f - t);
-    else if constexpr (M == M_ADDITIVE) return __builtin_fminf(b + t, 1.0f);
-    else if constexpr (M == M_REFLECT) return reflect_channel<F>(b, t);
-    else if constexpr (M == M_GLOW) return reflect_channel<F>(t, b);
-    else if constexpr (M == M_COLOR_BURN) return color_burn_channel<F>(b, t);
-    else if constexpr (M == M_COLOR_DODGE) return color_dodge_channel<F>(b, t);
-    else if constexpr (M == M_OVERLAY) return overlay_channel(b, t);
-    else if constexpr (M == M_DIFFERENCE) return __builtin_fabsf(b - t);
-    else if constexpr (M == M_NEGATION) return 1.0f - __builtin_fabsf(1.0f - b - t);
-    else if constexpr (M == M_LIGHTEN) return __builtin_fmaxf(b, t);
-    else if constexpr (M == M_DARKEN) return __builtin_fminf(b, t);
-    else if constexpr (M == M_HARD_LIGHT) return overlay_channel(t, b);
-    else if constexpr (M == M_SOFT_LIGHT) return soft_light_channel(b, t);
-    else if constexpr (M == M_EXCLUSION) return b + t - 2.0f * b * t;
-    else if constexpr (M == M_SUBTRACT) return __builtin_fmaxf(b - t, 0.0f);
-    else if constexpr (M == M_DIVIDE) return divide_channel<F>(b, t);
-    else if constexpr (M == M_LINEAR_BURN) return __builtin_fmaxf(b + t - 1.0f, 0.0f);
-    else if constexpr (M == M_VIVID_LIGHT) return vivid_light_channel<F>(b, t);
-    else if constexpr (M == M_LINEAR_LIGHT) return rs_clamp(b + 2.0f * t - 1.0f, 0.0f, 1.0f);
-    else if constexpr (M == M_PIN_LIGHT) return pin_light_channel(b, t);
-    else if constexpr (M == M_HARD_MIX) return (b + t >= 1.0f) ? 1.0f : 0.0f;
-    else return t;
-}
-
-// Rust `(v * 255.0).clamp(0.0, 255.0) as u8`, kept as an integer-valued float.  A -0.0 result is harmless: div255(-0.0)
-// is +0.0 and (uint32_t)(-0.0f) is 0.
-// CLAMP=false drops the clamp where it is provably the identity: every quotient q = n/d of blend_pixel_static with
-// d > 0 satisfies 0 <= q <= 1 + 3 ulp (all 23 separable blend functions return values in [0, 1] in f32 — checked
-// function by function in DESIGN.md §flatten — so 0 <= n <= d(1 + 2 ulp)); then 0 <= q*255 < 255.001 and
-// trunc() alone yields the clamped value.  The FAST=false instantiation keeps the clamp.
-template <bool CLAMP>
-PFX_DEV float q255(float v)
-{
-    if constexpr (CLAMP) return __builtin_truncf(__builtin_fminf(__builtin_fmaxf(v * 255.0f, 0.0f), 255.0f));
-    else return __builtin_truncf(v * 255.0f);
-}
-
-// One blend_pixel_static (canvas_state.rs:1246-1422).  `acc` = base as integer-valued floats (r,g,b,a);
-// `top` = packed RGBA8 of the layer pixel (alpha already masked); `opacity_raw` = layer.opacity as stored,
-// `opc` = opacity.clamp(0,1).
-// Branch-free on purpose: per-lane early-outs diverge on real data (a wave almost never agrees), so the early
-// returns of the reference become selects at the end; the discarded lanes may hold NaN/Inf (0/0), never stored.
-// OB ("opaque base", only with F): the caller has established wave-wide that acc alpha == 255.  Then base_a = 1.0 and
-// out_a = fl(top_a + fl(1 - top_a)) is exactly 1.0 for every f32 top_a in [0, 1] (top_a >= 0.5: 1 - top_a is exact; below,
-// fl(1 - top_a) is off by at most 2^-25, and 1 +- 2^-25 rounds to 1.0, ties to even), base_c * 1.0 = base_c and n / 1.0 = n:
-// the division, the alpha products and the alpha re-quantisation drop out with identical bits.  Typical documents (an opaque
-// background under everything) run this path for every layer.  tests: test_flatten_opaque_base_path_bitexact.
-// OB == 2: in addition the whole wave's top pixels are opaque and the layer opacity is >= 1 (a photo or texture layer with a
-// blend mode at 100 %): top_a = div255(255) * 1.0 = 1.0, 1 - top_a = 0, so n = f * 1.0 + base * 0.0 = f and the pixel is
-// `(f(base, top) * 255) as u8` with alpha 255; Normal is the reference's own early-out (:1258), the top pixel itself.
-template <uint32_t M, bool F, int OB = 0>
-PFX_DEV void blend_px(float (&acc)[4], uint32_t top, float opacity_raw, float opc)
-{
-    if constexpr (OB == 2 && F && M != M_XOR && M != M_OVERWRITE) {
-        const float t0 = ubyte0(top), t1 = ubyte1(top), t2 = ubyte2(top);
-        if constexpr (M == M_NORMAL) { acc[0] = t0; acc[1] = t1; acc[2] = t2; }
-        else {
-            const float r = blend_fn<M, F>(div255(acc[0]), div255(t0));
-            const float g = blend_fn<M, F>(div255(acc[1]), div255(t1));
-            const float b = blend_fn<M, F>(div255(acc[2]), div255(t2));
-            acc[0] = q255<false>(r); acc[1] = q255<false>(g); acc[2] = q255<false>(b);
-        }
-        acc[3] = 255.0f;
-        return;
-    }
-    const uint32_t ta8 = top >> 24;
-    const bool skip = (ta8 == 0u);                                     // :1253  -> keep base
-    const float t0 = ubyte0(top), t1 = ubyte1(top), t2 = ubyte2(top), t3 = (float)ta8;
-    const float top_r = div255(t0), top_g = div255(t1), top_b = div255(t2);
-    const float top_a = div255(t3) * opc;                              // :1272
-    float o0, o1, o2, o3;
-    constexpr bool CL = !F; // the FAST instantiation runs only when every layer opacity clamps into [2^-40, 1]
-    if constexpr (M == M_OVERWRITE) {                                  // :1275 (`as u8` without clamp == with clamp)
-        o0 = q255<CL>(top_r); o1 = q255<CL>(top_g); o2 = q255<CL>(top_b); o3 = q255<CL>(top_a);
-    } else {
-        constexpr bool UNIT = OB != 0 && F && M != M_XOR; // out_a == 1.0 exactly, see above
-        const float base_r = div255(acc[0]), base_g = div255(acc[1]), base_b = div255(acc[2]);
-        const float base_a = (OB != 0 && F) ? 1.0f : div255(acc[3]);
-        const float ita = 1.0f - top_a;
-        float den, nr, ng, nb;
-        if constexpr (UNIT) {
-            const float r = blend_fn<M, F>(base_r, top_r);
-            const float g = blend_fn<M, F>(base_g, top_g);
-            const float b = blend_fn<M, F>(base_b, top_b);
-            den = 1.0f;
-            nr = r * top_a + base_r * ita;
-            ng = g * top_a + base_g * ita;
-            nb = b * top_a + base_b * ita;
-        } else if constexpr (M == M_XOR) {                                    // :1283
-            const float iba = 1.0f - base_a;
-            den = base_a * ita + top_a * iba;
-            nr = base_r * base_a * ita + top_r * top_a * iba;
-            ng = base_g * base_a * ita + top_g * top_a * iba;
-            nb = base_b * base_a * ita + top_b * top_a * iba;
-        } else {
-            const float r = blend_fn<M, F>(base_r, top_r);
-            const float g = blend_fn<M, F>(base_g, top_g);
-            const float b = blend_fn<M, F>(base_b, top_b);
-            den = top_a + base_a * ita;                                // :1407
-            nr = r * top_a + base_r * base_a * ita;                    // :1412
-            ng = g * top_a + base_g * base_a * ita;
-            nb = b * top_a + base_b * base_a * ita;
-        }
-        float qr, qg, qb;
-        if constexpr (UNIT) { qr = nr; qg = ng; qb = nb; }
-        else if constexpr (F) { const rdiv k = rdiv_prepare(den); qr = rdiv_apply(k, nr); qg = rdiv_apply(k, ng); qb = rdiv_apply(k, nb); }
-        else { qr = nr / den; qg = ng / den; qb = nb / den; }
-        o0 = q255<CL>(qr); o1 = q255<CL>(qg); o2 = q255<CL>(qb); o3 = UNIT ? 255.0f : q255<CL>(den);
-        // :1285 / :1408 `den == 0 -> (0,0,0,0)`.  With opacity > 0 (FAST precondition) a non-skipped pixel has
-        // top_a > 0, hence out_a = top_a + base_a*(1-top_a) > 0: the check can only fire for Xor (both opaque).
-        if constexpr (!F || M == M_XOR) {
-            const bool zero = (den == 0.0f);
-            o0 = zero ? 0.0f : o0; o1 = zero ? 0.0f : o1; o2 = zero ? 0.0f : o2; o3 = zero ? 0.0f : o3;
-        }
-    }
-    if constexpr (M == M_NORMAL) {
-        if (opacity_raw >= 1.0f) {                                     // uniform; :1258 opaque overwrite
-            const bool opaque = (ta8 == 255u);
-            o0 = opaque ? t0 : o0; o1 = opaque ? t1 : o1; o2 = opaque ? t2 : o2; o3 = opaque ? 255.0f : o3;
-        }
-    }
-    acc[0] = skip ? acc[0] : o0; acc[1] = skip ? acc[1] : o1; acc[2] = skip ? acc[2] : o2; acc[3] = skip ? acc[3] : o3;
-}
-
-template <uint32_t M, bool F, int PX, int OB>
-PFX_DEV void blendN(float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw, float opc)
-{
-#pragma unroll
-    for (int p = 0; p < PX; ++p) blend_px<M, F, OB>(acc[p], top[p], opacity_raw, opc);
-}
-
-template <bool F, int PX = 4, int OB = 0>
-PFX_DEV void blend4_dispatch(uint32_t mode, float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw, float opc)
-{
-    switch (mode) { // wave-uniform: one scalar branch per layer
-#define PFX_CASE(M) case M: blendN<M, F, PX, OB>(acc, top, opacity_raw, opc); break;
-        PFX_CASE(M_NORMAL) PFX_CASE(M_MULTIPLY) PFX_CASE(M_SCREEN) PFX_CASE(M_ADDITIVE) PFX_CASE(M_REFLECT)
-        PFX_CASE(M_GLOW) PFX_CASE(M_COLOR_BURN) PFX_CASE(M_COLOR_DODGE) PFX_CASE(M_OVERLAY) PFX_CASE(M_DIFFERENCE)
-        PFX_CASE(M_NEGATION) PFX_CASE(M_LIGHTEN) PFX_CASE(M_DARKEN) PFX_CASE(M_XOR) PFX_CASE(M_OVERWRITE)
-        PFX_CASE(M_HARD_LIGHT) PFX_CASE(M_SOFT_LIGHT) PFX_CASE(M_EXCLUSION) PFX_CASE(M_SUBTRACT) PFX_CASE(M_DIVIDE)
-        PFX_CASE(M_LINEAR_BURN) PFX_CASE(M_VIVID_LIGHT) PFX_CASE(M_LINEAR_LIGHT) PFX_CASE(M_PIN_LIGHT)
-        PFX_CASE(M_HARD_MIX)
-#undef PFX_CASE
-    default: blendN<M_NORMAL, F, PX, OB>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
-    }
-}
-
-// the streaming kernels' per-layer entry: picks the opaque-base specialisation when the whole wave's accumulators are opaque
-template <int PX>
-PFX_DEV void blend_layer_fast(uint32_t mode, float (&acc)[PX][4], const uint32_t (&top)[PX], float opacity_raw)
-{
-    const float opc = rs_clamp(opacity_raw, 0.0f, 1.0f);
-    bool ob = true, ot = opacity_raw >= 1.0f;
-#pragma unroll
-    for (int p = 0; p < PX; ++p) { ob = ob && (acc[p][3] == 255.0f); ot = ot && (top[p] >> 24) == 255u; }
-    if (__all(ob)) {
-        if (__all(ot)) blend4_dispatch<true, PX, 2>(mode, acc, top, opacity_raw, opc);
-        else blend4_dispatch<true, PX, 1>(mode, acc, top, opacity_raw, opc);
-    } else blend4_dispatch<true, PX, 0>(mode, acc, top, opacity_raw, opc);
-}
 
 // live layer mask: top.a = (a * (255 - conceal)) / 255, integer (canvas_state.rs:660-665)
 PFX_DEV uint32_t apply_conceal(uint32_t px, uint32_t conceal)
@@ -428,52 +199,129 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
     }
 }
 
-// Raster-only, FAST-precondition stacks whose pixel count is a multiple of PX: the streaming core without the general
-// kernel's tail/mask/adjustment handling.  PX pixels per lane (PX*4-byte loads), MINW = waves/SIMD the register
-// allocator must allow.  Variants are selected with pfx_tune("flatten_variant", v) for measurement; all produce
-// identical results (same blend_px).
-template <int PX> struct px_vec;
-template <> struct px_vec<4> { using type = uint4; };
-template <> struct px_vec<2> { using type = uint2; };
-template <> struct px_vec<1> { using type = uint32_t; };
+// ---- the streaming compositor: raster-only stacks under the FAST precondition (every document without live masks,
+// adjustment layers or a tool preview; BASELINE's 8K x 32 configuration) ----------------------------------------------------------
+//   * a wave owns PX groups of 64 consecutive pixels; lane l handles pixel 64*j + l of group j, so every memory instruction of
+//     the wave covers 256 contiguous bytes;
+//   * a layer pixel is fetched with ONE typed buffer load (buffer_load_format_xyzw through an 8_8_8_8 UNORM resource): the
+//     texture path delivers the four f32 RN(byte / 255) that blend_pixel_static starts from (k_blend.h:blend_nx), and its range
+//     check returns (0,0,0,0) — "layer pixel transparent, keep the accumulator" — past the end of the image, so there is no
+//     tail code; the result is written with range-checked dword buffer stores;
+//   * the accumulator stays in registers as RN(k / 255) for the whole stack; layer k+1's PX pixels are in flight while layer k
+//     is blended (two register sets, the loop is unrolled by two so no copies are needed);
+//   * HBM traffic is the algorithmic minimum, 4 bytes per layer-pixel in and 4 bytes per pixel out.
+typedef float pfx_v4f __attribute__((ext_vector_type(4)));
+typedef int pfx_v4i __attribute__((ext_vector_type(4)));
+__device__ pfx_v4f pfx_buffer_load_format_v4f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
+__device__ void pfx_buffer_store_i32(int data, pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
 
-template <int PX, int MINW>
-__global__ __launch_bounds__(256, MINW) void flatten_fast_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
-                                                                 size_t n_groups, uint8_t* __restrict__ dst)
+// gfx9-family buffer resource (V#), stride 0 => offsets and num_records are bytes
+enum : uint32_t {
+    PFX_RSRC_UNORM8X4 = 0xFACu | (0u << 12) | (10u << 15), // dst_sel = x,y,z,w; num_format UNORM; data_format 8_8_8_8
+    PFX_RSRC_RAW32 = 0xFACu | (7u << 12) | (4u << 15)      // num_format FLOAT, data_format 32 (untyped dword access)
+};
+PFX_DEV pfx_v4i make_rsrc(const void* base, uint32_t bytes, uint32_t word3)
 {
-    using V = typename px_vec<PX>::type;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_groups; q += (size_t)gridDim.x * blockDim.x) {
-        float acc[PX][4];
+    const uint64_t a = (uint64_t)base;
+    pfx_v4i r;
+    r.x = (int)(uint32_t)a;
+    r.y = (int)((uint32_t)(a >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = (int)word3;
+    return r;
+}
+
+template <int PX>
+PFX_DEV void stream_fetch(float (&t)[PX][4], const uint8_t* pixels, uint32_t bytes, int voff)
+{
+    const pfx_v4i rs = make_rsrc(pixels, bytes, PFX_RSRC_UNORM8X4);
 #pragma unroll
-        for (int p = 0; p < PX; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.0f;
-        pfxk_layer_desc L = layers[0];
-        V v = reinterpret_cast<const V*>(L.pixels)[q];
-        for (uint32_t li = 0; li < n_layers; ++li) {
-            pfxk_layer_desc Ln = L;
-            V vn = v;
-            if (li + 1 < n_layers) { // prefetch layer li+1 before blending layer li
-                Ln = layers[li + 1];
-                vn = reinterpret_cast<const V*>(Ln.pixels)[q];
-            }
-            uint32_t top[PX];
-            __builtin_memcpy(top, &v, sizeof top);
-            uint32_t any_a = 0;
-#pragma unroll
-            for (int p = 0; p < PX; ++p) any_a |= top[p];
-            if (__any((any_a >> 24) != 0u)) blend_layer_fast<PX>(L.mode, acc, top, L.opacity);
-            L = Ln;
-            v = vn;
-        }
-        uint32_t out[PX];
-#pragma unroll
-        for (int p = 0; p < PX; ++p) out[p] = pack_rgba(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
-        V o;
-        __builtin_memcpy(&o, out, sizeof out);
-        reinterpret_cast<V*>(dst)[q] = o;
+    for (int j = 0; j < PX; ++j) {
+        const pfx_v4f v = pfx_buffer_load_format_v4f32(rs, voff + j * 256, 0, 0);
+        t[j][0] = v.x; t[j][1] = v.y; t[j][2] = v.z; t[j][3] = v.w;
     }
 }
 
-int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant)
+template <int PX>
+PFX_DEV void stream_layer(float (&acc)[PX][4], const float (&t)[PX][4], uint32_t mode, float opacity)
+{
+    float amax = t[0][3];
+#pragma unroll
+    for (int j = 1; j < PX; ++j) amax = __builtin_fmaxf(amax, t[j][3]);
+    // a wave whose 64*PX pixels are all transparent in this layer (sparse layers of real documents; the TiledImage analogue
+    // is a missing chunk, canvas_state.rs:600) skips the blend entirely
+    if (__any(amax != 0.0f)) blend_layer_nx<PX>(mode, acc, t, opacity);
+}
+
+template <int PX, int NB, int MINW>
+__global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
+                                                                   uint32_t n_px, uint8_t* __restrict__ dst)
+{
+    // NB register sets hold the layer pixels of NB consecutive layers: while layer k is blended, layers k+1 .. k+NB-1 are in
+    // flight (the typed load lands 16 bytes of registers per 4 bytes read, so the in-flight volume a CU needs to cover HBM
+    // latency — ~32 KB — is bought with registers: PX * NB * 4 VGPRs per lane)
+    static_assert(NB == 2 || NB == 3, "two or three layer register sets");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t n_tiles = (n_px + 64u * PX - 1u) / (64u * PX);
+    const uint32_t bytes = n_px * 4u;
+    const pfx_v4i rs_dst = make_rsrc(dst, bytes, PFX_RSRC_RAW32);
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const int voff = (int)((tile * (64u * PX) + lane) * 4u);
+        float acc[PX][4], tA[PX][4], tB[PX][4], tC[NB == 3 ? PX : 1][4];
+        uint32_t mA = 0, mB = 0, mC = 0;
+        uint32_t oA = 0, oB = 0, oC = 0; // opacity bits: kept integer so the loop-carried copies stay in SGPRs
+#pragma unroll
+        for (int j = 0; j < PX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; // :573
+        // the descriptor (scalar loads) of the layer fetched NEXT is requested one stage ahead, so no fetch waits for it
+        const uint8_t* npx = layers[0].pixels;
+        uint32_t nmode = layers[0].mode;
+        uint32_t nop = __builtin_bit_cast(uint32_t, layers[0].opacity);
+        const uint32_t last = n_layers - 1u;
+#define PFX_FETCH(T, M, O, K) { M = nmode; O = nop; stream_fetch<PX>(T, npx, bytes, voff); \
+                                const uint32_t kn = ((K) + 1u < last) ? (K) + 1u : last; \
+                                npx = layers[kn].pixels; nmode = layers[kn].mode; nop = __builtin_bit_cast(uint32_t, layers[kn].opacity); }
+        PFX_FETCH(tA, mA, oA, 0u)
+        if constexpr (NB == 2) {
+            for (uint32_t li = 0;;) {
+                const bool hasB = li + 1 < n_layers;
+                if (hasB) PFX_FETCH(tB, mB, oB, li + 1)
+                stream_layer<PX>(acc, tA, mA, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oA)));
+                if (!hasB) break;
+                li += 2;
+                const bool hasA = li < n_layers;
+                if (hasA) PFX_FETCH(tA, mA, oA, li)
+                stream_layer<PX>(acc, tB, mB, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oB)));
+                if (!hasA) break;
+            }
+        } else {
+            if (1 < n_layers) PFX_FETCH(tB, mB, oB, 1u)
+            for (uint32_t li = 0;;) { // invariant at the top: layers li (A) and li+1 (B) are in flight or landed
+                if (li + 2 < n_layers) PFX_FETCH(tC, mC, oC, li + 2)
+                stream_layer<PX>(acc, tA, mA, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oA)));
+                if (li + 1 >= n_layers) break;
+                if (li + 3 < n_layers) PFX_FETCH(tA, mA, oA, li + 3)
+                stream_layer<PX>(acc, tB, mB, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oB)));
+                if (li + 2 >= n_layers) break;
+                if (li + 4 < n_layers) PFX_FETCH(tB, mB, oB, li + 4)
+                stream_layer<PX>(acc, tC, mC, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oC)));
+                li += 3;
+                if (li >= n_layers) break;
+            }
+        }
+#undef PFX_FETCH
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            // bn = RN(k / 255)  =>  bn * 255 = k (1 + e), |e| < 2^-23: adding 0.5 and truncating recovers k
+            const uint32_t px = (uint32_t)(acc[j][0] * 255.0f + 0.5f) | ((uint32_t)(acc[j][1] * 255.0f + 0.5f) << 8) |
+                                ((uint32_t)(acc[j][2] * 255.0f + 0.5f) << 16) | ((uint32_t)(acc[j][3] * 255.0f + 0.5f) << 24);
+            pfx_buffer_store_i32((int)px, rs_dst, voff + j * 256, 0, 0);
+        }
+    }
+}
+
+int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant): 0 = shipped, 1-5 = PX / occupancy variants, +10 = grid-stride launch, 9 = the general kernel
 
 // chunk activity = union over visible raster layers of "chunk has any alpha != 0" (canvas_state.rs:529-550)
 __global__ __launch_bounds__(256) void chunk_active_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
@@ -616,15 +464,23 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
     const uint32_t block = 256;
     const size_t cap = 256u * 8u * 4u; // 256 CUs x 8 blocks, x4 waves of grid-stride work granularity
     const size_t n_px = (size_t)w * h;
-    if (!general && fast_div && n_layers > 0 && (n_px & 3u) == 0 && g_flatten_variant > 0) {
-        auto grid = [&](size_t groups) { size_t b = (groups + block - 1) / block; return (uint32_t)(b > cap ? cap : b); };
-        switch (g_flatten_variant) {
-        case 1: flatten_fast_kernel<4, 1><<<grid(n_px / 4), block, 0, stream>>>(d_layers, n_layers, n_px / 4, d_dst); break;
-        case 2: flatten_fast_kernel<4, 8><<<grid(n_px / 4), block, 0, stream>>>(d_layers, n_layers, n_px / 4, d_dst); break;
-        case 3: flatten_fast_kernel<2, 1><<<grid(n_px / 2), block, 0, stream>>>(d_layers, n_layers, n_px / 2, d_dst); break;
-        case 4: flatten_fast_kernel<2, 8><<<grid(n_px / 2), block, 0, stream>>>(d_layers, n_layers, n_px / 2, d_dst); break;
-        case 5: flatten_fast_kernel<1, 8><<<grid(n_px), block, 0, stream>>>(d_layers, n_layers, n_px, d_dst); break;
-        default: flatten_fast_kernel<4, 4><<<grid(n_px / 4), block, 0, stream>>>(d_layers, n_layers, n_px / 4, d_dst); break;
+    if (!general && fast_div && n_layers > 0 && n_px < (1u << 30) && g_flatten_variant != 9) {
+        // one 64*PX-pixel tile per wave while that stays below the cap (the dispatcher balances the tail), grid-stride beyond
+        auto grid = [&](uint32_t px_per_wave) {
+            size_t tiles = (n_px + px_per_wave - 1) / px_per_wave, b = (tiles + 3) / 4;
+            const size_t lim = (g_flatten_variant >= 10) ? cap : (size_t)1 << 20;
+            return (uint32_t)(b > lim ? lim : b);
+        };
+        switch (g_flatten_variant % 10) {
+#define PFX_STREAM(PX, NB, MINW) flatten_stream_kernel<PX, NB, MINW><<<grid(64 * PX), block, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst)
+        case 1: PFX_STREAM(2, 2, 1); break;
+        case 2: PFX_STREAM(2, 3, 1); break;
+        case 3: PFX_STREAM(4, 2, 1); break;
+        case 4: PFX_STREAM(4, 3, 1); break;
+        case 5: PFX_STREAM(1, 3, 1); break;
+        case 6: PFX_STREAM(3, 3, 1); break;
+        default: PFX_STREAM(3, 3, 1); break;
+#undef PFX_STREAM
         }
         return hipGetLastError();
     }
