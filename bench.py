@@ -213,10 +213,11 @@ def main() -> int:
 
     # per-kernel launch durations from HIP events recorded on the launch stream during the timed region
     kern = {}
-    for name in ("flatten", "gauss_h", "gauss_v"):
+    for name in ("flatten", "gauss_mfma", "gauss_h", "gauss_v"):
         ms, cnt = r.timing_read(name)
-        kern[name] = (ms / max(cnt, 1), cnt)
-    alg_bytes = {"flatten": (4 * n + 4) * px_per_launch, "gauss_h": 4 * px_per_launch, "gauss_v": 4 * px_per_launch}
+        if cnt:
+            kern[name] = (ms / cnt, cnt)
+    alg_bytes = {"flatten": (4 * n + 4) * px_per_launch}
     dominant = "flatten"  # carries 132 of the 140 algorithmic bytes/px; named in DESIGN.md
     d_ms = kern[dominant][0]
     achieved = alg_bytes[dominant] / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0

@@ -22,6 +22,13 @@ using namespace pfxk;
 
 #include "k_blend.h"
 
+// LLVM buffer intrinsics hipcc has no __builtin for (declared outside the anonymous namespace: they are external symbols)
+typedef float pfx_v4f __attribute__((ext_vector_type(4)));
+typedef int pfx_v4i __attribute__((ext_vector_type(4)));
+__device__ pfx_v4f pfx_buffer_load_format_v4f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
+__device__ void pfx_buffer_store_i32(int data, pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
+
+
 namespace {
 
 
@@ -210,11 +217,6 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
 //   * the accumulator stays in registers as RN(k / 255) for the whole stack; layer k+1's PX pixels are in flight while layer k
 //     is blended (two register sets, the loop is unrolled by two so no copies are needed);
 //   * HBM traffic is the algorithmic minimum, 4 bytes per layer-pixel in and 4 bytes per pixel out.
-typedef float pfx_v4f __attribute__((ext_vector_type(4)));
-typedef int pfx_v4i __attribute__((ext_vector_type(4)));
-__device__ pfx_v4f pfx_buffer_load_format_v4f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
-__device__ void pfx_buffer_store_i32(int data, pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
-
 // gfx9-family buffer resource (V#), stride 0 => offsets and num_records are bytes
 enum : uint32_t {
     PFX_RSRC_UNORM8X4 = 0xFACu | (0u << 12) | (10u << 15), // dst_sel = x,y,z,w; num_format UNORM; data_format 8_8_8_8

@@ -18,6 +18,8 @@
 //   Both inner loops are software-pipelined: the LDS reads and the scalar weight loads of step g+1 are issued
 //   before the MACs of step g, so the wave's own MACs cover the LDS latency (occupancy is LDS-limited).
 //   Tap weights are wave-uniform: they arrive through scalar loads, no VGPR or LDS traffic.
+#include <type_traits>
+
 #include "k_common.h"
 #include "pfx_kernels.h"
 
@@ -182,7 +184,7 @@ int g_v_cfg = 0; // tuning knob (pfxk_gauss_set_v_config); 0 is the shipped conf
 template <bool EXACT>
 hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const float* wts, int radius, uint32_t w, uint32_t h)
 {
-    int cfg = g_v_cfg;
+    int cfg = g_v_cfg & 0xff;
     if (radius > 380) cfg = 2; // narrowest tile for huge radii (LDS bound)
     switch (cfg) {
     case 1: return launch_v_cfg<EXACT, 16, 64, 16>(stream, tmp, d_dst, wts, radius, w, h);
@@ -191,6 +193,234 @@ hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const
     // shipped: 8 columns x 128 rows, 256 threads.  Measured at 8K, sigma=16 (profiles/r01_tuning.md): 0.344 ms vs
     // 0.368 (8x256 rows), 0.350 (4x256), 0.446 (16x256)
     default: return launch_v_cfg<EXACT, 8, 32, 10>(stream, tmp, d_dst, wts, radius, w, h);
+    }
+}
+
+
+// ---- fused H+V Gaussian on the matrix cores (default mode, radius <= 48) -------------------------------------------------------
+// Both passes are banded-Toeplitz products  D[m][n] = sum_k A[m][k] * T[k][n],  T[k][n] = w[k - n + r]  — a genuine contraction,
+// so they run on v_mfma_f32_32x32x16_f16 (16x the f32 FMA rate) while the VALU only converts and packs:
+//   * operands are split so that every product is exact in the f32 accumulator: a u8 sample is exact in f16; a weight is
+//     scaled by a power of two S and split w*S = w1 + w2 (two f16, 22 significant bits); the f32 horizontal result h is split
+//     h = h1 + h2 the same way.  H pass: p*w1 + p*w2.  V pass: h1*w1 + (h1*w2 + h2*w1); the dropped h2*w2 is < 2^-22 of the sum.
+//     Large and small terms accumulate in separate accumulators.  The result differs from the CPU path's f32 mul/add chain by
+//     rounding noise of the same order as the FMA-contracted VALU kernels (+-1 LSB class, tests assert it).
+//   * one workgroup (8 waves) produces an R x 32 output tile: the H pass computes (R + 2*R8) rows x 32 columns straight from the
+//     RGBA8 source (each wave 8 rows x 4 channels at a time: A = 32 (channel, row) lines x 16 source columns converted in registers, T fragments
+//     resident in VGPRs for the whole kernel) and leaves them in LDS as f16 pairs, transposed so that a column's rows are
+//     contiguous; the V pass reads its A fragments from there with ds_read_b128 (A = 8 columns x 4 channels, k = source rows),
+//     rounds, packs RGBA and stages the tile in LDS for 128-byte row stores.  The f32 intermediate never touches HBM:
+//     8 algorithmic bytes per pixel are the kernel's only HBM traffic (+ halo re-reads served by L2).
+//   * accumulation order inside the MFMA is the hardware's; the contraction index is only ever paired A-slot with B-slot, so
+//     the kernel relies on nothing but the documented C/D map (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
+typedef _Float16 pfx_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pfx_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pfx_f16x2 __attribute__((ext_vector_type(2)));
+typedef float pfx_f32x16 __attribute__((ext_vector_type(16)));
+// v_cvt_pkrtz_f16_f32: two f32 -> packed f16, round toward zero (exact for the integers 0..255)
+PFX_DEV pfx_f16x2 pkrtz(float a, float b) { return __builtin_bit_cast(pfx_f16x2, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+
+constexpr int GM_COLS = 32;             // output columns per tile (one MFMA N block)
+constexpr int GM_MAXR = 48;             // largest radius (sigma <= 16)
+constexpr int GM_ROWS = 224;            // LDS rows of H results per tile: R + 2 * R8 <= 224
+constexpr int GM_YP = 232;              // row pitch (f16) of one (part, channel, column) line: 224 + 8
+constexpr int GM_PLANE = GM_COLS * GM_YP + 8; // (part, channel) plane stride in f16: +16 bytes so the 4 channels spread over slots
+constexpr int GM_OUT_PITCH = 33;        // dwords per staged output row
+constexpr int GM_MAX_R = 192;           // largest R (small radii)
+constexpr int GM_WOFF = 48;             // wsplit[GM_WOFF + t] = tap t; zeros elsewhere
+constexpr int GM_WLEN = 192;            // entries per weight part
+constexpr size_t GM_LDS = (size_t)8 * GM_PLANE * 2 + (size_t)GM_MAX_R * GM_OUT_PITCH * 4;
+
+// RGBA8 -> four u8 planes (plane pitch = plane_stride bytes): the matrix-core kernel's A fragments are 8 consecutive samples of
+// ONE channel, so it reads each source byte exactly once per tile (interleaved RGBA would be fetched by four lanes each).
+__global__ __launch_bounds__(256) void gauss_planarize_kernel(const uint32_t* __restrict__ src, uint8_t* __restrict__ planes, size_t n_px,
+                                                              size_t plane_stride)
+{
+    const size_t n4 = n_px >> 2;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[q];
+        // byte k of the four pixels -> one dword per plane
+        const uint32_t lo01 = __builtin_amdgcn_perm(v.y, v.x, 0x05010400u), hi01 = __builtin_amdgcn_perm(v.y, v.x, 0x07030602u);
+        const uint32_t lo23 = __builtin_amdgcn_perm(v.w, v.z, 0x05010400u), hi23 = __builtin_amdgcn_perm(v.w, v.z, 0x07030602u);
+        // lo01 = [g1 g0 r1 r0] (bytes 3..0), hi01 = [a1 a0 b1 b0]
+        reinterpret_cast<uint32_t*>(planes)[q] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);                        // r3 r2 r1 r0
+        reinterpret_cast<uint32_t*>(planes + plane_stride)[q] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);          // g
+        reinterpret_cast<uint32_t*>(planes + 2 * plane_stride)[q] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);      // b
+        reinterpret_cast<uint32_t*>(planes + 3 * plane_stride)[q] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);      // a
+    }
+    for (size_t p = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_px; p += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t v = src[p];
+        planes[p] = (uint8_t)v; planes[plane_stride + p] = (uint8_t)(v >> 8);
+        planes[2 * plane_stride + p] = (uint8_t)(v >> 16); planes[3 * plane_stride + p] = (uint8_t)(v >> 24);
+    }
+}
+
+// FAST: every tile of the launch reads its source window with 16-byte loads (window inside the image, 16-byte aligned rows);
+// otherwise samples are fetched one by one with clamp-to-edge.  A launch covers the tile columns [col_a, col_a + n_a) followed by
+// [col_b, col_b + tiles_x - n_a): the host sends the interior columns to the FAST instantiation and the border columns to the other.
+template <bool FAST, int NKB>
+__global__ __launch_bounds__(512, 1) void gauss_mfma_kernel(const uint8_t* __restrict__ planes, size_t plane_stride, uint8_t* __restrict__ dst,
+                                                            const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8,
+                                                            int R, float inv_scale2, float bias_c, int tiles_x, int n_tiles, int col_a, int n_a, int col_b, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
+    _Float16* HR = reinterpret_cast<_Float16*>(gm_lds);                           // [part][c][x][GM_YP]
+    uint32_t* OUT = reinterpret_cast<uint32_t*>(gm_lds + (size_t)8 * GM_PLANE * 2); // [R][GM_OUT_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hh = lane >> 5;
+
+    // Toeplitz fragments.  The 16 NKB samples of a window are dealt to the two lane halves as two contiguous runs (half hh owns
+    // samples [8 NKB hh, 8 NKB (hh + 1)), K block kb takes 8 of each run): an A lane then reads ONE contiguous run per slot
+    // (whole cache lines, 16-byte loads), and since the MFMA only ever pairs A slot (hh, j) with B slot (hh, j) any such dealing is
+    // valid as long as T follows it:  B_kb[(hh, j)][n] = tap(8 NKB hh + 8 kb + j - n - (R8 - r)).  Resident for the whole kernel.
+    pfx_f16x8 B1[NKB], B2[NKB];
+    {
+        const _Float16* w1 = reinterpret_cast<const _Float16*>(wsplit) + GM_WOFF;
+        const _Float16* w2 = w1 + GM_WLEN;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int t0 = 8 * NKB * hh + 8 * kb - i - (R8 - r); // in [-46, 127]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { B1[kb][j] = w1[t0 + j]; B2[kb][j] = w2[t0 + j]; }
+        }
+    }
+    const int nrows = R + 2 * R8;
+    const int nnb = R >> 5;
+
+    // H-pass work of a wave: slots k = 0..3 of every tile, slot k = unit u = wave + 8k = 8 rows x 4 channels (A row m = c * 8 + row).
+    // raw[k][kb] holds the 8 source samples of K block kb of slot k of the CURRENT tile; as soon as a block is converted to its
+    // f16 fragment the same registers are refilled with the same block of the NEXT tile, so every global load has a whole tile of
+    // work to land in — HBM latency is not exposed although only 2 waves share a SIMD.
+    // No branches in this pass (the waitcnt bookkeeping stays exact): a slot past the tile's last unit recomputes the last unit
+    // (identical values to identical LDS addresses), the refill past the last tile re-reads the last tile.
+    uint32_t raw[4][NKB][2]; // [slot][K block]: slot k of the NEXT tile is requested once slot k of this tile is converted
+    const int n_units = nrows >> 3; // H units of 8 rows x 4 channels (<= 28)
+    struct hsrc { const uint8_t* line; int xs; };
+    auto tile_x0 = [&](int tile) { const int ci = tile % tiles_x; return (ci < n_a ? col_a + ci : col_b + (ci - n_a)) * GM_COLS; };
+    auto locate = [&](int tile, int k) -> hsrc {
+        hsrc s;
+        const int u = min(wave + 8 * k, n_units - 1), tl = min(tile, n_tiles - 1);
+        const int x0 = tile_x0(tl), y0 = (tl / tiles_x) * R;
+        s.xs = x0 - R8 + 8 * NKB * hh;                                               // first sample of this lane's run
+        const int ysrc = min(max(y0 - R8 + u * 8 + (i & 7), 0), h - 1);              // clamp-to-edge (filters.rs:296-298)
+        s.line = planes + (size_t)(i >> 3) * plane_stride + (size_t)ysrc * w;       // A row m = i = channel * 8 + row
+        return s;
+    };
+    auto fetch = [&](const hsrc& s, int k) { // the 8 NKB consecutive samples of this lane's run
+        if constexpr (FAST) {
+#pragma unroll
+            for (int q = 0; q < NKB / 2; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s.line + s.xs + 16 * q);
+                raw[k][2 * q][0] = v.x; raw[k][2 * q][1] = v.y; raw[k][2 * q + 1][0] = v.z; raw[k][2 * q + 1][1] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                uint32_t b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = s.line[min(max(s.xs + 8 * kb + j, 0), w - 1)]; // clamp-to-edge (filters.rs:268-270)
+                raw[k][kb][0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                raw[k][kb][1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+            }
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        fetch(locate(blockIdx.x, k), k);
+    }
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int x0 = tile_x0(tile), y0 = (tile / tiles_x) * R;
+
+        // ---- H pass ----
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dbg & 2) continue;
+            const int u = min(wave + 8 * k, n_units - 1);
+            // u8 -> f16 without arithmetic: the half with bit pattern 0x6400 | b is exactly 1024 + b, so one v_perm_b32 per two
+            // samples builds the fragment; the constant 1024 * sum(T[.][n]) it adds to every output is the accumulator's start value
+            pfx_f16x8 fr[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const uint32_t d0 = raw[k][kb][0], d1 = raw[k][kb][1];
+                uint32_t q[4];
+                q[0] = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00050004u); // [0x64 b1 0x64 b0]
+                q[1] = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00070006u); // [0x64 b3 0x64 b2]
+                q[2] = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00050004u);
+                q[3] = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00070006u);
+                fr[kb] = __builtin_bit_cast(pfx_f16x8, q);
+            }
+            __builtin_amdgcn_sched_barrier(0); // keep the refill HERE (the scheduler would sink it next to its use, one tile later)
+            if (!(dbg & 1)) fetch(locate(tile + (int)gridDim.x, k), k);
+            __builtin_amdgcn_sched_barrier(0);
+            pfx_f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = -bias_c;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B1[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], acc, 0, 0, 0);
+            }
+            // D[m][x]: lane holds x = i; reg q -> m = (q & 3) + 8 (q >> 2) + 4 hh = c * 8 + row_local with c = q >> 2,
+            // row_local = (q & 3) + 4 hh: regs 4c .. 4c+3 are four consecutive rows of channel c.  The value is S * h (S = the
+            // weights' power-of-two scale, S * 255 < 65504); it is stored as hi + lo, hi = the top 11 significant bits.
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                pfx_f16x4 h1, h2;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float va = acc[4 * g + e], vb = acc[4 * g + e + 1];
+                    const pfx_f16x2 hi = pkrtz(va, vb);
+                    const pfx_f16x2 lo = pkrtz(va - (float)hi[0], vb - (float)hi[1]);
+                    h1[e] = hi[0]; h1[e + 1] = hi[1]; h2[e] = lo[0]; h2[e + 1] = lo[1];
+                }
+                *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(0 * 4 + g) * GM_PLANE + i * GM_YP + u * 8 + 4 * hh) = h1;
+                *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * GM_PLANE + i * GM_YP + u * 8 + 4 * hh) = h2;
+            }
+        }
+        __syncthreads();
+
+        // ---- V pass: unit = (8-column block xb, 32-row output block nb); A row m = i = xl * 4 + c ----
+        for (int u = wave; u < 4 * nnb && !(dbg & 4); u += 8) {
+            const int xb = u & 3, nb = u >> 2;
+            const int xl = i >> 2, c = i & 3;
+            const _Float16* a1p = HR + (size_t)(0 * 4 + c) * GM_PLANE + (8 * xb + xl) * GM_YP + 32 * nb + 8 * NKB * hh;
+            const _Float16* a2p = HR + (size_t)(1 * 4 + c) * GM_PLANE + (8 * xb + xl) * GM_YP + 32 * nb + 8 * NKB * hh;
+            pfx_f32x16 accA, accB;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { accA[q] = 0.0f; accB[q] = 0.0f; }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const pfx_f16x8 a1 = *reinterpret_cast<const pfx_f16x8*>(a1p + 8 * kb);
+                const pfx_f16x8 a2 = *reinterpret_cast<const pfx_f16x8*>(a2p + 8 * kb);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, B1[kb], accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, B2[kb], accB, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, B1[kb], accB, 0, 0, 0);
+            }
+            // D[m][n]: n = output row i of block nb; reg q -> m = (q & 3) + 8 (q >> 2) + 4 hh = xl' * 4 + c' with c' = q & 3,
+            // xl' = 2 (q >> 2) + hh: regs 4g .. 4g+3 are the RGBA of pixel (8 xb + 2 g + hh, 32 nb + i)
+            uint32_t* orow = OUT + (32 * nb + i) * GM_OUT_PITCH + 8 * xb + hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // `.round().clamp(0, 255) as u8` (filters.rs:308-311) of a non-negative sum: trunc(v + 0.5) with the final scale
+                // fused in; v_cvt_u32_f32 saturates negatives (rounding noise around 0) to 0
+                uint32_t px[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    px[e] = min((uint32_t)__builtin_fmaf(accA[4 * g + e] + accB[4 * g + e], inv_scale2, 0.5f), 255u);
+                orow[2 * g] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+            }
+        }
+        __syncthreads();
+
+        // ---- store: R rows x 32 pixels, 128 contiguous bytes per row ----
+        for (int idx = tid; idx < R * GM_COLS && !(dbg & 8); idx += 512) {
+            const int rr = idx >> 5, cc = idx & 31;
+            if (y0 + rr < h && x0 + cc < w)
+                reinterpret_cast<uint32_t*>(dst)[(size_t)(y0 + rr) * w + x0 + cc] = OUT[rr * GM_OUT_PITCH + cc];
+        }
+        // the next tile's H pass writes HR (not OUT); OUT is rewritten only after the next tile's first barrier
     }
 }
 
@@ -217,4 +447,58 @@ extern "C" hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8
     if (w == 0 || h == 0) return hipSuccess;
     return exact ? launch_v<true>(stream, reinterpret_cast<const float4*>(d_tmp), d_dst, d_wts_tap0, radius, w, h)
                  : launch_v<false>(stream, reinterpret_cast<const float4*>(d_tmp), d_dst, d_wts_tap0, radius, w, h);
+}
+
+// fused matrix-core Gaussian (default mode): d_wsplit = 2 x GM_WLEN f16 (pfxk_gauss_mfma_weights layout)
+extern "C" int pfxk_gauss_mfma_max_radius(void) { return GM_MAXR; }
+extern "C" int pfxk_gauss_mfma_wlen(void) { return GM_WLEN; }
+extern "C" int pfxk_gauss_mfma_woff(void) { return GM_WOFF; }
+extern "C" size_t pfxk_gauss_mfma_scratch_bytes(uint32_t w, uint32_t h) { return 4 * ((((size_t)w * h) + 255) & ~(size_t)255); }
+extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, uint8_t* d_planes, const uint16_t* d_wsplit,
+                                      int radius, float inv_scale2, float bias_c, uint32_t w, uint32_t h, int n_cus)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    if (radius < 1 || radius > GM_MAXR) return hipErrorInvalidValue;
+    const int R8 = (radius + 15) & ~15;                    // window start x0 - R8: 16-byte aligned runs
+    const int nkb = (GM_COLS + R8 + radius + 15) / 16;      // 4, 6 or 8
+    int R = (GM_ROWS - 2 * R8) & ~31;
+    if (R > GM_MAX_R) R = GM_MAX_R;
+    const int tiles_x = ((int)w + GM_COLS - 1) / GM_COLS, tiles_y = ((int)h + R - 1) / R;
+    // interior tile columns: source window [x0 - R8, x0 - R8 + 16 nkb) inside the image, rows 16-byte aligned
+    const size_t n_px = (size_t)w * h, plane_stride = (n_px + 255) & ~(size_t)255;
+    {
+        size_t blocks = (n_px / 4 + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        if (blocks == 0) blocks = 1;
+        gauss_planarize_kernel<<<(uint32_t)blocks, 256, 0, stream>>>(reinterpret_cast<const uint32_t*>(d_src), d_planes, n_px, plane_stride);
+    }
+    const bool aligned = ((uintptr_t)d_planes & 15u) == 0 && (w & 15u) == 0; // 16-byte fragment loads
+    int c_lo = (R8 + GM_COLS - 1) / GM_COLS;                             // first column with x0 - R8 >= 0
+    int c_hi = ((int)w - 16 * nkb + R8) / GM_COLS + 1;                   // one past the last column with x0 - R8 + 16 nkb <= w
+    if (!aligned || (int)w - 16 * nkb + R8 < 0 || c_hi <= c_lo) { c_lo = 0; c_hi = 0; }
+    if (c_hi > tiles_x) c_hi = tiles_x;
+    const int n_int = c_hi - c_lo, n_brd = tiles_x - n_int;
+    hipError_t err = hipSuccess;
+    auto launch = [&](auto fast, auto nkb_c) {
+        constexpr bool F = decltype(fast)::value;
+        constexpr int NK = decltype(nkb_c)::value;
+        const int cols = F ? n_int : n_brd;
+        if (cols <= 0) return;
+        err = hipFuncSetAttribute((const void*)gauss_mfma_kernel<F, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM_LDS);
+        if (err) return;
+        const int n_tiles = cols * tiles_y, grid = n_tiles < n_cus ? n_tiles : n_cus; // persistent: one workgroup per CU (LDS-bound)
+        if (F) gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, c_lo, cols, 0, g_v_cfg >> 8);
+        else   gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, 0, c_lo, c_hi, g_v_cfg >> 8);
+    };
+    auto both = [&](auto nkb_c) {
+        launch(std::true_type{}, nkb_c);
+        if (!err) launch(std::false_type{}, nkb_c);
+    };
+    switch (nkb) { // = R8 / 8 + 2
+    case 4: both(std::integral_constant<int, 4>{}); break;
+    case 6: both(std::integral_constant<int, 6>{}); break;
+    default: both(std::integral_constant<int, 8>{}); break;
+    }
+    if (err) return err;
+    return hipGetLastError();
 }

@@ -256,15 +256,43 @@ int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void*
 int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, void* tmp_dev)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_gaussian_blur_dev"));
-    std::vector<float> k;
-    const int radius = pfx_host_gaussian_kernel(sigma, k);
+    // radius first: a huge sigma must be refused before a tap array of that size is built (the C ABI must not throw)
+    const int radius = pfx_host_gaussian_radius(sigma);
     if (radius > pfxk_gauss_max_radius())
         return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "gaussian radius %d beyond the device tile limit %d", radius, pfxk_gauss_max_radius());
+    uint32_t sigma_bits; std::memcpy(&sigma_bits, &sigma, 4);
+    if (!ctx->exact && radius >= 1 && radius <= pfxk_gauss_mfma_max_radius() && ((uintptr_t)src_dev & 15u) == 0) {
+        // default mode: fused H+V on the matrix cores, no f32 intermediate in HBM (k_gauss.hip:gauss_mfma_kernel)
+        if (ctx->wsplit_sigma_bits != sigma_bits) {
+            std::vector<float> k;
+            pfx_host_gaussian_kernel(sigma, k);
+            std::vector<uint16_t> ws;
+            ctx->wsplit_inv_scale = pfx_host_gaussian_split_f16(k, pfxk_gauss_mfma_wlen(), pfxk_gauss_mfma_woff(), ws, &ctx->wsplit_bias);
+            PFX_TRY(pfx_reserve(ctx, ctx->d_wsplit, ws.size() * sizeof(uint16_t)));
+            PFX_TRY(pfx_h2d(ctx, ctx->d_wsplit.p, ws.data(), ws.size() * sizeof(uint16_t)));
+            ctx->wsplit_sigma_bits = sigma_bits;
+        }
+        // scratch: the source as four u8 planes (4 bytes / pixel); a caller-provided f32 intermediate buffer (16 bytes / pixel) is big enough
+        void* planes = tmp_dev;
+        if (!planes || ((uintptr_t)planes & 255u) != 0 || pfxk_gauss_mfma_scratch_bytes(w, h) > (size_t)w * h * 16) {
+            PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, pfxk_gauss_mfma_scratch_bytes(w, h)));
+            planes = ctx->st_tmp.p;
+        }
+        pfx_timer t(ctx, "gauss_mfma");
+        PFX_HIP(ctx, pfxk_gauss_mfma(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (uint8_t*)planes, (const uint16_t*)ctx->d_wsplit.p,
+                                     radius, ctx->wsplit_inv_scale, ctx->wsplit_bias, w, h, ctx->n_cus > 0 ? ctx->n_cus : 256));
+        return PFX_OK;
+    }
     const int pad = pfxk_gauss_weight_pad(); // zero taps on both sides: the kernels' register blocking reads past the ends
-    std::vector<float> padded(k.size() + 2 * (size_t)pad, 0.0f);
-    std::copy(k.begin(), k.end(), padded.begin() + pad);
-    PFX_TRY(pfx_reserve(ctx, ctx->d_wts, padded.size() * sizeof(float)));
-    PFX_TRY(pfx_h2d(ctx, ctx->d_wts.p, padded.data(), padded.size() * sizeof(float)));
+    if (ctx->wts_sigma_bits != sigma_bits) {
+        std::vector<float> k;
+        pfx_host_gaussian_kernel(sigma, k);
+        std::vector<float> padded(k.size() + 2 * (size_t)pad, 0.0f);
+        std::copy(k.begin(), k.end(), padded.begin() + pad);
+        PFX_TRY(pfx_reserve(ctx, ctx->d_wts, padded.size() * sizeof(float)));
+        PFX_TRY(pfx_h2d(ctx, ctx->d_wts.p, padded.data(), padded.size() * sizeof(float)));
+        ctx->wts_sigma_bits = sigma_bits;
+    }
     if (!tmp_dev) {
         PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 16));
         tmp_dev = ctx->st_tmp.p;

@@ -2,7 +2,9 @@
 // tap weights, LUTs, scalar gains, displacement-brush scatter, stroke point lists.  They use glibc's
 // expf/powf/sqrtf, which is what Rust's f32::exp/powf/sqrt call on Linux, so the device kernels receive
 // bit-identical constants.  Compiled with -ffp-contract=off: every f32 operation rounds once, as in Rust.
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <cstdint>
 #include <vector>
 
@@ -33,6 +35,68 @@ inline int32_t f32_as_i32(float v)
 inline uint8_t round_u8(float v) { return f32_as_u8(pfx_clampf(roundf(v), 0.0f, 255.0f)); }
 
 } // namespace
+
+int pfx_host_gaussian_radius(float sigma)
+{
+    const uint32_t radius = f32_as_u32(ceilf(sigma * 3.0f));
+    return radius > 0x7fffffffu ? 0x7fffffff : (int)radius;
+}
+
+namespace {
+// f32 -> IEEE binary16, round to nearest even (values here are finite, non-negative or tiny residuals of either sign)
+uint16_t f32_to_f16_rn(float f)
+{
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | 0x7bffu); // >= 65536: clamp to the largest finite value (never reached here)
+    if (x < 0x38800000u) { // below 2^-14: subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign; // < 2^-25 rounds to zero
+        const int e = (int)(x >> 23);
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e; // 14..24
+        uint32_t q = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (q & 1u))) ++q;
+        return (uint16_t)(sign | q);
+    }
+    uint32_t q = (x - 0x38000000u) >> 13; // rebias exponent 127 -> 15, keep 10 mantissa bits
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (q & 1u))) ++q;
+    return (uint16_t)(sign | q);
+}
+float f16_to_f32(uint16_t hv)
+{
+    const uint32_t sign = (uint32_t)(hv & 0x8000u) << 16, e = (hv >> 10) & 31u, m = hv & 0x3ffu;
+    float r;
+    if (e == 0) r = std::ldexp((float)m, -24);
+    else r = std::ldexp((float)(m | 0x400u), (int)e - 25);
+    uint32_t b; std::memcpy(&b, &r, 4); b |= sign; std::memcpy(&r, &b, 4);
+    return r;
+}
+} // namespace
+
+// The matrix-core Gaussian (k_gauss.hip:gauss_mfma_kernel) multiplies f16 operands with exact f32 products: each weight is
+// scaled by S = 256 (the largest power of two for which S * 255, the scaled horizontal result, stays below the largest f16;
+// weights are < 1, so w * S is in range too) and split w * S = w1 + w2, two f16: 22 significant bits, or an absolute 2^-25 where
+// w2 is subnormal.  Returns 1 / S^2 (the two passes' scales, applied once at the end); *bias = 1024 * sum(w1 + w2), the constant
+// the kernel's 0x6400 | byte sample encoding adds to every horizontal sum.
+float pfx_host_gaussian_split_f16(const std::vector<float>& k, int wlen, int woff, std::vector<uint16_t>& out, float* bias)
+{
+    const int s = 8;
+    out.assign((size_t)2 * wlen, 0);
+    double sum = 0.0;
+    for (size_t t = 0; t < k.size() && (int)t + woff < wlen; ++t) {
+        const float ws = std::ldexp(k[t], s);
+        const uint16_t h1 = f32_to_f16_rn(ws);
+        const uint16_t h2 = f32_to_f16_rn(ws - f16_to_f32(h1));
+        out[(size_t)woff + t] = h1;
+        out[(size_t)wlen + woff + t] = h2;
+        sum += (double)f16_to_f32(h1) + (double)f16_to_f32(h2);
+    }
+    if (bias) *bias = (float)(1024.0 * sum);
+    return std::ldexp(1.0f, -2 * s);
+}
 
 // ref: build_gaussian_kernel, src/ops/filters.rs:214-234
 int pfx_host_gaussian_kernel(float sigma, std::vector<float>& out)

@@ -44,6 +44,11 @@ struct pfx_ctx {
     std::map<uint32_t, pfx_layer_state> layers;
     bool timing = false;
     std::vector<pfx_timing_rec> timings;
+    int n_cus = 0;                  // multiProcessorCount of `device` (persistent-kernel grids)
+    // Gaussian tap weights currently resident in d_wts / d_wsplit (re-uploaded only when sigma changes)
+    uint32_t wts_sigma_bits = 0xffffffffu, wsplit_sigma_bits = 0xffffffffu;
+    float wsplit_inv_scale = 1.0f, wsplit_bias = 0.0f;
+    pfx_devbuf d_wsplit;
 };
 
 // ---- error plumbing ----
@@ -94,6 +99,9 @@ int pfx_int_script_run_dev(pfx_ctx* ctx, const char* source, uint32_t* w, uint32
 int pfx_int_project_run_script(pfx_ctx* ctx, pfx_project* p, const char* source, pfx_script_result* result, std::vector<std::string>* console);
 
 // host-side restatements that the reference also runs on the host (pfx_host_math.cpp)
+int  pfx_host_gaussian_radius(float sigma);                            // ceil(3 sigma) as the reference casts it
 int  pfx_host_gaussian_kernel(float sigma, std::vector<float>& out);  // ref: src/ops/filters.rs:214-234
+// w * 2^s = w1 + w2 as two f16 arrays (pfxk_gauss_mfma layout); returns 2^-2s, *bias = 1024 * sum(w1 + w2)
+float pfx_host_gaussian_split_f16(const std::vector<float>& k, int wlen, int woff, std::vector<uint16_t>& out, float* bias);
 float pfx_host_bc_factor(float contrast);                             // ref: src/ops/adjustments.rs:273
 float pfx_host_exposure_gain(float ev);                               // ref: src/ops/adjustments.rs:353

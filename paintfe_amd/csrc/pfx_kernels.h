@@ -58,6 +58,12 @@ int        pfxk_gauss_weight_pad(void);
 void       pfxk_gauss_set_v_config(int cfg); // tuning knob, 0 = shipped
 hipError_t pfxk_gauss_h(hipStream_t stream, const uint8_t* d_src, float* d_tmp, const float* d_wts_tap0, int radius,
                         uint32_t w, uint32_t h, int exact);
+int        pfxk_gauss_mfma_max_radius(void);
+int        pfxk_gauss_mfma_wlen(void);
+int        pfxk_gauss_mfma_woff(void);
+size_t     pfxk_gauss_mfma_scratch_bytes(uint32_t w, uint32_t h); // u8 planes of the source
+hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, uint8_t* d_planes, const uint16_t* d_wsplit,
+                           int radius, float inv_scale2, float bias_c, uint32_t w, uint32_t h, int n_cus);
 hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8_t* d_dst, const float* d_wts_tap0, int radius,
                         uint32_t w, uint32_t h, int exact);
 
