@@ -357,6 +357,10 @@ int pfx_flatten_preview_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, con
 /* `tmp_dev` = w*h*16 bytes of scratch for the f32 horizontal pass (ref: filters.rs:255 buf_h); NULL = context scratch */
 int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma,
                           void* tmp_dev);
+/* the same on a BAND of a taller image (rows [first_row, first_row + h) of it, halo rows included): results equal, bit for bit,
+ * the rows a whole-image call produces wherever the band holds the full +-ceil(3 sigma) neighbourhood (row-band sharding) */
+int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma,
+                               void* tmp_dev, uint32_t first_row);
 int pfx_box_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius,
                      const void* mask_dev, void* tmp_dev /* w*h*4 or NULL */);
 int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius,
@@ -571,6 +575,38 @@ int      pfx_project_run_script(pfx_ctx* ctx, pfx_project* p, const char* source
 #define PFX_NO_CHUNK 0xffffffffu
 int pfx_tiled_import_dev(pfx_ctx* ctx, const void* packed_dev, const uint32_t* slot_host, uint32_t w, uint32_t h, void* flat_dev);
 int pfx_tiled_export_dev(pfx_ctx* ctx, const void* flat_dev, uint32_t w, uint32_t h, const uint32_t* slot_host, void* packed_dev);
+
+/* ================= multi-GPU: one document across the GPUs of a node =================
+ * The reference has no multi-device layer.  Its unit of independence is the 64x64 TiledImage chunk: the compositor is
+ * `populated_chunks.par_iter()` (ref: src/canvas/canvas_state.rs:565), filters are row-parallel (ref: src/ops/filters.rs:258-313),
+ * and one level up the CLI loops over independent files (ref: src/cli.rs:159-216).  A pfx_group maps that onto N HIP devices driven
+ * by ONE process: a document is cut into bands of whole chunk rows, member k keeps its band of every layer resident, flatten needs
+ * no communication, the Gaussian pulls ceil(3 sigma) rows of the flattened u8 neighbours' bands over xGMI (peer-to-peer copies
+ * ordered by events), and an optional all-gather leaves the whole result on every member.  All work is asynchronous on the
+ * members' streams.  Results are bit-identical to the single-GPU calls on the whole document. */
+typedef struct pfx_group pfx_group;
+/* rows [y0, y1) of `rank`'s band of an h-row image cut for `world` members: whole chunk rows, remainder to the first members */
+void        pfx_band_rows(uint32_t h, uint32_t world, uint32_t rank, uint32_t* y0, uint32_t* y1);
+/* one context per entry of `devices` (the same device may appear more than once: a 1-GPU box can exercise the whole path) */
+int         pfx_group_create(const int* devices, uint32_t n, pfx_group** out);
+void        pfx_group_destroy(pfx_group* g);
+uint32_t    pfx_group_size(const pfx_group* g);
+pfx_ctx*    pfx_group_ctx(pfx_group* g, uint32_t rank);
+const char* pfx_group_last_error(const pfx_group* g);   /* never NULL */
+/* allocate the members' bands for a w x h document of n_layers raster layers */
+int         pfx_group_set_document(pfx_group* g, uint32_t w, uint32_t h, uint32_t n_layers);
+int         pfx_group_band(const pfx_group* g, uint32_t rank, uint32_t* y0, uint32_t* y1);
+/* scatter one full-size host layer (w*h*4) to the members' bands; blocking */
+int         pfx_group_upload_layer(pfx_group* g, uint32_t index, const uint8_t* rgba_host);
+/* device pointer of member `rank`'s band of layer `index` ((y1-y0)*w*4 bytes), for producers that already live on the device */
+void*       pfx_group_layer_band_dev(pfx_group* g, uint32_t rank, uint32_t index);
+/* CanvasState::composite() of the document followed by parallel_gaussian_blur(sigma) (sigma <= 0: flatten only).
+ * layers[k].layer_idx indexes the document's layers.  all_gather != 0: afterwards every member holds the whole result. */
+int         pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, float sigma, int all_gather);
+int         pfx_group_synchronize(pfx_group* g);
+void*       pfx_group_result_band_dev(pfx_group* g, uint32_t rank);  /* rows [y0, y1) of the last result on member `rank` */
+void*       pfx_group_gathered_dev(pfx_group* g, uint32_t rank);     /* w*h*4 on member `rank` after an all_gather call */
+int         pfx_group_download(pfx_group* g, uint8_t* dst_host);     /* concatenated bands -> host w*h*4; blocking */
 
 #ifdef __cplusplus
 }

@@ -223,6 +223,12 @@ static void apply_preview(uint8_t top[4], const uint8_t pp[4], const pfxo_previe
     }
 }
 
+/* Reference-faithful tail (canvas_state.rs:565-695): the rayon closure returns each chunk's pixels, `.collect()` gathers them and
+ * ONE thread then writes them back with a put_pixel per pixel.  0 (default) = write-back inside the parallel loop (the fair,
+ * fully parallel variant the parity tests use: same bytes), 1 = collect + serial write-back, for bench.py's `cpu_baseline.faithful`. */
+static int g_serial_writeback = 0;
+void pfxo_set_serial_writeback(int on) { g_serial_writeback = on; }
+
 /* canvas_state.rs:505-698 with viewport=None */
 void pfxo_composite_preview(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t h, const pfxo_preview* pv, uint8_t* dst, int threads)
 {
@@ -249,6 +255,7 @@ void pfxo_composite_preview(const pfxo_layer* layers, int n_layers, uint32_t w, 
         for (size_t i = 0; i < n_chunks; ++i) active[i] |= (uint8_t)(pv_pop[i] != 0);
     }
 
+    uint8_t* collected = g_serial_writeback ? (uint8_t*)malloc(n_chunks * (size_t)PFXO_CHUNK * PFXO_CHUNK * 4) : NULL; /* chunk_results, :565-684 */
     o_set_threads(threads);
 #pragma omp parallel for schedule(dynamic, 1)
     for (long ci = 0; ci < (long)n_chunks; ++ci) { /* :565 par_iter over active chunks */
@@ -293,8 +300,24 @@ void pfxo_composite_preview(const pfxo_layer* layers, int n_layers, uint32_t w, 
                 }
             }
         }
+        if (collected) { memcpy(collected + (size_t)ci * sizeof acc, acc, sizeof acc); continue; }
         for (uint32_t ly = 0; ly < ch; ++ly) /* :686-695 (parallel here; the reference's tail is serial) */
             memcpy(&dst[((size_t)(by + ly) * w + bx) * 4], &acc[(size_t)ly * cw * 4], (size_t)cw * 4);
+    }
+    if (collected) { /* :686-695: serial, one put_pixel per pixel */
+        for (size_t ci = 0; ci < n_chunks; ++ci) {
+            if (!active[ci]) continue;
+            const uint32_t cx = (uint32_t)(ci % cxn), cy = (uint32_t)(ci / cxn), bx = cx * PFXO_CHUNK, by = cy * PFXO_CHUNK;
+            const uint32_t cw = (w - bx < PFXO_CHUNK) ? w - bx : PFXO_CHUNK, ch = (h - by < PFXO_CHUNK) ? h - by : PFXO_CHUNK;
+            const uint8_t* px = collected + ci * (size_t)PFXO_CHUNK * PFXO_CHUNK * 4;
+            for (uint32_t ly = 0; ly < ch; ++ly)
+                for (uint32_t lx = 0; lx < cw; ++lx) {
+                    uint8_t* d = &dst[((size_t)(by + ly) * w + bx + lx) * 4];
+                    const uint8_t* q = &px[((size_t)ly * cw + lx) * 4];
+                    d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3];
+                }
+        }
+        free(collected);
     }
 
     for (int li = 0; li < n_layers; ++li) free(pop[li]);

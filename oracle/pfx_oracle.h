@@ -72,6 +72,8 @@ typedef struct pfxo_preview {
 } pfxo_preview;
 void pfxo_composite_preview(const pfxo_layer* layers, int n_layers, uint32_t w, uint32_t h, const pfxo_preview* preview, uint8_t* dst, int threads);
 /* dense flavour used by the benchmark baseline: n layers stored back to back (layer stride w*h*4) */
+/* 1 = the reference's collect + single-threaded put_pixel write-back (canvas_state.rs:686-695); 0 = parallel write-back */
+void pfxo_set_serial_writeback(int on);
 void pfxo_flatten_stack(const uint8_t* stack, int n_layers, const uint8_t* modes, const float* opacities,
                         uint32_t w, uint32_t h, uint8_t* dst, int threads);
 

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void gauss_planarize_kernel(const uint32_t* __
 template <bool FAST, int NKB>
 __global__ __launch_bounds__(512, 1) void gauss_mfma_kernel(const uint8_t* __restrict__ planes, size_t plane_stride, uint8_t* __restrict__ dst,
                                                             const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8,
-                                                            int R, float inv_scale2, float bias_c, int tiles_x, int n_tiles, int col_a, int n_a, int col_b, int dbg)
+                                                            int R, float inv_scale2, float bias_c, int tiles_x, int n_tiles, int col_a, int n_a, int col_b, int y_phase, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
     _Float16* HR = reinterpret_cast<_Float16*>(gm_lds);                           // [part][c][x][GM_YP]
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void gauss_mfma_kernel(const uint8_t* __res
     auto locate = [&](int tile, int k) -> hsrc {
         hsrc s;
         const int u = min(wave + 8 * k, n_units - 1), tl = min(tile, n_tiles - 1);
-        const int x0 = tile_x0(tl), y0 = (tl / tiles_x) * R;
+        const int x0 = tile_x0(tl), y0 = (tl / tiles_x) * R - y_phase;
         s.xs = x0 - R8 + 8 * NKB * hh;                                               // first sample of this lane's run
         const int ysrc = min(max(y0 - R8 + u * 8 + (i & 7), 0), h - 1);              // clamp-to-edge (filters.rs:296-298)
         s.line = planes + (size_t)(i >> 3) * plane_stride + (size_t)ysrc * w;       // A row m = i = channel * 8 + row
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void gauss_mfma_kernel(const uint8_t* __res
     }
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int x0 = tile_x0(tile), y0 = (tile / tiles_x) * R;
+        const int x0 = tile_x0(tile), y0 = (tile / tiles_x) * R - y_phase; // tile rows start at multiples of R of the WHOLE image
 
         // ---- H pass ----
 #pragma unroll
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void gauss_mfma_kernel(const uint8_t* __res
         // ---- store: R rows x 32 pixels, 128 contiguous bytes per row ----
         for (int idx = tid; idx < R * GM_COLS && !(dbg & 8); idx += 512) {
             const int rr = idx >> 5, cc = idx & 31;
-            if (y0 + rr < h && x0 + cc < w)
+            if (y0 + rr >= 0 && y0 + rr < h && x0 + cc < w)
                 reinterpret_cast<uint32_t*>(dst)[(size_t)(y0 + rr) * w + x0 + cc] = OUT[rr * GM_OUT_PITCH + cc];
         }
         // the next tile's H pass writes HR (not OUT); OUT is rewritten only after the next tile's first barrier
@@ -455,7 +455,7 @@ extern "C" int pfxk_gauss_mfma_wlen(void) { return GM_WLEN; }
 extern "C" int pfxk_gauss_mfma_woff(void) { return GM_WOFF; }
 extern "C" size_t pfxk_gauss_mfma_scratch_bytes(uint32_t w, uint32_t h) { return 4 * ((((size_t)w * h) + 255) & ~(size_t)255); }
 extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, uint8_t* d_planes, const uint16_t* d_wsplit,
-                                      int radius, float inv_scale2, float bias_c, uint32_t w, uint32_t h, int n_cus)
+                                      int radius, float inv_scale2, float bias_c, uint32_t w, uint32_t h, uint32_t first_row, int n_cus)
 {
     if (w == 0 || h == 0) return hipSuccess;
     if (radius < 1 || radius > GM_MAXR) return hipErrorInvalidValue;
@@ -463,7 +463,10 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     const int nkb = (GM_COLS + R8 + radius + 15) / 16;      // 4, 6 or 8
     int R = (GM_ROWS - 2 * R8) & ~31;
     if (R > GM_MAX_R) R = GM_MAX_R;
-    const int tiles_x = ((int)w + GM_COLS - 1) / GM_COLS, tiles_y = ((int)h + R - 1) / R;
+    // `first_row` = index of the buffer's row 0 in the whole image when the buffer is a band of it: tiles are laid out on the whole
+    // image's grid, so every output sees the same K-block grouping (the same f32 summation order) as in a whole-image call
+    const int y_phase = (int)(first_row % (uint32_t)R);
+    const int tiles_x = ((int)w + GM_COLS - 1) / GM_COLS, tiles_y = ((int)h + y_phase + R - 1) / R;
     // interior tile columns: source window [x0 - R8, x0 - R8 + 16 nkb) inside the image, rows 16-byte aligned
     const size_t n_px = (size_t)w * h, plane_stride = (n_px + 255) & ~(size_t)255;
     {
@@ -487,8 +490,8 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
         err = hipFuncSetAttribute((const void*)gauss_mfma_kernel<F, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM_LDS);
         if (err) return;
         const int n_tiles = cols * tiles_y, grid = n_tiles < n_cus ? n_tiles : n_cus; // persistent: one workgroup per CU (LDS-bound)
-        if (F) gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, c_lo, cols, 0, g_v_cfg >> 8);
-        else   gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, 0, c_lo, c_hi, g_v_cfg >> 8);
+        if (F) gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, c_lo, cols, 0, y_phase, g_v_cfg >> 8);
+        else   gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, 0, c_lo, c_hi, y_phase, g_v_cfg >> 8);
     };
     auto both = [&](auto nkb_c) {
         launch(std::true_type{}, nkb_c);

@@ -255,6 +255,12 @@ int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void*
 
 int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, void* tmp_dev)
 {
+    return pfx_gaussian_blur_band_dev(ctx, src_dev, dst_dev, w, h, sigma, tmp_dev, 0);
+}
+
+int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, void* tmp_dev,
+                               uint32_t first_row)
+{
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_gaussian_blur_dev"));
     // radius first: a huge sigma must be refused before a tap array of that size is built (the C ABI must not throw)
     const int radius = pfx_host_gaussian_radius(sigma);
@@ -280,7 +286,7 @@ int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint
         }
         pfx_timer t(ctx, "gauss_mfma");
         PFX_HIP(ctx, pfxk_gauss_mfma(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (uint8_t*)planes, (const uint16_t*)ctx->d_wsplit.p,
-                                     radius, ctx->wsplit_inv_scale, ctx->wsplit_bias, w, h, ctx->n_cus > 0 ? ctx->n_cus : 256));
+                                     radius, ctx->wsplit_inv_scale, ctx->wsplit_bias, w, h, first_row, ctx->n_cus > 0 ? ctx->n_cus : 256));
         return PFX_OK;
     }
     const int pad = pfxk_gauss_weight_pad(); // zero taps on both sides: the kernels' register blocking reads past the ends

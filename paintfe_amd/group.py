@@ -1,0 +1,99 @@
+"""ctypes mirror of the pfx_group_* C ABI (include/pfx.h): one document across the GPUs of a node, one process.
+
+Binding only — band geometry, peer copies and kernels live in libpfx.so (paintfe_amd/csrc/pfx_group.cpp)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+def band_rows(h: int, world: int, rank: int) -> Tuple[int, int]:
+    lib = L.load()
+    y0, y1 = C.c_uint32(), C.c_uint32()
+    lib.pfx_band_rows(C.c_uint32(h), C.c_uint32(world), C.c_uint32(rank), C.byref(y0), C.byref(y1))
+    return int(y0.value), int(y1.value)
+
+
+class GpuGroup:
+    def __init__(self, devices: Sequence[int]):
+        self.lib = L.load()
+        self.lib.pfx_group_last_error.restype = C.c_char_p
+        self.lib.pfx_group_last_error.argtypes = [C.c_void_p]
+        for name in ("pfx_group_layer_band_dev", "pfx_group_result_band_dev", "pfx_group_gathered_dev", "pfx_group_ctx"):
+            getattr(self.lib, name).restype = C.c_void_p
+        self.g = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        st = self.lib.pfx_group_create(arr, C.c_uint32(len(devices)), C.byref(self.g))
+        if st != L.OK:
+            raise L.PfxError(st, "pfx_group_create failed")
+        self.n = len(devices)
+        self.w = self.h = 0
+
+    def _check(self, st: int):
+        if st != L.OK:
+            raise L.PfxError(st, (self.lib.pfx_group_last_error(self.g) or b"").decode())
+
+    def close(self):
+        if self.g:
+            self.lib.pfx_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_document(self, w: int, h: int, n_layers: int):
+        self._check(self.lib.pfx_group_set_document(self.g, C.c_uint32(w), C.c_uint32(h), C.c_uint32(n_layers)))
+        self.w, self.h = w, h
+
+    def band(self, rank: int) -> Tuple[int, int]:
+        y0, y1 = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.pfx_group_band(self.g, C.c_uint32(rank), C.byref(y0), C.byref(y1)))
+        return int(y0.value), int(y1.value)
+
+    def upload_layer(self, index: int, rgba: np.ndarray):
+        a = np.ascontiguousarray(rgba, dtype=np.uint8)
+        assert a.shape == (self.h, self.w, 4)
+        self._check(self.lib.pfx_group_upload_layer(self.g, C.c_uint32(index), a.ctypes.data_as(C.c_void_p)))
+
+    def layer_band_ptr(self, rank: int, index: int) -> int:
+        return int(self.lib.pfx_group_layer_band_dev(self.g, C.c_uint32(rank), C.c_uint32(index)) or 0)
+
+    def flatten_blur(self, infos: List[Tuple[int, float, bool, int]], sigma: float, all_gather: bool = False):
+        arr = (L.LayerInfo * len(infos))()
+        for k, (idx, op, vis, mode) in enumerate(infos):
+            arr[k].layer_idx, arr[k].opacity, arr[k].visible, arr[k].blend_mode, arr[k].kind = idx, op, 1 if vis else 0, mode, 0
+        self._check(self.lib.pfx_group_flatten_blur(self.g, arr, C.c_uint32(len(infos)), C.c_float(sigma), C.c_int(1 if all_gather else 0)))
+
+    def synchronize(self):
+        self._check(self.lib.pfx_group_synchronize(self.g))
+
+    def result_band_ptr(self, rank: int) -> int:
+        return int(self.lib.pfx_group_result_band_dev(self.g, C.c_uint32(rank)) or 0)
+
+    def gathered_ptr(self, rank: int) -> int:
+        return int(self.lib.pfx_group_gathered_dev(self.g, C.c_uint32(rank)) or 0)
+
+    def ctx(self, rank: int) -> int:
+        return int(self.lib.pfx_group_ctx(self.g, C.c_uint32(rank)) or 0)
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.h, self.w, 4), np.uint8)
+        self._check(self.lib.pfx_group_download(self.g, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def download_gathered(self, rank: int) -> np.ndarray:
+        """the all-gathered image as member `rank` holds it"""
+        out = np.empty((self.h, self.w, 4), np.uint8)
+        self.synchronize()
+        st = self.lib.pfx_dev_download(C.c_void_p(self.ctx(rank)), out.ctypes.data_as(C.c_void_p), C.c_void_p(self.gathered_ptr(rank)),
+                                       C.c_size_t(out.nbytes))
+        if st != L.OK:
+            raise L.PfxError(st, "download of the gathered image failed")
+        return out

@@ -569,9 +569,10 @@ class GpuRenderer:
         self._check(self._lib.pfx_flatten_dev(self._h, lp, mp, arr, C.c_uint32(n), C.c_uint32(w), C.c_uint32(h),
                                               C.c_void_p(dst_ptr)))
 
-    def gaussian_blur_dev(self, src_ptr: int, dst_ptr: int, w: int, h: int, sigma: float, tmp_ptr: int = 0):
-        self._check(self._lib.pfx_gaussian_blur_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w),
-                                                    C.c_uint32(h), C.c_float(sigma), C.c_void_p(tmp_ptr or None)))
+    def gaussian_blur_dev(self, src_ptr: int, dst_ptr: int, w: int, h: int, sigma: float, tmp_ptr: int = 0, first_row: int = 0):
+        """first_row: index of the buffer's row 0 in the whole image when the buffer is a band of it (pfx_gaussian_blur_band_dev)"""
+        self._check(self._lib.pfx_gaussian_blur_band_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w),
+                                                         C.c_uint32(h), C.c_float(sigma), C.c_void_p(tmp_ptr or None), C.c_uint32(first_row)))
 
     def adjust_dev(self, src_ptr, dst_ptr, w, h, op, params=(), lut=None, mask_ptr=0, sparse=DENSE):
         opi = ADJUST_OPS.index(op) if isinstance(op, str) else int(op)

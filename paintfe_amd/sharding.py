@@ -106,6 +106,93 @@ def gather_bands(band, height: int, group=None):
     return torch.cat([o[:b1 - b0] for o, (b0, b1) in zip(outs, bands)], dim=0)
 
 
+class BandPipeline:
+    """flatten -> halo exchange -> Gaussian -> all-gather of ONE document on this rank's band, buffers allocated once.
+
+    Everything is enqueued on the current stream: the flatten writes straight into the centre of [top halo | band | bottom halo],
+    the halo rows arrive in place through one batched RCCL send/recv group (no concatenation, no host synchronisation), the blur
+    runs on band + halo with its tiles on the whole image's grid (pfx_gaussian_blur_band_dev: results equal the single-GPU ones bit
+    for bit), and the result bands are all-gathered into the full image on every rank."""
+
+    def __init__(self, renderer, w: int, h: int, radius: int, sigma: float, device, gather: bool = True, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.r, self.w, self.h, self.radius, self.sigma, self.group, self.gather = renderer, w, h, radius, sigma, group, gather
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.y0, self.y1 = band_rows(h, self.world, self.rank)
+        self.rows = self.y1 - self.y0
+        self.top = min(radius, self.y0) if self.rows else 0
+        self.bottom = min(radius, h - self.y1) if self.rows else 0
+        prow = max(self.top + self.rows + self.bottom, 1)
+        self.padded = torch.empty((prow, w, 4), dtype=torch.uint8, device=device)
+        self.blurred = torch.empty((prow, w, 4), dtype=torch.uint8, device=device)
+        self.bands = all_bands(h, self.world)
+        self.max_rows = max(b1 - b0 for b0, b1 in self.bands)
+        # all-gather staging: equal-size slots (bands are ragged by at most one chunk row), then one view per band
+        self.slot = torch.zeros((max(self.max_rows, 1), w, 4), dtype=torch.uint8, device=device)
+        self.slots = torch.empty((self.world, max(self.max_rows, 1), w, 4), dtype=torch.uint8, device=device) if gather else None
+        self.full = torch.empty((h, w, 4), dtype=torch.uint8, device=device) if gather else None
+        # static exchange plan: (what I receive, what I send)
+        lo0 = self.y0 - self.top
+        self.recvs = [(src, s0 - lo0, s1 - lo0) for (src, s0, s1) in halo_plan(h, self.world, self.rank, radius)]
+        self.sends = []
+        for other in range(self.world):
+            if other == self.rank:
+                continue
+            for (src, s0, s1) in halo_plan(h, self.world, other, radius):
+                if src == self.rank:
+                    self.sends.append((other, self.top + s0 - self.y0, self.top + s1 - self.y0))
+
+    def flat_band(self):
+        return self.padded[self.top:self.top + self.rows]
+
+    def _exchange_via_host(self):
+        import torch
+        import torch.distributed as dist
+
+        bufs = [(a, b, torch.empty((b - a, self.w, 4), dtype=torch.uint8)) for (_, a, b) in self.recvs]
+        ops = [dist.P2POp(dist.irecv, buf, src, self.group) for (src, _, _), (_, _, buf) in zip(self.recvs, bufs)]
+        keep = [self.padded[a:b].cpu() for (_, a, b) in self.sends]
+        ops += [dist.P2POp(dist.isend, piece, dst, self.group) for (dst, _, _), piece in zip(self.sends, keep)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for (a, b, buf) in bufs:
+            self.padded[a:b].copy_(buf)
+
+    def step(self, layer_ptrs, info):
+        import torch.distributed as dist
+
+        if self.rows:
+            self.r.flatten_dev(layer_ptrs, info, self.w, self.rows, self.padded[self.top:].data_ptr())
+        if dist.get_backend(self.group) == "gloo" and self.padded.device.type == "cuda":
+            self._exchange_via_host()  # plumbing self-test on a 1-GPU box (gloo moves host memory); RCCL moves device memory
+        else:
+            ops = [dist.P2POp(dist.irecv, self.padded[a:b], src, self.group) for (src, a, b) in self.recvs]
+            ops += [dist.P2POp(dist.isend, self.padded[a:b], dst, self.group) for (dst, a, b) in self.sends]
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()  # RCCL: orders the current stream behind the transfer, does not block the host
+        if self.rows:
+            prow = self.top + self.rows + self.bottom
+            self.r.gaussian_blur_dev(self.padded.data_ptr(), self.blurred.data_ptr(), self.w, prow, self.sigma, first_row=self.y0 - self.top)
+        if not self.gather:
+            return self.blurred[self.top:self.top + self.rows]
+        self.slot[:self.rows] = self.blurred[self.top:self.top + self.rows]
+        if dist.get_backend(self.group) == "gloo" and self.slot.device.type == "cuda":
+            outs = [self.slot.cpu() for _ in range(self.world)]
+            dist.all_gather(outs, self.slot.cpu(), group=self.group)
+            for k in range(self.world):
+                self.slots[k].copy_(outs[k])
+        else:
+            dist.all_gather_into_tensor(self.slots, self.slot, group=self.group)
+        for k, (b0, b1) in enumerate(self.bands):
+            if b1 > b0:
+                self.full[b0:b1] = self.slots[k, :b1 - b0]
+        return self.full
+
+
 def max_over_ranks(value: float, device=None, group=None) -> float:
     """wall time of a step = slowest rank (bench.py contract)"""
     import torch

@@ -148,6 +148,11 @@ def composite(layers, w, h, threads=0, preview=None):
     return out
 
 
+def set_serial_writeback(on: bool):
+    """the reference's single-threaded compositor write-back (canvas_state.rs:686-695) for the faithful CPU baseline"""
+    lib().pfxo_set_serial_writeback(C.c_int(1 if on else 0))
+
+
 def flatten_stack(stack, modes, opacities, threads=0):
     n, h, w, _ = stack.shape
     s, ps = _u8(stack)

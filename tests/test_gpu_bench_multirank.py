@@ -25,7 +25,7 @@ def _run(nproc, extra, port):
 
 
 def test_doc_mode_two_ranks_contract():
-    d = _run(2, [], 29621)
+    d = _run(2, ["--shard", "doc"], 29621)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 1
     assert d["unit"] == "Mpixels/s" and d["higher_is_better"] is True and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["value"] > 0 and d["ms_per_step"] > 0
@@ -36,9 +36,11 @@ def test_doc_mode_two_ranks_contract():
 
 
 @pytest.mark.parametrize("nproc", [2, 3])
-def test_band_mode_matches_single_process(nproc):
-    d = _run(nproc, ["--shard", "band", "--exact"], 29630 + nproc)
-    assert d["scaling"] == "strong" and d["n_gpus"] == nproc
-    assert d["check"]["band_blur_max_diff_vs_single_process"] == 0  # exact Gaussian: bit-identical to the unsharded pipeline
-    d = _run(nproc, ["--shard", "band"], 29640 + nproc)
-    assert d["check"]["band_blur_max_diff_vs_single_process"] <= 1  # FMA Gaussian: the stated +-1 LSB
+def test_band_mode_is_the_default_and_matches_single_process(nproc):
+    d = _run(nproc, ["--exact"], 29630 + nproc)  # no --shard: the driver's command line
+    assert d["scaling"] == "strong" and d["n_gpus"] == nproc and "all-gather" in d["config"]["sharding"]
+    assert d["check"]["band_blur_max_diff_vs_oracle"] == 0  # exact Gaussian: bit-identical to the unsharded pipeline
+    assert abs(d["value"] - 640 * 400 / d["ms_per_step"] / 1e3) / d["value"] < 0.01  # ONE document per step for the whole job
+    assert d["doc_mode"]["scaling"] == "weak" and d["doc_mode"]["value"] > 0
+    d = _run(nproc, [], 29640 + nproc)
+    assert d["check"]["band_blur_max_diff_vs_oracle"] <= 1  # matrix-core Gaussian: the stated +-1 LSB
