@@ -81,8 +81,10 @@ int pfx_hsl_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uin
 /* invert_rgba; numerics: invert_colors (ref: src/ops/adjustments.rs:115) */
 int pfx_invert_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h);
 /* median_rgba(radius) -> Option<Vec<u8>>; numerics: median_core (ref: src/ops/effects/noise.rs:357-410).
- * The reference returns None for radius > 7; here PFX_ERR_UNSUPPORTED is returned beyond PFX_MEDIAN_MAX_RADIUS. */
-#define PFX_MEDIAN_MAX_RADIUS 24
+ * The reference's GPU method returns None for radius > 7 and its CPU median_core has no cap; here radii up to 24 run the tile
+ * kernels (selection networks / binary search) and larger ones a sliding-histogram kernel; PFX_ERR_UNSUPPORTED only beyond
+ * PFX_MEDIAN_MAX_RADIUS (a 255 x 255 window, the 16-bit histogram counters' limit). */
+#define PFX_MEDIAN_MAX_RADIUS 127
 int pfx_median_rgba(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t radius);
 
 /* ================= B4: pure `_core` functions with optional selection mask ================= */
@@ -283,6 +285,12 @@ int pfx_blend_pixels(pfx_ctx* ctx, const uint8_t* base, const uint8_t* top, uint
  * (ref: src/ops/transform.rs:1288-1345).  Field and output are w*h; source is sw*sh. */
 int pfx_warp_displacement(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_t sh, const float* disp_xy,
                           uint32_t w, uint32_t h, uint8_t* dst);
+/* The pipeline's source cache (ref: src/gpu/compute/liquify.rs:166-176): warp_into uploads the source texture once and reuses it
+ * until invalidate_source; an interactive session then only sends displacement fields.  _cached fails with PFX_ERR_INVALID when
+ * no source is set (or it was invalidated) and leaves dst untouched. */
+int pfx_warp_set_source(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_t sh);
+int pfx_warp_invalidate_source(pfx_ctx* ctx);
+int pfx_warp_displacement_cached(pfx_ctx* ctx, const float* disp_xy, uint32_t w, uint32_t h, uint8_t* dst);
 /* generate_displacement_from_mesh (ref: src/ops/transform.rs:1670-1705); orig_pts may be NULL =>
  * generate_displacement_from_mesh_fast / GpuMeshWarpDisplacementPipeline::generate_displacement
  * (ref: src/ops/transform.rs:1712, src/gpu/compute/mesh_warp.rs:131) */
@@ -607,6 +615,37 @@ int         pfx_group_synchronize(pfx_group* g);
 void*       pfx_group_result_band_dev(pfx_group* g, uint32_t rank);  /* rows [y0, y1) of the last result on member `rank` */
 void*       pfx_group_gathered_dev(pfx_group* g, uint32_t rank);     /* w*h*4 on member `rank` after an all_gather call */
 int         pfx_group_download(pfx_group* g, uint8_t* dst_host);     /* concatenated bands -> host w*h*4; blocking */
+
+/* ================= batch of independent images across the GPUs of a node (BASELINE config 5; ref: src/cli.rs:159-216) =========
+ * The reference's CLI runs `run_one` per input file, serially.  pfx_batch_pipeline streams a batch through the devices instead:
+ * image i goes to device i mod n_devices (no data-path collective), and on every device `slots` pipeline slots keep the upload of
+ * one image, the kernels of another and the download of a third in flight (pinned host memory, one stream per slot).  Per image:
+ * parallel_gaussian_blur(sigma) -> hue_saturation_lightness(hue, saturation, lightness) -> CanvasState::composite() of the result
+ * under `n_overlays` overlay layers (resident on every device).  Sources are taken round-robin from a pool of host images
+ * (image i = pool[i mod n_pool]; the pool is pinned for the duration of the call); results of the images listed in keep_indices
+ * are copied to keep_out[k] (w*h*4 each) — the rest only cross PCIe. */
+typedef struct pfx_batch_params {
+    uint32_t w, h;
+    float    sigma;
+    float    hue, saturation, lightness;
+    uint32_t n_overlays;                  /* <= 8 */
+    const uint8_t* const* overlays_host;  /* n_overlays x w*h*4 */
+    const uint8_t* overlay_modes;         /* BlendMode::to_u8 per overlay */
+    const float*   overlay_opacity;       /* NULL = 1.0 */
+    uint32_t slots;                       /* pipeline depth per device, 1..8 (0 = 3) */
+    uint32_t n_keep;
+    const uint32_t* keep_indices;
+    uint8_t* const* keep_out;
+} pfx_batch_params;
+typedef struct pfx_batch_stats {
+    double   seconds;              /* first enqueue .. last result back on the host, slowest device */
+    double   images_per_s;         /* whole job */
+    double   h2d_gbs, d2h_gbs;     /* whole job, each direction */
+    double   kernel_ms_per_image;  /* blur + HSL + flatten on resident data (HIP events on every 8th image) */
+    uint32_t images, devices;
+} pfx_batch_stats;
+int pfx_batch_pipeline(const int* devices, uint32_t n_devices, uint32_t n_images, const pfx_batch_params* params,
+                       const uint8_t* const* image_pool_host, uint32_t n_pool, pfx_batch_stats* stats, char* err, size_t err_cap);
 
 #ifdef __cplusplus
 }

@@ -265,6 +265,57 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
     return hipGetLastError();
 }
 
+// Large radii (beyond the tile kernels' LDS): Huang's sliding histogram.  One lane owns a run of MH_RUN consecutive pixels of one
+// row and a private 4 x 256-bin histogram in LDS ([bin][lane] u16: lanes never share a counter); sliding one pixel to the right
+// removes the window's left column and adds its right one (2 (2r+1) updates), the per-channel median follows by walking a few
+// bins from the previous position.  Same result as the reference's sort (`sorted[len / 2]`, noise.rs:357-410), any radius whose
+// window count fits the 16-bit counters (r <= 127).
+constexpr int MH_RUN = 32;
+__global__ __launch_bounds__(64) void median_hist_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                        const uint8_t* __restrict__ mask, int r, int w, int h)
+{
+    extern __shared__ uint16_t mh_hist[]; // [c][bin][lane]
+    const int lane = threadIdx.x;
+    const int runs_x = (w + MH_RUN - 1) / MH_RUN;
+    const int run = blockIdx.x * 64 + lane;
+    const bool live = run < runs_x * h;
+    const int y = live ? run / runs_x : 0, xs = live ? (run % runs_x) * MH_RUN : 0;
+    for (int i = lane; i < 4 * 256 * 64; i += 64) mh_hist[i] = 0;
+    __syncthreads();
+    if (!live) return;
+    auto bin = [&](int c, uint32_t v) -> uint16_t& { return mh_hist[((c * 256) + (int)v) * 64 + lane]; };
+    const int side = 2 * r + 1, th = (side * side) / 2;
+    int med[4] = {0, 0, 0, 0}, lt[4] = {0, 0, 0, 0}; // lt[c] = window elements of channel c below med[c]
+    auto add = [&](uint32_t px, int sgn) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t v = (px >> (8 * c)) & 0xffu;
+            bin(c, v) = (uint16_t)(bin(c, v) + sgn);
+            if ((int)v < med[c]) lt[c] += sgn;
+        }
+    };
+    auto column = [&](int x, int sgn) {
+        const int cx = min(max(x, 0), w - 1);
+        for (int dy = -r; dy <= r; ++dy) add(src[(size_t)min(max(y + dy, 0), h - 1) * w + cx], sgn);
+    };
+    for (int dx = -r; dx <= r; ++dx) column(xs + dx, +1);
+    const int xe = min(xs + MH_RUN, w);
+    for (int x = xs; x < xe; ++x) {
+        uint32_t out = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int m = med[c], l = lt[c];
+            while (l > th) { --m; l -= bin(c, (uint32_t)m); }
+            while (l + (int)bin(c, (uint32_t)m) <= th) { l += bin(c, (uint32_t)m); ++m; }
+            med[c] = m; lt[c] = l;
+            out |= (uint32_t)m << (8 * c);
+        }
+        const size_t gi = (size_t)y * w + x;
+        dst[gi] = (mask && mask[gi] == 0) ? src[gi] : out;
+        if (x + 1 < xe) { column(x - r, -1); column(x + r + 1, +1); }
+    }
+}
+
 extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, int radius,
                                   uint32_t w, uint32_t h)
 {
@@ -279,6 +330,14 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         const dim3 g((w + MD_TX - 1) / MD_TX, (h + MD_TY - 1) / MD_TY);
         if (radius == 2) median_net_kernel<2><<<g, MD_TX * MD_TY, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         else median_net_kernel<3><<<g, MD_TX * MD_TY, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        return hipGetLastError();
+    }
+    if (radius > PFXK_MEDIAN_TILE_MAX_RADIUS) { // sliding histogram
+        const size_t lds_h = (size_t)4 * 256 * 64 * sizeof(uint16_t);
+        hipError_t eh = hipFuncSetAttribute((const void*)median_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+        if (eh) return eh;
+        const size_t runs = (size_t)((w + MH_RUN - 1) / MH_RUN) * h;
+        median_hist_kernel<<<(uint32_t)((runs + 63) / 64), 64, lds_h, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, (int)w, (int)h);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(MD_TX + 2 * radius) * (MD_TY + 2 * radius) * 8;

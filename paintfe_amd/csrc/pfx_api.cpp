@@ -883,6 +883,41 @@ int pfx_warp_displacement(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_
     return finish_out(ctx, dst, w, h);
 }
 
+// GpuLiquifyPipeline keeps the source texture across warp_into calls until invalidate_source (ref: src/gpu/compute/liquify.rs:166-176):
+// an interactive Liquify session re-sends only the displacement field
+int pfx_warp_set_source(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_t sh)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, src && sw && sh, "pfx_warp_set_source: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    ctx->warp_src_w = ctx->warp_src_h = 0;
+    PFX_TRY(pfx_reserve(ctx, ctx->warp_src, img_bytes(sw, sh)));
+    PFX_TRY(pfx_h2d(ctx, ctx->warp_src.p, src, img_bytes(sw, sh)));
+    PFX_TRY(pfx_sync(ctx)); // the host buffer may be released after the call
+    ctx->warp_src_w = sw; ctx->warp_src_h = sh;
+    return PFX_OK;
+}
+
+int pfx_warp_invalidate_source(pfx_ctx* ctx)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    ctx->warp_src_w = ctx->warp_src_h = 0;
+    return PFX_OK;
+}
+
+int pfx_warp_displacement_cached(pfx_ctx* ctx, const float* disp_xy, uint32_t w, uint32_t h, uint8_t* dst)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, disp_xy && dst && w && h, "pfx_warp_displacement_cached: bad arguments");
+    PFX_REQUIRE(ctx, ctx->warp_src_w != 0, "pfx_warp_displacement_cached: no source (pfx_warp_set_source, or it was invalidated)");
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
+    PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 8));
+    PFX_TRY(pfx_h2d(ctx, ctx->st_tmp.p, disp_xy, (size_t)w * h * 8));
+    PFX_TRY(pfx_warp_displacement_dev(ctx, ctx->warp_src.p, ctx->warp_src_w, ctx->warp_src_h, ctx->st_tmp.p, w, h, ctx->st_out.p));
+    return finish_out(ctx, dst, w, h);
+}
+
 int pfx_mesh_displacement(pfx_ctx* ctx, const float* orig_pts_xy, const float* deformed_pts_xy, uint32_t cols, uint32_t rows,
                           uint32_t w, uint32_t h, float* disp_xy_out)
 {

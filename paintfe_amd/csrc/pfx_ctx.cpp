@@ -124,7 +124,7 @@ void pfx_ctx_destroy(pfx_ctx* ctx)
     for (auto& t : ctx->timings) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto& kv : ctx->layers) { free_buf(kv.second.pixels); free_buf(kv.second.mask); }
     pfx_devbuf* bufs[] = {&ctx->st_in, &ctx->st_out, &ctx->st_mask, &ctx->st_tmp, &ctx->st_aux, &ctx->st_aux2, &ctx->fx_a, &ctx->fx_b, &ctx->d_desc,
-                          &ctx->d_adj, &ctx->d_chunks, &ctx->d_wts, &ctx->d_wsplit, &ctx->d_lut, &ctx->d_pts, &ctx->d_misc};
+                          &ctx->d_adj, &ctx->d_chunks, &ctx->d_wts, &ctx->d_wsplit, &ctx->warp_src, &ctx->d_lut, &ctx->d_pts, &ctx->d_misc};
     for (auto* b : bufs) free_buf(*b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -49,6 +49,9 @@ struct pfx_ctx {
     uint32_t wts_sigma_bits = 0xffffffffu, wsplit_sigma_bits = 0xffffffffu;
     float wsplit_inv_scale = 1.0f, wsplit_bias = 0.0f;
     pfx_devbuf d_wsplit;
+    // GpuLiquifyPipeline's cached source texture (ref: src/gpu/compute/liquify.rs:166-176); 0 x 0 = none / invalidated
+    pfx_devbuf warp_src;
+    uint32_t warp_src_w = 0, warp_src_h = 0;
 };
 
 // ---- error plumbing ----

@@ -89,6 +89,7 @@ hipError_t pfxk_minmax_rgb(hipStream_t s, const uint8_t* d_src, const uint8_t* d
 // ---- k_stencil.hip ---- box blur / median / pixelate
 hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst, const uint8_t* d_mask,
                          int radius, uint32_t w, uint32_t h);
+#define PFXK_MEDIAN_TILE_MAX_RADIUS 24 /* beyond: sliding histograms */
 hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, int radius,
                        uint32_t w, uint32_t h);
 hipError_t pfxk_pixelate(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, uint32_t bs,

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <glob.h>
@@ -176,12 +177,13 @@ int pfx_cli_main(int argc, char** argv)
     std::vector<std::string> inputs_raw;
     std::string script_path, output, output_dir, format;
     bool have_output = false, have_dir = false, have_format = false, verbose = false;
-    int device = 0;
+    int device = 0, gpus = 1;
     auto usage = [](int rc) {
         std::printf("pfx — headless batch image processor (HIP back-end of PaintFE's CLI)\n"
                     "  -i, --input <FILE>...   input file(s), glob patterns accepted\n  -s, --script <SCRIPT.rhai>\n  -o, --output <FILE>\n"
                     "      --output-dir <DIR>\n  -f, --format <FORMAT>   png, pfe (other formats are not built in)\n  -q, --quality <1-100>\n"
-                    "      --webp-lossy  --tiff-compression <MODE>  --flatten  -v, --verbose  --device <N>\n");
+                    "      --webp-lossy  --tiff-compression <MODE>  --flatten  -v, --verbose  --device <N>\n"
+                    "      --gpus <N>              process the input files on N GPUs at once (file i -> GPU i mod N)\n");
         return rc;
     };
     for (int i = 1; i < argc; ++i) {
@@ -198,6 +200,7 @@ int pfx_cli_main(int argc, char** argv)
         else if (a == "--webp-lossy" || a == "--flatten") {}
         else if (a == "-v" || a == "--verbose") verbose = true;
         else if (a == "--device") { if (!need(dummy)) return usage(2); device = std::atoi(dummy.c_str()); }
+        else if (a == "--gpus") { if (!need(dummy)) return usage(2); gpus = std::atoi(dummy.c_str()); if (gpus < 1) gpus = 1; }
         else if (a == "-h" || a == "--help") return usage(0);
         else { std::fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
     }
@@ -236,15 +239,15 @@ int pfx_cli_main(int argc, char** argv)
     }
     if (have_dir && mkdir_p(output_dir) != 0) { std::fprintf(stderr, "error: could not create output directory '%s'\n", output_dir.c_str()); return 1; }
 
-    pfx_ctx* ctx = nullptr;
-    if (pfx_ctx_create(device, &ctx) != PFX_OK) { std::fprintf(stderr, "error: no usable HIP device: %s\n", pfx_last_error(nullptr)); return 1; }
-
     const size_t total = inputs.size();
     const bool multi = total > 1;
-    bool any_failure = false;
-    for (size_t idx = 0; idx < total; ++idx) {
+    // run_one (cli.rs:222-308) on one device context; returns what the serial loop would have printed for this file
+    struct file_report { std::string out_text, err_text; bool failed = false; };
+    auto process = [&](pfx_ctx* ctx, size_t idx) -> file_report {
+        file_report rep;
+        char line[1024];
         const std::string& in = inputs[idx];
-        if (multi || verbose) std::printf("[%zu/%zu] %s\n", idx + 1, total, in.c_str());
+        if (multi || verbose) { std::snprintf(line, sizeof line, "[%zu/%zu] %s\n", idx + 1, total, in.c_str()); rep.out_text += line; }
         const auto t0 = std::chrono::steady_clock::now();
         // build_output_path (cli.rs:399-427)
         std::string out;
@@ -253,7 +256,7 @@ int pfx_cli_main(int argc, char** argv)
         else { out = dir_of(in) + "/" + stem_of(in) + "." + fmt; if (out == in || out == "./" + in) out = dir_of(in) + "/" + stem_of(in) + "_out." + fmt; }
 
         std::string error;
-        do { // run_one (cli.rs:222-308)
+        do {
             // Step 1, load_image_sync (io.rs:693-760): a .pfe project keeps its layers, every other format becomes a one-layer
             // document named after the file; layers are TiledImages (all-transparent chunks dropped)
             doc_guard doc;
@@ -280,7 +283,7 @@ int pfx_cli_main(int argc, char** argv)
                 const int st = pfx_int_project_run_script(ctx, doc.p, script_src.c_str(), &res, &console);
                 if (st != PFX_OK) { error = std::string("script error: ") + (res.error[0] ? res.error : pfx_last_error(ctx)); break; }
                 if (verbose)
-                    for (const std::string& line : console) std::printf("  [script] %s\n", line.c_str());
+                    for (const std::string& l : console) rep.out_text += "  [script] " + l + "\n";
             }
 
             // Step 3, save (cli.rs:272-306): PFE keeps the layers; raster formats get the composite of a multi-layer document
@@ -298,13 +301,44 @@ int pfx_cli_main(int argc, char** argv)
             if (!png_encode(out, px.data(), w, h)) { error = "save failed: cannot write '" + out + "'"; break; }
         } while (false);
 
-        if (!error.empty()) { std::fprintf(stderr, "  error: %s\n", error.c_str()); any_failure = true; continue; } // keep going (cli.rs:204-208)
+        if (!error.empty()) { rep.err_text = "  error: " + error + "\n"; rep.failed = true; return rep; } // keep going (cli.rs:204-208)
         if (verbose || multi) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            std::printf("  \xe2\x86\x92 %s (%.0fms)\n", out.c_str(), ms);
+            std::snprintf(line, sizeof line, "  \xe2\x86\x92 %s (%.0fms)\n", out.c_str(), ms);
+            rep.out_text += line;
         }
+        return rep;
+    };
+
+    // The reference loops over the files on one thread (cli.rs:159-216).  Files are independent units, so with --gpus N worker k
+    // owns device (device + k) mod device_count and takes files k, k + N, ...; reports are printed in input order.
+    int n_dev = pfx_device_count();
+    if (n_dev <= 0) { std::fprintf(stderr, "error: no usable HIP device: %s\n", pfx_last_error(nullptr)); return 1; }
+    const size_t workers = std::min<size_t>((size_t)gpus, total);
+    std::vector<pfx_ctx*> ctxs(workers, nullptr);
+    for (size_t k = 0; k < workers; ++k)
+        if (pfx_ctx_create((device + (int)k) % n_dev, &ctxs[k]) != PFX_OK) {
+            std::fprintf(stderr, "error: no usable HIP device: %s\n", pfx_last_error(nullptr));
+            for (pfx_ctx* c : ctxs) pfx_ctx_destroy(c);
+            return 1;
+        }
+    bool any_failure = false;
+    auto emit = [&](const file_report& rep) {
+        std::fputs(rep.out_text.c_str(), stdout);
+        if (!rep.err_text.empty()) { std::fflush(stdout); std::fputs(rep.err_text.c_str(), stderr); }
+        any_failure = any_failure || rep.failed;
+    };
+    if (workers <= 1) {
+        for (size_t idx = 0; idx < total; ++idx) emit(process(ctxs[0], idx));
+    } else {
+        std::vector<file_report> reports(total);
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < workers; ++k)
+            th.emplace_back([&, k] { for (size_t idx = k; idx < total; idx += workers) reports[idx] = process(ctxs[k], idx); });
+        for (auto& t : th) t.join();
+        for (const auto& rep : reports) emit(rep);
     }
-    pfx_ctx_destroy(ctx);
+    for (pfx_ctx* c : ctxs) pfx_ctx_destroy(c);
     return any_failure ? 1 : 0;
 }
 

@@ -334,7 +334,9 @@ int ScriptHost::call(rhai::Interp& in, const std::string& name, std::vector<Valu
         if (need_image()) return 2;                                                                      \
         return dev(pingpong([&](const void* s, void* d) { return CALL; }));                              \
     }
-    FN("apply_blur") if (sig({VT::Float})) { // :825 blur_with_selection_pub(img, sigma as f32, mask)
+    // `apply_gaussian_blur` is BASELINE.json config 1's spelling of the reference's `apply_blur` (registered at scripting.rs:825-829):
+    // an alias, so that the literal config-1 script runs
+    if ((name == "apply_blur" || name == "apply_gaussian_blur") && (known = true)) if (sig({VT::Float})) { // :825 blur_with_selection_pub(img, sigma as f32, mask)
         if (need_image()) return 2;
         if (has_mask) { const int st = mask_host_ready(); if (st != PFX_OK) return dev(st); }
         return dev(pingpong([&](const void* s, void* d) { return pfx_int_blur_with_selection_dev(ctx, s, d, w, h, (float)a[0].f, has_mask ? host_mask.data() : nullptr, d_mask()); }));

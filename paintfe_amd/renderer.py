@@ -225,6 +225,20 @@ class GpuRenderer:
     def box_blur_core(self, img, radius: float, mask=None):
         return self._img_call(self._lib.pfx_box_blur_core, img, C.c_float(radius), mask=mask)
 
+    # GpuLiquifyPipeline source cache (liquify.rs:166-176)
+    def warp_set_source(self, src):
+        a = _u8(src)
+        self._check(self._lib.pfx_warp_set_source(self._h, _p(a), C.c_uint32(a.shape[1]), C.c_uint32(a.shape[0])))
+
+    def warp_invalidate_source(self):
+        self._check(self._lib.pfx_warp_invalidate_source(self._h))
+
+    def warp_displacement_cached(self, disp, w: int, h: int):
+        d = np.ascontiguousarray(disp, dtype=np.float32)
+        out = np.zeros((h, w, 4), np.uint8)
+        self._check(self._lib.pfx_warp_displacement_cached(self._h, d.ctypes.data_as(C.c_void_p), C.c_uint32(w), C.c_uint32(h), _p(out)))
+        return out
+
     def median_core(self, img, radius: int, mask=None):
         return self._img_call(self._lib.pfx_median_core, img, C.c_uint32(radius), mask=mask)
 

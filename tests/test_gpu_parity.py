@@ -260,7 +260,18 @@ def test_median_3x3_network_paths(gpu, oracle, size):
 
 
 def test_median_beyond_device_radius_returns_none(gpu):
-    assert gpu.r.median_rgba(I.random_rgba(32, 32, 1), 25) is None  # ref: median_rgba -> None, renderer.rs:945
+    assert gpu.r.median_rgba(I.random_rgba(32, 32, 1), 128) is None  # ref: median_rgba -> None, renderer.rs:945
+
+
+@pytest.mark.parametrize("radius,size", [(25, (90, 70)), (31, (64, 40)), (40, (33, 130)), (100, (48, 37))])
+def test_median_large_radius_sliding_histogram_bitexact(gpu, oracle, radius, size):
+    """median_core has no radius cap (noise.rs:357-410): beyond the tile kernels a sliding-histogram kernel takes over"""
+    img = I.random_rgba(size[0], size[1], radius)
+    img[::3, ::5] = 255
+    img[1::4, 2::7] = 0
+    mask = (I.random_rgba(size[0], size[1], radius + 1)[..., 0] > 60).astype(np.uint8) * 255
+    assert np.array_equal(gpu.r.median_core(img, radius, None), oracle.median(img, radius))
+    assert np.array_equal(gpu.r.median_core(img, radius, mask), oracle.median(img, radius, mask))
 
 
 @pytest.mark.parametrize("block", [0, 1, 2, 5, 8, 64, 1000])
@@ -382,6 +393,20 @@ def test_warp_source_size_differs_from_field(gpu, oracle):
     img = I.random_rgba(90, 60, 4)
     disp = (np.random.default_rng(7).random((80, 120, 2)).astype(np.float32) - np.float32(0.5)) * np.float32(30.0)
     assert_same(gpu.warp_displacement(img, disp), oracle.warp_displacement(img, disp), 0, "src != field size")
+
+
+def test_warp_source_cache_contract(gpu, oracle):
+    """liquify.rs:166-176: the source is uploaded once and reused until invalidate_source"""
+    from paintfe_amd import _lib as L
+    src = I.random_rgba(120, 90, 5)
+    rng = np.random.default_rng(9)
+    gpu.r.warp_set_source(src)
+    for k in range(3):
+        disp = rng.uniform(-9, 9, size=(90, 120, 2)).astype(np.float32)
+        assert np.array_equal(gpu.r.warp_displacement_cached(disp, 120, 90), oracle.warp_displacement(src, disp))
+    gpu.r.warp_invalidate_source()
+    with pytest.raises(L.PfxError):
+        gpu.r.warp_displacement_cached(disp, 120, 90)
 
 
 @pytest.mark.parametrize("grid", [(2, 2), (6, 6), (1, 1), (9, 4), (63, 40)])  # (63,40): > 2048 points, non-LDS path

@@ -135,6 +135,35 @@ def test_cli_batch(tmp_path):
     assert p.returncode == 1 and "not built into this back-end" in p.stderr
 
 
+def test_cli_config1_literal_1024_and_gpus_flag(tmp_path):
+    """BASELINE config 1 as written: a 1024x1024 PNG of create_test_gradient + the script `apply_gaussian_blur(4.0);` (the alias of
+    the reference's apply_blur) through the CLI; and --gpus N shards a file list over worker contexts with the same results."""
+    exe = os.path.join(ROOT, "paintfe_amd", "pfx")
+    img = I.create_test_gradient(1024, 1024)
+    _write_png(tmp_path / "in.png", img)
+    (tmp_path / "blur.rhai").write_text("apply_gaussian_blur(4.0);\n")
+    p = subprocess.run([exe, "-i", str(tmp_path / "in.png"), "-s", str(tmp_path / "blur.rhai"), "-o", str(tmp_path / "out.png")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = _read_png(tmp_path / "out.png")
+    ref = O.tiled_roundtrip(O.gaussian_blur(O.tiled_roundtrip(img), 4.0))
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    assert got.shape == (1024, 1024, 4) and d.max() <= 1 and (d > 0).mean() < 1e-3
+    # the same script on five files over three workers (they share device 0 on a 1-GPU box): identical outputs, reports in input order
+    names = []
+    for k in range(5):
+        _write_png(tmp_path / f"f{k}.png", I.random_rgba(120 + 8 * k, 90 + k, k))
+        names.append(str(tmp_path / f"f{k}.png"))
+    p1 = subprocess.run([exe, "-i", *names, "-s", str(tmp_path / "blur.rhai"), "--output-dir", str(tmp_path / "o1")], capture_output=True, text=True)
+    p3 = subprocess.run([exe, "-i", *names, "-s", str(tmp_path / "blur.rhai"), "--output-dir", str(tmp_path / "o3"), "--gpus", "3"],
+                        capture_output=True, text=True)
+    assert p1.returncode == 0 and p3.returncode == 0, p1.stderr + p3.stderr
+    order = [l for l in p3.stdout.splitlines() if l.startswith("[")]
+    assert [l.split("]")[0] for l in order] == [f"[{k + 1}/5" for k in range(5)]
+    for k in range(5):
+        assert np.array_equal(_read_png(tmp_path / "o1" / f"f{k}.png"), _read_png(tmp_path / "o3" / f"f{k}.png"))
+
+
 def test_cli_png_decoder_variants(tmp_path):
     from PIL import Image
     exe = os.path.join(ROOT, "paintfe_amd", "pfx")
