@@ -1,0 +1,143 @@
+"""Known-answer pins for corners the reference's own tests leave open: non-identity Curves LUTs and the .pfe byte
+layout.  The vectors are derived from the published algorithm / the declared structs, not produced by the oracle or the product:
+ * tests/golden/curves_kat.json — Fritsch-Carlson in 60-digit decimal arithmetic (tests/golden/make_curves_kat.py);
+ * the .pfe files below are assembled by hand, field by field, from the struct declarations (src/io.rs:85-208,
+   src/canvas/layers.rs:192-235,378-387) and bincode 1.x's documented default encoding (little endian, fixed-width integers,
+   usize as u64, String / Vec = u64 length + items, bool and Option tag = one byte, enum = u32 variant index).
+Both the oracle (where it has the function) and the product's host code must reproduce them; no GPU needed."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------ Curves
+def _kat():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "curves_kat.json")))
+
+
+@pytest.mark.parametrize("name", sorted(_kat().keys()))
+def test_curves_lut_known_answers(name):
+    import ctypes as C
+    from paintfe_amd import _lib as L
+    case = _kat()[name]
+    pts = np.asarray(case["points"], np.float32)
+    idx = np.asarray(sorted(int(k) for k in case["lut"]), np.int64)
+    want = np.asarray([case["lut"][str(k)] for k in idx], np.uint8)
+    assert len(idx) >= 250
+    got_oracle = O.curves_lut(pts)
+    assert np.array_equal(got_oracle[idx], want), f"oracle: {np.flatnonzero(got_oracle[idx] != want)[:8]}"
+    lut = np.zeros(256, np.uint8)
+    L.load().pfx_build_curves_lut(pts.ctypes.data_as(C.c_void_p), C.c_uint32(len(pts)), lut.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(lut[idx], want), "product host builder (pfx_build_curves_lut)"
+    assert np.array_equal(lut, got_oracle)  # and the two agree on the boundary-adjacent entries too
+
+
+# ------------------------------------------------------------------------------------------------ .pfe layout
+def _hex(s: str) -> bytes:
+    return bytes.fromhex("".join(part.split("#")[0] for part in s.splitlines()).replace(" ", ""))
+
+
+PIXEL = bytes([10, 20, 30, 255])
+CHUNK = PIXEL * (64 * 64)  # one 64x64 chunk, 16384 bytes, every pixel (10, 20, 30, 255)
+
+# ProjectFileV1 { magic: String, width: u32, height: u32, active_layer_index: usize, layers: Vec<LayerDataV1> }
+# LayerDataV1 { name: String, visible: bool, opacity: f32, blend_mode: u8, chunks: Vec<ChunkData> }; ChunkData { cx: u32, cy: u32, pixels: Vec<u8> }
+PFE_V1_HEAD = _hex("""
+    04 00 00 00 00 00 00 00  50 46 45 31     # magic: len 4, "PFE1"
+    40 00 00 00                              # width  = 64
+    40 00 00 00                              # height = 64
+    00 00 00 00 00 00 00 00                  # active_layer_index = 0 (usize -> u64)
+    01 00 00 00 00 00 00 00                  # layers: 1 element
+    02 00 00 00 00 00 00 00  42 67           #   name: len 2, "Bg"
+    01                                       #   visible = true
+    00 00 00 3f                              #   opacity = 0.5f32
+    01                                       #   blend_mode = 1 (Multiply)
+    01 00 00 00 00 00 00 00                  #   chunks: 1 element
+    00 00 00 00                              #     cx = 0
+    00 00 00 00                              #     cy = 0
+    00 40 00 00 00 00 00 00                  #     pixels: len 16384
+""")
+PFE_V1 = PFE_V1_HEAD + CHUNK
+
+# ProjectFileV3 { magic, width, height, active_layer_index, folders: Vec<LayerFolder>, next_layer_folder_id: u64, layers: Vec<LayerDataV3> }
+# LayerFolder { id: u64, name: String, visible: bool, collapsed: bool, insert_above_layer: Option<usize>, color_index: Option<u8> }
+# LayerDataV3 { name, visible, folder_id: Option<u64>, opacity, blend_mode, layer_type: u8, chunks, content_data: Option<Vec<u8>>,
+#               pixel_format: PixelFormat (enum), hdr_metadata: HdrMetadata { enabled: bool, 3 x Option }, source_metadata: ImageMetadata
+#               { 3 x Option<String>, png_text_chunks: Vec<(String, String)>, raw_png_chunks: Vec<Vec<u8>> },
+#               webp_frame_compression: enum (Lossy = 0, Lossless = 1), deep_pixels: Option<DeepRgbaBuffer> }
+PFE_V3_HEAD = _hex("""
+    04 00 00 00 00 00 00 00  50 46 45 33     # magic "PFE3"
+    40 00 00 00  40 00 00 00                 # 64 x 64
+    00 00 00 00 00 00 00 00                  # active_layer_index = 0
+    01 00 00 00 00 00 00 00                  # folders: 1 element
+    07 00 00 00 00 00 00 00                  #   id = 7
+    03 00 00 00 00 00 00 00  47 72 70        #   name "Grp"
+    01                                       #   visible = true
+    00                                       #   collapsed = false
+    00                                       #   insert_above_layer = None
+    01 02                                    #   color_index = Some(2)
+    08 00 00 00 00 00 00 00                  # next_layer_folder_id = 8
+    01 00 00 00 00 00 00 00                  # layers: 1 element
+    02 00 00 00 00 00 00 00  4c 30           #   name "L0"
+    01                                       #   visible = true
+    01  07 00 00 00 00 00 00 00              #   folder_id = Some(7)
+    00 00 80 3f                              #   opacity = 1.0f32
+    00                                       #   blend_mode = 0 (Normal)
+    00                                       #   layer_type = 0 (Raster)
+    01 00 00 00 00 00 00 00                  #   chunks: 1 element
+    00 00 00 00  00 00 00 00                 #     cx = 0, cy = 0
+    00 40 00 00 00 00 00 00                  #     pixels: len 16384
+""")
+PFE_V3_TAIL = _hex("""
+    00                                       #   content_data = None
+    00 00 00 00                              #   pixel_format = RgbaU8 (variant 0)
+    00  00  00  00                           #   hdr_metadata: enabled = false, three None
+    00  00  00                               #   source_metadata: source_format, source_name, color_profile_name = None
+    00 00 00 00 00 00 00 00                  #     png_text_chunks: empty
+    00 00 00 00 00 00 00 00                  #     raw_png_chunks: empty
+    01 00 00 00                              #   webp_frame_compression = Lossless (variant 1)
+    00                                       #   deep_pixels = None
+""")
+PFE_V3 = PFE_V3_HEAD + CHUNK + PFE_V3_TAIL
+
+
+def test_hand_assembled_pfe_v1_loads_and_resaves_identically():
+    from paintfe_amd.project import Project
+    from tests import pfe_format as F
+    p = Project.load_bytes(PFE_V1)
+    assert (p.width, p.height, len(p)) == (64, 64, 1)
+    info = p.layer(0)
+    assert info["name"] == "Bg" and info["visible"] and info["blend_mode"] == 1 and abs(info["opacity"] - 0.5) == 0.0
+    px = p.layer_pixels(0)
+    assert px.shape == (64, 64, 4) and (px == np.array([10, 20, 30, 255], np.uint8)).all()
+    assert p.save_bytes() == PFE_V1                      # build_pfe picks V1 for a plain raster document (io.rs:254)
+    d = F.decode(PFE_V1)                                  # the Python restatement reads the same bytes the same way
+    assert d["version"] == 1 and d["layers"][0]["name"] == "Bg" and d["layers"][0]["blend_mode"] == 1
+
+
+def test_hand_assembled_pfe_v3_loads_and_resaves_identically():
+    from paintfe_amd.project import Project
+    from tests import pfe_format as F
+    p = Project.load_bytes(PFE_V3)
+    assert (p.width, p.height, len(p)) == (64, 64, 1)
+    info = p.layer(0)
+    assert info["name"] == "L0" and info["visible"] and info["blend_mode"] == 0 and info["opacity"] == 1.0
+    assert (p.layer_pixels(0) == np.array([10, 20, 30, 255], np.uint8)).all()
+    assert p.save_bytes() == PFE_V3                      # a folder forces V3 on save; every field survives
+    d = F.decode(PFE_V3)
+    assert d["version"] == 3 and d["folders"][0]["id"] == 7 and d["folders"][0]["name"] == "Grp" and d["next_layer_folder_id"] == 8
+    assert d["layers"][0]["folder_id"] == 7
+
+
+def test_hand_assembled_pfe_truncations_are_rejected():
+    from paintfe_amd.project import PfeError, Project
+    for cut in (3, 12, len(PFE_V1_HEAD) - 1, len(PFE_V1) - 1):
+        with pytest.raises(PfeError):
+            Project.load_bytes(PFE_V1[:cut])
