@@ -18,6 +18,10 @@
  *   device-resident calls (`..._dev`)            = same kernels on caller-owned device memory and the
  *                                                  context's HIP stream: upload once, chain ops, download once.
  *
+ * Device pointers handed to `_dev` calls must be 16-byte aligned (hipMalloc / pfx_dev_alloc results and row-aligned sub-buffers
+ * are): the kernels move pixels in 16-byte vectors.  No C++ exception leaves the library: entry points that parse untrusted bytes or run
+ * scripts convert allocation failures into PFX_ERR_OOM.
+ *
  * One pfx_ctx = one HIP device + one stream.  A context is not thread-safe (neither is the reference's
  * `&mut GpuRenderer`); distinct contexts are independent.  No torch / C++ types cross this boundary.
  */

@@ -451,7 +451,7 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                                    const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
-                                   uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region)
+                                   int chunk_active_ready, uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region)
 {
     size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
@@ -459,7 +459,7 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
     if (preview && preview->pixels) { PV = *preview; general = 1; }
     pfxk_region RG{};
     if (region && region->rw && region->rh) { RG = *region; general = 1; n_quads = (size_t)((RG.rw + 3u) / 4u) * RG.rh; }
-    if (general && d_chunk_active) {
+    if (general && d_chunk_active && !chunk_active_ready) {
         const uint32_t nchunks = ((w + 63u) / 64u) * ((h + 63u) / 64u);
         chunk_active_kernel<<<nchunks, 256, 0, stream>>>(d_layers, n_layers, w, h, d_chunk_active, PV.pixels ? PV.chunk_present : nullptr);
     }

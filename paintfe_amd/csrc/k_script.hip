@@ -63,7 +63,7 @@ __global__ void vm_kernel(const pfxk_vm_args A)
     // One bytecode instruction.  Inlined twice below: with a wave-uniform instruction (fields in SGPRs: scalar fetch, scalar
     // jump table, uniform LDS offsets) and with a per-lane one (lanes of a wave at different program counters).
     auto step = [&](const BcIns I) {
-        if (++steps > 4000000u) { err = BCE_TOO_MANY_OPS; return; }
+        if (++steps > A.step_budget) { err = BCE_TOO_MANY_OPS; return; }
         const int64_t ia = (int64_t)R(I.a), ib = (int64_t)R(I.b);
         int64_t ir;
         switch (I.op) {

@@ -177,7 +177,7 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
 
 int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
                    uint32_t n_layers, uint32_t w, uint32_t h, bool from_store, void* dst_dev, const preview_arg* pv = nullptr,
-                   const pfxk_region* region = nullptr)
+                   const pfxk_region* region = nullptr, const uint8_t* chunk_keys_host = nullptr)
 {
     PFX_REQUIRE(ctx, n_layers <= PFX_MAX_LAYERS, "too many layers");
     PFX_REQUIRE(ctx, n_layers == 0 || layers, "null layer list");
@@ -188,9 +188,13 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
                         pv ? pv->info.active_layer : 0xFFFFFFFFu, &active_pos, &active_pixels));
     const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
     uint8_t* d_chunks = nullptr;
+    bool chunks_ready = false;
     if (has_adj) { // adjustment layers only run on chunks populated in some visible layer (canvas_state.rs:529-550)
         PFX_TRY(pfx_reserve(ctx, ctx->d_chunks, nchunks));
         d_chunks = (uint8_t*)ctx->d_chunks.p;
+        // a caller that still has the layers' TiledImage chunk keys (a loaded document) passes their union: a chunk that is present
+        // but fully transparent counts, exactly as in the reference; flat layers can only offer "some alpha != 0" (the kernel's pre-pass)
+        if (chunk_keys_host && !(pv && pv->d_pixels)) { PFX_TRY(pfx_h2d(ctx, d_chunks, chunk_keys_host, nchunks)); chunks_ready = true; }
     }
     pfxk_preview PV{};
     if (pv && pv->d_pixels) { // chunk flags: [preview present | active layer present] (canvas_state.rs:541-548,587,593-597)
@@ -211,7 +215,7 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
     for (uint32_t i = 0; i < n_layers; ++i) fast_div = fast_div && opacity_allows_fast_div(layers[i].opacity);
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
-                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region));
+                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region));
     return PFX_OK;
 }
 
@@ -251,6 +255,17 @@ int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void*
     PFX_REQUIRE(ctx, dst_dev && w && h && (n_layers == 0 || layer_ptrs_dev), "pfx_flatten_dev: bad arguments");
     PFX_TRY(pfx_use(ctx));
     return flatten_common(ctx, layer_ptrs_dev, mask_ptrs_dev, layers, n_layers, w, h, false, dst_dev);
+}
+
+// pfx_flatten_dev for a document whose layers are TiledImages: chunk_keys_host[c] != 0 where some visible raster layer HOLDS chunk c
+// (canvas_state.rs:528-550 `chunk_keys()`), whatever its pixels are
+int pfx_int_flatten_with_chunk_keys_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const pfx_layer_info* layers, uint32_t n_layers,
+                                        uint32_t w, uint32_t h, void* dst_dev, const uint8_t* chunk_keys_host)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, dst_dev && w && h && (n_layers == 0 || layer_ptrs_dev), "pfx_int_flatten_with_chunk_keys_dev: bad arguments");
+    PFX_TRY(pfx_use(ctx));
+    return flatten_common(ctx, layer_ptrs_dev, nullptr, layers, n_layers, w, h, false, dst_dev, nullptr, nullptr, chunk_keys_host);
 }
 
 int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, void* tmp_dev)

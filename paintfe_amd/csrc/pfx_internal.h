@@ -89,6 +89,10 @@ struct pfx_timer {
     ~pfx_timer();
 };
 
+// flatten of device-resident flat layers + the union of the visible layers' TiledImage chunk keys (pfx_api.cpp)
+extern "C" int pfx_int_flatten_with_chunk_keys_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const pfx_layer_info* layers, uint32_t n_layers,
+                                                   uint32_t w, uint32_t h, void* dst_dev, const uint8_t* chunk_keys_host);
+
 // blur_with_selection on device-resident images (pfx_api.cpp); mask_host may be NULL (= no selection)
 int pfx_int_blur_with_selection_dev(pfx_ctx* ctx, const void* d_src, void* d_dst, uint32_t w, uint32_t h, float sigma,
                                     const uint8_t* mask_host, const void* d_mask);

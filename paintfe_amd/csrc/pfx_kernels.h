@@ -45,7 +45,7 @@ typedef struct pfxk_preview {
 // dirty rectangle: composite only [x0, x0+rw) x [y0, y0+rh) into a compact rw x rh destination (rw == 0: whole canvas)
 typedef struct pfxk_region { uint32_t x0, y0, rw, rh; } pfxk_region;
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
-                        const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, uint32_t w,
+                        const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, int chunk_active_ready, uint32_t w,
                         uint32_t h, uint8_t* d_dst, const pfxk_preview* preview /* may be NULL */,
                         const pfxk_region* region /* may be NULL */);
 void       pfxk_flatten_set_variant(int v); // tuning knob: 0 = shipped kernel, 1.. = experimental pixels-per-lane / occupancy variants
@@ -133,6 +133,7 @@ typedef struct pfxk_vm_args {
     int heavy;                // the program uses fmod / pow / sin / cos / tan / atan2 / exp / ln (selects the kernel that carries them)
     int w, h;
     int x0, y0, x1, y1;       // region processed (for_region); the rest of dst must already equal src
+    uint32_t step_budget;     // bytecode steps one pixel may execute before the launch reports 'Too many operations'
 } pfxk_vm_args;
 hipError_t pfxk_vm_run(hipStream_t s, const pfxk_vm_args* A);
 // mode: 0 flip_horizontal, 1 flip_vertical, 2 rotate180, 3 rotate90 (cw), 4 rotate270 (ccw); (w, h) = source size

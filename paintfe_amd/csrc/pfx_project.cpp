@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -233,6 +235,7 @@ bool read_layer(Reader& R, pfx_project& P, int version, Layer& L)
     if (!R.str(L.name) || !R.boolean(L.visible)) return false;
     if (version >= 3) { if (!R.tag(L.has_folder)) return false; if (L.has_folder && !R.u64(L.folder_id)) return false; }
     if (!R.f32(L.opacity) || !R.u8(L.blend_mode)) return false;
+    if (L.blend_mode > 24) L.blend_mode = 0; // BlendMode::from_u8: unknown ids are Normal, and a re-save writes to_u8() of that (layers.rs:125-185)
     if (version == 0) { // LayerDataV0: flat pixels, converted with from_rgba_image (io.rs:1247-1274)
         uint64_t l;
         if (!R.len(l, 1)) return false;
@@ -486,10 +489,18 @@ extern "C" {
 
 pfx_project* pfx_project_load(const uint8_t* bytes, size_t n_bytes, char* err, size_t err_cap)
 {
-    std::string why;
-    pfx_project* P = load_bytes(bytes, n_bytes, why);
-    if (!P) set_err(err, err_cap, why);
-    return P;
+    // exception barrier: nothing may unwind through the C ABI (a corrupt length field must not become std::terminate)
+    try {
+        std::string why;
+        pfx_project* P = load_bytes(bytes, n_bytes, why);
+        if (!P) set_err(err, err_cap, why);
+        return P;
+    } catch (const std::bad_alloc&) {
+        set_err(err, err_cap, "out of memory while reading the project");
+    } catch (const std::exception& e) {
+        set_err(err, err_cap, std::string("internal error: ") + e.what());
+    }
+    return nullptr;
 }
 
 pfx_project* pfx_project_load_file(const char* path, char* err, size_t err_cap)
@@ -596,7 +607,7 @@ int pfx_project_save(const pfx_project* p, uint8_t** bytes_out, size_t* n_out)
 {
     if (!p || !bytes_out || !n_out) return PFX_ERR_INVALID;
     Writer W;
-    serialize(*p, W);
+    try { serialize(*p, W); } catch (const std::exception&) { return PFX_ERR_OOM; } // exception barrier of the C ABI
     *bytes_out = (uint8_t*)std::malloc(W.out.size() ? W.out.size() : 1);
     if (!*bytes_out) return PFX_ERR_OOM;
     std::memcpy(*bytes_out, W.out.data(), W.out.size());
@@ -653,8 +664,12 @@ int pfx_project_composite_dev(pfx_ctx* ctx, const pfx_project* p, void* dst_dev)
     PFX_TRY(tmp.alloc(ctx, P.n_canvas_chunks() * sizeof(uint32_t), &d_slot));
     std::vector<pfx_layer_info> infos;
     std::vector<const void*> ptrs;
+    std::vector<uint8_t> chunk_keys(P.n_canvas_chunks(), 0); // union of the visible layers' chunk_keys() (canvas_state.rs:528-540)
     for (const Layer& L : P.layers) {
         if (!(L.visible && folder_visible(P, L))) continue; // layer_effectively_visible (canvas_state.rs:216-227,576)
+        if (L.kind == PFX_LAYER_RASTER)
+            for (size_t c = 0; c < chunk_keys.size() && c < L.slot.size(); ++c)
+                if (L.slot[c] != PFX_NO_CHUNK) chunk_keys[c] = 1;
         pfx_layer_info I{};
         I.layer_idx = (uint32_t)infos.size();
         I.opacity = L.opacity;
@@ -674,7 +689,7 @@ int pfx_project_composite_dev(pfx_ctx* ctx, const pfx_project* p, void* dst_dev)
         PFX_HIP(ctx, hipMemsetAsync(dst_dev, 0, bytes, ctx->stream));
         return pfx_sync(ctx);
     }
-    PFX_TRY(pfx_flatten_dev(ctx, ptrs.data(), nullptr, infos.data(), (uint32_t)infos.size(), P.w, P.h, dst_dev));
+    PFX_TRY(pfx_int_flatten_with_chunk_keys_dev(ctx, ptrs.data(), infos.data(), (uint32_t)infos.size(), P.w, P.h, dst_dev, chunk_keys.data()));
     return pfx_sync(ctx); // the temporaries are freed on return
 }
 

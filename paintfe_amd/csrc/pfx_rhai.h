@@ -9,6 +9,12 @@
 // interpolation — as a tree-walking interpreter for the *control plane* of a script, plus a compiler that lowers
 // per-pixel closures (`map_channels`, `for_each_pixel`, `for_region`) to a register bytecode executed by one GPU
 // kernel (k_script.hip).  Pixel data never goes through the interpreter except for the scalar get_pixel/set_pixel API.
+//
+// Operation budget (scripting.rs:288 set_max_operations(50_000_000)): the interpreter counts like Rhai.  A per-pixel closure
+// compiled for the GPU gets, per pixel, max(4096, (50 M - operations so far) / pixels of the call) bytecode steps
+// (pfx_script_host.cpp): a runaway loop ends with 'Too many operations' after a bounded launch, a closure whose per-pixel cost
+// exceeds both the floor and its share of the budget fails as in the reference.  Remaining divergence, on purpose: a cheap
+// closure over a large image (7 steps x 33 Mpx) exhausts the reference's global budget but runs here.
 #pragma once
 #include <cstdint>
 #include <functional>

@@ -16,6 +16,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -136,6 +138,19 @@ struct ScriptHost : rhai::Host {
                 ins.op == rhai::BC_FATAN2 || ins.op == rhai::BC_FEXP || ins.op == rhai::BC_FLN) A.heavy = 1;
         A.w = (int)w; A.h = (int)h;
         A.x0 = x0; A.y0 = y0; A.x1 = x1; A.y1 = y1;
+        // Operation budget.  The reference counts a closure's operations against the script's single 50 M budget (set_max_operations,
+        // scripting.rs:288; closures run through call_within_context), serially, and can be cancelled between operations.  A kernel
+        // launch cannot be cancelled, so the budget is made launch-wide up front: what is left of the 50 M is divided over the pixels
+        // of the call, with a floor of 4096 steps per pixel so that ordinary closures on large images — which the reference's serial
+        // interpreter could never finish — still run.  A runaway loop therefore costs at most 4096 steps per pixel before the launch
+        // reports 'Too many operations'; scripts whose closures need more than the floor AND more than the reference's budget per
+        // pixel fail here as they do there.  (Remaining divergence, see pfx_rhai.h: cheap closures on big images succeed here.)
+        {
+            const uint64_t used = in.ops(), left = used < 50000000ull ? 50000000ull - used : 0ull;
+            const uint64_t n_px = (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0);
+            const uint64_t share = n_px ? left / n_px : left;
+            A.step_budget = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(share, 4096ull), 4000000ull);
+        }
         {
             pfx_timer t(ctx, "script_vm");
             PFX_HIP(ctx, pfxk_vm_run(ctx->stream, &A));
@@ -525,7 +540,7 @@ uint64_t time_seed() // scripting.rs:1745-1751
 
 int pfx_int_script_run_dev(pfx_ctx* ctx, const char* source, uint32_t* w, uint32_t* h, const uint8_t* mask, pfx_script_result* result,
                            std::vector<std::string>* console, std::vector<pfx_canvas_op>* ops)
-{
+try {
     ScriptHost host;
     host.ctx = ctx;
     host.w = *w;
@@ -559,6 +574,10 @@ int pfx_int_script_run_dev(pfx_ctx* ctx, const char* source, uint32_t* w, uint32
     *h = host.h;
     if (ops) *ops = host.ops;
     return PFX_OK;
+} catch (const std::bad_alloc&) { // exception barrier: nothing may unwind through the C ABI
+    return pfx_fail(ctx, PFX_ERR_OOM, "out of memory while running the script");
+} catch (const std::exception& e) {
+    return pfx_fail(ctx, PFX_ERR_SCRIPT, "internal error while running the script: %s", e.what());
 }
 
 extern "C" {

@@ -73,6 +73,28 @@ def test_project_composite_matches_the_oracle(r, size):
     assert q.version == 3 and np.array_equal(q.composite(r), ref)
 
 
+def test_present_but_transparent_chunk_counts_for_adjustment_layers(r):
+    """canvas_state.rs:528-550: an adjustment layer runs on every chunk some visible layer HOLDS (chunk_keys()), pixels or not.
+    A .pfe file can store a fully transparent chunk; Invert over it yields (255, 255, 255, 0), and a layer above that blends
+    against that colour.  Chunks no layer holds stay (0, 0, 0, 0).  (The flat-image oracle cannot express this: expected values
+    are derived by hand from layers.rs:276-325.)"""
+    from paintfe_amd.project import Project
+    from tests import pfe_format as F
+    w = h = 128
+    solid = np.zeros((64, 64, 4), np.uint8); solid[...] = (10, 200, 90, 255)
+    clear = np.zeros((64, 64, 4), np.uint8)
+    base = {"name": "base", "visible": True, "folder_id": None, "opacity": 1.0, "blend_mode": 0, "layer_type": 0,
+            "chunks": [(0, 0, solid.tobytes()), (1, 0, clear.tobytes())],          # chunk (1,0) is stored although transparent
+            "content_data": None, "pixel_format": 0, "hdr_metadata": dict(F.DEFAULT_HDR), "source_metadata": dict(F.DEFAULT_META),
+            "webp_frame_compression": 1, "deep_pixels": None}
+    inv = dict(base, name="invert", layer_type=2, chunks=[], content_data=F.adjustment_bytes(2))
+    raw = F.encode({"version": 3, "width": w, "height": h, "active_layer_index": 0, "folders": [], "next_layer_folder_id": 1, "layers": [base, inv]})
+    got = Project.load_bytes(raw).composite(r)
+    assert (got[:64, :64] == np.array([245, 55, 165, 255], np.uint8)).all()       # inverted solid chunk
+    assert (got[:64, 64:] == np.array([255, 255, 255, 0], np.uint8)).all()        # held-but-transparent chunk: colour inverted, alpha 0
+    assert (got[64:] == 0).all()                                                   # chunks nobody holds
+
+
 def test_project_composite_nothing_visible_and_legacy_versions(r):
     from paintfe_amd.project import Project
     w, h = 100, 70

@@ -335,6 +335,11 @@ def test_closure_runtime_errors_leave_the_image_untouched(r):
     with pytest.raises(PfxError) as e:
         run(r, "map_channels(|r, g, b, a| { let n = 0; loop { n += 1; } });", img)
     assert "Too many operations" in str(e.value)
+    # a long but finite loop per pixel: 1e6 iterations x 1024 pixels is far beyond the script's 50 M operations (scripting.rs:288);
+    # the launch-wide budget ends it after a bounded number of steps per pixel instead of running 1e9+ VM steps
+    with pytest.raises(PfxError) as e:
+        run(r, "map_channels(|r, g, b, a| { let i = 0; while i < 1000000 { i += 1; } [r, g, b, a] });", img)
+    assert "Too many operations" in str(e.value)
     with pytest.raises(PfxError) as e:
         run(r, "map_channels(|r, g| [r, g, 0, 0]);", img)  # wrong arity
     assert "Function not found" in str(e.value)
