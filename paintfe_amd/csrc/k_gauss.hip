@@ -224,7 +224,8 @@ constexpr int GM_COLS = 32;             // output columns per tile (one MFMA N b
 constexpr int GM_MAXR = 48;             // largest radius (sigma <= 16)
 constexpr int GM_ROWS = 224;            // LDS rows of H results per tile: R + 2 * R8 <= 224
 constexpr int GM_YP = 232;              // row pitch (f16) of one (part, channel, column) line: 224 + 8
-constexpr int GM_PLANE = GM_COLS * GM_YP + 8; // (part, channel) plane stride in f16: +16 bytes so the 4 channels spread over slots
+constexpr int GM_PLANE = GM_COLS * GM_YP + 32; // (part, channel) plane stride in f16, +64 bytes: with the 29-slot column pitch (mod 16 = 13)
+                                               // the V pass's ds_read_b128 lane groups (4 columns x 4 channels) hit 16 distinct 16-byte slots
 constexpr int GM_OUT_PITCH = 33;        // dwords per staged output row
 constexpr int GM_MAX_R = 192;           // largest R (small radii)
 constexpr int GM_WOFF = 48;             // wsplit[GM_WOFF + t] = tap t; zeros elsewhere
@@ -424,6 +425,180 @@ __global__ __launch_bounds__(512, 1) void gauss_mfma_kernel(const uint8_t* __res
     }
 }
 
+
+// ---- the same two matrix passes as a column-strip walk: no recomputed rows -------------------------------------------------------
+// gauss_mfma_kernel recomputes the horizontal pass for the 2 * R8 halo rows of every R-row tile (1.75x at sigma = 16).  Here a
+// workgroup owns a 32-column strip and walks down it in steps of 32 rows with the horizontal results in an LDS RING of
+// 16 NKB + 32 rows: waves 0-3 produce the 32 new rows of step i (one 8-row x 4-channel unit each) while waves 4-7 run the
+// vertical pass of step i - NKB / 2 on the 16 NKB rows already in the ring (one 8-column block each) — disjoint ring slots, one
+// barrier per step, both roles share a SIMD pairwise so one wave's conversions and packing overlap the other's MFMAs.  The
+// previous step's output tile is written to global memory by the producer waves (128-byte row segments, double-buffered in LDS).
+// A strip is cut into `n_seg` row segments so that a launch has about two workgroups per CU; a segment pays NKB / 2 - 1 producer
+// steps of run-in.  Arithmetic per output is identical to gauss_mfma_kernel's (same fragments, same K-block grouping relative to
+// the 32-row output block, blocks on the whole image's 32-row grid).
+template <bool FAST, int NKB>
+__global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __restrict__ planes, size_t plane_stride, uint8_t* __restrict__ dst,
+                                                             const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8, float inv_scale2,
+                                                             float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg)
+{
+    constexpr int RING = 16 * NKB + 32, YP = RING + 8, PLANE = GM_COLS * YP + 32, HALF = NKB / 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
+    _Float16* HR = reinterpret_cast<_Float16*>(gm_lds);                            // [part][c][x][YP], rows = ring slots
+    uint32_t* OUT = reinterpret_cast<uint32_t*>(gm_lds + (size_t)8 * PLANE * 2);    // [2][32][GM_OUT_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hh = lane >> 5;
+    const bool producer = wave < 4;
+
+    pfx_f16x8 B1[NKB], B2[NKB]; // Toeplitz fragments, as in gauss_mfma_kernel
+    {
+        const _Float16* w1 = reinterpret_cast<const _Float16*>(wsplit) + GM_WOFF;
+        const _Float16* w2 = w1 + GM_WLEN;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int t0 = 8 * NKB * hh + 8 * kb - i - (R8 - r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { B1[kb][j] = w1[t0 + j]; B2[kb][j] = w2[t0 + j]; }
+        }
+    }
+    const int ci = blockIdx.x % n_cols, seg = blockIdx.x / n_cols;
+    const int x0 = ci * GM_COLS;
+    const int t_first = seg * steps_per_seg, t_last = min(t_first + steps_per_seg, n_steps); // output blocks [t_first, t_last)
+    if (t_first >= t_last) return;
+    const int nst = t_last - t_first;
+    const int a0 = 32 * t_first - y_phase - R8; // image row of ring slot 0 (producer step 0)
+
+    // producer state: the 8 NKB samples of this lane's run for the NEXT producer step (requested one step ahead)
+    uint32_t raw[NKB][2];
+    const uint8_t* plane_c = planes + (size_t)(i >> 3) * plane_stride; // A row m = i = channel * 8 + row
+    const int xs = x0 - R8 + 8 * NKB * hh;
+    // FAST (rows 16-byte aligned, w % 16 == 0): the run is fetched as 16-byte pieces.  A piece is either wholly inside the row or
+    // wholly outside it (clamp-to-edge, filters.rs:268-270: every sample of it is then the row's first / last byte), so border
+    // strips cost one clamp of the piece address and a byte broadcast; interior strips (wave-uniform test) skip even that.
+    const bool interior = __builtin_amdgcn_readfirstlane((x0 - R8 >= 0 && x0 - R8 + 16 * NKB <= w) ? 1 : 0) != 0;
+    auto fetch = [&](int hs) {
+        const int ysrc = min(max(a0 + 32 * hs + 8 * wave + (i & 7), 0), h - 1);      // clamp-to-edge (filters.rs:296-298)
+        const uint8_t* line = plane_c + (size_t)ysrc * w;
+        if constexpr (FAST) {
+            if (interior) {
+#pragma unroll
+                for (int q = 0; q < NKB / 2; ++q) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(line + xs + 16 * q);
+                    raw[2 * q][0] = v.x; raw[2 * q][1] = v.y; raw[2 * q + 1][0] = v.z; raw[2 * q + 1][1] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NKB / 2; ++q) {
+                    const int xp = xs + 16 * q, xc = min(max(xp, 0), w - 16);
+                    uint4 v = *reinterpret_cast<const uint4*>(line + xc);
+                    if (xp < 0) { const uint32_t e = __builtin_amdgcn_perm(0u, v.x, 0x00000000u); v = make_uint4(e, e, e, e); }      // row's first byte
+                    else if (xp >= w) { const uint32_t e = __builtin_amdgcn_perm(0u, v.w, 0x03030303u); v = make_uint4(e, e, e, e); } // row's last byte
+                    raw[2 * q][0] = v.x; raw[2 * q][1] = v.y; raw[2 * q + 1][0] = v.z; raw[2 * q + 1][1] = v.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                uint32_t b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = line[min(max(xs + 8 * kb + j, 0), w - 1)]; // clamp-to-edge (filters.rs:268-270)
+                raw[kb][0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                raw[kb][1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+            }
+        }
+    };
+    const int n_hsteps = nst + HALF - 1; // producer steps 0 .. n_hsteps - 1; consumer step v needs producer steps v .. v + HALF - 1
+    if (producer) fetch(0);
+
+    for (int it = 0; it <= nst + HALF; ++it) {
+        if (producer) {
+            // (a) write the output block the consumers finished in the previous iteration
+            const int vp = it - 1 - HALF;
+            if (vp >= 0) {
+                const uint32_t* ob = OUT + (vp & 1) * 32 * GM_OUT_PITCH;
+                const int yb = 32 * (t_first + vp) - y_phase;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = tid + 256 * q, rr = idx >> 5, cc = idx & 31;
+                    if (yb + rr >= 0 && yb + rr < h && x0 + cc < w)
+                        reinterpret_cast<uint32_t*>(dst)[(size_t)(yb + rr) * w + x0 + cc] = ob[rr * GM_OUT_PITCH + cc];
+                }
+            }
+            // (b) horizontal pass of 32 new rows into ring slots [32 it mod RING, +32)
+            if (it < n_hsteps) {
+                pfx_f16x8 fr[NKB];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    const uint32_t d0 = raw[kb][0], d1 = raw[kb][1];
+                    uint32_t q[4];
+                    q[0] = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00050004u); // 0x6400 | byte = 1024 + byte as f16
+                    q[1] = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00070006u);
+                    q[2] = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00050004u);
+                    q[3] = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00070006u);
+                    fr[kb] = __builtin_bit_cast(pfx_f16x8, q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(min(it + 1, n_hsteps - 1)); // next step's samples land during this step's MFMAs (the last one re-reads, unused)
+                __builtin_amdgcn_sched_barrier(0);
+                pfx_f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = -bias_c;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B1[kb], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], acc, 0, 0, 0);
+                }
+                const int ro = (32 * it) % RING + 8 * wave + 4 * hh; // regs 4c .. 4c+3 = four consecutive rows of channel c at column i
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pfx_f16x4 h1, h2;
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const float va = acc[4 * g + e], vb = acc[4 * g + e + 1];
+                        const pfx_f16x2 hi = pkrtz(va, vb);
+                        const pfx_f16x2 lo = pkrtz(va - (float)hi[0], vb - (float)hi[1]);
+                        h1[e] = hi[0]; h1[e + 1] = hi[1]; h2[e] = lo[0]; h2[e + 1] = lo[1];
+                    }
+                    *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(0 * 4 + g) * PLANE + i * YP + ro) = h1;
+                    *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * PLANE + i * YP + ro) = h2;
+                }
+            }
+        } else {
+            // vertical pass of output block v on ring slots [32 v mod RING, + 16 NKB); A row m = i = xl * 4 + c
+            const int v = it - HALF;
+            if (v >= 0 && v < nst) {
+                const int xb = wave - 4, xl = i >> 2, c = i & 3;
+                const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP;
+                const _Float16* a2p = HR + (size_t)(1 * 4 + c) * PLANE + (8 * xb + xl) * YP;
+                const int rb = (32 * v) % RING + 8 * NKB * hh;
+                pfx_f32x16 accA, accB;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { accA[q] = 0.0f; accB[q] = 0.0f; }
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    int ro = rb + 8 * kb;
+                    ro = ro >= RING ? ro - RING : ro;
+                    const pfx_f16x8 a1 = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
+                    const pfx_f16x8 a2 = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, B1[kb], accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, B2[kb], accB, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, B1[kb], accB, 0, 0, 0);
+                }
+                uint32_t* orow = OUT + (v & 1) * 32 * GM_OUT_PITCH + i * GM_OUT_PITCH + 8 * xb + hh; // regs 4g..4g+3 = RGBA of (8 xb + 2 g + hh, row i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t px[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        px[e] = min((uint32_t)__builtin_fmaf(accA[4 * g + e] + accB[4 * g + e], inv_scale2, 0.5f), 255u); // filters.rs:308-311
+                    orow[2 * g] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 } // namespace
 
 // LDS bounds: H tile (1024 + 2r + 12) x 20 B and the narrowest V tile (256 + 2r + 4) rows x 5 x 16 B <= 160 KiB
@@ -480,6 +655,42 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     int c_hi = ((int)w - 16 * nkb + R8) / GM_COLS + 1;                   // one past the last column with x0 - R8 + 16 nkb <= w
     if (!aligned || (int)w - 16 * nkb + R8 < 0 || c_hi <= c_lo) { c_lo = 0; c_hi = 0; }
     if (c_hi > tiles_x) c_hi = tiles_x;
+    if (!(g_v_cfg & 0x100)) { // shipped: column-strip walk (tune gauss_v_cfg = 256 selects the tile kernel for A/B)
+        const int y_ph = (int)(first_row % 32u);
+        const int n_steps = ((int)h + y_ph + 31) / 32;
+        const bool fast = ((uintptr_t)d_planes & 15u) == 0 && (w & 15u) == 0 && w >= 16;
+        hipError_t errs = hipSuccess;
+        auto launch_s = [&](auto nkb_c) {
+            constexpr int NK = decltype(nkb_c)::value;
+            constexpr int RING = 16 * NK + 32;
+            const size_t lds = (size_t)8 * (GM_COLS * (RING + 8) + 32) * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4;
+            // cut every strip into n_seg row segments so that the launch has just under two workgroups per CU (one is resident per CU,
+            // LDS-bound; measured at 8K: 1 / 2 / 3 segments per strip = 0.359 / 0.340 / 0.341 ms); a segment pays NK/2 - 1 run-in steps
+            int n_seg = (int)((18L * n_cus / 10 + tiles_x - 1) / tiles_x);
+            if (g_v_cfg & 0xff) n_seg = g_v_cfg & 0xff; // tuning override
+            if (n_seg < 1) n_seg = 1;
+            int per = (n_steps + n_seg - 1) / n_seg;
+            if (per < 4) per = n_steps < 4 ? n_steps : 4;
+            n_seg = (n_steps + per - 1) / per;
+            const int grid = tiles_x * n_seg;
+            if (fast) {
+                errs = hipFuncSetAttribute((const void*)gauss_strip_kernel<true, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (errs) return;
+                gauss_strip_kernel<true, NK><<<grid, 512, lds, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per);
+            } else {
+                errs = hipFuncSetAttribute((const void*)gauss_strip_kernel<false, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (errs) return;
+                gauss_strip_kernel<false, NK><<<grid, 512, lds, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per);
+            }
+        };
+        switch (nkb) {
+        case 4: launch_s(std::integral_constant<int, 4>{}); break;
+        case 6: launch_s(std::integral_constant<int, 6>{}); break;
+        default: launch_s(std::integral_constant<int, 8>{}); break;
+        }
+        if (errs) return errs;
+        return hipGetLastError();
+    }
     const int n_int = c_hi - c_lo, n_brd = tiles_x - n_int;
     hipError_t err = hipSuccess;
     auto launch = [&](auto fast, auto nkb_c) {
@@ -490,8 +701,8 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
         err = hipFuncSetAttribute((const void*)gauss_mfma_kernel<F, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM_LDS);
         if (err) return;
         const int n_tiles = cols * tiles_y, grid = n_tiles < n_cus ? n_tiles : n_cus; // persistent: one workgroup per CU (LDS-bound)
-        if (F) gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, c_lo, cols, 0, y_phase, g_v_cfg >> 8);
-        else   gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, 0, c_lo, c_hi, y_phase, g_v_cfg >> 8);
+        if (F) gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, c_lo, cols, 0, y_phase, g_v_cfg >> 9);
+        else   gauss_mfma_kernel<F, NK><<<grid, 512, GM_LDS, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, R, inv_scale2, bias_c, cols, n_tiles, 0, c_lo, c_hi, y_phase, g_v_cfg >> 9);
     };
     auto both = [&](auto nkb_c) {
         launch(std::true_type{}, nkb_c);
