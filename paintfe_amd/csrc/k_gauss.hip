@@ -179,6 +179,7 @@ hipError_t launch_v_cfg(hipStream_t stream, const float4* tmp, uint8_t* d_dst, c
     return hipGetLastError();
 }
 
+unsigned long long* g_dbg_buf = nullptr; // development: phase timestamps of gauss_strip_kernel (pfxk_gauss_set_dbg_buf)
 int g_v_cfg = 0; // tuning knob (pfxk_gauss_set_v_config); 0 is the shipped configuration
 
 template <bool EXACT>
@@ -436,10 +437,11 @@ __global__ __launch_bounds__(512, 1) void gauss_mfma_kernel(const uint8_t* __res
 // A strip is cut into `n_seg` row segments so that a launch has about two workgroups per CU; a segment pays NKB / 2 - 1 producer
 // steps of run-in.  Arithmetic per output is identical to gauss_mfma_kernel's (same fragments, same K-block grouping relative to
 // the 32-row output block, blocks on the whole image's 32-row grid).
+constexpr int GS_DEPTH = 3; // register sets of source samples in flight per producer lane
 template <bool FAST, int NKB>
 __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __restrict__ planes, size_t plane_stride, uint8_t* __restrict__ dst,
                                                              const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8, float inv_scale2,
-                                                             float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg)
+                                                             float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg, int dbg, unsigned long long* __restrict__ dbg_buf)
 {
     constexpr int RING = 16 * NKB + 32, YP = RING + 8, PLANE = GM_COLS * YP + 32, HALF = NKB / 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
@@ -460,6 +462,10 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 #pragma unroll
             for (int j = 0; j < 8; ++j) { B1[kb][j] = w1[t0 + j]; B2[kb][j] = w2[t0 + j]; }
         }
+        // settle the fragments here: otherwise the waitcnt bookkeeping treats them as "possibly still loading" at their first use in
+        // every loop iteration and drains the wave's prefetches / stores there (vmcnt(3) .. vmcnt(0) in front of the MFMAs)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) { asm volatile("" : "+v"(B1[kb])); asm volatile("" : "+v"(B2[kb])); }
     }
     const int ci = blockIdx.x % n_cols, seg = blockIdx.x / n_cols;
     const int x0 = ci * GM_COLS;
@@ -468,33 +474,28 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
     const int nst = t_last - t_first;
     const int a0 = 32 * t_first - y_phase - R8; // image row of ring slot 0 (producer step 0)
 
-    // producer state: the 8 NKB samples of this lane's run for the NEXT producer step (requested one step ahead)
-    uint32_t raw[NKB][2];
+    // producer state: the 8 NKB samples of this lane's run for the next GS_DEPTH - 1 producer steps (a ring of register sets,
+    // requested GS_DEPTH - 1 steps ahead: one step is ~1.5k cycles, HBM latency under load is several thousand)
+    uint32_t raw[GS_DEPTH][NKB][2];
     const uint8_t* plane_c = planes + (size_t)(i >> 3) * plane_stride; // A row m = i = channel * 8 + row
     const int xs = x0 - R8 + 8 * NKB * hh;
     // FAST (rows 16-byte aligned, w % 16 == 0): the run is fetched as 16-byte pieces.  A piece is either wholly inside the row or
     // wholly outside it (clamp-to-edge, filters.rs:268-270: every sample of it is then the row's first / last byte), so border
     // strips cost one clamp of the piece address and a byte broadcast; interior strips (wave-uniform test) skip even that.
-    const bool interior = __builtin_amdgcn_readfirstlane((x0 - R8 >= 0 && x0 - R8 + 16 * NKB <= w) ? 1 : 0) != 0;
-    auto fetch = [&](int hs) {
+    const int n_hsteps = nst + HALF - 1; // producer steps 0 .. n_hsteps - 1; consumer step v needs producer steps v .. v + HALF - 1
+    auto walk = [&](auto borderc) { // BORDER: the strip's source window leaves the image; chosen once per workgroup, so the loop
+    constexpr bool BORDER = decltype(borderc)::value; // body below has no data-dependent branch around its loads (exact vmcnt waits)
+    auto fetch = [&](auto bufc, int hs_req) {
+        constexpr int BUF = decltype(bufc)::value;
+        const int hs = min(hs_req, n_hsteps - 1);                                    // past the end: re-read the last step (unused)
         const int ysrc = min(max(a0 + 32 * hs + 8 * wave + (i & 7), 0), h - 1);      // clamp-to-edge (filters.rs:296-298)
         const uint8_t* line = plane_c + (size_t)ysrc * w;
         if constexpr (FAST) {
-            if (interior) {
 #pragma unroll
-                for (int q = 0; q < NKB / 2; ++q) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(line + xs + 16 * q);
-                    raw[2 * q][0] = v.x; raw[2 * q][1] = v.y; raw[2 * q + 1][0] = v.z; raw[2 * q + 1][1] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < NKB / 2; ++q) {
-                    const int xp = xs + 16 * q, xc = min(max(xp, 0), w - 16);
-                    uint4 v = *reinterpret_cast<const uint4*>(line + xc);
-                    if (xp < 0) { const uint32_t e = __builtin_amdgcn_perm(0u, v.x, 0x00000000u); v = make_uint4(e, e, e, e); }      // row's first byte
-                    else if (xp >= w) { const uint32_t e = __builtin_amdgcn_perm(0u, v.w, 0x03030303u); v = make_uint4(e, e, e, e); } // row's last byte
-                    raw[2 * q][0] = v.x; raw[2 * q][1] = v.y; raw[2 * q + 1][0] = v.z; raw[2 * q + 1][1] = v.w;
-                }
+            for (int q = 0; q < NKB / 2; ++q) { // BORDER: the piece address is clamped here, its bytes are replaced when they are consumed
+                const int xp = xs + 16 * q, xc = BORDER ? min(max(xp, 0), w - 16) : xp;
+                const uint4 v = *reinterpret_cast<const uint4*>(line + xc);
+                raw[BUF][2 * q][0] = v.x; raw[BUF][2 * q][1] = v.y; raw[BUF][2 * q + 1][0] = v.z; raw[BUF][2 * q + 1][1] = v.w;
             }
         } else {
 #pragma unroll
@@ -502,52 +503,59 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 uint32_t b[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) b[j] = line[min(max(xs + 8 * kb + j, 0), w - 1)]; // clamp-to-edge (filters.rs:268-270)
-                raw[kb][0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-                raw[kb][1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                raw[BUF][kb][0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                raw[BUF][kb][1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
             }
         }
     };
-    const int n_hsteps = nst + HALF - 1; // producer steps 0 .. n_hsteps - 1; consumer step v needs producer steps v .. v + HALF - 1
-    if (producer) fetch(0);
 
-    for (int it = 0; it <= nst + HALF; ++it) {
-        if (producer) {
-            // (a) write the output block the consumers finished in the previous iteration
-            const int vp = it - 1 - HALF;
-            if (vp >= 0) {
-                const uint32_t* ob = OUT + (vp & 1) * 32 * GM_OUT_PITCH;
-                const int yb = 32 * (t_first + vp) - y_phase;
+    auto stamp = [&](int it, int slot) { // development: s_memtime at phase boundaries of iterations 10..13, block 0, waves 0 and 4
+        if ((dbg & 16) && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && it >= 10 && it < 14)
+            dbg_buf[((wave >> 2) * 4 + (it - 10)) * 8 + slot] = __builtin_readcyclecounter();
+    };
+    // The two roles run separate loops with the same number of barriers.  The producer loop is unrolled GS_DEPTH times with the
+    // refill of register set BUF unconditional and straight after its conversion: the loads then write their final registers and
+    // every vmcnt wait is exact (a refill inside a conditional ends up as load-to-temporary + s_waitcnt vmcnt(0) + copy).
+    const int last = nst + HALF, n_iter = ((last + GS_DEPTH) / GS_DEPTH) * GS_DEPTH; // iterations 0 .. n_iter - 1 (the surplus ones only synchronise)
+    if (producer) {
+        auto produce = [&](auto bufc, int it) {
+            constexpr int BUF = decltype(bufc)::value;
+            stamp(it, 0);
+            pfx_f16x8 fr[NKB];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int idx = tid + 256 * q, rr = idx >> 5, cc = idx & 31;
-                    if (yb + rr >= 0 && yb + rr < h && x0 + cc < w)
-                        reinterpret_cast<uint32_t*>(dst)[(size_t)(yb + rr) * w + x0 + cc] = ob[rr * GM_OUT_PITCH + cc];
+            for (int kb = 0; kb < NKB; ++kb) {
+                uint32_t d0 = raw[BUF][kb][0], d1 = raw[BUF][kb][1];
+                if constexpr (BORDER && FAST) { // a 16-byte piece left / right of the row is the row's first / last byte throughout
+                    const int xp = xs + 16 * (kb >> 1);
+                    const uint32_t first = __builtin_amdgcn_perm(0u, raw[BUF][kb & ~1][0], 0x00000000u), lastb = __builtin_amdgcn_perm(0u, raw[BUF][kb | 1][1], 0x03030303u);
+                    d0 = xp < 0 ? first : (xp >= w ? lastb : d0);
+                    d1 = xp < 0 ? first : (xp >= w ? lastb : d1);
                 }
+                uint32_t q[4];
+                q[0] = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00050004u); // 0x6400 | byte = 1024 + byte as f16
+                q[1] = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00070006u);
+                q[2] = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00050004u);
+                q[3] = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00070006u);
+                fr[kb] = __builtin_bit_cast(pfx_f16x8, q);
             }
-            // (b) horizontal pass of 32 new rows into ring slots [32 it mod RING, +32)
-            if (it < n_hsteps) {
-                pfx_f16x8 fr[NKB];
+            stamp(it, 1);
+            __builtin_amdgcn_sched_barrier(0); // keep the refill HERE: the scheduler would sink it next to its use, steps later
+            if (!(dbg & 8)) fetch(std::integral_constant<int, BUF>{}, it + GS_DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(it, 2);
+            if (it < n_hsteps && !(dbg & 2)) { // horizontal pass of 32 new rows into ring slots [32 it mod RING, +32)
+                // two independent accumulator chains, summed in the epilogue
+                pfx_f32x16 acc, acc2;
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) {
-                    const uint32_t d0 = raw[kb][0], d1 = raw[kb][1];
-                    uint32_t q[4];
-                    q[0] = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00050004u); // 0x6400 | byte = 1024 + byte as f16
-                    q[1] = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00070006u);
-                    q[2] = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00050004u);
-                    q[3] = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00070006u);
-                    fr[kb] = __builtin_bit_cast(pfx_f16x8, q);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                fetch(min(it + 1, n_hsteps - 1)); // next step's samples land during this step's MFMAs (the last one re-reads, unused)
-                __builtin_amdgcn_sched_barrier(0);
-                pfx_f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = -bias_c;
+                for (int q = 0; q < 16; ++q) { acc[q] = -bias_c; acc2[q] = 0.0f; }
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B1[kb], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], acc2, 0, 0, 0);
                 }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] += acc2[q];
+                stamp(it, 3);
                 const int ro = (32 * it) % RING + 8 * wave + 4 * hh; // regs 4c .. 4c+3 = four consecutive rows of channel c at column i
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -563,17 +571,50 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                     *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * PLANE + i * YP + ro) = h2;
                 }
             }
-        } else {
+            // write the output block the consumers finished in the previous iteration (the barrier has passed): 128-byte row segments.
+            // Measured per iteration: a consumer wave needs ~3900 cycles for reads + 24 MFMAs + rounding / packing, a producer wave
+            // ~2200 for conversion + refill + 16 MFMAs + split / pack — the store belongs to the lighter role.
+            {
+                const int vp = it - 1 - HALF;
+                if (vp >= 0 && vp < nst && !(dbg & 1)) {
+                    const uint32_t* ob = OUT + (vp & 1) * 32 * GM_OUT_PITCH;
+                    const int yb = 32 * (t_first + vp) - y_phase;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int idx = tid + 256 * q, rr = idx >> 5, cc = idx & 31;
+                        if (yb + rr >= 0 && yb + rr < h && x0 + cc < w)
+                            reinterpret_cast<uint32_t*>(dst)[(size_t)(yb + rr) * w + x0 + cc] = ob[rr * GM_OUT_PITCH + cc];
+                    }
+                }
+            }
+            stamp(it, 4);
+            __syncthreads();
+            stamp(it, 5);
+        };
+        fetch(std::integral_constant<int, 0>{}, 0);
+        if constexpr (GS_DEPTH > 1) fetch(std::integral_constant<int, 1>{}, 1);
+        if constexpr (GS_DEPTH > 2) fetch(std::integral_constant<int, 2>{}, 2);
+        if constexpr (GS_DEPTH > 3) fetch(std::integral_constant<int, 3>{}, 3);
+        for (int it = 0; it < n_iter; it += GS_DEPTH) {
+            produce(std::integral_constant<int, 0>{}, it);
+            if constexpr (GS_DEPTH > 1) produce(std::integral_constant<int, 1>{}, it + 1);
+            if constexpr (GS_DEPTH > 2) produce(std::integral_constant<int, 2>{}, it + 2);
+            if constexpr (GS_DEPTH > 3) produce(std::integral_constant<int, 3>{}, it + 3);
+        }
+    } else {
+        for (int it = 0; it < n_iter; ++it) {
+            stamp(it, 0);
             // vertical pass of output block v on ring slots [32 v mod RING, + 16 NKB); A row m = i = xl * 4 + c
             const int v = it - HALF;
-            if (v >= 0 && v < nst) {
+            if (v >= 0 && v < nst && !(dbg & 4)) {
                 const int xb = wave - 4, xl = i >> 2, c = i & 3;
                 const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP;
                 const _Float16* a2p = HR + (size_t)(1 * 4 + c) * PLANE + (8 * xb + xl) * YP;
                 const int rb = (32 * v) % RING + 8 * NKB * hh;
-                pfx_f32x16 accA, accB;
+                stamp(it, 1);
+                pfx_f32x16 accA, accB, accC; // three independent chains
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { accA[q] = 0.0f; accB[q] = 0.0f; }
+                for (int q = 0; q < 16; ++q) { accA[q] = 0.0f; accB[q] = 0.0f; accC[q] = 0.0f; }
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
                     int ro = rb + 8 * kb;
@@ -582,8 +623,11 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                     const pfx_f16x8 a2 = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
                     accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, B1[kb], accA, 0, 0, 0);
                     accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, B2[kb], accB, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, B1[kb], accB, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, B1[kb], accC, 0, 0, 0);
                 }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) accB[q] += accC[q];
+                stamp(it, 3);
                 uint32_t* orow = OUT + (v & 1) * 32 * GM_OUT_PITCH + i * GM_OUT_PITCH + 8 * xb + hh; // regs 4g..4g+3 = RGBA of (8 xb + 2 g + hh, row i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -594,9 +638,14 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                     orow[2 * g] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
                 }
             }
+            stamp(it, 4);
+            __syncthreads();
+            stamp(it, 5);
         }
-        __syncthreads();
     }
+    }; // walk
+    const bool interior = __builtin_amdgcn_readfirstlane((x0 - R8 >= 0 && x0 - R8 + 16 * NKB <= w) ? 1 : 0) != 0;
+    if (interior) walk(std::false_type{}); else walk(std::true_type{});
 }
 
 } // namespace
@@ -604,6 +653,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 // LDS bounds: H tile (1024 + 2r + 12) x 20 B and the narrowest V tile (256 + 2r + 4) rows x 5 x 16 B <= 160 KiB
 extern "C" int pfxk_gauss_max_radius(void) { return 850; }
 extern "C" void pfxk_gauss_set_v_config(int cfg) { g_v_cfg = cfg; }
+extern "C" void pfxk_gauss_set_dbg_buf(unsigned long long* p) { g_dbg_buf = p; }
 extern "C" int pfxk_gauss_weight_pad(void) { return W_PAD; }
 
 // horizontal pass: u8 -> f32 intermediate (w*h*16 bytes)
@@ -676,11 +726,11 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
             if (fast) {
                 errs = hipFuncSetAttribute((const void*)gauss_strip_kernel<true, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (errs) return;
-                gauss_strip_kernel<true, NK><<<grid, 512, lds, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per);
+                gauss_strip_kernel<true, NK><<<grid, 512, lds, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, g_v_cfg >> 9, g_dbg_buf);
             } else {
                 errs = hipFuncSetAttribute((const void*)gauss_strip_kernel<false, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (errs) return;
-                gauss_strip_kernel<false, NK><<<grid, 512, lds, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per);
+                gauss_strip_kernel<false, NK><<<grid, 512, lds, stream>>>(d_planes, plane_stride, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, g_v_cfg >> 9, g_dbg_buf);
             }
         };
         switch (nkb) {
