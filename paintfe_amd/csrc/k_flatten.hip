@@ -276,42 +276,38 @@ __global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_la
         uint32_t oA = 0, oB = 0, oC = 0; // opacity bits: kept integer so the loop-carried copies stay in SGPRs
 #pragma unroll
         for (int j = 0; j < PX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; // :573
-        // the descriptor (scalar loads) of the layer fetched NEXT is requested one stage ahead, so no fetch waits for it
+        // Every fetch is unconditional (past the last layer it re-reads the last one, unused): with no load inside a conditional the
+        // compiler's s_waitcnt bookkeeping is exact — vmcnt(PX * (NB - 1)) in front of a blend, NB - 1 layers genuinely in flight —
+        // instead of the vmcnt(0) it falls back to when a prefetch sits behind a branch.  The descriptor (scalar loads) of the layer
+        // fetched NEXT is requested one stage ahead, so no fetch waits for it either.
+        const uint32_t last = n_layers - 1u;
         const uint8_t* npx = layers[0].pixels;
         uint32_t nmode = layers[0].mode;
         uint32_t nop = __builtin_bit_cast(uint32_t, layers[0].opacity);
-        const uint32_t last = n_layers - 1u;
 #define PFX_FETCH(T, M, O, K) { M = nmode; O = nop; stream_fetch<PX>(T, npx, bytes, voff); \
                                 const uint32_t kn = ((K) + 1u < last) ? (K) + 1u : last; \
                                 npx = layers[kn].pixels; nmode = layers[kn].mode; nop = __builtin_bit_cast(uint32_t, layers[kn].opacity); }
+#define PFX_LAYER(T, M, O, K) if ((K) < n_layers) stream_layer<PX>(acc, T, M, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(O)));
         PFX_FETCH(tA, mA, oA, 0u)
         if constexpr (NB == 2) {
-            for (uint32_t li = 0;;) {
-                const bool hasB = li + 1 < n_layers;
-                if (hasB) PFX_FETCH(tB, mB, oB, li + 1)
-                stream_layer<PX>(acc, tA, mA, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oA)));
-                if (!hasB) break;
-                li += 2;
-                const bool hasA = li < n_layers;
-                if (hasA) PFX_FETCH(tA, mA, oA, li)
-                stream_layer<PX>(acc, tB, mB, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oB)));
-                if (!hasA) break;
+            for (uint32_t li = 0; li < n_layers; li += 2) {
+                PFX_FETCH(tB, mB, oB, li + 1)
+                PFX_LAYER(tA, mA, oA, li)
+                PFX_FETCH(tA, mA, oA, li + 2)
+                PFX_LAYER(tB, mB, oB, li + 1)
             }
         } else {
-            if (1 < n_layers) PFX_FETCH(tB, mB, oB, 1u)
-            for (uint32_t li = 0;;) { // invariant at the top: layers li (A) and li+1 (B) are in flight or landed
-                if (li + 2 < n_layers) PFX_FETCH(tC, mC, oC, li + 2)
-                stream_layer<PX>(acc, tA, mA, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oA)));
-                if (li + 1 >= n_layers) break;
-                if (li + 3 < n_layers) PFX_FETCH(tA, mA, oA, li + 3)
-                stream_layer<PX>(acc, tB, mB, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oB)));
-                if (li + 2 >= n_layers) break;
-                if (li + 4 < n_layers) PFX_FETCH(tB, mB, oB, li + 4)
-                stream_layer<PX>(acc, tC, mC, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(oC)));
-                li += 3;
-                if (li >= n_layers) break;
+            PFX_FETCH(tB, mB, oB, 1u)
+            for (uint32_t li = 0; li < n_layers; li += 3) { // at the top: layers li (A) and li + 1 (B) are in flight or landed
+                PFX_FETCH(tC, mC, oC, li + 2)
+                PFX_LAYER(tA, mA, oA, li)
+                PFX_FETCH(tA, mA, oA, li + 3)
+                PFX_LAYER(tB, mB, oB, li + 1)
+                PFX_FETCH(tB, mB, oB, li + 4)
+                PFX_LAYER(tC, mC, oC, li + 2)
             }
         }
+#undef PFX_LAYER
 #undef PFX_FETCH
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
