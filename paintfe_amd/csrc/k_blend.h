@@ -44,10 +44,29 @@ template <bool F> PFX_DEV float reflect_channel(float base, float top)
 {
     return (top >= 1.0f) ? 1.0f : clamp01(fdiv<F>(base * base, 1.0f - top));
 }
+// v_max_f32 / v_min_f32 as ONE instruction: fmaxf / fminf make hipcc canonicalise both operands first (two more v_max x, x) because
+// it cannot prove that values read from memory are not signalling NaNs; the blend operands are bytes / 255.
+PFX_DEV float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PFX_DEV float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// Correctly rounded sqrt for a normal positive argument: the core of the sequence hipcc emits for sqrtf
+// (-fhip-fp32-correctly-rounded-divide-sqrt) — hardware estimate, its two neighbours, two exact residuals, two selects — without the
+// scaling of tiny arguments and the zero / inf / NaN pass-through around it, which are identities for an argument in (0.25, 1].
+PFX_DEV float sqrt_normal(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) - 1u), sp = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
+}
+
 PFX_DEV float soft_light_channel(float base, float top)
 {
     if (top <= 0.5f) return base - (1.0f - 2.0f * top) * base * (1.0f - base);
-    float d = (base <= 0.25f) ? ((16.0f * base - 12.0f) * base + 4.0f) * base : __builtin_sqrtf(base);
+    // base <= 0.25 takes the polynomial; the sqrt lane value for such a base is discarded (and sqrt_normal(0) is a harmless 0 or NaN)
+    float d = (base <= 0.25f) ? ((16.0f * base - 12.0f) * base + 4.0f) * base : sqrt_normal(base);
     return base + (2.0f * top - 1.0f) * (d - base);
 }
 template <bool F> PFX_DEV float divide_channel(float base, float top)
@@ -69,7 +88,7 @@ template <bool F> PFX_DEV float vivid_light_channel(float base, float top)
 }
 PFX_DEV float pin_light_channel(float base, float top)
 {
-    return (top <= 0.5f) ? __builtin_fminf(base, 2.0f * top) : __builtin_fmaxf(base, 2.0f * (top - 0.5f));
+    return (top <= 0.5f) ? vmin(base, 2.0f * top) : vmax(base, 2.0f * (top - 0.5f));
 }
 
 template <uint32_t M, bool F>
@@ -86,8 +105,8 @@ PFX_DEV float blend_fn(float b, float t)
     else if constexpr (M == M_OVERLAY) return overlay_channel(b, t);
     else if constexpr (M == M_DIFFERENCE) return __builtin_fabsf(b - t);
     else if constexpr (M == M_NEGATION) return 1.0f - __builtin_fabsf(1.0f - b - t);
-    else if constexpr (M == M_LIGHTEN) return __builtin_fmaxf(b, t);
-    else if constexpr (M == M_DARKEN) return __builtin_fminf(b, t);
+    else if constexpr (M == M_LIGHTEN) return vmax(b, t);
+    else if constexpr (M == M_DARKEN) return vmin(b, t);
     else if constexpr (M == M_HARD_LIGHT) return overlay_channel(t, b);
     else if constexpr (M == M_SOFT_LIGHT) return soft_light_channel(b, t);
     else if constexpr (M == M_EXCLUSION) return b + t - 2.0f * b * t;
@@ -347,7 +366,7 @@ PFX_DEV void blend_layer_nx(uint32_t mode, float (&acc)[PX][4], const float (&to
     const float opc = rs_clamp(opacity_raw, 0.0f, 1.0f);
     float amin = acc[0][3], tmin = top[0][3];
 #pragma unroll
-    for (int p = 1; p < PX; ++p) { amin = __builtin_fminf(amin, acc[p][3]); tmin = __builtin_fminf(tmin, top[p][3]); }
+    for (int p = 1; p < PX; ++p) { amin = vmin(amin, acc[p][3]); tmin = vmin(tmin, top[p][3]); }
     if (__all(amin == 1.0f)) {
         if (opacity_raw >= 1.0f && __all(tmin == 1.0f)) blend_nx_dispatch<PX, 2>(mode, acc, top, opacity_raw, opc);
         else blend_nx_dispatch<PX, 1>(mode, acc, top, opacity_raw, opc);

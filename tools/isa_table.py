@@ -2,7 +2,7 @@
 """tools/isa_table.py [out.md] — per-blend-mode gfx950 instruction table of the compositor's pixel code.
 
 Compiles one probe kernel per (blend mode, accumulator specialisation) that runs paintfe_amd/csrc/k_blend.h's
-blendN<M, true, 4, OB> on 4 pixels per lane — exactly what one layer of flatten_kernel executes per lane — and counts
+blendN_nx<M, 4, OB> on 4 pixels per lane — the pixel code one layer of flatten_stream_kernel executes per lane — and counts
 the instructions hipcc emits (same flags as the library).  The harness (4 accumulator pixels and the layer's pixel
 quad loaded from / stored to global memory) is measured by a probe that blends nothing and subtracted.
 No GPU needed (cross-compile only)."""
@@ -22,19 +22,22 @@ FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded
 SRC = r'''
 #include "k_blend.h"
 using namespace pfxk;
+// one layer of flatten_stream_kernel on 4 pixels per lane: the layer pixel arrives as four normalised f32 (typed buffer load),
+// the accumulator is held as RN(k / 255) (k_blend.h: blend_nx)
 template <int M, int OB>
-__global__ __launch_bounds__(256) void probe(const uint4* __restrict__ top, float4* __restrict__ accs, float opacity)
+__global__ __launch_bounds__(256) void probe(const float4* __restrict__ top, float4* __restrict__ accs, float opacity)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    float acc[4][4];
-    for (int p = 0; p < 4; ++p) { const float4 a = accs[i * 4 + p]; acc[p][0] = a.x; acc[p][1] = a.y; acc[p][2] = a.z; acc[p][3] = a.w; }
-    const uint4 v = top[i];
-    const uint32_t t[4] = {v.x, v.y, v.z, v.w};
-    if constexpr (M >= 0) blendN<(uint32_t)M, true, 4, OB>(acc, t, opacity, rs_clamp(opacity, 0.0f, 1.0f));
-    else { acc[0][0] += (float)(t[0] ^ t[1] ^ t[2] ^ t[3]); }
+    float acc[4][4], t[4][4];
+    for (int p = 0; p < 4; ++p) {
+        const float4 a = accs[i * 4 + p]; acc[p][0] = a.x; acc[p][1] = a.y; acc[p][2] = a.z; acc[p][3] = a.w;
+        const float4 v = top[i * 4 + p]; t[p][0] = v.x; t[p][1] = v.y; t[p][2] = v.z; t[p][3] = v.w;
+    }
+    if constexpr (M >= 0) blendN_nx<(uint32_t)M, 4, OB>(acc, t, opacity, rs_clamp(opacity, 0.0f, 1.0f));
+    else { acc[0][0] += t[0][0] + t[1][1] + t[2][2] + t[3][3]; }
     for (int p = 0; p < 4; ++p) accs[i * 4 + p] = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
 }
-template __global__ void probe<-1, 0>(const uint4*, float4*, float);
+template __global__ void probe<-1, 0>(const float4*, float4*, float);
 '''
 
 
@@ -43,7 +46,7 @@ def main():
     src = SRC
     for m in range(25):
         for ob in (0, 1, 2):
-            src += f"template __global__ void probe<{m}, {ob}>(const uint4*, float4*, float);\n"
+            src += f"template __global__ void probe<{m}, {ob}>(const float4*, float4*, float);\n"
     with tempfile.TemporaryDirectory() as td:
         f = os.path.join(td, "probe.hip")
         open(f, "w").write(src)
@@ -52,18 +55,18 @@ def main():
                                os.path.join(ROOT, "include"), "-o", asm, f], stderr=subprocess.DEVNULL)
         text = open(asm).read()
     counts = {}
-    for mm in re.finditer(r"^_Z5probeILi(n?\d+)ELi(\d)EEvPK15HIP_vector_typeIjLj4EEPS0_IfLj4EEf:(.*?)s_endpgm", text, re.S | re.M):
+    for mm in re.finditer(r"^_Z5probeILi(n?\d+)ELi(\d)EEvPK15HIP_vector_typeIfLj4EEPS1_f:(.*?)s_endpgm", text, re.S | re.M):
         m, ob, body = int(mm.group(1).replace("n", "-")), int(mm.group(2)), mm.group(3)
         ins = [l.split()[0] for l in body.split("\n") if l.startswith("\t") and l.strip() and not l.strip().startswith((";", "."))]
         valu = sum(1 for i in ins if i.startswith("v_"))
         salu = sum(1 for i in ins if i.startswith("s_") and not i.startswith(("s_waitcnt", "s_nop", "s_load")))
         trans = sum(1 for i in ins if i.startswith(("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log")))
         counts[(m, ob)] = (valu, salu, trans)
-    base = counts[(-1, 0)][0] - 5  # the empty probe's own xor/cvt/add: 5 VALU
+    base = counts[(-1, 0)][0] - 4  # the empty probe's own four adds
     lines = ["# Compositor pixel code: gfx950 instructions per layer-pixel, by blend mode",
              "",
-             "`tools/isa_table.py`: static count of what hipcc emits for `blendN<M, true, 4, OB>` (4 pixels per lane, the",
-             "unit one layer of `flatten_kernel` executes), harness subtracted, divided by 4.  OB 0 = general accumulator,",
+             "`tools/isa_table.py`: static count of what hipcc emits for `blendN_nx<M, 4, OB>` (k_blend.h) on 4 pixels per lane — the",
+             "pixel code one layer of `flatten_stream_kernel` executes — harness subtracted, divided by 4.  OB 0 = general accumulator,",
              "OB 1 = wave-uniform opaque accumulator (out_a == 1), OB 2 = additionally an opaque layer at 100 % opacity.",
              "VALU/px is what bounds the kernel (one wave64 VALU instruction = 2 issue cycles on a SIMD);",
              "`trans` = quarter-rate instructions among them (v_rcp / v_sqrt).", "",
