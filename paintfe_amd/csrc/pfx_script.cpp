@@ -64,37 +64,75 @@ bool png_decode(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgba, ui
         pos += 12 + (size_t)len;
     }
     if (!w || !h || (uint64_t)w * h > 256000000ull) { why = "bad dimensions"; return false; }
-    if (bit_depth != 8 || interlace != 0) { why = "only 8-bit non-interlaced PNGs are supported by this build"; return false; }
     int ch;
     switch (color_type) { case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break; default: why = "bad colour type"; return false; }
-    const size_t stride = (size_t)w * ch;
-    std::vector<uint8_t> raw((stride + 1) * h);
+    const bool depth_ok = (color_type == 0 && (bit_depth == 1 || bit_depth == 2 || bit_depth == 4 || bit_depth == 8 || bit_depth == 16)) ||
+                          (color_type == 3 && (bit_depth == 1 || bit_depth == 2 || bit_depth == 4 || bit_depth == 8)) ||
+                          ((color_type == 2 || color_type == 4 || color_type == 6) && (bit_depth == 8 || bit_depth == 16));
+    if (!depth_ok || interlace > 1) { why = "bad bit depth / interlace method"; return false; }
+    // passes: the whole image, or Adam7's seven sub-images (PNG spec 8.2); each is filtered on its own
+    struct pass { uint32_t x0, y0, dx, dy; };
+    static const pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const pass whole = {0, 0, 1, 1};
+    const int n_pass = interlace ? 7 : 1;
+    const size_t bpp_bits = (size_t)ch * bit_depth, fbpp = std::max<size_t>(1, bpp_bits / 8); // filter unit (PNG spec 9.2)
+    size_t total = 0;
+    for (int p = 0; p < n_pass; ++p) {
+        const pass& P = interlace ? adam7[p] : whole;
+        if (w <= P.x0 || h <= P.y0) continue;
+        const size_t pw = (w - P.x0 + P.dx - 1) / P.dx, ph = (h - P.y0 + P.dy - 1) / P.dy;
+        total += ph * (1 + (pw * bpp_bits + 7) / 8);
+    }
+    std::vector<uint8_t> raw(total);
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) { why = "zlib inflate failed"; return false; }
-    std::vector<uint8_t> img(stride * h);
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t ft = raw[(stride + 1) * y];
-        const uint8_t* in = &raw[(stride + 1) * y + 1];
-        uint8_t* out = &img[stride * y];
-        const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= (size_t)ch ? out[i - ch] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)ch) ? up[i - ch] : 0;
-            int v = in[i];
-            switch (ft) { case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break; case 4: v += paeth(a, b, c); break; default: break; }
-            out[i] = (uint8_t)v;
-        }
-    }
-    rgba.resize((size_t)w * h * 4);
-    for (size_t i = 0; i < (size_t)w * h; ++i) {
-        uint8_t* o = &rgba[i * 4];
-        const uint8_t* p = &img[i * ch];
-        switch (color_type) {
-        case 0: o[0] = o[1] = o[2] = p[0]; o[3] = (trns.size() >= 2 && trns[1] == p[0]) ? 0 : 255; break;
-        case 2: o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = (trns.size() >= 6 && trns[1] == p[0] && trns[3] == p[1] && trns[5] == p[2]) ? 0 : 255; break;
-        case 3: { const size_t k = p[0]; o[0] = k * 3 + 2 < plte.size() ? plte[k * 3] : 0; o[1] = k * 3 + 2 < plte.size() ? plte[k * 3 + 1] : 0;
-                  o[2] = k * 3 + 2 < plte.size() ? plte[k * 3 + 2] : 0; o[3] = k < trns.size() ? trns[k] : 255; break; }
-        case 4: o[0] = o[1] = o[2] = p[0]; o[3] = p[1]; break;
-        default: std::memcpy(o, p, 4);
+    // 16 -> 8 bits like the `image` crate's to_rgba8 (rounded v / 257); 1 / 2 / 4-bit grey is stretched to 0..255
+    auto to8 = [&](uint32_t v) -> uint8_t {
+        if (bit_depth == 16) return (uint8_t)((v + 128u) / 257u);
+        if (bit_depth == 8) return (uint8_t)v;
+        return (uint8_t)(v * 255u / ((1u << bit_depth) - 1u));
+    };
+    auto trns16 = [&](size_t k) -> uint32_t { return ((uint32_t)trns[2 * k] << 8) | trns[2 * k + 1]; };
+    rgba.assign((size_t)w * h * 4, 0);
+    size_t off = 0;
+    std::vector<uint8_t> cur, prev;
+    for (int p = 0; p < n_pass; ++p) {
+        const pass& P = interlace ? adam7[p] : whole;
+        if (w <= P.x0 || h <= P.y0) continue;
+        const size_t pw = (w - P.x0 + P.dx - 1) / P.dx, ph = (h - P.y0 + P.dy - 1) / P.dy, rb = (pw * bpp_bits + 7) / 8;
+        cur.assign(rb, 0); prev.assign(rb, 0);
+        for (size_t py = 0; py < ph; ++py) {
+            const uint8_t ft = raw[off];
+            const uint8_t* in = &raw[off + 1];
+            off += 1 + rb;
+            if (ft > 4) { why = "bad filter type"; return false; }
+            for (size_t i = 0; i < rb; ++i) {
+                const int a = i >= fbpp ? cur[i - fbpp] : 0, b = py ? prev[i] : 0, c = (py && i >= fbpp) ? prev[i - fbpp] : 0;
+                int v = in[i];
+                switch (ft) { case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break; case 4: v += paeth(a, b, c); break; default: break; }
+                cur[i] = (uint8_t)v;
+            }
+            const size_t y = P.y0 + py * P.dy;
+            for (size_t px = 0; px < pw; ++px) {
+                uint32_t sm[4] = {0, 0, 0, 0}; // samples at their native depth
+                for (int k = 0; k < ch; ++k) {
+                    const size_t bit = (px * ch + k) * bit_depth;
+                    if (bit_depth == 16) sm[k] = ((uint32_t)cur[bit / 8] << 8) | cur[bit / 8 + 1];
+                    else if (bit_depth == 8) sm[k] = cur[bit / 8];
+                    else sm[k] = (cur[bit / 8] >> (8 - bit_depth - (bit & 7))) & ((1u << bit_depth) - 1u);
+                }
+                uint8_t* o = &rgba[(y * w + P.x0 + px * P.dx) * 4];
+                switch (color_type) {
+                case 0: o[0] = o[1] = o[2] = to8(sm[0]); o[3] = (trns.size() >= 2 && trns16(0) == sm[0]) ? 0 : 255; break;
+                case 2: o[0] = to8(sm[0]); o[1] = to8(sm[1]); o[2] = to8(sm[2]);
+                        o[3] = (trns.size() >= 6 && trns16(0) == sm[0] && trns16(1) == sm[1] && trns16(2) == sm[2]) ? 0 : 255; break;
+                case 3: { const size_t k = sm[0]; const bool ok = k * 3 + 2 < plte.size();
+                          o[0] = ok ? plte[k * 3] : 0; o[1] = ok ? plte[k * 3 + 1] : 0; o[2] = ok ? plte[k * 3 + 2] : 0; o[3] = k < trns.size() ? trns[k] : 255; break; }
+                case 4: o[0] = o[1] = o[2] = to8(sm[0]); o[3] = to8(sm[1]); break;
+                default: o[0] = to8(sm[0]); o[1] = to8(sm[1]); o[2] = to8(sm[2]); o[3] = to8(sm[3]);
+                }
+            }
+            cur.swap(prev);
         }
     }
     return true;

@@ -164,6 +164,69 @@ def test_cli_config1_literal_1024_and_gpus_flag(tmp_path):
         assert np.array_equal(_read_png(tmp_path / "o1" / f"f{k}.png"), _read_png(tmp_path / "o3" / f"f{k}.png"))
 
 
+def _png_bytes(arr, color_type, bit_depth, interlace):
+    """a minimal PNG writer for the decoder test: any colour type / bit depth, filter 0, optional Adam7 (PNG spec 8.2)"""
+    import struct, zlib
+    h, w = arr.shape[:2]
+    ch = {0: 1, 2: 3, 4: 2, 6: 4}[color_type]
+    a = arr.reshape(h, w, ch)
+
+    def rows(sub):
+        out = bytearray()
+        for row in sub:
+            out.append(0)
+            if bit_depth == 16:
+                out += row.astype(">u2").tobytes()
+            elif bit_depth == 8:
+                out += row.astype(np.uint8).tobytes()
+            else:
+                bits = "".join(format(int(v), f"0{bit_depth}b") for v in row.reshape(-1))
+                bits += "0" * (-len(bits) % 8)
+                out += int(bits, 2).to_bytes(len(bits) // 8, "big") if bits else b""
+        return bytes(out)
+
+    if interlace:
+        raw = b""
+        for (x0, y0, dx, dy) in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
+            sub = a[y0::dy, x0::dx]
+            if sub.size:
+                raw += rows(sub)
+    else:
+        raw = rows(a)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bit_depth, color_type, 0, 0, 1 if interlace else 0)) +
+            chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("color_type,bit_depth,interlace", [(6, 16, 0), (6, 8, 1), (2, 16, 1), (0, 16, 0), (0, 4, 1), (0, 1, 0), (4, 16, 1), (4, 8, 0)])
+def test_cli_png_16bit_and_interlaced(tmp_path, color_type, bit_depth, interlace):
+    """16-bit samples become 8-bit like the `image` crate's to_rgba8 ((v + 128) / 257), low-bit grey is stretched, Adam7 is undone"""
+    exe = os.path.join(ROOT, "paintfe_amd", "pfx")
+    rng = np.random.default_rng(color_type * 100 + bit_depth + interlace)
+    w, h = 37, 23
+    ch = {0: 1, 2: 3, 4: 2, 6: 4}[color_type]
+    arr = rng.integers(0, 1 << bit_depth, size=(h, w, ch), dtype=np.uint32)
+    (tmp_path / "in.png").write_bytes(_png_bytes(arr, color_type, bit_depth, interlace))
+    p = subprocess.run([exe, "-i", str(tmp_path / "in.png"), "-o", str(tmp_path / "out.png")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    to8 = (lambda v: (v + 128) // 257) if bit_depth == 16 else ((lambda v: v) if bit_depth == 8 else (lambda v: v * 255 // ((1 << bit_depth) - 1)))
+    v = to8(arr).astype(np.uint8)
+    want = np.empty((h, w, 4), np.uint8)
+    if color_type == 0:
+        want[..., :3] = v[..., :1]; want[..., 3] = 255
+    elif color_type == 2:
+        want[..., :3] = v; want[..., 3] = 255
+    elif color_type == 4:
+        want[..., :3] = v[..., :1]; want[..., 3] = v[..., 1]
+    else:
+        want[...] = v
+    got = _read_png(tmp_path / "out.png")
+    # the CLI stores the image as a TiledImage: chunks with no alpha at all lose their colour (tiled_image.rs:50-104)
+    assert np.array_equal(got, O.tiled_roundtrip(want))
+
+
 def test_cli_png_decoder_variants(tmp_path):
     from PIL import Image
     exe = os.path.join(ROOT, "paintfe_amd", "pfx")
