@@ -8,7 +8,8 @@
  * [floor(c - support*sratio), ceil(c + support*sratio)) clamped to the image, weights kernel((i - (c - 0.5)) / sratio)
  * normalised by their f32 running sum, accumulation `t += v * w` in source order).  Pinned by the reference's goldens
  * transforms/resize_2x_nearest, resize_half_bilinear and resize_half_lanczos (tests/visual_transforms.rs:134-164) with
- * tolerance 0; the Catmull-Rom (bicubic) kernel has no golden: parity unpinned for that filter.
+ * tolerance 0; the Catmull-Rom (bicubic) kernel has no golden in the reference; it is pinned by tests/golden/bicubic_kat.json
+ * (exact-rational evaluation of the published kernel, tests/golden/make_bicubic_kat.py).
  */
 #include "o_common.h"
 

@@ -1,5 +1,5 @@
-"""Known-answer pins for corners the reference's own tests leave open: non-identity Curves LUTs and the .pfe byte
-layout.  The vectors are derived from the published algorithm / the declared structs, not produced by the oracle or the product:
+"""Known-answer pins for corners the reference's own tests leave open: non-identity Curves LUTs the bicubic resize
+kernel and the .pfe byte layout.  The vectors are derived from the published algorithm / the declared structs, not produced by the oracle or the product:
  * tests/golden/curves_kat.json — Fritsch-Carlson in 60-digit decimal arithmetic (tests/golden/make_curves_kat.py);
  * the .pfe files below are assembled by hand, field by field, from the struct declarations (src/io.rs:85-208,
    src/canvas/layers.rs:192-235,378-387) and bincode 1.x's documented default encoding (little endian, fixed-width integers,
@@ -37,6 +37,19 @@ def test_curves_lut_known_answers(name):
     L.load().pfx_build_curves_lut(pts.ctypes.data_as(C.c_void_p), C.c_uint32(len(pts)), lut.ctypes.data_as(C.c_void_p))
     assert np.array_equal(lut[idx], want), "product host builder (pfx_build_curves_lut)"
     assert np.array_equal(lut, got_oracle)  # and the two agree on the boundary-adjacent entries too
+
+
+# ------------------------------------------------------------------------------------------------ bicubic resize
+def test_bicubic_resize_known_answers():
+    """the Catmull-Rom kernel has no golden in the reference (its three resize goldens are nearest / bilinear / Lanczos3): pinned here
+    by an exact-rational evaluation of the published kernel and the `image` crate's sampling scheme (tests/golden/make_bicubic_kat.py)"""
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "bicubic_kat.json")))
+    img = np.asarray(d["image"], np.uint8)
+    out = O.resize(img, d["nw"], d["nh"], "bicubic")
+    assert len(d["expected"]) > 350
+    for key, want in d["expected"].items():
+        y, x, c = map(int, key.split(","))
+        assert int(out[y, x, c]) == want, key
 
 
 # ------------------------------------------------------------------------------------------------ .pfe layout
