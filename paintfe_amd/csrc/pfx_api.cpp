@@ -282,8 +282,8 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
     if (radius > pfxk_gauss_max_radius())
         return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "gaussian radius %d beyond the device tile limit %d", radius, pfxk_gauss_max_radius());
     uint32_t sigma_bits; std::memcpy(&sigma_bits, &sigma, 4);
-    if (!ctx->exact && radius >= 1 && radius <= pfxk_gauss_mfma_max_radius() && ((uintptr_t)src_dev & 15u) == 0) {
-        // default mode: fused H+V on the matrix cores, no f32 intermediate in HBM (k_gauss.hip:gauss_mfma_kernel)
+    if (!ctx->exact && radius >= 1 && radius <= pfxk_gauss_mfma_max_radius() && src_dev != dst_dev) {
+        // default mode: fused H+V on the matrix cores, no intermediate in HBM, no scratch (k_gauss.hip:gauss_strip_kernel)
         if (ctx->wsplit_sigma_bits != sigma_bits) {
             std::vector<float> k;
             pfx_host_gaussian_kernel(sigma, k);
@@ -293,14 +293,8 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
             PFX_TRY(pfx_h2d(ctx, ctx->d_wsplit.p, ws.data(), ws.size() * sizeof(uint16_t)));
             ctx->wsplit_sigma_bits = sigma_bits;
         }
-        // scratch: the source as four u8 planes (4 bytes / pixel); a caller-provided f32 intermediate buffer (16 bytes / pixel) is big enough
-        void* planes = tmp_dev;
-        if (!planes || ((uintptr_t)planes & 255u) != 0 || pfxk_gauss_mfma_scratch_bytes(w, h) > (size_t)w * h * 16) {
-            PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, pfxk_gauss_mfma_scratch_bytes(w, h)));
-            planes = ctx->st_tmp.p;
-        }
         pfx_timer t(ctx, "gauss_mfma");
-        PFX_HIP(ctx, pfxk_gauss_mfma(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (uint8_t*)planes, (const uint16_t*)ctx->d_wsplit.p,
+        PFX_HIP(ctx, pfxk_gauss_mfma(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint16_t*)ctx->d_wsplit.p,
                                      radius, ctx->wsplit_inv_scale, ctx->wsplit_bias, w, h, first_row, ctx->n_cus > 0 ? ctx->n_cus : 256));
         return PFX_OK;
     }

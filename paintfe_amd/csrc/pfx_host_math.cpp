@@ -76,7 +76,7 @@ float f16_to_f32(uint16_t hv)
 }
 } // namespace
 
-// The matrix-core Gaussian (k_gauss.hip:gauss_mfma_kernel) multiplies f16 operands with exact f32 products: each weight is
+// The matrix-core Gaussian (k_gauss.hip:gauss_strip_kernel) multiplies f16 operands with exact f32 products: each weight is
 // scaled by S = 256 (the largest power of two for which S * 255, the scaled horizontal result, stays below the largest f16;
 // weights are < 1, so w * S is in range too) and split w * S = w1 + w2, two f16: 22 significant bits, or an absolute 2^-25 where
 // w2 is subnormal.  Returns 1 / S^2 (the two passes' scales, applied once at the end); *bias = 1024 * sum(w1 + w2), the constant

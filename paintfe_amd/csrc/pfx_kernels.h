@@ -61,8 +61,7 @@ hipError_t pfxk_gauss_h(hipStream_t stream, const uint8_t* d_src, float* d_tmp, 
 int        pfxk_gauss_mfma_max_radius(void);
 int        pfxk_gauss_mfma_wlen(void);
 int        pfxk_gauss_mfma_woff(void);
-size_t     pfxk_gauss_mfma_scratch_bytes(uint32_t w, uint32_t h); // u8 planes of the source
-hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, uint8_t* d_planes, const uint16_t* d_wsplit,
+hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit,
                            int radius, float inv_scale2, float bias_c, uint32_t w, uint32_t h, uint32_t first_row, int n_cus);
 hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8_t* d_dst, const float* d_wts_tap0, int radius,
                         uint32_t w, uint32_t h, int exact);
