@@ -325,23 +325,37 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
             auto produce = [&](auto bufc, int it) {
                 constexpr int BUF = decltype(bufc)::value;
                 stamp(it, 0);
-                // (1) de-interleave: four pixels (r g b a) x 4 -> one dword per channel, into the wave's LDS patch [c][row][sample]
+                // (1) de-interleave: four pixels (r g b a) x 4 -> one dword per channel; a lane's PPL samples of a channel are contiguous
+                // in the wave's LDS patch [c][row][sample], so they leave as 16-byte stores
+                {
+                    uint32_t pl[4][PPL / 4];
 #pragma unroll
-                for (int q = 0; q < PPL / 4; ++q) {
-                    uint32_t p0 = raw[BUF][4 * q], p1 = raw[BUF][4 * q + 1], p2 = raw[BUF][4 * q + 2], p3 = raw[BUF][4 * q + 3];
-                    if constexpr (BORDER && FAST) { // the piece lies left / right of the row: every pixel of it is the row's first / last one
-                        const int xp = fx + 4 * q;
-                        const uint32_t e = xp < 0 ? p0 : p3;
-                        const bool out = xp < 0 || xp >= w;
-                        p0 = out ? e : p0; p1 = out ? e : p1; p2 = out ? e : p2; p3 = out ? e : p3;
+                    for (int q = 0; q < PPL / 4; ++q) {
+                        uint32_t p0 = raw[BUF][4 * q], p1 = raw[BUF][4 * q + 1], p2 = raw[BUF][4 * q + 2], p3 = raw[BUF][4 * q + 3];
+                        if constexpr (BORDER && FAST) { // the piece lies left / right of the row: every pixel of it is the row's first / last one
+                            const int xp = fx + 4 * q;
+                            const uint32_t e = xp < 0 ? p0 : p3;
+                            const bool out = xp < 0 || xp >= w;
+                            p0 = out ? e : p0; p1 = out ? e : p1; p2 = out ? e : p2; p3 = out ? e : p3;
+                        }
+                        const uint32_t lo01 = __builtin_amdgcn_perm(p1, p0, 0x05010400u), hi01 = __builtin_amdgcn_perm(p1, p0, 0x07030602u); // [g1 g0 r1 r0], [a1 a0 b1 b0]
+                        const uint32_t lo23 = __builtin_amdgcn_perm(p3, p2, 0x05010400u), hi23 = __builtin_amdgcn_perm(p3, p2, 0x07030602u);
+                        pl[0][q] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u); // r3 r2 r1 r0
+                        pl[1][q] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u); // g
+                        pl[2][q] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u); // b
+                        pl[3][q] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u); // a
                     }
-                    const uint32_t lo01 = __builtin_amdgcn_perm(p1, p0, 0x05010400u), hi01 = __builtin_amdgcn_perm(p1, p0, 0x07030602u); // [g1 g0 r1 r0], [a1 a0 b1 b0]
-                    const uint32_t lo23 = __builtin_amdgcn_perm(p3, p2, 0x05010400u), hi23 = __builtin_amdgcn_perm(p3, p2, 0x07030602u);
-                    const uint32_t off = (uint32_t)(frow * GS_XROW + fs * PPL + 4 * q);
-                    *reinterpret_cast<uint32_t*>(xp_w + 0 * 8 * GS_XROW + off) = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u); // r3 r2 r1 r0
-                    *reinterpret_cast<uint32_t*>(xp_w + 1 * 8 * GS_XROW + off) = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u); // g
-                    *reinterpret_cast<uint32_t*>(xp_w + 2 * 8 * GS_XROW + off) = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u); // b
-                    *reinterpret_cast<uint32_t*>(xp_w + 3 * 8 * GS_XROW + off) = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u); // a
+                    const uint32_t off = (uint32_t)(frow * GS_XROW + fs * PPL);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint8_t* d = xp_w + c * 8 * GS_XROW + off;
+                        if constexpr (PPL == 16) *reinterpret_cast<uint4*>(d) = make_uint4(pl[c][0], pl[c][1], pl[c][2], pl[c][3]);
+                        else if constexpr (PPL == 8) *reinterpret_cast<uint2*>(d) = make_uint2(pl[c][0], pl[c][1]);
+                        else {
+#pragma unroll
+                            for (int q = 0; q < PPL / 4; ++q) reinterpret_cast<uint32_t*>(d)[q] = pl[c][q];
+                        }
+                    }
                 }
                 stamp(it, 1);
                 __builtin_amdgcn_sched_barrier(0); // keep the refill HERE: the scheduler would sink it next to its use, steps later
