@@ -64,11 +64,11 @@ def main() -> int:
     for _ in range(40):  # bring the GPU to its steady clocks before the first measured row
         r.gaussian_blur_dev(s, d, w, h, 16.0, t)
     torch.cuda.synchronize()
-    timed("gaussian sigma=16 (fma)", ["gauss_h", "gauss_v"], lambda: r.gaussian_blur_dev(s, d, w, h, 16.0, t), px, 8, "776 MAC/px: VALU-bound")
+    timed("gaussian sigma=16 (matrix cores)", ["gauss_mfma"], lambda: r.gaussian_blur_dev(s, d, w, h, 16.0, t), px, 8, "fused H+V strip walk on v_mfma_f32_32x32x16_f16")
     r.set_exact(True)
     timed("gaussian sigma=16 (exact, no FMA)", ["gauss_h", "gauss_v"], lambda: r.gaussian_blur_dev(s, d, w, h, 16.0, t), px, 8, "bit-exact mode")
     r.set_exact(False)
-    timed("gaussian sigma=4", ["gauss_h", "gauss_v"], lambda: r.gaussian_blur_dev(s, d, w, h, 4.0, t), px, 8)
+    timed("gaussian sigma=4", ["gauss_mfma"], lambda: r.gaussian_blur_dev(s, d, w, h, 4.0, t), px, 8)
     timed("hsl(30,-20,10)", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "hsl", [30.0, -20.0, 10.0]), px, 8)
     timed("hsl masked + FROM_FLAT", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "hsl", [30.0, -20.0, 10.0], mask_ptr=m, sparse=1), px, 9)
     timed("invert", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "invert"), px, 8)
@@ -94,7 +94,7 @@ def main() -> int:
     timed("twist 45", ["twist"], lambda: r.twist_dev(s, d, w, h, 45.0), px, 8, "f64 sin + cos per pixel")
     timed("zoom_blur 16 samples", ["zoom_blur"], lambda: r.zoom_blur_dev(s, d, w, h, 0.5, 0.5, 0.3, 16), px, 8)
     timed("outline width=2", ["outline"], lambda: r.outline_dev(s, d, w, h, 2, (0, 0, 255, 255)), px, 8, "7x7 window search")
-    timed("drop shadow blur=3", ["shadow_alpha", "gauss_h", "gauss_v", "shadow_composite"], lambda: r.shadow_dev(s, d, w, h, 5, 5, 3.0, False, (0, 0, 0, 255), 0.8), px, 8)
+    timed("drop shadow blur=3", ["shadow_alpha", "gauss_mfma", "gauss_h", "gauss_v", "shadow_composite"], lambda: r.shadow_dev(s, d, w, h, 5, 5, 3.0, False, (0, 0, 0, 255), 0.8), px, 8)
     half = torch.empty((h // 2, w // 2, 4), dtype=torch.uint8, device=dev)
     timed("resize 8K -> 4K bilinear", ["resize"], lambda: r.resize_image_dev(s, w, h, half.data_ptr(), w // 2, h // 2, "bilinear"), px, 5, "4 B read + 1 B/px (quarter-size) written")
     timed("resize 8K -> 4K lanczos3", ["resize"], lambda: r.resize_image_dev(s, w, h, half.data_ptr(), w // 2, h // 2, "lanczos3"), px, 5)
@@ -140,9 +140,9 @@ def main() -> int:
         r.gaussian_blur_dev(img.data_ptr(), a.data_ptr(), w, h, 4.0, tmp4.data_ptr())
         r.adjust_dev(a.data_ptr(), b.data_ptr(), w, h, "hsl", [30.0, -20.0, 10.0])
         r.flatten_dev([b.data_ptr()] + [o.data_ptr() for o in overlays], info4, w, h, a.data_ptr())
-    timed("config-5 per-image pipeline at 4K (blur s=4 + HSL + 4-layer flatten)", ["gauss_h", "gauss_v", "adjust", "flatten"], pipeline, px, 36,
+    timed("config-5 per-image pipeline at 4K (blur s=4 + HSL + 4-layer flatten)", ["gauss_mfma", "adjust", "flatten"], pipeline, px, 36,
           "8 + 8 + 20 algorithmic B/px; images/s = 1000 / ms")
-    for name in ("gauss_h", "gauss_v", "adjust", "flatten"):
+    for name in ("gauss_mfma", "adjust", "flatten"):
         print("   ", name, round(r.timing_read(name)[0] / args.reps, 4), "ms", flush=True)
     del img, overlays, a, b, tmp4
 
