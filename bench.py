@@ -384,7 +384,7 @@ def main() -> int:
                 # rows of the window whose +-radius neighbourhood is inside the window (or clamps at the true image edge)
                 a0 = 0 if lo == 0 else radius
                 a1 = (hi - lo) if hi == h else (hi - lo) - radius
-                got_rows = state["result"][lo + a0:lo + a1].contiguous().cpu().numpy() if not args.no_gather else None
+                got_rows = pipe.assemble()[lo + a0:lo + a1].contiguous().cpu().numpy() if not args.no_gather else None
                 if got_rows is not None:
                     dmax = int(np.abs(ref_blur[a0:a1].astype(np.int16) - got_rows.astype(np.int16)).max())
                     out.setdefault("check", {})["band_blur_max_diff_vs_oracle"] = dmax

@@ -125,14 +125,15 @@ class BandPipeline:
         self.top = min(radius, self.y0) if self.rows else 0
         self.bottom = min(radius, h - self.y1) if self.rows else 0
         prow = max(self.top + self.rows + self.bottom, 1)
-        self.padded = torch.empty((prow, w, 4), dtype=torch.uint8, device=device)
-        self.blurred = torch.empty((prow, w, 4), dtype=torch.uint8, device=device)
         self.bands = all_bands(h, self.world)
-        self.max_rows = max(b1 - b0 for b0, b1 in self.bands)
-        # all-gather staging: equal-size slots (bands are ragged by at most one chunk row), then one view per band
-        self.slot = torch.zeros((max(self.max_rows, 1), w, 4), dtype=torch.uint8, device=device)
-        self.slots = torch.empty((self.world, max(self.max_rows, 1), w, 4), dtype=torch.uint8, device=device) if gather else None
-        self.full = torch.empty((h, w, 4), dtype=torch.uint8, device=device) if gather else None
+        self.max_rows = max(max(b1 - b0 for b0, b1 in self.bands), 1)
+        self.padded = torch.empty((prow, w, 4), dtype=torch.uint8, device=device)
+        # the blur output doubles as the all-gather's send buffer: rows [top, top + max_rows) — bands are ragged by at most one chunk
+        # row, so the buffer carries that much slack and the gather needs no staging copy
+        self.blurred = torch.zeros((self.top + self.max_rows + radius + 1, w, 4), dtype=torch.uint8, device=device)
+        # all-gather target: one equal-size slot per rank (slot k holds band k in its first rows); `assemble()` makes the contiguous image
+        self.slots = torch.empty((self.world, self.max_rows, w, 4), dtype=torch.uint8, device=device) if gather else None
+        self.full = None
         # static exchange plan: (what I receive, what I send)
         lo0 = self.y0 - self.top
         self.recvs = [(src, s0 - lo0, s1 - lo0) for (src, s0, s1) in halo_plan(h, self.world, self.rank, radius)]
@@ -179,14 +180,22 @@ class BandPipeline:
             self.r.gaussian_blur_dev(self.padded.data_ptr(), self.blurred.data_ptr(), self.w, prow, self.sigma, first_row=self.y0 - self.top)
         if not self.gather:
             return self.blurred[self.top:self.top + self.rows]
-        self.slot[:self.rows] = self.blurred[self.top:self.top + self.rows]
-        if dist.get_backend(self.group) == "gloo" and self.slot.device.type == "cuda":
-            outs = [self.slot.cpu() for _ in range(self.world)]
-            dist.all_gather(outs, self.slot.cpu(), group=self.group)
+        send = self.blurred[self.top:self.top + self.max_rows]
+        if dist.get_backend(self.group) == "gloo" and send.device.type == "cuda":
+            outs = [send.cpu() for _ in range(self.world)]
+            dist.all_gather(outs, send.cpu(), group=self.group)
             for k in range(self.world):
                 self.slots[k].copy_(outs[k])
         else:
-            dist.all_gather_into_tensor(self.slots, self.slot, group=self.group)
+            dist.all_gather_into_tensor(self.slots, send, group=self.group)
+        return self.slots
+
+    def assemble(self):
+        """the gathered bands as one contiguous h x w x 4 image (not part of the timed step: every rank already holds every band)"""
+        import torch
+
+        if self.full is None:
+            self.full = torch.empty((self.h, self.w, 4), dtype=torch.uint8, device=self.slots.device)
         for k, (b0, b1) in enumerate(self.bands):
             if b1 > b0:
                 self.full[b0:b1] = self.slots[k, :b1 - b0]
