@@ -237,7 +237,7 @@ PFX_DEV pfx_f16x2 pkrtz(float a, float b) { return __builtin_bit_cast(pfx_f16x2,
 
 constexpr int GM_COLS = 32;             // output columns per strip (one MFMA N block)
 constexpr int GM_MAXR = 48;             // largest radius (sigma <= 16)
-constexpr int GM_OUT_PITCH = 33;        // dwords per staged output row
+constexpr int GM_OUT_PITCH = 36;        // dwords per staged output row (16-byte aligned rows: the block leaves as ds_read_b128)
 constexpr int GM_WOFF = 48;             // wsplit[GM_WOFF + t] = tap t; zeros elsewhere
 constexpr int GM_WLEN = 192;            // entries per weight part
 constexpr int GS_DEPTH = 3;             // register sets of source pixels in flight per producer lane
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
     const int last = nst + HALF, n_iter = ((last + GS_DEPTH) / GS_DEPTH) * GS_DEPTH; // iterations 0 .. n_iter - 1 (surplus ones only synchronise)
 
     auto stamp = [&](int it, int slot) { // development: s_memtime at phase boundaries of iterations 10..13, block 0, waves 0 and 4
-        if ((dbg & 16) && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && it >= 10 && it < 14)
+        if ((dbg & 16) && blockIdx.x == 8 && (wave == 0 || wave == 4) && lane == 0 && it >= 10 && it < 14)
             dbg_buf[((wave >> 2) * 4 + (it - 10)) * 8 + slot] = __builtin_readcyclecounter();
     };
 
@@ -407,22 +407,6 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                         *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * PLANE + i * YP + ro) = h2;
                     }
                 }
-                // (3) write the output block the consumers finished in the previous iteration (the barrier has passed).  Measured per
-                // iteration: a consumer wave needs ~3900 cycles for reads + 3 NKB MFMAs + rounding / packing, a producer wave ~2200 for its
-                // part — the store belongs to the lighter role.
-                {
-                    const int vp = it - 1 - HALF;
-                    if (vp >= 0 && vp < nst && !(dbg & 1)) {
-                        const uint32_t* ob = OUT + (vp & 1) * 32 * GM_OUT_PITCH;
-                        const int yb = 32 * (t_first + vp) - y_phase;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int idx = tid + 256 * q, rr = idx >> 5, cc = idx & 31;
-                            if (yb + rr >= 0 && yb + rr < h && x0 + cc < w)
-                                reinterpret_cast<uint32_t*>(dst)[(size_t)(yb + rr) * w + x0 + cc] = ob[rr * GM_OUT_PITCH + cc];
-                        }
-                    }
-                }
                 stamp(it, 4);
                 __syncthreads();
                 stamp(it, 5);
@@ -439,6 +423,24 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
         const bool interior = __builtin_amdgcn_readfirstlane((x0 - R8 >= 0 && x0 - R8 + 16 * NKB <= w) ? 1 : 0) != 0;
         if (interior) walk(std::false_type{}); else walk(std::true_type{});
     } else {
+        // the block finished in the previous iteration leaves as 128-byte row segments: 256 consumer lanes x 16 bytes.  It is requested
+        // behind this iteration's fragment reads, so its LDS / HBM latency hides under the MFMAs.
+        auto store_prev = [&](int it) {
+            const int vp = it - 1 - HALF;
+            if (vp < 0 || vp >= nst || (dbg & 1)) return;
+            const int t = tid - 256, rr = t >> 3, cg = 4 * (t & 7);
+            const int y = 32 * (t_first + vp) - y_phase + rr;
+            const uint32_t* ob = OUT + (vp & 1) * 32 * GM_OUT_PITCH + rr * GM_OUT_PITCH + cg;
+            if (y < 0 || y >= h) return;
+            uint32_t* drow = reinterpret_cast<uint32_t*>(dst) + (size_t)y * w + x0 + cg;
+            if constexpr (FAST) { // w % 4 == 0 and dst 16-byte aligned: the 4-pixel piece is wholly inside or outside the row
+                if (x0 + cg < w) *reinterpret_cast<uint4*>(drow) = *reinterpret_cast<const uint4*>(ob);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (x0 + cg + q < w) drow[q] = ob[q];
+            }
+        };
         for (int it = 0; it < n_iter; ++it) {
             stamp(it, 0);
             // vertical pass of output block v on ring slots [32 v mod RING, + 16 NKB); A row m = i = xl * 4 + c
@@ -449,18 +451,27 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 const _Float16* a2p = HR + (size_t)(1 * 4 + c) * PLANE + (8 * xb + xl) * YP;
                 const int rb = (32 * v) % RING + 8 * NKB * hh;
                 stamp(it, 1);
+                // all 2 NKB fragments are requested before the first MFMA (left alone, the scheduler issues a pair, waits for it,
+                // multiplies, issues the next pair: NKB serialised LDS round trips, ~1500 cycles per step)
+                pfx_f16x8 a1[NKB], a2[NKB];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    int ro = rb + 8 * kb;
+                    ro = ro >= RING ? ro - RING : ro;
+                    a1[kb] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
+                    a2[kb] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                store_prev(it);
+                __builtin_amdgcn_sched_barrier(0);
                 pfx_f32x16 accA, accB, accC; // three independent chains
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { accA[q] = 0.0f; accB[q] = 0.0f; accC[q] = 0.0f; }
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
-                    int ro = rb + 8 * kb;
-                    ro = ro >= RING ? ro - RING : ro;
-                    const pfx_f16x8 a1 = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
-                    const pfx_f16x8 a2 = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
-                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, B1[kb], accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, B2[kb], accB, 0, 0, 0);
-                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, B1[kb], accC, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B1[kb], accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], accB, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], accC, 0, 0, 0);
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) accB[q] += accC[q];
@@ -478,7 +489,8 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                         px[e] = min((uint32_t)__builtin_fmaf(accA[4 * g + e] + accB[4 * g + e], inv_scale2, 0.5f), 255u);
                     orow[2 * g] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
                 }
-            }
+            } else
+                store_prev(it);
             stamp(it, 4);
             __syncthreads();
             stamp(it, 5);
@@ -528,7 +540,7 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     // the whole image's grid, so every output sees the same K-block grouping (the same f32 summation order) as in a whole-image call
     const int y_ph = (int)(first_row % 32u);
     const int n_steps = ((int)h + y_ph + 31) / 32;
-    const bool fast = ((uintptr_t)d_src & 15u) == 0 && (w & 3u) == 0 && w >= 4;
+    const bool fast = (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0 && (w & 3u) == 0 && w >= 4;
     hipError_t errs = hipSuccess;
     auto launch_s = [&](auto nkb_c) {
         constexpr int NK = decltype(nkb_c)::value;
