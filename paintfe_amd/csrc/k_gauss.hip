@@ -205,28 +205,37 @@ hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const
 //     scaled by S = 256 and split w*S = w1 + w2 (two f16, 22 significant bits); the f32 horizontal result h (kept scaled, S*h <
 //     65504) is split S*h = h1 + h2 the same way.  H pass: p*w1 + p*w2.  V pass: h1*w1 + h1*w2 + h2*w1; the dropped h2*w2 is < 2^-22
 //     of the sum.  The result differs from the CPU path's f32 mul/add chain by rounding noise only (+-1 LSB class, tests and
-//     bench.py assert it; at 8K 4e-5 of the channels differ).
+//     bench.py assert it; at 8K ~1e-4 of the channels differ).
 //   * u8 -> f16 without arithmetic: the half with bit pattern 0x6400 | b is exactly 1024 + b, so one v_perm_b32 per two samples
 //     builds a fragment; the constant 1024 * sum(T[.][n]) it adds to every output is the H accumulator's start value.
-//   * the 16 NKB samples of a window are dealt to the two lane halves of an MFMA operand as two contiguous runs (half hh owns samples
-//     [8 NKB hh, 8 NKB (hh + 1)), K block kb takes 8 of each run).  The MFMA only ever pairs A slot (hh, j) with B slot (hh, j), so
-//     any such dealing is valid as long as T follows it:  B_kb[(hh, j)][n] = tap(8 NKB hh + 8 kb + j - n - (R8 - r)).  The kernel
-//     relies on nothing but the documented C/D map (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
+//   * the 16 NKB samples of a window are dealt to the MFMA's K slots as runs of 8: slot (lane half hh, K block kb) holds samples
+//     [16 kb + 8 hh, +8).  The MFMA only ever pairs A slot (hh, j) with B slot (hh, j), so any such dealing is valid as long as T
+//     follows it:  B_kb[(hh, j)][n] = tap(16 kb + 8 hh + j - n - (R8 - r)).  This one makes K block kb cover window rows
+//     [16 kb, 16 kb + 16): the 32 newest rows of a vertical window are its last two K blocks (used below).  The kernel relies on
+//     nothing but the documented C/D map (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
 //
 // Column-strip walk: a workgroup owns a 32-column strip and walks down it in steps of 32 rows with the horizontal results in an
 // LDS RING of 16 NKB + 32 rows (f16 pairs, transposed so that a column's rows are contiguous).  Waves 0-3 ("producers") compute the
-// 32 new rows of step i (8 rows x 4 channels each, 2 NKB MFMAs) while waves 4-7 ("consumers") run the vertical pass of step
-// i - NKB / 2 on the 16 NKB rows already in the ring (8 columns x 4 channels each, 3 NKB MFMAs) — disjoint ring slots, one barrier per
-// step, each SIMD hosts one wave of either role.  No row is computed twice, the f32 intermediate never touches HBM: 8 algorithmic
+// 32 new rows of a step (8 rows x 4 channels each, 2 NKB MFMAs); waves 4-7 ("consumers") run the vertical pass of a 32-row output
+// block on the 16 NKB rows in the ring (8 columns x 4 channels each, 3 NKB MFMAs) — disjoint ring slots, one barrier per iteration,
+// each SIMD hosts one wave of either role.  No row is computed twice, the f32 intermediate never touches HBM: 8 algorithmic
 // bytes per pixel are the kernel's only HBM traffic (+ the x-halo re-reads, served by L2).
+//   * the two waves of a SIMD share its matrix pipe (32 cycles per MFMA, 40 MFMAs per iteration) and a wave issues a VALU
+//     instruction only every ~6 cycles, so an iteration is arranged in ANTI-PHASE (s_memtime timeline: tools/gauss_timeline.py):
+//     first the consumers multiply — the fragments of all but the last two K blocks were requested one iteration ahead, the
+//     last two (the rows finished before the barrier) arrive under those MFMAs — while the producers split and store the rows
+//     whose MFMAs they issued BEFORE the barrier, de-interleave the next step and build its fragments; then the producers issue
+//     their MFMAs (and go to the barrier without waiting for them) while the consumers round and pack.  Step s is multiplied in
+//     iteration s, reaches the ring in s + 1; block v runs in iteration v + NKB / 2 + 1 and leaves in the one after.
 //   * a producer lane fetches 2 NKB consecutive RGBA pixels of one row (16-byte loads, whole cache lines across the wave), requested
 //     GS_DEPTH steps ahead into a ring of register sets (the refill is unconditional and straight after the set's last use: loads
 //     write their final registers, every vmcnt wait is exact).  Before the MFMAs the wave de-interleaves the four channels through a
-//     private 4.6 KB LDS patch (v_perm gathers, ds_write_b128 / ds_read_b128, no barrier: one wave, in-order LDS) so that A row
-//     m = channel * 8 + row holds 8 NKB consecutive samples of ONE channel per lane half.
-//   * the previous output block leaves through LDS as 128-byte row segments, written by the producers (the lighter role);
-//   * a strip is cut into row segments so that the launch has just under two workgroups per CU; a segment pays NKB / 2 - 1
-//     producer steps of run-in; output blocks lie on the whole image's 32-row grid (y_phase), so a band of a sharded document gets
+//     private 4.6 KB LDS patch (v_perm gathers, ds_write_b128 / ds_read_b64, no barrier: one wave, in-order LDS) so that A row
+//     m = channel * 8 + row holds runs of 8 consecutive samples of ONE channel.
+//   * the previous output block leaves through LDS as 128-byte row segments, 16 bytes per consumer lane, between the consumers'
+//     MFMA groups;
+//   * a strip is cut into row segments so that the launch has just under two workgroups per CU; a segment pays NKB / 2
+//     iterations of run-in; output blocks lie on the whole image's 32-row grid (y_phase), so a band of a sharded document gets
 //     the same K-block grouping — the same f32 summation order — as the whole image.
 typedef _Float16 pfx_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 pfx_f16x4 __attribute__((ext_vector_type(4)));
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
         const _Float16* w2 = w1 + GM_WLEN;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const int t0 = 8 * NKB * hh + 8 * kb - i - (R8 - r); // in [-46, 127]
+            const int t0 = 16 * kb + 8 * hh - i - (R8 - r); // in [-46, 120]
 #pragma unroll
             for (int j = 0; j < 8; ++j) { B1[kb][j] = w1[t0 + j]; B2[kb][j] = w2[t0 + j]; }
         }
@@ -287,11 +296,25 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
     const int nst = t_last - t_first;
     const int a0 = 32 * t_first - y_phase - R8; // image row of ring slot 0 (producer step 0)
     const int n_hsteps = nst + HALF - 1;        // producer steps 0 .. n_hsteps - 1; consumer step v needs producer steps v .. v + HALF - 1
-    const int last = nst + HALF, n_iter = ((last + GS_DEPTH) / GS_DEPTH) * GS_DEPTH; // iterations 0 .. n_iter - 1 (surplus ones only synchronise)
+    // a step's MFMAs are issued in iteration `step`, its rows reach the ring in step + 1; block v runs in iteration v + HALF + 1 and leaves in
+    // v + HALF + 2
+    const int last = nst + HALF + 1, n_iter = ((last + GS_DEPTH) / GS_DEPTH) * GS_DEPTH; // iterations 0 .. n_iter - 1 (surplus ones only synchronise)
 
-    auto stamp = [&](int it, int slot) { // development: s_memtime at phase boundaries of iterations 10..13, block 0, waves 0 and 4
-        if ((dbg & 16) && blockIdx.x == 8 && (wave == 0 || wave == 4) && lane == 0 && it >= 10 && it < 14)
-            dbg_buf[((wave >> 2) * 4 + (it - 10)) * 8 + slot] = __builtin_readcyclecounter();
+    // development: s_memtime at phase boundaries of iterations 10..13, one interior block, waves 0 and 4.  The reads are not waited for
+    // where they are issued (that would drain the wave's LDS queue and distort the phase); flush_stamps() waits once per iteration.
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamping = (dbg & 16) && blockIdx.x == 8 && (wave == 0 || wave == 4);
+    auto stamp = [&](int it, int slot) {
+        if (stamping && it >= 10 && it < 14) asm volatile("s_memtime %0" : "=s"(ts[slot]));
+    };
+    auto flush_stamps = [&](int it) {
+        if (stamping && it >= 10 && it < 14) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dbg_buf[((wave >> 2) * 4 + (it - 10)) * 8 + k] = ts[k];
+            }
+        }
     };
 
     if (producer) {
@@ -322,9 +345,40 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 }
             };
             uint8_t* xp_w = XP + (size_t)wave * 4 * 8 * GS_XROW;
+            pfx_f32x16 acc, acc2; // two independent accumulator chains of one step; they live across the barrier (summed in the epilogue)
+            pfx_f32x16 neg_bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) neg_bias[q] = -bias_c;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { acc[q] = 0.0f; acc2[q] = 0.0f; }
+            // One producer iteration, arranged so that its VALU phases face the consumers' MFMA phase and vice versa: (0) split and
+            // store the 32 rows whose MFMAs were issued before the last barrier (step it - 1) — the consumers are multiplying; (1) - (2)
+            // de-interleave step it, refill that register set, build the fragments; (3) issue step it's MFMAs and go to the barrier
+            // without waiting for them — the consumers are rounding and packing by then.
             auto produce = [&](auto bufc, int it) {
                 constexpr int BUF = decltype(bufc)::value;
                 stamp(it, 0);
+                if (it >= 1 && it - 1 < n_hsteps && !(dbg & 2)) {
+                    // D[m][x]: lane holds column x = i; reg q -> m = (q & 3) + 8 (q >> 2) + 4 hh = c * 8 + row with c = q >> 2: regs 4c .. 4c+3
+                    // are four consecutive rows of channel c.  The value S * h goes to ring slots [32 (it - 1) mod RING, +32) as hi + lo,
+                    // hi = its top 11 significant bits.
+                    const int ro = (32 * (it - 1)) % RING + 8 * wave + 4 * hh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        pfx_f16x4 h1, h2;
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            const float va = acc[4 * g + e] + acc2[4 * g + e], vb = acc[4 * g + e + 1] + acc2[4 * g + e + 1];
+                            const pfx_f16x2 hi = pkrtz(va, vb);
+                            const pfx_f16x2 lo = pkrtz(va - (float)hi[0], vb - (float)hi[1]);
+                            h1[e] = hi[0]; h1[e + 1] = hi[1]; h2[e] = lo[0]; h2[e + 1] = lo[1];
+                        }
+                        *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(0 * 4 + g) * PLANE + i * YP + ro) = h1;
+                        *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * PLANE + i * YP + ro) = h2;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                stamp(it, 1);
                 // (1) de-interleave: four pixels (r g b a) x 4 -> one dword per channel; a lane's PPL samples of a channel are contiguous
                 // in the wave's LDS patch [c][row][sample], so they leave as 16-byte stores
                 {
@@ -357,59 +411,36 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                         }
                     }
                 }
-                stamp(it, 1);
+                stamp(it, 2);
                 __builtin_amdgcn_sched_barrier(0); // keep the refill HERE: the scheduler would sink it next to its use, steps later
                 if (!(dbg & 8)) fetch(std::integral_constant<int, BUF>{}, it + GS_DEPTH);
                 __builtin_amdgcn_sched_barrier(0);
-                // (2) A fragments: row m = i = channel * 8 + row, lane half hh owns samples [8 NKB hh, +8 NKB); 0x6400 | byte = 1024 + byte
+                // (2) A fragments: row m = i = channel * 8 + row, K slot (hh, kb) holds samples [16 kb + 8 hh, +8); 0x6400 | byte = 1024 + byte
                 pfx_f16x8 fr[NKB];
                 {
-                    const uint8_t* mine = xp_w + (size_t)(i >> 3) * 8 * GS_XROW + (i & 7) * GS_XROW + 8 * NKB * hh;
-#pragma unroll
-                    for (int kb = 0; kb < NKB; kb += 2) {
-                        const uint4 d = *reinterpret_cast<const uint4*>(mine + 8 * kb);
-                        uint32_t qa[4], qb[4];
-                        qa[0] = __builtin_amdgcn_perm(d.x, 0x64646464u, 0x00050004u); qa[1] = __builtin_amdgcn_perm(d.x, 0x64646464u, 0x00070006u);
-                        qa[2] = __builtin_amdgcn_perm(d.y, 0x64646464u, 0x00050004u); qa[3] = __builtin_amdgcn_perm(d.y, 0x64646464u, 0x00070006u);
-                        qb[0] = __builtin_amdgcn_perm(d.z, 0x64646464u, 0x00050004u); qb[1] = __builtin_amdgcn_perm(d.z, 0x64646464u, 0x00070006u);
-                        qb[2] = __builtin_amdgcn_perm(d.w, 0x64646464u, 0x00050004u); qb[3] = __builtin_amdgcn_perm(d.w, 0x64646464u, 0x00070006u);
-                        fr[kb] = __builtin_bit_cast(pfx_f16x8, qa);
-                        fr[kb + 1] = __builtin_bit_cast(pfx_f16x8, qb);
-                    }
-                }
-                stamp(it, 2);
-                if (it < n_hsteps && !(dbg & 2)) { // horizontal pass of 32 new rows into ring slots [32 it mod RING, +32)
-                    pfx_f32x16 acc, acc2;          // two independent accumulator chains, summed in the epilogue
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) { acc[q] = -bias_c; acc2[q] = 0.0f; }
+                    const uint8_t* mine = xp_w + (size_t)(i >> 3) * 8 * GS_XROW + (i & 7) * GS_XROW + 8 * hh;
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B1[kb], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], acc2, 0, 0, 0);
+                        const uint2 d = *reinterpret_cast<const uint2*>(mine + 16 * kb); // 2-way bank conflict (all addresses 8 mod 16 or 0 mod 16)
+                        uint32_t qa[4];
+                        qa[0] = __builtin_amdgcn_perm(d.x, 0x64646464u, 0x00050004u); qa[1] = __builtin_amdgcn_perm(d.x, 0x64646464u, 0x00070006u);
+                        qa[2] = __builtin_amdgcn_perm(d.y, 0x64646464u, 0x00050004u); qa[3] = __builtin_amdgcn_perm(d.y, 0x64646464u, 0x00070006u);
+                        fr[kb] = __builtin_bit_cast(pfx_f16x8, qa);
                     }
+                }
+                stamp(it, 3);
+                if (it < n_hsteps && !(dbg & 2)) { // horizontal pass of 32 new rows
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[q] += acc2[q];
-                    stamp(it, 3);
-                    // D[m][x]: lane holds column x = i; reg q -> m = (q & 3) + 8 (q >> 2) + 4 hh = c * 8 + row with c = q >> 2: regs 4c .. 4c+3
-                    // are four consecutive rows of channel c.  The value S * h is stored as hi + lo, hi = its top 11 significant bits.
-                    const int ro = (32 * it) % RING + 8 * wave + 4 * hh;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        pfx_f16x4 h1, h2;
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            const float va = acc[4 * g + e], vb = acc[4 * g + e + 1];
-                            const pfx_f16x2 hi = pkrtz(va, vb);
-                            const pfx_f16x2 lo = pkrtz(va - (float)hi[0], vb - (float)hi[1]);
-                            h1[e] = hi[0]; h1[e + 1] = hi[1]; h2[e] = lo[0]; h2[e + 1] = lo[1];
-                        }
-                        *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(0 * 4 + g) * PLANE + i * YP + ro) = h1;
-                        *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * PLANE + i * YP + ro) = h2;
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B1[kb], kb ? acc : neg_bias, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], kb ? acc2 : pfx_f32x16{}, 0, 0, 0);
                     }
                 }
                 stamp(it, 4);
+                stamp(it, 6);
                 __syncthreads();
-                stamp(it, 5);
+                stamp(it, 7);
+                flush_stamps(it);
             };
             fetch(std::integral_constant<int, 0>{}, 0);
             if constexpr (GS_DEPTH > 1) fetch(std::integral_constant<int, 1>{}, 1);
@@ -423,77 +454,96 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
         const bool interior = __builtin_amdgcn_readfirstlane((x0 - R8 >= 0 && x0 - R8 + 16 * NKB <= w) ? 1 : 0) != 0;
         if (interior) walk(std::false_type{}); else walk(std::true_type{});
     } else {
-        // the block finished in the previous iteration leaves as 128-byte row segments: 256 consumer lanes x 16 bytes.  It is requested
-        // behind this iteration's fragment reads, so its LDS / HBM latency hides under the MFMAs.
-        auto store_prev = [&](int it) {
-            const int vp = it - 1 - HALF;
-            if (vp < 0 || vp >= nst || (dbg & 1)) return;
-            const int t = tid - 256, rr = t >> 3, cg = 4 * (t & 7);
-            const int y = 32 * (t_first + vp) - y_phase + rr;
-            const uint32_t* ob = OUT + (vp & 1) * 32 * GM_OUT_PITCH + rr * GM_OUT_PITCH + cg;
-            if (y < 0 || y >= h) return;
-            uint32_t* drow = reinterpret_cast<uint32_t*>(dst) + (size_t)y * w + x0 + cg;
-            if constexpr (FAST) { // w % 4 == 0 and dst 16-byte aligned: the 4-pixel piece is wholly inside or outside the row
-                if (x0 + cg < w) *reinterpret_cast<uint4*>(drow) = *reinterpret_cast<const uint4*>(ob);
-            } else {
+        // Consumer iteration `it` runs block v = it - HALF - 1 on ring rows [32 v, 32 v + 16 NKB) (mod RING).  K slot (hh, kb) holds window rows
+        // [16 kb + 8 hh, +8), so only the last two K blocks touch the 32 rows the producers finished in the previous iteration: the
+        // fragments of K blocks 0 .. NKB - 3 are requested one iteration ahead (straight after the MFMAs that free their registers)
+        // and the matrix pipe starts at the top of the iteration.  (1) request the previous block's packed pixels (one 16-byte LDS
+        // read per lane) and the two late K blocks; (2) MFMAs of the early K blocks; (3) the previous block goes to memory as 128-byte
+        // row segments (256 lanes x 16 bytes); (4) late MFMAs; (5) request block v + 1's early fragments; (6) round, pack, stage
+        // block v.  Every LDS address is valid in every iteration (the ring offset just keeps turning), so no load sits behind a branch.
+        constexpr int EARLY = NKB - 2;
+        const int xb = wave - 4, xl = i >> 2, c = i & 3;
+        const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
+        const _Float16* a2p = HR + (size_t)(1 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
+        const int st_t = tid - 256, st_rr = st_t >> 3, st_cg = 4 * (st_t & 7);
+        pfx_f16x8 a1[NKB], a2[NKB];
+        auto request = [&](int rbase, auto k0c, auto k1c) { // K blocks [K0, K1) of the block whose window starts at ring row rbase
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (x0 + cg + q < w) drow[q] = ob[q];
+            for (int kb = decltype(k0c)::value; kb < decltype(k1c)::value; ++kb) {
+                int ro = rbase + 16 * kb;
+                ro = ro >= RING ? ro - RING : ro;
+                a1[kb] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
+                a2[kb] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
             }
         };
+        int rbase = 0; // (32 v) mod RING for v = -HALF - 1 (RING = 32 (HALF + 1))
+        request(rbase, std::integral_constant<int, 0>{}, std::integral_constant<int, EARLY>{});
         for (int it = 0; it < n_iter; ++it) {
             stamp(it, 0);
-            // vertical pass of output block v on ring slots [32 v mod RING, + 16 NKB); A row m = i = xl * 4 + c
-            const int v = it - HALF;
-            if (v >= 0 && v < nst && !(dbg & 4)) {
-                const int xb = wave - 4, xl = i >> 2, c = i & 3;
-                const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP;
-                const _Float16* a2p = HR + (size_t)(1 * 4 + c) * PLANE + (8 * xb + xl) * YP;
-                const int rb = (32 * v) % RING + 8 * NKB * hh;
-                stamp(it, 1);
-                // all 2 NKB fragments are requested before the first MFMA (left alone, the scheduler issues a pair, waits for it,
-                // multiplies, issues the next pair: NKB serialised LDS round trips, ~1500 cycles per step)
-                pfx_f16x8 a1[NKB], a2[NKB];
+            const int v = it - HALF - 1, vp = v - 1;
+            const bool active = v >= 0 && v < nst && !(dbg & 4);
+            const int st_y = 32 * (t_first + vp) - y_phase + st_rr;
+            const bool do_store = vp >= 0 && vp < nst && !(dbg & 1) && st_y >= 0 && st_y < h && (!FAST || x0 + st_cg < w);
+            const uint4 ov = *reinterpret_cast<const uint4*>(OUT + (vp & 1) * 32 * GM_OUT_PITCH + st_rr * GM_OUT_PITCH + st_cg);
+            request(rbase, std::integral_constant<int, EARLY>{}, std::integral_constant<int, NKB>{});
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(it, 1);
+            // chain A = h1 * w1; chain X = h1 * w2 + h2 * w1 (the two small terms share an accumulator, A's MFMA sits between them)
+            pfx_f32x16 accA, accX;
+            if (active) {
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) {
-                    int ro = rb + 8 * kb;
-                    ro = ro >= RING ? ro - RING : ro;
-                    a1[kb] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
-                    a2[kb] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
+                for (int kb = 0; kb < EARLY; ++kb) {
+                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], kb ? accX : pfx_f32x16{}, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B1[kb], kb ? accA : pfx_f32x16{}, 0, 0, 0);
+                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], accX, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                store_prev(it);
-                __builtin_amdgcn_sched_barrier(0);
-                pfx_f32x16 accA, accB, accC; // three independent chains
+            }
+            stamp(it, 2);
+            if (do_store) {
+                uint32_t* drow = reinterpret_cast<uint32_t*>(dst) + (size_t)st_y * w + x0 + st_cg;
+                if constexpr (FAST) *reinterpret_cast<uint4*>(drow) = ov; // w % 4 == 0, dst 16-byte aligned: the piece is wholly inside the row
+                else {
+                    const uint32_t o4[4] = {ov.x, ov.y, ov.z, ov.w};
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { accA[q] = 0.0f; accB[q] = 0.0f; accC[q] = 0.0f; }
+                    for (int q = 0; q < 4; ++q)
+                        if (x0 + st_cg + q < w) drow[q] = o4[q];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) {
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) {
+                for (int kb = EARLY; kb < NKB; ++kb) {
+                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], accX, 0, 0, 0);
                     accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B1[kb], accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], accB, 0, 0, 0);
-                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], accC, 0, 0, 0);
+                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], accX, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) accB[q] += accC[q];
-                stamp(it, 3);
+            }
+            stamp(it, 3);
+            rbase = rbase + 32 >= RING ? rbase + 32 - RING : rbase + 32;
+            request(rbase, std::integral_constant<int, 0>{}, std::integral_constant<int, EARLY>{}); // block v + 1: rows complete since the last barrier
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(it, 4);
+            if (active) {
                 // D[m][n]: n = output row i of the block; reg q -> m = (q & 3) + 8 (q >> 2) + 4 hh = xl' * 4 + c' with c' = q & 3,
                 // xl' = 2 (q >> 2) + hh: regs 4g .. 4g+3 are the RGBA of pixel (8 xb + 2 g + hh, row i)
                 uint32_t* orow = OUT + (v & 1) * 32 * GM_OUT_PITCH + i * GM_OUT_PITCH + 8 * xb + hh;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    // `.round().clamp(0, 255) as u8` (filters.rs:308-311) of a non-negative sum: trunc(v + 0.5) with the final scale
-                    // fused in; v_cvt_u32_f32 saturates negatives (rounding noise around 0) to 0
-                    uint32_t px[4];
+                    // `.round().clamp(0, 255) as u8` (filters.rs:308-311) with the final scale fused in: v_cvt_pk_u8_f32 rounds to nearest
+                    // (ties to even — an exact .5 is where it can differ from the CPU's half-away rounding, inside the +-1 LSB that
+                    // the f32 summation order already costs) and saturates to [0, 255]
+                    uint32_t px = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        px[e] = min((uint32_t)__builtin_fmaf(accA[4 * g + e] + accB[4 * g + e], inv_scale2, 0.5f), 255u);
-                    orow[2 * g] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+                    for (int e = 0; e < 4; ++e) px = __builtin_amdgcn_cvt_pk_u8_f32((accA[4 * g + e] + accX[4 * g + e]) * inv_scale2, e, px);
+                    orow[2 * g] = px;
                 }
-            } else
-                store_prev(it);
-            stamp(it, 4);
+            }
+            stamp(it, 6);
             __syncthreads();
-            stamp(it, 5);
+            stamp(it, 7);
+            flush_stamps(it);
         }
     }
 }

@@ -22,4 +22,4 @@ for role, name in ((0, "producer w0"), (1, "consumer w4")):
     for it in range(4):
         row = t[role, it]
         base = t[0, 0, 0]
-        print(name, "it", 10 + it, " ".join(f"{int(v - base):6d}" if v else "     -" for v in row[:6]))
+        print(name, "it", 10 + it, " ".join(f"{int(v - base):6d}" if v else "     -" for v in row[:8]))
