@@ -111,7 +111,8 @@ PCIE_GEN5_X16_GBS = 63.0  # guides/MI355X_MICROARCH.md: host link, spec, per dir
 def run_batch4k(args, torch, dist, rank, world, dev_index, device) -> int:
     """BASELINE config 5 / SURVEY 8d S4: `--images` independent 3840x2160 images, per image Gaussian sigma=4 -> HSL(30,-20,10) ->
     flatten under 3 overlays (Multiply / Screen / Overlay).  Sharded by image: rank r streams images r, r+world, ... through its GPU
-    with pfx_batch_pipeline (pinned host memory, `--slots` pipeline slots: H2D, kernels and D2H of different images overlap).
+    with pfx_batch_pipeline (pinned host memory; an upload, a kernel and a download stream over `--slots` buffer sets: H2D, kernels
+    and D2H of different images overlap).
     36 algorithmic HBM bytes per pixel; the pace is set by PCIe (33 MB per image each way), which the line reports."""
     from paintfe_amd.batch import run_batch
     w, h = (3840, 2160) if (args.width, args.height) == (W8K, H8K) else (args.width, args.height)
@@ -195,7 +196,7 @@ def main() -> int:
                     help="'batch4k' = BASELINE config 5 (S4): a batch of 3840x2160 images, per image Gaussian sigma=4 -> HSL -> 4-layer "
                          "flatten, streamed over PCIe with pinned double-buffering and sharded by image across the GPUs")
     ap.add_argument("--images", type=int, default=1024, help="batch4k: images in the batch (whole job)")
-    ap.add_argument("--slots", type=int, default=3, help="batch4k: pipeline slots per GPU")
+    ap.add_argument("--slots", type=int, default=3, help="batch4k: buffer sets in the per-GPU upload / kernels / download pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], help="key=value kernel tuning knob (development)")
     ap.add_argument("--exact", action="store_true", help="Gaussian without FMA contraction (bit-exact with the CPU path)")

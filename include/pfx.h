@@ -622,8 +622,9 @@ int         pfx_group_download(pfx_group* g, uint8_t* dst_host);     /* concaten
 
 /* ================= batch of independent images across the GPUs of a node (BASELINE config 5; ref: src/cli.rs:159-216) =========
  * The reference's CLI runs `run_one` per input file, serially.  pfx_batch_pipeline streams a batch through the devices instead:
- * image i goes to device i mod n_devices (no data-path collective), and on every device `slots` pipeline slots keep the upload of
- * one image, the kernels of another and the download of a third in flight (pinned host memory, one stream per slot).  Per image:
+ * image i goes to device i mod n_devices (no data-path collective), and on every device a ring of `slots` buffer sets keeps the
+ * upload of one image, the kernels of another and the download of a third in flight (pinned host memory; one in-order stream each
+ * for uploads, kernels and downloads, chained by events).  Per image:
  * parallel_gaussian_blur(sigma) -> hue_saturation_lightness(hue, saturation, lightness) -> CanvasState::composite() of the result
  * under `n_overlays` overlay layers (resident on every device).  Sources are taken round-robin from a pool of host images
  * (image i = pool[i mod n_pool]; the pool is pinned for the duration of the call); results of the images listed in keep_indices
@@ -636,7 +637,7 @@ typedef struct pfx_batch_params {
     const uint8_t* const* overlays_host;  /* n_overlays x w*h*4 */
     const uint8_t* overlay_modes;         /* BlendMode::to_u8 per overlay */
     const float*   overlay_opacity;       /* NULL = 1.0 */
-    uint32_t slots;                       /* pipeline depth per device, 1..8 (0 = 3) */
+    uint32_t slots;                       /* buffer sets per device, 2..8 (0 = 3: measured best; more sets let the upload queue run ahead and the rate drops) */
     uint32_t n_keep;
     const uint32_t* keep_indices;
     uint8_t* const* keep_out;

@@ -3,10 +3,13 @@
 //
 // BASELINE config 5 / SURVEY.md §8(d) S4: a batch of independent images, per image  Gaussian(sigma) -> HSL -> flatten under
 // `n_overlays` overlay layers.  Images are sharded BY IMAGE across the devices (image i -> device i mod N: no data-path
-// collective); on every device a ring of `slots` pipeline slots — each with its own context, stream, pinned host
-// result buffer and device buffers — keeps the H2D copy of image k+1, the kernels of image k and the D2H copy of image k-1 in
-// flight at once, so the PCIe link (Gen5 x16: 33 MB per 4K image each way ~ 0.6 ms) and not the 0.2 ms of kernels sets the pace.
-// One host thread per device enqueues; nothing touches pixels on the CPU.
+// collective).  On every device three in-order HIP streams form the pipeline — one for the H2D copies, one for the
+// kernels, one for the D2H copies, chained by events — over a ring of `slots` buffer sets, so that the upload of image k+1, the
+// kernels of image k and the download of image k-1 are in flight at once and each copy direction keeps ONE DMA queue busy back to
+// back.  (One stream per slot, the first version, let the runtime spread the copies of 3+ streams over its hardware queues:
+// 830-1110 images/s depending on the slot count, against 1440 images/s that the link gives both ways at once —
+// tools/lab/pcie_duplex.py.)  The PCIe link (Gen5 x16: 33 MB per 4K image each way ~ 0.7 ms), not the 0.15 ms of kernels, sets the
+// pace.  One host thread per device enqueues; nothing touches pixels on the CPU.
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -20,10 +23,9 @@
 namespace {
 
 struct slot {
-    pfx_ctx* ctx = nullptr;
-    void *d_in = nullptr, *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
+    void *d_in = nullptr, *d_out = nullptr;
     uint8_t* h_out = nullptr;         // pinned
-    hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr;
+    hipEvent_t uploaded = nullptr, computed = nullptr, done = nullptr, k0 = nullptr, k1 = nullptr;
     int64_t image = -1;               // image whose result is in flight in this slot
     bool timed = false;
 };
@@ -41,21 +43,31 @@ void run_device(int device, uint32_t rank, uint32_t world, uint32_t n_images, co
                 uint32_t n_pool, worker_result& R)
 {
     const size_t bytes = (size_t)P.w * P.h * 4;
-    const uint32_t n_slots = P.slots >= 1 && P.slots <= 8 ? P.slots : 3;
+    const uint32_t n_slots = P.slots >= 2 && P.slots <= 8 ? P.slots : 3;
     std::vector<slot> S(n_slots);
     std::vector<void*> d_ov(P.n_overlays, nullptr);
+    pfx_ctx* ctx = nullptr;            // kernels of all slots run in order on this context's stream: one scratch set serves them
+    void *d_a = nullptr, *d_b = nullptr;
+    hipStream_t s_up = nullptr, s_down = nullptr;
     auto fail = [&](int st, const std::string& m) { if (R.status == PFX_OK) { R.status = st; R.err = m; } };
     auto hip = [&](hipError_t e, const char* what) { if (e != hipSuccess) fail(e == hipErrorOutOfMemory ? PFX_ERR_OOM : PFX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
 
     if (!hip(hipSetDevice(device), "hipSetDevice")) return;
-    for (auto& s : S) {
-        if (pfx_ctx_create(device, &s.ctx) != PFX_OK) { fail(PFX_ERR_HIP, "pfx_ctx_create failed"); break; }
-        if (!hip(hipMalloc(&s.d_in, bytes), "hipMalloc") || !hip(hipMalloc(&s.d_a, bytes), "hipMalloc") || !hip(hipMalloc(&s.d_b, bytes), "hipMalloc") ||
-            !hip(hipMalloc(&s.d_out, bytes), "hipMalloc") || !hip(hipHostMalloc((void**)&s.h_out, bytes, hipHostMallocDefault), "hipHostMalloc") ||
-            !hip(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate") || !hip(hipEventCreate(&s.k0), "hipEventCreate") ||
-            !hip(hipEventCreate(&s.k1), "hipEventCreate"))
-            break;
+    if (pfx_ctx_create(device, &ctx) != PFX_OK) fail(PFX_ERR_HIP, "pfx_ctx_create failed");
+    if (R.status == PFX_OK) {
+        (void)(hip(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking), "hipStreamCreate") && hip(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking), "hipStreamCreate") &&
+               hip(hipMalloc(&d_a, bytes), "hipMalloc") && hip(hipMalloc(&d_b, bytes), "hipMalloc"));
     }
+    if (R.status == PFX_OK)
+        for (auto& s : S) {
+            if (!hip(hipMalloc(&s.d_in, bytes), "hipMalloc") || !hip(hipMalloc(&s.d_out, bytes), "hipMalloc") ||
+                !hip(hipHostMalloc((void**)&s.h_out, bytes, hipHostMallocDefault), "hipHostMalloc") ||
+                !hip(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming), "hipEventCreate") ||
+                !hip(hipEventCreateWithFlags(&s.computed, hipEventDisableTiming), "hipEventCreate") ||
+                !hip(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate") || !hip(hipEventCreate(&s.k0), "hipEventCreate") ||
+                !hip(hipEventCreate(&s.k1), "hipEventCreate"))
+                break;
+        }
     // overlays: resident on the device for the whole batch (uploaded once)
     if (R.status == PFX_OK)
         for (uint32_t o = 0; o < P.n_overlays; ++o) {
@@ -88,44 +100,48 @@ void run_device(int device, uint32_t rank, uint32_t world, uint32_t n_images, co
 
     R.t_begin = std::chrono::steady_clock::now();
     uint32_t turn = 0;
+    const hipStream_t s_comp = R.status == PFX_OK ? (hipStream_t)pfx_ctx_stream(ctx) : nullptr;
     for (uint32_t img = rank; img < n_images && R.status == PFX_OK; img += world, ++turn) {
         slot& s = S[turn % n_slots];
-        retire(s);
+        retire(s); // its d_in was consumed and its d_out downloaded: the buffers are free
         if (R.status != PFX_OK) break;
-        hipStream_t st = (hipStream_t)pfx_ctx_stream(s.ctx);
         const uint8_t* src = pool[img % n_pool]; // pinned (registered) by the caller of run_device
-        if (!hip(hipMemcpyAsync(s.d_in, src, bytes, hipMemcpyHostToDevice, st), "H2D")) break;
+        if (!hip(hipMemcpyAsync(s.d_in, src, bytes, hipMemcpyHostToDevice, s_up), "H2D") || !hip(hipEventRecord(s.uploaded, s_up), "hipEventRecord") ||
+            !hip(hipStreamWaitEvent(s_comp, s.uploaded, 0), "hipStreamWaitEvent"))
+            break;
         s.timed = (turn % 8) == 0;
-        if (s.timed) (void)hipEventRecord(s.k0, st);
+        if (s.timed) (void)hipEventRecord(s.k0, s_comp);
         const void* ptrs[1 + 8];
-        ptrs[0] = s.d_b;
+        ptrs[0] = d_b;
         for (uint32_t o = 0; o < P.n_overlays; ++o) ptrs[1 + o] = d_ov[o];
-        int rc = pfx_gaussian_blur_dev(s.ctx, s.d_in, s.d_a, P.w, P.h, P.sigma, nullptr);
-        if (rc == PFX_OK) rc = pfx_adjust_dev(s.ctx, s.d_a, s.d_b, P.w, P.h, PFX_OP_HSL, hsl, 3, nullptr, nullptr, PFX_DENSE);
-        if (rc == PFX_OK) rc = pfx_flatten_dev(s.ctx, ptrs, nullptr, li.data(), 1 + P.n_overlays, P.w, P.h, s.d_out);
-        if (rc != PFX_OK) { fail(rc, pfx_last_error(s.ctx)); break; }
-        if (s.timed) (void)hipEventRecord(s.k1, st);
-        if (!hip(hipMemcpyAsync(s.h_out, s.d_out, bytes, hipMemcpyDeviceToHost, st), "D2H")) break;
-        if (!hip(hipEventRecord(s.done, st), "hipEventRecord")) break;
+        int rc = pfx_gaussian_blur_dev(ctx, s.d_in, d_a, P.w, P.h, P.sigma, nullptr);
+        if (rc == PFX_OK) rc = pfx_adjust_dev(ctx, d_a, d_b, P.w, P.h, PFX_OP_HSL, hsl, 3, nullptr, nullptr, PFX_DENSE);
+        if (rc == PFX_OK) rc = pfx_flatten_dev(ctx, ptrs, nullptr, li.data(), 1 + P.n_overlays, P.w, P.h, s.d_out);
+        if (rc != PFX_OK) { fail(rc, pfx_last_error(ctx)); break; }
+        if (s.timed) (void)hipEventRecord(s.k1, s_comp);
+        if (!hip(hipEventRecord(s.computed, s_comp), "hipEventRecord") || !hip(hipStreamWaitEvent(s_down, s.computed, 0), "hipStreamWaitEvent") ||
+            !hip(hipMemcpyAsync(s.h_out, s.d_out, bytes, hipMemcpyDeviceToHost, s_down), "D2H") || !hip(hipEventRecord(s.done, s_down), "hipEventRecord"))
+            break;
         s.image = img;
     }
     for (uint32_t k = 0; k < n_slots && R.status == PFX_OK; ++k) retire(S[(turn + k) % n_slots]); // drain in issue order
     R.t_end = std::chrono::steady_clock::now();
 
     (void)hipSetDevice(device);
+    if (ctx) (void)pfx_ctx_synchronize(ctx);
+    if (s_up) { (void)hipStreamSynchronize(s_up); (void)hipStreamDestroy(s_up); }
+    if (s_down) { (void)hipStreamSynchronize(s_down); (void)hipStreamDestroy(s_down); }
     for (auto& s : S) {
-        if (s.ctx) (void)pfx_ctx_synchronize(s.ctx);
         if (s.d_in) (void)hipFree(s.d_in);
-        if (s.d_a) (void)hipFree(s.d_a);
-        if (s.d_b) (void)hipFree(s.d_b);
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.h_out) (void)hipHostFree(s.h_out);
-        if (s.done) (void)hipEventDestroy(s.done);
-        if (s.k0) (void)hipEventDestroy(s.k0);
-        if (s.k1) (void)hipEventDestroy(s.k1);
-        if (s.ctx) pfx_ctx_destroy(s.ctx);
+        for (hipEvent_t e : {s.uploaded, s.computed, s.done, s.k0, s.k1})
+            if (e) (void)hipEventDestroy(e);
     }
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
     for (void* p : d_ov) if (p) (void)hipFree(p);
+    if (ctx) pfx_ctx_destroy(ctx);
 }
 
 } // namespace
