@@ -258,10 +258,12 @@ inline size_t gauss_strip_lds_bytes(int nkb)
     return (size_t)8 * (GM_COLS * (ring + 8) + 32) * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * GS_XROW;
 }
 
-template <bool FAST, int NKB>
+// DBG: the development instantiation (switchable parts, s_memtime stamps); the shipped one has none of those branches — a dozen
+// skipped-over stamps per iteration were 10 % of the kernel
+template <bool FAST, int NKB, bool DBG>
 __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8, float inv_scale2,
-                                                             float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg, int dbg,
+                                                             float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg, int dbg_arg,
                                                              unsigned long long* __restrict__ dbg_buf)
 {
     constexpr int RING = 16 * NKB + 32, YP = RING + 8, PLANE = GM_COLS * YP + 32, HALF = NKB / 2, PPL = 2 * NKB; // PPL: pixels per producer lane
@@ -302,12 +304,27 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 
     // development: s_memtime at phase boundaries of iterations 10..13, one interior block, waves 0 and 4.  The reads are not waited for
     // where they are issued (that would drain the wave's LDS queue and distort the phase); flush_stamps() waits once per iteration.
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool stamping = (dbg & 16) && blockIdx.x == 8 && (wave == 0 || wave == 4);
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp0 = 0, tp1 = 0;
+    const int dbg = DBG ? dbg_arg : 0; // a compile-time zero in the shipped instantiation: every `dbg &` test folds away
+    const bool stamping = DBG && (dbg & 48) && blockIdx.x == 8 && (wave == 0 || wave == 4);
     auto stamp = [&](int it, int slot) {
+        if constexpr (!DBG) return;
+        if (dbg & 32) { // period probe: iteration starts 10 and 40 only, one flush at the end
+            if (stamping && slot == 0 && it == 10) asm volatile("s_memtime %0" : "=s"(tp0));
+            if (stamping && slot == 0 && it == 40) asm volatile("s_memtime %0" : "=s"(tp1));
+            return;
+        }
         if (stamping && it >= 10 && it < 14) asm volatile("s_memtime %0" : "=s"(ts[slot]));
     };
     auto flush_stamps = [&](int it) {
+        if constexpr (!DBG) return;
+        if (dbg & 32) {
+            if (stamping && it == 40) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) { dbg_buf[(wave >> 2) * 32] = tp0; dbg_buf[(wave >> 2) * 32 + 1] = tp1; }
+            }
+            return;
+        }
         if (stamping && it >= 10 && it < 14) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) {
@@ -604,15 +621,15 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
         if (per < 4) per = n_steps < 4 ? n_steps : 4;
         n_seg = (n_steps + per - 1) / per;
         const int grid = tiles_x * n_seg;
-        if (fast) {
-            errs = hipFuncSetAttribute((const void*)gauss_strip_kernel<true, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int dbg = g_v_cfg >> 9;
+        auto go = [&](auto kern) {
+            errs = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (errs) return;
-            gauss_strip_kernel<true, NK><<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, g_v_cfg >> 9, g_dbg_buf);
-        } else {
-            errs = hipFuncSetAttribute((const void*)gauss_strip_kernel<false, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (errs) return;
-            gauss_strip_kernel<false, NK><<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, g_v_cfg >> 9, g_dbg_buf);
-        }
+            kern<<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, dbg, g_dbg_buf);
+        };
+        if (fast && dbg) go(gauss_strip_kernel<true, NK, true>); // development (tools/gauss_dbg.py, tools/gauss_timeline.py)
+        else if (fast) go(gauss_strip_kernel<true, NK, false>);
+        else go(gauss_strip_kernel<false, NK, false>);
     };
     switch (nkb) {
     case 4: launch_s(std::integral_constant<int, 4>{}); break;

@@ -23,3 +23,12 @@ for role, name in ((0, "producer w0"), (1, "consumer w4")):
         row = t[role, it]
         base = t[0, 0, 0]
         print(name, "it", 10 + it, " ".join(f"{int(v - base):6d}" if v else "     -" for v in row[:8]))
+
+# iteration period without the per-iteration flush (dbg bit 32: stamps at the start of iterations 10 and 40 only)
+buf.zero_()
+r.tune("gauss_v_cfg", 32 << 9)
+r.gaussian_blur_dev(src.data_ptr(), dst.data_ptr(), w, h, 16.0)
+torch.cuda.synchronize()
+t = buf.cpu().numpy()
+for role, name in ((0, "producer w0"), (1, "consumer w4")):
+    print(name, "mean iteration period over 30 iterations:", int(t[role * 32 + 1] - t[role * 32]) // 30, "ticks")
