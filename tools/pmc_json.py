@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""tools/pmc_json.py <prof dir> <out.json> — the per-launch figures bench.py quotes (profiles/rNN_pmc.json) from the summary that
+tools/prof.sh + tools/prof_summary.py wrote: kernel durations from the --stats pass, HBM bytes from the FETCH_SIZE / WRITE_SIZE
+passes (FETCH_SIZE doubled, as guides/MI355X_MICROARCH.md prescribes for gfx950), VALU / MFMA / LDS occupancy from the SQ passes.
+GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles per launch = value / 8."""
+import json, re, sys
+
+W, H, N = 7680, 4320, 32
+root, out = sys.argv[1], sys.argv[2]
+txt = open(f"{root}/summary.txt").read()
+
+
+def val(kernel, counter):
+    m = re.search(rf"^{re.escape(kernel)}\S*\s+.*?{counter}\s+([0-9.e+]+)", txt, re.M)
+    return float(m.group(1)) if m else None
+
+
+def avg_ns(kernel):
+    m = re.search(rf"^{re.escape(kernel)}.*?avg_ns=([0-9.]+)", txt, re.M)
+    return float(m.group(1))
+
+
+def hbm(kernel, counter):
+    m = re.search(rf"^{re.escape(kernel)}\S*\s+.*?{counter}.*?= ([0-9.e+]+)$", txt, re.M)
+    return float(m.group(1))
+
+
+def name(kernel):
+    m = re.search(rf"^({re.escape(kernel)}.*?)\s+calls=", txt, re.M)
+    return m.group(1).strip()
+
+
+px = W * H
+fl, gs = "flatten_stream_kernel", "gauss_strip_kernel"
+cyc_f, cyc_g = val(fl, "GRBM_GUI_ACTIVE") / 8, val(gs, "GRBM_GUI_ACTIVE") / 8
+d = {
+    "source": "tools/prof.sh -> tools/prof_summary.py -> tools/pmc_json.py (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group; "
+              "FETCH_SIZE x 2 per the gfx950 guide; GRBM_GUI_ACTIVE / 8 XCDs); bench.py workload 7680x4320 x 32 layers, sigma 16",
+    "flatten": {
+        "kernel": name(fl), "avg_ns_profiled": round(avg_ns(fl), 1),
+        "fetch_bytes": hbm(fl, "FETCH_SIZE"), "write_bytes": hbm(fl, "WRITE_SIZE"),
+        "hbm_bytes": int(round(hbm(fl, "FETCH_SIZE") + hbm(fl, "WRITE_SIZE"), -5)), "algorithmic_bytes": (4 * N + 4) * px,
+        "valu_wave_insts": val(fl, "SQ_INSTS_VALU"), "salu_wave_insts": val(fl, "SQ_INSTS_SALU"),
+        "clock_ghz": round(cyc_f / avg_ns(fl), 3),
+        "valu_issue_frac_profiled": round(val(fl, "SQ_INSTS_VALU") * 2 / (1024 * cyc_f), 3),  # 2 issue cycles per wave64 VALU, 1024 SIMDs
+        "valu_insts_per_layer_px": round(val(fl, "SQ_INSTS_VALU") * 64 / (px * N), 2),
+    },
+    "gauss_strip": {
+        "kernel": name(gs), "avg_ns_profiled": round(avg_ns(gs), 1),
+        "fetch_bytes": hbm(gs, "FETCH_SIZE"), "write_bytes": hbm(gs, "WRITE_SIZE"),
+        "hbm_bytes": int(round(hbm(gs, "FETCH_SIZE") + hbm(gs, "WRITE_SIZE"), -5)), "algorithmic_bytes": 8 * px,
+        "valu_wave_insts": val(gs, "SQ_INSTS_VALU"), "mfma_insts": val(gs, "SQ_INSTS_MFMA"), "mfma_busy_cycles": val(gs, "SQ_VALU_MFMA_BUSY_CYCLES"),
+        "clock_ghz": round(cyc_g / avg_ns(gs), 3),
+        "mfma_pipe_frac_profiled": round(val(gs, "SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * cyc_g), 3),
+        "lds_idx_active": val(gs, "SQ_LDS_IDX_ACTIVE"), "lds_bank_conflict": val(gs, "SQ_LDS_BANK_CONFLICT"),
+        "lds_busy_frac_profiled": round(val(gs, "SQ_LDS_IDX_ACTIVE") / (256 * cyc_g), 3),
+    },
+}
+f, g = d["flatten"], d["gauss_strip"]
+d["bounds"] = {
+    "flatten": f"VALU issue ({f['valu_issue_frac_profiled'] * 100:.0f} % of the issue slots at the profiled {f['clock_ghz']:.2f} GHz; HBM traffic = algorithmic, "
+               f"{f['hbm_bytes'] / f['algorithmic_bytes']:.3f}x)",
+    "gauss_strip": f"barrier-to-barrier dependency chain of the producer / consumer wave roles (MFMA pipe {g['mfma_pipe_frac_profiled'] * 100:.0f} % busy, LDS "
+                   f"{g['lds_busy_frac_profiled'] * 100:.0f} %; HBM-side fetch {g['fetch_bytes'] / 1e9:.2f} GB = {g['fetch_bytes'] / (4 * px):.0f}x the {4 * px / 1e9:.2f} GB source because "
+                   "neighbouring strips re-read the x halo through L2 / MALL)",
+}
+json.dump(d, open(out, "w"), indent=1)
+print(json.dumps(d["bounds"], indent=1))
