@@ -354,7 +354,7 @@ def main() -> int:
                       "width": w, "height": h, "layers": n, "sigma": args.sigma,
                       "gaussian_mode": "exact (f32, no FMA)" if args.exact else "f16-split MFMA, f32 accumulate (+-1 LSB class)",
                       "sharding": ("ONE document in chunk-row bands: RCCL send/recv of %d halo rows before the blur%s" %
-                                   (radius, "" if args.no_gather else ", all-gather of the result bands")) if band_mode else
+                                   (radius, "" if args.no_gather else ", all-gather of the result bands (asynchronous: it overlaps the next step's flatten)")) if band_mode else
                                   ("one independent document per GPU, no collective" if world > 1 else "single GPU")},
            "roofline": roofline}
     if doc_mode:

@@ -112,7 +112,12 @@ class BandPipeline:
     Everything is enqueued on the current stream: the flatten writes straight into the centre of [top halo | band | bottom halo],
     the halo rows arrive in place through one batched RCCL send/recv group (no concatenation, no host synchronisation), the blur
     runs on band + halo with its tiles on the whole image's grid (pfx_gaussian_blur_band_dev: results equal the single-GPU ones bit
-    for bit), and the result bands are all-gathered into the full image on every rank."""
+    for bit), and the result bands are all-gathered into every rank.  Over RCCL the all-gather is asynchronous and double-buffered:
+    step k's gather runs on RCCL's stream while step k + 1's flatten runs on the compute stream; a buffer set is only waited for
+    when it comes round again (two steps later) or in finish().  The gather moves (N - 1) / N of the image into every GPU — at 8
+    GPUs more time than a rank's kernels — so back-to-back documents are paced by max(kernels, gather), not by their sum."""
+
+    SETS = 2
 
     def __init__(self, renderer, w: int, h: int, radius: int, sigma: float, device, gather: bool = True, group=None):
         import torch
@@ -128,11 +133,14 @@ class BandPipeline:
         self.bands = all_bands(h, self.world)
         self.max_rows = max(max(b1 - b0 for b0, b1 in self.bands), 1)
         self.padded = torch.empty((prow, w, 4), dtype=torch.uint8, device=device)
+        n_sets = self.SETS if gather else 1
         # the blur output doubles as the all-gather's send buffer: rows [top, top + max_rows) — bands are ragged by at most one chunk
         # row, so the buffer carries that much slack and the gather needs no staging copy
-        self.blurred = torch.zeros((self.top + self.max_rows + radius + 1, w, 4), dtype=torch.uint8, device=device)
+        self.blurred = [torch.zeros((self.top + self.max_rows + radius + 1, w, 4), dtype=torch.uint8, device=device) for _ in range(n_sets)]
         # all-gather target: one equal-size slot per rank (slot k holds band k in its first rows); `assemble()` makes the contiguous image
-        self.slots = torch.empty((self.world, self.max_rows, w, 4), dtype=torch.uint8, device=device) if gather else None
+        self.slots = [torch.empty((self.world, self.max_rows, w, 4), dtype=torch.uint8, device=device) for _ in range(n_sets)] if gather else None
+        self.pending = [None] * n_sets  # the asynchronous all-gather that is reading blurred[s] / writing slots[s]
+        self.turn, self.last = 0, 0
         self.full = None
         # static exchange plan: (what I receive, what I send)
         lo0 = self.y0 - self.top
@@ -165,6 +173,8 @@ class BandPipeline:
     def step(self, layer_ptrs, info):
         import torch.distributed as dist
 
+        s = self.turn % len(self.blurred)
+        self.turn += 1
         if self.rows:
             self.r.flatten_dev(layer_ptrs, info, self.w, self.rows, self.padded[self.top:].data_ptr())
         if dist.get_backend(self.group) == "gloo" and self.padded.device.type == "cuda":
@@ -175,30 +185,46 @@ class BandPipeline:
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()  # RCCL: orders the current stream behind the transfer, does not block the host
+        if self.pending[s] is not None:
+            self.pending[s].wait()  # this set's previous all-gather (two steps ago): the compute stream waits, the host does not
+            self.pending[s] = None
+        blurred = self.blurred[s]
         if self.rows:
             prow = self.top + self.rows + self.bottom
-            self.r.gaussian_blur_dev(self.padded.data_ptr(), self.blurred.data_ptr(), self.w, prow, self.sigma, first_row=self.y0 - self.top)
+            self.r.gaussian_blur_dev(self.padded.data_ptr(), blurred.data_ptr(), self.w, prow, self.sigma, first_row=self.y0 - self.top)
         if not self.gather:
-            return self.blurred[self.top:self.top + self.rows]
-        send = self.blurred[self.top:self.top + self.max_rows]
+            return blurred[self.top:self.top + self.rows]
+        send = blurred[self.top:self.top + self.max_rows]
+        self.last = s
         if dist.get_backend(self.group) == "gloo" and send.device.type == "cuda":
             outs = [send.cpu() for _ in range(self.world)]
             dist.all_gather(outs, send.cpu(), group=self.group)
             for k in range(self.world):
-                self.slots[k].copy_(outs[k])
+                self.slots[s][k].copy_(outs[k])
+        elif dist.get_backend(self.group) == "gloo":
+            dist.all_gather_into_tensor(self.slots[s], send, group=self.group)
         else:
-            dist.all_gather_into_tensor(self.slots, send, group=self.group)
-        return self.slots
+            self.pending[s] = dist.all_gather_into_tensor(self.slots[s], send, group=self.group, async_op=True)
+        return self.slots[s]
+
+    def finish(self):
+        """order the current stream behind every all-gather still in flight (the host does not block)"""
+        for s, work in enumerate(self.pending):
+            if work is not None:
+                work.wait()
+                self.pending[s] = None
 
     def assemble(self):
-        """the gathered bands as one contiguous h x w x 4 image (not part of the timed step: every rank already holds every band)"""
+        """the last step's gathered bands as one contiguous h x w x 4 image (not part of the timed step: every rank already holds every band)"""
         import torch
 
+        self.finish()
+        slots = self.slots[self.last]
         if self.full is None:
-            self.full = torch.empty((self.h, self.w, 4), dtype=torch.uint8, device=self.slots.device)
+            self.full = torch.empty((self.h, self.w, 4), dtype=torch.uint8, device=slots.device)
         for k, (b0, b1) in enumerate(self.bands):
             if b1 > b0:
-                self.full[b0:b1] = self.slots[k, :b1 - b0]
+                self.full[b0:b1] = slots[k, :b1 - b0]
         return self.full
 
 
