@@ -37,7 +37,7 @@ def main() -> int:
     rows = []
 
     def timed(name, timer_names, fn, px, alg_bytes_per_px, note=""):
-        for _ in range(2):
+        for _ in range(5):  # clocks ramp over the first launches
             fn()
         torch.cuda.synchronize()
         r.timing_reset()
