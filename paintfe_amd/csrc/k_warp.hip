@@ -207,7 +207,9 @@ PFX_DEV float2 cr_column_eval(cr_column& C, const float2* __restrict__ pts, uint
 }
 
 constexpr uint32_t MESH_LDS_PTS = 2048; // control points per grid staged in LDS (2 grids x 16 KiB)
-constexpr uint32_t MESH_YR = 8;         // rows walked by one lane (a block covers 64 x 32 pixels)
+constexpr uint32_t MESH_YR = 8;         // rows per batch: their taps are all requested before any is consumed
+constexpr uint32_t MESH_YB = 4;         // batches walked by one lane (a block covers 64 x 128 pixels): the u-dependent half of the surface —
+                                        // column weights, 2 x 56 operations + 64 LDS reads of per-control-row sums — is set up once per walk
 
 // MODE 0: write displacement field; MODE 1: fused field + gather.  IN_LDS: control points staged in LDS (the normal
 // case: a 6x6 grid is 49 points); the pointer's address space is then known at compile time (ds_read, not flat_load).
@@ -227,8 +229,8 @@ __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ 
         }
         __syncthreads();
     }
-    const uint32_t x_lane = blockIdx.x * 64u + (threadIdx.x & 63u), y_first = (blockIdx.y * 4u + (threadIdx.x >> 6)) * MESH_YR;
-    if (y_first >= h) return;              // whole wave
+    const uint32_t x_lane = blockIdx.x * 64u + (threadIdx.x & 63u), y_walk = (blockIdx.y * 4u + (threadIdx.x >> 6)) * (MESH_YR * MESH_YB);
+    if (y_walk >= h) return;               // whole wave
     const bool x_valid = x_lane < w;       // lanes past the right edge stay alive: the row halves below are exchanged by lane index
     const uint32_t x = x_valid ? x_lane : w - 1u;
     // :1687-1688; operands in [0.5, 2^15]: k_common.h:fdiv_fast is bit-identical to '/'
@@ -236,37 +238,41 @@ __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ 
     cr_column cd, co;
     cr_column_init(cd, cols, u);
     if (g_orig) cr_column_init(co, cols, u);
-    // a wave shares its rows: lane k (< MESH_YR) evaluates row k's v-dependent half once, everyone reads it back through
-    // v_readlane (scalar operands from then on) instead of recomputing ~30 operations per pixel
     const uint32_t lane = threadIdx.x & 63u;
-    cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_first + (lane & (MESH_YR - 1u))) + 0.5f, (float)h) * (float)rows);
-    const uint32_t y_end = min(y_first + MESH_YR, h);
-    bilinear_taps taps[MESH_YR]; // MODE 1: every row's four taps are requested before any is consumed (latency-bound otherwise)
-#pragma unroll
-    for (uint32_t k = 0; k < MESH_YR; ++k) {
-        const uint32_t y = y_first + k;
-        if (y >= y_end) { taps[k].ok = false; taps[k].tl = taps[k].tr = taps[k].bl = taps[k].br = 0u; taps[k].fx = taps[k].fy = 0.0f; continue; } // uniform
-        cr_row R;
-        R.ri = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, (int)k);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) R.wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.wv[j]), (int)k));
-        float2 d, o;
-        if constexpr (IN_LDS) d = cr_column_eval(cd, s_def, cols, rows, R);
-        else d = cr_column_eval(cd, g_def, cols, rows, R);
-        if (g_orig) {
-            if constexpr (IN_LDS) o = cr_column_eval(co, s_orig, cols, rows, R);
-            else o = cr_column_eval(co, g_orig, cols, rows, R);
-        } else o = make_float2((float)x + 0.5f, (float)y + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
-        const float ddx = d.x - o.x, ddy = d.y - o.y;
-        const size_t i = (size_t)y * w + x;
-        if constexpr (MODE == 0) { if (x_valid) disp[i] = make_float2(ddx, ddy); }
-        else taps[k] = bilinear_fetch(src, (int32_t)w, (int32_t)h, (float)x, (float)y, ddx, ddy);
-    }
-    if constexpr (MODE == 1) {
+    for (uint32_t b = 0; b < MESH_YB; ++b) {
+        const uint32_t y_first = y_walk + b * MESH_YR;
+        if (y_first >= h) break;           // whole wave
+        // a wave shares its rows: lane k (< MESH_YR) evaluates row k's v-dependent half once, everyone reads it back through
+        // v_readlane (scalar operands from then on) instead of recomputing ~30 operations per pixel
+        cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_first + (lane & (MESH_YR - 1u))) + 0.5f, (float)h) * (float)rows);
+        const uint32_t y_end = min(y_first + MESH_YR, h);
+        bilinear_taps taps[MESH_YR]; // MODE 1: every row's four taps are requested before any is consumed (latency-bound otherwise)
 #pragma unroll
         for (uint32_t k = 0; k < MESH_YR; ++k) {
             const uint32_t y = y_first + k;
-            if (y < y_end && x_valid) dst[(size_t)y * w + x] = bilinear_finish(taps[k]);
+            if (y >= y_end) { taps[k].ok = false; taps[k].tl = taps[k].tr = taps[k].bl = taps[k].br = 0u; taps[k].fx = taps[k].fy = 0.0f; continue; } // uniform
+            cr_row R;
+            R.ri = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, (int)k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) R.wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.wv[j]), (int)k));
+            float2 d, o;
+            if constexpr (IN_LDS) d = cr_column_eval(cd, s_def, cols, rows, R);
+            else d = cr_column_eval(cd, g_def, cols, rows, R);
+            if (g_orig) {
+                if constexpr (IN_LDS) o = cr_column_eval(co, s_orig, cols, rows, R);
+                else o = cr_column_eval(co, g_orig, cols, rows, R);
+            } else o = make_float2((float)x + 0.5f, (float)y + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
+            const float ddx = d.x - o.x, ddy = d.y - o.y;
+            const size_t i = (size_t)y * w + x;
+            if constexpr (MODE == 0) { if (x_valid) disp[i] = make_float2(ddx, ddy); }
+            else taps[k] = bilinear_fetch(src, (int32_t)w, (int32_t)h, (float)x, (float)y, ddx, ddy);
+        }
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (uint32_t k = 0; k < MESH_YR; ++k) {
+                const uint32_t y = y_first + k;
+                if (y < y_end && x_valid) dst[(size_t)y * w + x] = bilinear_finish(taps[k]);
+            }
         }
     }
 }
@@ -339,7 +345,7 @@ extern "C" hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig,
                                              uint32_t rows, uint32_t w, uint32_t h, float* d_disp)
 {
     if (w == 0 || h == 0) return hipSuccess;
-    dim3 g((w + 63) / 64, (h + 4 * MESH_YR - 1) / (4 * MESH_YR));
+    dim3 g((w + 63) / 64, (h + 4 * MESH_YR * MESH_YB - 1) / (4 * MESH_YR * MESH_YB));
     if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
         mesh_kernel<0, true><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr);
     else
@@ -351,7 +357,7 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
                                      uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst)
 {
     if (w == 0 || h == 0) return hipSuccess;
-    dim3 g((w + 63) / 64, (h + 4 * MESH_YR - 1) / (4 * MESH_YR));
+    dim3 g((w + 63) / 64, (h + 4 * MESH_YR * MESH_YB - 1) / (4 * MESH_YR * MESH_YB));
     if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
         mesh_kernel<1, true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst);
     else
