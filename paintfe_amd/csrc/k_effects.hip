@@ -58,8 +58,7 @@ __global__ __launch_bounds__(256) void bokeh_kernel(const uint32_t* __restrict__
         }
     }
     // `totals[c] as f32 * inv_count` (u64 -> f32 conversion rounds to nearest, same as u32 -> f32 for these magnitudes)
-    dst[oi] = pack_rgba(round_u8f((float)t0 * inv_count), round_u8f((float)t1 * inv_count), round_u8f((float)t2 * inv_count),
-                        round_u8f((float)t3 * inv_count));
+    dst[oi] = pack_round_rgba((float)t0 * inv_count, (float)t1 * inv_count, (float)t2 * inv_count, (float)t3 * inv_count);
 }
 
 PFX_DEV int rs_round_i32(float v) // `.round() as i32`
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(256) void motion_kernel(const uint32_t* __restrict_
         const uint32_t p = src[(size_t)sy * w + sx];
         s0 += ubyte0(p); s1 += ubyte1(p); s2 += ubyte2(p); s3 += ubyte3(p);
     }
-    dst[oi] = pack_rgba(round_u8f(s0 * inv_steps), round_u8f(s1 * inv_steps), round_u8f(s2 * inv_steps), round_u8f(s3 * inv_steps));
+    dst[oi] = pack_round_rgba(s0 * inv_steps, s1 * inv_steps, s2 * inv_steps, s3 * inv_steps);
 }
 
 } // namespace

@@ -32,7 +32,7 @@ PFX_DEV uint32_t rs_u32(float v) // `as u32`
     return (uint32_t)v;
 }
 PFX_DEV int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
-PFX_DEV uint32_t pack_round(float r, float g, float b, float a) { return pack_rgba(round_u8f(r), round_u8f(g), round_u8f(b), round_u8f(a)); }
+PFX_DEV uint32_t pack_round(float r, float g, float b, float a) { return pack_round_rgba(r, g, b, a); }
 
 // effects.rs:143-161
 PFX_DEV uint32_t hash_u32(uint32_t x)

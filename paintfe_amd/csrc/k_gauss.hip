@@ -149,7 +149,7 @@ __global__ __launch_bounds__(TX* YG) void gauss_v_kernel(const float4* __restric
         if (y0 + o < h) {
             const float4 a = acc[o];
             reinterpret_cast<uint32_t*>(dst)[(size_t)(y0 + o) * w + x] =
-                pack_rgba(round_u8f(a.x), round_u8f(a.y), round_u8f(a.z), round_u8f(a.w)); // filters.rs:308-311
+                pack_round_rgba(a.x, a.y, a.z, a.w); // filters.rs:308-311
         }
     }
 }

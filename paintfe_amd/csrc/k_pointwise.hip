@@ -208,7 +208,7 @@ PFX_DEV uint32_t apply_px(const pfxk_params& P, const uint8_t* __restrict__ lut,
         return pack_rgba(o[0], o[1], o[2], o[3]);
     } else {
         adjust_px<OP>(P, lut, ubyte0(px), ubyte1(px), ubyte2(px), ubyte3(px), o);
-        return pack_rgba(round_u8f(o[0]), round_u8f(o[1]), round_u8f(o[2]), round_u8f(o[3]));
+        return pack_round_rgba(o[0], o[1], o[2], o[3]);
     }
 }
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const float4* __restrict_
         t0 += v.x * wt; t1 += v.y * wt; t2 += v.z * wt; t3 += v.w * wt;
     }
     // NumCast::from(FloatNearest(clamp(t, 0, 255))): round half away from zero
-    dst[(size_t)oy * nw + ox] = pack_rgba(round_u8f(t0), round_u8f(t1), round_u8f(t2), round_u8f(t3));
+    dst[(size_t)oy * nw + ox] = pack_round_rgba(t0, t1, t2, t3);
 }
 
 // ---- layer affine / perspective resampler (apply_affine, src/ops/transform.rs:826-946) --------------------------------------

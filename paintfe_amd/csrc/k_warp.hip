@@ -53,7 +53,7 @@ PFX_DEV uint32_t sample_bilinear(const uint32_t* __restrict__ src, int32_t src_w
 //    the compiler from treating an out-of-range conversion as undefined);
 //  * when every lane of the wave samples strictly inside the source, the four per-tap bounds tests (and their exec-mask
 //    branches) are skipped: one wave-uniform branch instead;
-//  * the lerp of bytes with weights in [0, 1) stays within [-eps, 255 + eps], so `.round().clamp(0, 255) as u8` needs no clamp.
+//  * the lerp of bytes with weights in [0, 1) is finite, so `.round().clamp(0, 255) as u8` is k_common.h's 2-instruction-per-channel form.
 PFX_DEV int32_t cvt_i32_sat(float v)
 {
     int32_t r;
@@ -82,11 +82,6 @@ PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t s
     }
     return T;
 }
-PFX_DEV float round_byte_noclamp(float v) // round half away from zero for v in (-0.5, 255.5): result is an integer in [0, 255]
-{
-    const float t = __builtin_truncf(v);
-    return (v - t >= 0.5f) ? t + 1.0f : __builtin_fabsf(t); // fabs: -0.0 -> +0.0
-}
 PFX_DEV uint32_t bilinear_finish(const bilinear_taps& T)
 {
     if (!T.ok) return 0u;
@@ -97,9 +92,9 @@ PFX_DEV uint32_t bilinear_finish(const bilinear_taps& T)
         const float fbl = (float)((T.bl >> (8 * c)) & 0xffu), fbr = (float)((T.br >> (8 * c)) & 0xffu);
         const float top = ftl + (ftr - ftl) * T.fx; // :1337-1339
         const float bot = fbl + (fbr - fbl) * T.fx;
-        o[c] = round_byte_noclamp(top + (bot - top) * T.fy);
+        o[c] = top + (bot - top) * T.fy;
     }
-    return pack_rgba(o[0], o[1], o[2], o[3]);
+    return pack_round_rgba_finite(o[0], o[1], o[2], o[3]); // finite, within [-eps, 255 + eps]: `.round().clamp(0, 255) as u8` in 8 instructions
 }
 
 constexpr uint32_t WARP_YR = 4; // rows per lane: the field entries of all of them, then all 16 taps, are requested before any is consumed
