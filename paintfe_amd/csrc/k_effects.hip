@@ -28,14 +28,17 @@ __global__ __launch_bounds__(256) void combine_kernel(const uint32_t* __restrict
         for (int c = 0; c < 3; ++c) {
             const float sv = (float)((s >> (8 * c)) & 0xffu), bv = (float)((b >> (8 * c)) & 0xffu);
             if constexpr (OP == PFXK_FX_SHARPEN) { // stylize.rs:135-137: s + amount * (s - b)
-                o[c] = round_u8f(sv + p0 * (sv - bv));
+                o[c] = sv + p0 * (sv - bv);
             } else {                               // stylize.rs:60-64: screen blend 1 - (1 - s)(1 - b*intensity)
                 const float sn = div255(sv), bn = div255(bv);
                 const float result = 1.0f - (1.0f - sn) * (1.0f - bn * p0);
-                o[c] = round_u8f(result * 255.0f);
+                o[c] = result * 255.0f;
             }
         }
-        dst[i] = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | (s & 0xff000000u);
+        // `.round().clamp(0, 255) as u8` of the three colour channels written over the source pixel's bytes: its alpha stays
+        uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[0]), 0, s);
+        px = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[1]), 1, px);
+        dst[i] = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[2]), 2, px);
     }
 }
 

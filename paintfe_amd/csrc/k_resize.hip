@@ -89,9 +89,9 @@ __global__ __launch_bounds__(256) void affine_kernel(const uint32_t* __restrict_
                     const float a = (float)((tl >> (8 * c)) & 0xffu), b = (float)((tr >> (8 * c)) & 0xffu);
                     const float cc = (float)((bl >> (8 * c)) & 0xffu), d = (float)((br >> (8 * c)) & 0xffu);
                     const float top = a + (b - a) * fx, bot = cc + (d - cc) * fx;
-                    o[c] = round_u8f(top + (bot - top) * fy);
+                    o[c] = top + (bot - top) * fy;
                 }
-                out = pack_rgba(o[0], o[1], o[2], o[3]);
+                out = pack_round_rgba(o[0], o[1], o[2], o[3]);
             }
         }
     }

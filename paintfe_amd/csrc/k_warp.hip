@@ -24,31 +24,9 @@ PFX_DEV int32_t rs_f32_as_i32(float v) // Rust `as i32`: saturating, NaN -> 0
     return (int32_t)v;
 }
 
-PFX_DEV uint32_t sample_bilinear(const uint32_t* __restrict__ src, int32_t src_w, int32_t src_h, float x, float y,
-                                 float ddx, float ddy)
-{
-    const float sx = x - ddx, sy = y - ddy;
-    const int32_t x0 = rs_f32_as_i32(__builtin_floorf(sx)), y0 = rs_f32_as_i32(__builtin_floorf(sy));
-    if (x0 < -1 || y0 < -1 || x0 >= src_w || y0 >= src_h) return 0u; // :1310
-    const float fx = sx - (float)x0, fy = sy - (float)y0;
-    auto tap = [&](int32_t tx, int32_t ty) -> uint32_t {
-        return (tx < 0 || ty < 0 || tx >= src_w || ty >= src_h) ? 0u : src[(size_t)ty * src_w + tx];
-    };
-    const uint32_t tl = tap(x0, y0), tr = tap(x0 + 1, y0), bl = tap(x0, y0 + 1), br = tap(x0 + 1, y0 + 1);
-    float o[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float ftl = (float)((tl >> (8 * c)) & 0xffu), ftr = (float)((tr >> (8 * c)) & 0xffu);
-        const float fbl = (float)((bl >> (8 * c)) & 0xffu), fbr = (float)((br >> (8 * c)) & 0xffu);
-        const float top = ftl + (ftr - ftl) * fx; // :1337-1339, lerp form a + (b-a)*t
-        const float bot = fbl + (fbr - fbl) * fx;
-        o[c] = round_u8f(top + (bot - top) * fy);
-    }
-    return pack_rgba(o[0], o[1], o[2], o[3]);
-}
-
-// The same sampler split at the memory boundary, so that a lane can have the taps of several pixels in flight at once, and
-// trimmed where the hardware or the value range makes a step free:
+// warp_displacement_full's sampler (:1288-1345: bilinear, lerp form a + (b - a) * t, texels outside the source are 0, output
+// transparent when floor(sx) < -1 || floor(sy) < -1 || >= size), split at the memory boundary so that a lane can have the taps of
+// several pixels in flight at once, and trimmed where the hardware or the value range makes a step free:
 //  * v_cvt_i32_f32 saturates and maps NaN to 0 — exactly Rust's `as i32` — so the explicit range tests go (inline asm keeps
 //    the compiler from treating an out-of-range conversion as undefined);
 //  * when every lane of the wave samples strictly inside the source, the four per-tap bounds tests (and their exec-mask
