@@ -16,14 +16,6 @@ using namespace pfxk;
 
 namespace {
 
-PFX_DEV int32_t rs_f32_as_i32(float v) // Rust `as i32`: saturating, NaN -> 0
-{
-    if (v != v) return 0;
-    if (v >= 2147483648.0f) return 2147483647;
-    if (v <= -2147483648.0f) return (-2147483647 - 1);
-    return (int32_t)v;
-}
-
 // warp_displacement_full's sampler (:1288-1345: bilinear, lerp form a + (b - a) * t, texels outside the source are 0, output
 // transparent when floor(sx) < -1 || floor(sy) < -1 || >= size), split at the memory boundary so that a lane can have the taps of
 // several pixels in flight at once, and trimmed where the hardware or the value range makes a step free:
