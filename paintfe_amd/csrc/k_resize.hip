@@ -50,6 +50,53 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const float4* __restrict_
     dst[(size_t)oy * nw + ox] = pack_round_rgba(t0, t1, t2, t3);
 }
 
+// Both passes in one kernel: a block owns RZ_TOX x RZ_TOY output pixels, runs the vertical pass for the source columns its
+// horizontal taps reach (h_left[first] .. h_left[last] + h_count[last], both monotone in the output column) into an f32 RGBA tile in
+// LDS, then the horizontal pass out of it.  The same operations in the same order as the two kernels above — bit-identical — without
+// the 16 B/sample intermediate in HBM (3/4 of the two-pass traffic at 8K -> 4K).
+constexpr int RZ_TOX = 64, RZ_TOY = 8;
+__global__ __launch_bounds__(256) void resize_fused_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ v_left,
+                                                           const uint32_t* __restrict__ v_count, const uint32_t* __restrict__ v_off, const float* __restrict__ v_wts,
+                                                           const uint32_t* __restrict__ h_left, const uint32_t* __restrict__ h_count, const uint32_t* __restrict__ h_off,
+                                                           const float* __restrict__ h_wts, int w, int nw, int nh, int span_max)
+{
+    extern __shared__ float4 rz_tile[]; // [RZ_TOY][span_max]
+    const int ox0 = blockIdx.x * RZ_TOX, oy0 = blockIdx.y * RZ_TOY, ox_last = min(ox0 + RZ_TOX, nw) - 1;
+    const int L = (int)h_left[ox0], span = (int)(h_left[ox_last] + h_count[ox_last]) - L;
+    for (int ry = 0; ry < RZ_TOY; ++ry) { // oy uniform: window bounds and weights come through scalar loads
+        const int oy = oy0 + ry;
+        if (oy >= nh) break;
+        const uint32_t l = v_left[oy], n = v_count[oy];
+        const float* wp = v_wts + v_off[oy];
+        for (int xs = threadIdx.x; xs < span; xs += 256) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+            const uint32_t* p = src + (size_t)l * w + L + xs;
+            for (uint32_t i = 0; i < n; ++i, p += w) {
+                const uint32_t v = *p;
+                const float wt = wp[i];
+                t0 += ubyte0(v) * wt; t1 += ubyte1(v) * wt; t2 += ubyte2(v) * wt; t3 += ubyte3(v) * wt;
+            }
+            rz_tile[ry * span_max + xs] = make_float4(t0, t1, t2, t3);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RZ_TOX * RZ_TOY / 256; ++k) {
+        const int idx = threadIdx.x + 256 * k, ox = ox0 + (idx & (RZ_TOX - 1)), ry = idx / RZ_TOX, oy = oy0 + ry;
+        if (ox >= nw || oy >= nh) continue;
+        const uint32_t n = h_count[ox];
+        const float* wp = h_wts + h_off[ox];
+        const float4* p = rz_tile + ry * span_max + ((int)h_left[ox] - L);
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float4 v = p[i];
+            const float wt = wp[i];
+            t0 += v.x * wt; t1 += v.y * wt; t2 += v.z * wt; t3 += v.w * wt;
+        }
+        dst[(size_t)oy * nw + ox] = pack_round_rgba(t0, t1, t2, t3); // NumCast::from(FloatNearest(clamp(t, 0, 255))): round half away from zero
+    }
+}
+
 // ---- layer affine / perspective resampler (apply_affine, src/ops/transform.rs:826-946) --------------------------------------
 // Inverse homography hi[9] from the host; per pixel: u, v in canvas-centred coordinates, projective divide, bilinear against a
 // transparent outside (lerp form a + (b - a) * t, `.round().clamp(0,255) as u8`) or nearest.  Pixels that map outside stay 0.
@@ -108,13 +155,23 @@ extern "C" hipError_t pfxk_affine(hipStream_t s, const uint8_t* d_src, uint32_t 
     return hipGetLastError();
 }
 
-// tables: v_* index by output row (nh entries), h_* by output column (nw entries)
+// tables: v_* index by output row (nh entries), h_* by output column (nw entries).  span_max = the widest source-column range a
+// 64-column output tile reaches (pfx_resize.cpp); 0 or a tile beyond 64 KiB of LDS takes the two-pass path through d_tmp.
+extern "C" int pfxk_resize_tile_cols(void) { return RZ_TOX; }
 extern "C" hipError_t pfxk_resize(hipStream_t s, const uint8_t* d_src, float* d_tmp, uint8_t* d_dst, const uint32_t* v_left, const uint32_t* v_count,
                                   const uint32_t* v_off, const float* v_wts, const uint32_t* h_left, const uint32_t* h_count, const uint32_t* h_off,
-                                  const float* h_wts, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh)
+                                  const float* h_wts, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint32_t span_max)
 {
     (void)h;
     if (w == 0 || nw == 0 || nh == 0) return hipSuccess;
+    const size_t lds = (size_t)span_max * RZ_TOY * sizeof(float4);
+    if (span_max != 0 && lds <= 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute((const void*)resize_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e) return e;
+        resize_fused_kernel<<<dim3((nw + RZ_TOX - 1) / RZ_TOX, (nh + RZ_TOY - 1) / RZ_TOY), 256, lds, s>>>(
+            (const uint32_t*)d_src, (uint32_t*)d_dst, v_left, v_count, v_off, v_wts, h_left, h_count, h_off, h_wts, (int)w, (int)nw, (int)nh, (int)span_max);
+        return hipGetLastError();
+    }
     resize_v_kernel<<<dim3((w + 255) / 256, nh), 256, 0, s>>>((const uint32_t*)d_src, (float4*)d_tmp, v_left, v_count, v_off, v_wts, (int)w);
     resize_h_kernel<<<dim3((nw + 63) / 64, (nh + 3) / 4), 256, 0, s>>>((const float4*)d_tmp, (uint32_t*)d_dst, h_left, h_count, h_off, h_wts, (int)w, (int)nw,
                                                                        (int)nh);

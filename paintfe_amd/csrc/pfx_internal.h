@@ -34,6 +34,7 @@ struct pfx_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool exact = false;
+    bool resize_two_pass = false;       // pfx_tune("resize_two_pass"): keep the resamplers' f32 intermediate in HBM (the pre-fusion path)
     std::string err;
     // staging for the host-buffer tier (the reference keeps cached staging/ping-pong textures the same way,
     // ref: src/gpu/renderer.rs:232-236)

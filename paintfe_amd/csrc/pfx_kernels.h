@@ -147,7 +147,8 @@ hipError_t pfxk_fill_masked(hipStream_t s, uint8_t* d_img, const uint8_t* d_mask
 // ---- k_resize.hip ---- separable resampling with per-axis window / weight tables (v_*: per output row, h_*: per output column)
 hipError_t pfxk_resize(hipStream_t s, const uint8_t* d_src, float* d_tmp /* w*nh*4 f32 */, uint8_t* d_dst, const uint32_t* v_left, const uint32_t* v_count,
                        const uint32_t* v_off, const float* v_wts, const uint32_t* h_left, const uint32_t* h_count, const uint32_t* h_off, const float* h_wts,
-                       uint32_t w, uint32_t h, uint32_t nw, uint32_t nh);
+                       uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, uint32_t span_max /* 0: two passes through d_tmp */);
+int pfxk_resize_tile_cols(void);
 
 typedef struct pfxk_affine_params { float hi[9]; float cx, cy, off_x, off_y, inv_scale; int32_t nearest; } pfxk_affine_params;
 hipError_t pfxk_affine(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, uint8_t* d_dst, uint32_t canvas_w, uint32_t canvas_h,

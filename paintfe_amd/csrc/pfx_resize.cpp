@@ -105,13 +105,22 @@ int pfx_resize_image_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t
     PFX_TRY(pfx_reserve(ctx, ctx->fx_a, blob.size() * 4));
     PFX_TRY(pfx_h2d(ctx, ctx->fx_a.p, blob.data(), blob.size() * 4));
     PFX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `blob` is pageable host memory about to go out of scope
-    PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * new_h * 16));
+    // the widest source-column range one output tile's horizontal taps reach: decides between the fused kernel (vertical results in
+    // LDS) and the two-pass path with its f32 intermediate in HBM (strong downscales)
+    uint32_t span_max = 0;
+    const uint32_t tile = (uint32_t)pfxk_resize_tile_cols();
+    for (uint32_t ox0 = 0; ox0 < new_w; ox0 += tile) {
+        const uint32_t last = std::min(ox0 + tile, new_w) - 1;
+        span_max = std::max(span_max, hz.left[last] + hz.count[last] - hz.left[ox0]);
+    }
+    const bool fused = (size_t)span_max * 8 * 16 <= 64u * 1024u && !ctx->resize_two_pass;
+    if (!fused) PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * new_h * 16));
     const uint32_t* d = (const uint32_t*)ctx->fx_a.p;
     const float* dw = (const float*)(d + n_u32);
     pfx_timer t(ctx, "resize");
-    PFX_HIP(ctx, pfxk_resize(ctx->stream, (const uint8_t*)src_dev, (float*)ctx->st_tmp.p, (uint8_t*)dst_dev, d, d + new_h, d + 2 * (size_t)new_h,
+    PFX_HIP(ctx, pfxk_resize(ctx->stream, (const uint8_t*)src_dev, fused ? nullptr : (float*)ctx->st_tmp.p, (uint8_t*)dst_dev, d, d + new_h, d + 2 * (size_t)new_h,
                              dw, d + 3 * (size_t)new_h, d + 3 * (size_t)new_h + new_w, d + 3 * (size_t)new_h + 2 * (size_t)new_w, dw + v.wts.size(), w, h,
-                             new_w, new_h));
+                             new_w, new_h, fused ? span_max : 0u));
     return PFX_OK;
 }
 

@@ -672,3 +672,23 @@ def test_bokeh_bitexact(gpu, oracle, radius):
 def test_motion_blur_bitexact(gpu, oracle, angle, distance):
     img = I.random_rgba(173, 88, 12)
     assert_same(gpu.motion_blur(img, angle, distance), oracle.motion_blur(img, angle, distance), 0, f"motion {angle} {distance}")
+
+
+# ------------------------------------------------------------------ resamplers: fused kernel vs the two-pass path and the oracle
+@pytest.mark.parametrize("filt", ["nearest", "bilinear", "bicubic", "lanczos3"])
+@pytest.mark.parametrize("src,dst", [((331, 257), (166, 129)), ((200, 150), (431, 322)), ((640, 480), (77, 601)), ((4099, 70), (33, 35)),
+                                     ((64, 64), (64, 63)), ((129, 5), (1, 1))])
+def test_resize_fused_equals_two_pass_and_oracle(gpu, filt, src, dst):
+    """pfx_resize_image: both passes in one kernel (vertical results in LDS) against the two-pass path with its f32 intermediate in HBM
+    (pfx_tune resize_two_pass) — the same operations in the same order, so bit-identical — and against the oracle.  (4099 -> 33 columns:
+    a 64-column output tile would need more LDS than a block has, the call falls back to two passes by itself.)"""
+    (w, h), (nw, nh) = src, dst
+    img = I.random_rgba(w, h, 1234 + w + nw)
+    fused = gpu.r.resize_image(img, nw, nh, filt)
+    gpu.r.tune("resize_two_pass", 1)
+    try:
+        two = gpu.r.resize_image(img, nw, nh, filt)
+    finally:
+        gpu.r.tune("resize_two_pass", 0)
+    assert np.array_equal(fused, two)
+    assert_same(fused, O.resize(img, nw, nh, filt), 0, f"resize {filt} {src}->{dst}")
