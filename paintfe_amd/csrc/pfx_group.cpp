@@ -12,7 +12,8 @@
 //     kept — the 1.47 MB per neighbour and direction at 8K / sigma = 16 that SURVEY §8(e) prices, not the 5.9 MB of f32
 //     intermediate rows;
 //   * all-gather (optional): every member pushes its result band into every member's full-size image, one peer copy per pair —
-//     xGMI is point-to-point, so the N-1 copies of a member travel on N-1 different links at once (no ring).
+//     xGMI is point-to-point, so the N-1 copies of a member travel on N-1 different links at once (no ring).  The pushes run on a
+//     copy stream per member, so the next call's flatten overlaps them (only its blur, which rewrites the source, waits).
 // Everything is asynchronous on the members' streams; the host thread only enqueues.  Nothing here touches pixels on the CPU.
 #include <algorithm>
 #include <cstdarg>
@@ -33,7 +34,10 @@ struct pfx_group_member {
     void* blurred = nullptr;            // same shape: blur of `padded`
     void* gathered = nullptr;           // full w * h * 4 image (all-gather target), allocated on first use
     size_t padded_cap = 0;
-    hipEvent_t ev_flat = nullptr, ev_done = nullptr;
+    hipEvent_t ev_flat = nullptr, ev_done = nullptr; // flatten finished / result band final (halo pulls and blur done), on the compute stream
+    hipStream_t s_copy = nullptr;       // the all-gather's pushes run here, behind ev_done, so that the next call's flatten overlaps them
+    hipEvent_t ev_gather = nullptr;     // this member's pushes finished (s_copy)
+    bool gather_pending = false;        // ev_gather was recorded and not yet waited for by the compute stream
 };
 
 struct pfx_group {
@@ -143,7 +147,9 @@ int pfx_group_create(const int* devices, uint32_t n, pfx_group** out)
         const int s = pfx_ctx_create(devices[k], &g->m[k].ctx);
         if (s != PFX_OK) { pfx_group_destroy(g); return s; }
         if (hipSetDevice(devices[k]) != hipSuccess || hipEventCreateWithFlags(&g->m[k].ev_flat, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g->m[k].ev_done, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&g->m[k].ev_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->m[k].ev_gather, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&g->m[k].s_copy, hipStreamNonBlocking) != hipSuccess) {
             pfx_group_destroy(g);
             return PFX_ERR_HIP;
         }
@@ -168,9 +174,12 @@ void pfx_group_destroy(pfx_group* g)
     if (!g) return;
     for (auto& mem : g->m) {
         if (mem.ctx) (void)pfx_ctx_synchronize(mem.ctx);
+        (void)hipSetDevice(mem.device);
+        if (mem.s_copy) { (void)hipStreamSynchronize(mem.s_copy); (void)hipStreamDestroy(mem.s_copy); }
         free_member_buffers(mem);
         if (mem.ev_flat) (void)hipEventDestroy(mem.ev_flat);
         if (mem.ev_done) (void)hipEventDestroy(mem.ev_done);
+        if (mem.ev_gather) (void)hipEventDestroy(mem.ev_gather);
         if (mem.ctx) pfx_ctx_destroy(mem.ctx);
     }
     delete g;
@@ -184,7 +193,12 @@ int pfx_group_set_document(pfx_group* g, uint32_t w, uint32_t h, uint32_t n_laye
 {
     if (!g) return PFX_ERR_INVALID;
     if (w == 0 || h == 0 || n_layers == 0 || n_layers > PFX_MAX_LAYERS) return gfail(g, PFX_ERR_INVALID, "bad document geometry");
-    for (auto& mem : g->m) { if (mem.ctx) (void)pfx_ctx_synchronize(mem.ctx); free_member_buffers(mem); }
+    for (auto& mem : g->m) {
+        if (mem.ctx) (void)pfx_ctx_synchronize(mem.ctx);
+        if (mem.s_copy) { (void)hipSetDevice(mem.device); (void)hipStreamSynchronize(mem.s_copy); }
+        mem.gather_pending = false;
+        free_member_buffers(mem);
+    }
     g->w = w; g->h = h; g->n_layers = n_layers; g->halo_cap = 0; g->have_result = false;
     const uint32_t world = (uint32_t)g->m.size();
     for (uint32_t k = 0; k < world; ++k) {
@@ -244,11 +258,16 @@ int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t 
     const uint32_t world = (uint32_t)g->m.size(), w = g->w, h = g->h;
     const size_t row_bytes = (size_t)w * 4;
 
-    // 0. a member may not overwrite buffers its neighbours are still reading from the previous call
+    // 0. a member may not overwrite what the previous call is still reading: its neighbours' halo pulls out of its padded buffer
+    // (finished when their ev_done fires) and — when that call gathered an un-blurred result — its own pushes out of it
     for (auto& mem : g->m) {
         PFXG_HIP(g, hipSetDevice(mem.device));
         for (auto& other : g->m)
             if (&other != &mem && g->have_result) PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), other.ev_done, 0));
+        if (mem.gather_pending && !g->result_blurred) {
+            PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), mem.ev_gather, 0));
+            mem.gather_pending = false;
+        }
     }
     // 1. every member flattens its band straight into the centre of its padded buffer
     for (auto& mem : g->m) {
@@ -288,13 +307,19 @@ int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t 
                     PFXG_HIP(g, copy_between(mem, d, src, s, (size_t)(s1 - s0) * row_bytes));
                 }
             }
-            // 3. blur band + halo; rows [top, top + rows) of the output are the member's result
+            // 3. blur band + halo; rows [top, top + rows) of the output are the member's result (the previous call's pushes read it)
+            if (mem.gather_pending) { PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), mem.ev_gather, 0)); mem.gather_pending = false; }
             const uint32_t prow = mem.top + (mem.y1 - mem.y0) + mem.bottom;
             PFXG_CTX(g, mem, pfx_gaussian_blur_band_dev(mem.ctx, mem.padded, mem.blurred, w, prow, sigma, nullptr, lo0));
         }
     }
     g->result_blurred = blur;
-    // 4. all-gather: every member pushes its result band into every member's full image (one xGMI link per pair)
+    for (auto& mem : g->m) {
+        PFXG_HIP(g, hipSetDevice(mem.device));
+        PFXG_HIP(g, hipEventRecord(mem.ev_done, stream_of(mem)));
+    }
+    // 4. all-gather: every member pushes its result band into every member's full image (one xGMI link per pair).  The pushes run on
+    // the member's copy stream behind ev_done: the next call's flatten (compute stream) overlaps them, its blur waits for them.
     if (all_gather) {
         for (auto& mem : g->m)
             if (!mem.gathered) {
@@ -305,18 +330,17 @@ int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t 
             const uint32_t rows = mem.y1 - mem.y0;
             if (!rows) continue;
             PFXG_HIP(g, hipSetDevice(mem.device));
+            PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
             const uint8_t* band = (const uint8_t*)(blur ? mem.blurred : mem.padded) + (size_t)mem.top * row_bytes;
             for (auto& dst : g->m) {
-                // the copy is enqueued on the PRODUCER's stream (ordered behind its blur); hipMemcpyPeerAsync accepts any stream
+                // enqueued on the PRODUCER's copy stream; hipMemcpyPeerAsync accepts any stream
                 uint8_t* d = (uint8_t*)dst.gathered + (size_t)mem.y0 * row_bytes;
-                if (dst.device == mem.device) PFXG_HIP(g, hipMemcpyAsync(d, band, (size_t)rows * row_bytes, hipMemcpyDeviceToDevice, stream_of(mem)));
-                else PFXG_HIP(g, hipMemcpyPeerAsync(d, dst.device, band, mem.device, (size_t)rows * row_bytes, stream_of(mem)));
+                if (dst.device == mem.device) PFXG_HIP(g, hipMemcpyAsync(d, band, (size_t)rows * row_bytes, hipMemcpyDeviceToDevice, mem.s_copy));
+                else PFXG_HIP(g, hipMemcpyPeerAsync(d, dst.device, band, mem.device, (size_t)rows * row_bytes, mem.s_copy));
             }
+            PFXG_HIP(g, hipEventRecord(mem.ev_gather, mem.s_copy));
+            mem.gather_pending = true;
         }
-    }
-    for (auto& mem : g->m) {
-        PFXG_HIP(g, hipSetDevice(mem.device));
-        PFXG_HIP(g, hipEventRecord(mem.ev_done, stream_of(mem)));
     }
     g->have_result = true;
     return PFX_OK;
@@ -325,7 +349,11 @@ int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t 
 int pfx_group_synchronize(pfx_group* g)
 {
     if (!g) return PFX_ERR_INVALID;
-    for (auto& mem : g->m) PFXG_CTX(g, mem, pfx_ctx_synchronize(mem.ctx));
+    for (auto& mem : g->m) {
+        PFXG_CTX(g, mem, pfx_ctx_synchronize(mem.ctx));
+        PFXG_HIP(g, hipSetDevice(mem.device));
+        PFXG_HIP(g, hipStreamSynchronize(mem.s_copy));
+    }
     return PFX_OK;
 }
 

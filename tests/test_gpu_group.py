@@ -69,3 +69,31 @@ def test_group_errors():
     with pytest.raises(L.PfxError):
         g.flatten_blur([(3, 1.0, True, 0)], 2.0)  # layer outside the document
     g.close()
+
+
+def test_group_back_to_back_calls_with_overlapping_gathers():
+    """the all-gather's pushes run on per-member copy streams: calls enqueued back to back — different layer selections, with and
+    without the blur (the un-blurred gather reads the buffer the next flatten overwrites) — must each leave the right image behind"""
+    from paintfe_amd import GpuRenderer
+    from paintfe_amd.group import GpuGroup
+    w, h, n, world = 384, 520, 6, 3
+    stack, modes, opac = I.layer_stack(w, h, n, seed=77)
+    r = GpuRenderer(0)
+    for k in range(n):
+        r.ensure_layer_texture(k, stack[k], generation=1)
+    g = GpuGroup(_devices(world))
+    g.set_document(w, h, n)
+    for k in range(n):
+        g.upload_layer(k, stack[k])
+    plans = [(list(range(n)), 3.0), ([0, 2, 4], 0.0), ([5, 1, 3, 0], 0.0), (list(range(n)), 6.0), ([1, 2], 2.0), ([4, 3], 0.0)]
+    for upto in (1, 3, 4, 6):  # enqueue the first `upto` calls without a host synchronisation in between; check the last one
+        for sel, sigma in plans[:upto]:
+            g.flatten_blur([(k, float(opac[k]), True, int(modes[k])) for k in sel], sigma, all_gather=True)
+        sel, sigma = plans[upto - 1]
+        ref = r.composite(w, h, [(k, float(opac[k]), True, int(modes[k])) for k in sel])
+        if sigma > 0:
+            ref = r.blur_rgba(ref, sigma)
+        for k in range(world):
+            assert np.array_equal(g.download_gathered(k), ref), f"after {upto} calls: gathered image on member {k}"
+        assert np.array_equal(g.download(), ref)
+    g.close()
