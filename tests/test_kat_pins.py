@@ -154,3 +154,62 @@ def test_hand_assembled_pfe_truncations_are_rejected():
     for cut in (3, 12, len(PFE_V1_HEAD) - 1, len(PFE_V1) - 1):
         with pytest.raises(PfeError):
             Project.load_bytes(PFE_V1[:cut])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Tool preview layer in the compositor (canvas_state.rs:593-658).  The reference holds no golden for it; what it adds on top of
+# blend_pixel_static (pinned by the 26 blend goldens) is restated here in numpy float32, one IEEE operation per step, independent of the
+# C oracle: the preview pixel is folded into the ACTIVE layer's pixel before that layer is composited as usual — so compositing the
+# stack with the folded layer and no preview must equal compositing with the preview.
+def _as_u8(v):  # Rust `f32 as u8`: truncation toward zero, saturating
+    return np.uint8(min(max(int(np.trunc(np.float32(v))), 0), 255))
+
+
+def _fold_preview(top, pp, mode, is_eraser, replaces):
+    f = np.float32
+    top = top.copy()
+    if replaces:                                        # :619-620
+        return pp.copy()
+    if pp[3] == 0:                                      # :621
+        return top
+    if is_eraser:                                       # :622-628: alpha scaled by (1 - mask strength), truncated
+        strength = f(pp[3]) / f(255.0)
+        cur = f(top[3]) / f(255.0)
+        new_a = max(f(cur * f(f(1.0) - strength)), f(0.0))
+        top[3] = _as_u8(f(new_a * f(255.0)))
+        return top
+    if mode in (13, 14):                                # :629-652 Xor / Overwrite: coverage-weighted lerp towards the blend result
+        ow = O.blend_pixel(top, pp, mode, 1.0)
+        cov = f(pp[3]) / f(255.0)
+        inv = f(f(1.0) - cov)
+        out = top.copy()
+        for c in range(4):
+            out[c] = _as_u8(f(f(f(f(top[c]) * inv) + f(f(ow[c]) * cov)) + f(0.5)))
+        return out
+    return O.blend_pixel(top, pp, mode, 1.0)            # :653-655
+
+
+@pytest.mark.parametrize("kind", ["eraser", "overwrite", "xor", "replace", "multiply"])
+def test_preview_layer_known_answers(kind):
+    rng = np.random.default_rng(20260929)
+    w = h = 24
+    bg = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    bg[..., 3] = 255
+    active = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    active[::3, ::2, 3] = 0                              # transparent-but-coloured pixels
+    active[1::3, 1::2, 3] = 255
+    above = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    preview = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    preview[:, ::4, 3] = 0                               # untouched pixels
+    preview[:, 1::4, 3] = 255                            # full coverage
+    mode = {"overwrite": 14, "xor": 13, "multiply": 1}.get(kind, 0)
+    folded = active.copy()
+    for y in range(h):
+        for x in range(w):
+            folded[y, x] = _fold_preview(active[y, x], preview[y, x], mode, kind == "eraser", kind == "replace")
+    layers = [dict(pixels=bg), dict(pixels=active, mode=8, opacity=0.8), dict(pixels=above, mode=2, opacity=0.6)]
+    got = O.composite(layers, w, h, preview=dict(pixels=preview, active_layer=1, blend_mode=mode, is_eraser=kind == "eraser",
+                                                 replaces_layer=kind == "replace"))
+    layers[1] = dict(layers[1], pixels=folded)
+    want = O.composite(layers, w, h)
+    assert np.array_equal(got, want), f"{kind}: {int((got != want).any(-1).sum())} px differ"
