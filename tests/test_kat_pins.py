@@ -190,9 +190,12 @@ def _fold_preview(top, pp, mode, is_eraser, replaces):
 
 
 @pytest.mark.parametrize("kind", ["eraser", "overwrite", "xor", "replace", "multiply"])
-def test_preview_layer_known_answers(kind):
+@pytest.mark.parametrize("sparse", [False, True])
+def test_preview_layer_known_answers(kind, sparse):
+    """sparse: the active layer's right-hand 64x64 chunk is fully transparent (but coloured): the TiledImage holds no chunk there, so the
+    preview folds into (0, 0, 0, 0) rather than into the stale colours (:609-613), and where the preview has no chunk either nothing is drawn"""
     rng = np.random.default_rng(20260929)
-    w = h = 24
+    w, h = (128, 64) if sparse else (24, 24)
     bg = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
     bg[..., 3] = 255
     active = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
@@ -202,11 +205,16 @@ def test_preview_layer_known_answers(kind):
     preview = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
     preview[:, ::4, 3] = 0                               # untouched pixels
     preview[:, 1::4, 3] = 255                            # full coverage
+    seen = active.copy()                                 # what get_chunk() hands the compositor
+    if sparse:
+        active[:, 64:, 3] = 0
+        seen = active.copy()
+        seen[:, 64:] = 0
     mode = {"overwrite": 14, "xor": 13, "multiply": 1}.get(kind, 0)
-    folded = active.copy()
+    folded = seen.copy()
     for y in range(h):
         for x in range(w):
-            folded[y, x] = _fold_preview(active[y, x], preview[y, x], mode, kind == "eraser", kind == "replace")
+            folded[y, x] = _fold_preview(seen[y, x], preview[y, x], mode, kind == "eraser", kind == "replace")
     layers = [dict(pixels=bg), dict(pixels=active, mode=8, opacity=0.8), dict(pixels=above, mode=2, opacity=0.6)]
     got = O.composite(layers, w, h, preview=dict(pixels=preview, active_layer=1, blend_mode=mode, is_eraser=kind == "eraser",
                                                  replaces_layer=kind == "replace"))
