@@ -291,7 +291,10 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) { asm volatile("" : "+v"(B1[kb])); asm volatile("" : "+v"(B2[kb])); }
     }
-    const int ci = blockIdx.x % n_cols, seg = blockIdx.x / n_cols;
+    // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the swizzle hands every XCD a run of NEIGHBOURING strips, whose
+    // source windows overlap by 3/4 (a 32-column strip reads 16 NKB columns), so the overlap is fetched into one L2 instead of up to 8
+    const int bid = (int)xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ci = bid % n_cols, seg = bid / n_cols;
     const int x0 = ci * GM_COLS;
     const int t_first = seg * steps_per_seg, t_last = min(t_first + steps_per_seg, n_steps); // output blocks [t_first, t_last)
     if (t_first >= t_last) return;
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
     // where they are issued (that would drain the wave's LDS queue and distort the phase); flush_stamps() waits once per iteration.
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp0 = 0, tp1 = 0;
     const int dbg = DBG ? dbg_arg : 0; // a compile-time zero in the shipped instantiation: every `dbg &` test folds away
-    const bool stamping = DBG && (dbg & 48) && blockIdx.x == 8 && (wave == 0 || wave == 4);
+    const bool stamping = DBG && (dbg & 48) && bid == 8 && (wave == 0 || wave == 4);
     auto stamp = [&](int it, int slot) {
         if constexpr (!DBG) return;
         if (dbg & 32) { // period probe: iteration starts 10 and 40 only, one flush at the end
