@@ -61,8 +61,8 @@ d["bounds"] = {
     "flatten": f"VALU issue ({f['valu_issue_frac_profiled'] * 100:.0f} % of the issue slots at the profiled {f['clock_ghz']:.2f} GHz; HBM traffic = algorithmic, "
                f"{f['hbm_bytes'] / f['algorithmic_bytes']:.3f}x)",
     "gauss_strip": f"barrier-to-barrier dependency chain of the producer / consumer wave roles (MFMA pipe {g['mfma_pipe_frac_profiled'] * 100:.0f} % busy, LDS "
-                   f"{g['lds_busy_frac_profiled'] * 100:.0f} %; HBM-side fetch {g['fetch_bytes'] / 1e9:.2f} GB = {g['fetch_bytes'] / (4 * px):.0f}x the {4 * px / 1e9:.2f} GB source because "
-                   "neighbouring strips re-read the x halo through L2 / MALL)",
+                   f"{g['lds_busy_frac_profiled'] * 100:.0f} %; HBM traffic {g['hbm_bytes'] / g['algorithmic_bytes']:.2f}x algorithmic: the 4x x-halo overlap of neighbouring strips "
+                   "is served by one XCD's L2 since the strip order is XCD-aware)",
 }
 json.dump(d, open(out, "w"), indent=1)
 print(json.dumps(d["bounds"], indent=1))
