@@ -343,6 +343,16 @@ def main() -> int:
             clk = fl.get("clock_ghz", 2.0)
             roofline["valu_frac"] = round(fl["valu_wave_insts"] * 2 / (1024 * clk * 1e9 * d_ms * 1e-3), 3)
             roofline["valu_insts_per_layer_px"] = round(fl["valu_wave_insts"] * 64 / (n * px_per_launch), 1)
+            # against what the chip's VALU sustains: a pure v_fma_f32 loop (tools/ubench_valu, profiles/rNN_valu_peak.json); a quarter-rate
+            # (transcendental) instruction takes four plain instructions' worth of the pipe
+            try:
+                import glob
+                vp = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_peak.json")))[-1]))
+                slots = fl["valu_wave_insts"] + 3 * vp["flatten"]["transcendental_wave_insts"]
+                roofline["valu_frac_of_sustained_fma_rate"] = round(slots * 64 / (d_ms * 1e-3) / (vp["fma_sustained_T_lane_ops_s"] * 1e12), 3)
+                roofline["fma_sustained_T_lane_ops_s"] = vp["fma_sustained_T_lane_ops_s"]
+            except Exception:
+                pass
         roofline["per_kernel_bound"] = pmc.get("bounds")
 
     out = {"metric": "Mpixels/sec: 8K 32-layer flatten + Gaussian sigma=16; HBM GB/s vs peak", "value": round(value, 1),

@@ -92,6 +92,17 @@ int main()
     run("pk_mul+add", k_pkmuladd, 8, out, 1.0001f, 0.5f);
     run("div", k_div, 4, out, 1.0001f, 0.5f);
     run("cvt_ubyte", k_cvt, 4, out, 7u);
+    { // sustained: the same FMA loop for ~0.1 s (the clock settles under the power limit), what a VALU-bound kernel can hope for
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int blocks = 256 * 8, threads = 256, reps = 400;
+        for (int r = 0; r < 50; ++r) k_fma<<<blocks, threads>>>(out, 1.0001f, 0.5f);
+        hipEventRecord(e0);
+        for (int r = 0; r < reps; ++r) k_fma<<<blocks, threads>>>(out, 1.0001f, 0.5f);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double ops = (double)blocks * threads * ITERS * 8 * reps;
+        printf("fma sustained %8.3f ms  %8.2f T elem-ops/s  (= %.3f GHz x 256 CUs x 4 SIMDs x 32 lanes)\n", ms, ops / ms * 1e-9, ops / ms * 1e-9 / (256 * 4 * 32) * 1e3);
+    }
     // HBM copy rate
     size_t n = (size_t)1 << 30; void *a, *b; CHK(hipMalloc(&a, n)); CHK(hipMalloc(&b, n));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
