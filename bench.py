@@ -286,6 +286,17 @@ def main() -> int:
 
         elapsed, kern = timed(step)
         flat_view = pipe.flat_band()
+        band_sharded = None
+        if not args.no_gather:
+            # the same band pipeline with the result left sharded (every rank keeps its band of the blurred image: halo exchange only) —
+            # SURVEY 8(e) names skipping the all-gather as the way past it when a consumer can take bands; reported beside the headline
+            pipe.finish()
+            pipe.gather = False
+            b_el, _ = timed(step)
+            pipe.gather = True
+            band_sharded = {"value": round(w * h * args.steps / b_el / 1e6, 1), "unit": "Mpixels/s", "scaling": "strong",
+                            "ms_per_step": round(b_el / args.steps * 1e3, 4),
+                            "sharding": "ONE document in chunk-row bands, halo exchange only: the blurred result stays sharded (no all-gather)"}
         # the collective-free mode in the same run (one independent 8K document per rank), reported beside the headline
         del stack
         torch.cuda.empty_cache()
@@ -369,6 +380,8 @@ def main() -> int:
            "roofline": roofline}
     if doc_mode:
         out["doc_mode"] = doc_mode
+    if band_mode and band_sharded:
+        out["band_sharded_result"] = band_sharded
     failed = []
 
     if rank == 0:

@@ -42,6 +42,7 @@ def test_band_mode_is_the_default_and_matches_single_process(nproc):
     assert d["check"]["band_blur_max_diff_vs_oracle"] == 0  # exact Gaussian: bit-identical to the unsharded pipeline
     assert abs(d["value"] - 640 * 400 / d["ms_per_step"] / 1e3) / d["value"] < 0.01  # ONE document per step for the whole job
     assert d["doc_mode"]["scaling"] == "weak" and d["doc_mode"]["value"] > 0
+    assert d["band_sharded_result"]["scaling"] == "strong" and d["band_sharded_result"]["value"] > 0  # the same pipeline without the all-gather
     d = _run(nproc, [], 29640 + nproc)
     assert d["check"]["band_blur_max_diff_vs_oracle"] <= 1  # matrix-core Gaussian: the stated +-1 LSB
 
