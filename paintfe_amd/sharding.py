@@ -109,8 +109,9 @@ def gather_bands(band, height: int, group=None):
 class BandPipeline:
     """flatten -> halo exchange -> Gaussian -> all-gather of ONE document on this rank's band, buffers allocated once.
 
-    Everything is enqueued on the current stream: the flatten writes straight into the centre of [top halo | band | bottom halo],
-    the halo rows arrive in place through one batched RCCL send/recv group (no concatenation, no host synchronisation), the blur
+    Everything is enqueued on the current stream: the flatten writes straight into the centre of [top halo | band | bottom halo]
+    (edge rows first, so that the halo exchange overlaps the flatten of the band's interior), the halo rows arrive in place through one
+    batched RCCL send/recv group (no concatenation, no host synchronisation), the blur
     runs on band + halo with its tiles on the whole image's grid (pfx_gaussian_blur_band_dev: results equal the single-GPU ones bit
     for bit), and the result bands are all-gathered into every rank.  Over RCCL the all-gather is asynchronous and double-buffered:
     step k's gather runs on RCCL's stream while step k + 1's flatten runs on the compute stream; a buffer set is only waited for
@@ -175,16 +176,33 @@ class BandPipeline:
 
         s = self.turn % len(self.blurred)
         self.turn += 1
-        if self.rows:
-            self.r.flatten_dev(layer_ptrs, info, self.w, self.rows, self.padded[self.top:].data_ptr())
+        row_bytes = self.w * 4
+        base = self.padded[self.top:].data_ptr()
+
+        def flatten_rows(r0, r1):  # rows [r0, r1) of the band: every layer's band buffer is contiguous, so a row range is a pointer offset
+            if r1 > r0:
+                self.r.flatten_dev([p + r0 * row_bytes for p in layer_ptrs], info, self.w, r1 - r0, base + r0 * row_bytes)
+
+        # the rows the neighbours need (whole chunk rows covering `radius` at either edge of the band) are flattened first, the halo
+        # exchange starts on RCCL's stream, and the interior of the band is flattened while the halo rows travel
+        edge = min(self.rows, 64 * ((self.radius + 63) // 64))
+        split = self.rows > 2 * edge and bool(self.sends or self.recvs)
+        if split:
+            flatten_rows(0, edge)
+            flatten_rows(self.rows - edge, self.rows)
+        else:
+            flatten_rows(0, self.rows)
         if dist.get_backend(self.group) == "gloo" and self.padded.device.type == "cuda":
             self._exchange_via_host()  # plumbing self-test on a 1-GPU box (gloo moves host memory); RCCL moves device memory
+            reqs = []
         else:
             ops = [dist.P2POp(dist.irecv, self.padded[a:b], src, self.group) for (src, a, b) in self.recvs]
             ops += [dist.P2POp(dist.isend, self.padded[a:b], dst, self.group) for (dst, a, b) in self.sends]
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()  # RCCL: orders the current stream behind the transfer, does not block the host
+            reqs = dist.batch_isend_irecv(ops) if ops else []  # ordered behind the edge rows' flatten (the current stream at this point)
+        if split:
+            flatten_rows(edge, self.rows - edge)
+        for req in reqs:
+            req.wait()  # RCCL: orders the current stream behind the transfer, does not block the host
         if self.pending[s] is not None:
             self.pending[s].wait()  # this set's previous all-gather (two steps ago): the compute stream waits, the host does not
             self.pending[s] = None

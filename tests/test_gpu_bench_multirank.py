@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(nproc, extra, port):
+def _run(nproc, extra, port, height=400):
     env = dict(os.environ, PFX_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
-           "--width", "640", "--height", "400", "--layers", "6", "--sigma", "3.0", "--no-cpu-baseline"] + extra
+           "--width", "640", "--height", str(height), "--layers", "6", "--sigma", "3.0", "--no-cpu-baseline"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
@@ -45,6 +45,14 @@ def test_band_mode_is_the_default_and_matches_single_process(nproc):
     assert d["band_sharded_result"]["scaling"] == "strong" and d["band_sharded_result"]["value"] > 0  # the same pipeline without the all-gather
     d = _run(nproc, [], 29640 + nproc)
     assert d["check"]["band_blur_max_diff_vs_oracle"] <= 1  # matrix-core Gaussian: the stated +-1 LSB
+
+
+def test_band_mode_with_split_flatten_matches_single_process():
+    """bands taller than two edge regions: the edge rows are flattened first, the halo exchange starts, the interior follows (the overlap
+    itself needs RCCL; here the ordering and the row-range pointer arithmetic are checked bit for bit)"""
+    d = _run(2, ["--exact"], 29655, height=900)
+    assert d["check"]["band_blur_max_diff_vs_oracle"] == 0  # flatten + halo rows + exact Gaussian of rank 0's window, bit for bit
+    assert abs(d["value"] - 640 * 900 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
 
 
 def test_band_mode_over_rccl_when_two_gpus_are_visible():
