@@ -166,11 +166,24 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
         desc.push_back(d);
     }
     *n_desc = (uint32_t)desc.size();
-    PFX_TRY(pfx_reserve(ctx, ctx->d_desc, std::max<size_t>(desc.size(), 1) * sizeof(pfxk_layer_desc)));
-    PFX_TRY(pfx_h2d(ctx, ctx->d_desc.p, desc.data(), desc.size() * sizeof(pfxk_layer_desc)));
+    // the tables only travel when they differ from what the device already holds (a render loop re-composites the same stack: the
+    // small pageable-memory copy in front of every launch was a ~10 us bubble on the stream)
+    const size_t desc_bytes = desc.size() * sizeof(pfxk_layer_desc), adj_bytes = adj.size() * sizeof(float);
+    const bool same_desc = ctx->d_desc.p && ctx->desc_cache.size() == desc_bytes && (desc_bytes == 0 || std::memcmp(ctx->desc_cache.data(), desc.data(), desc_bytes) == 0);
+    if (!same_desc) {
+        ctx->desc_cache.clear();
+        PFX_TRY(pfx_reserve(ctx, ctx->d_desc, std::max<size_t>(desc.size(), 1) * sizeof(pfxk_layer_desc)));
+        PFX_TRY(pfx_h2d(ctx, ctx->d_desc.p, desc.data(), desc_bytes));
+        ctx->desc_cache.assign((const uint8_t*)desc.data(), (const uint8_t*)desc.data() + desc_bytes);
+    }
     if (!adj.empty()) {
-        PFX_TRY(pfx_reserve(ctx, ctx->d_adj, adj.size() * sizeof(float)));
-        PFX_TRY(pfx_h2d(ctx, ctx->d_adj.p, adj.data(), adj.size() * sizeof(float)));
+        const bool same_adj = ctx->d_adj.p && ctx->adj_cache.size() == adj_bytes && std::memcmp(ctx->adj_cache.data(), adj.data(), adj_bytes) == 0;
+        if (!same_adj) {
+            ctx->adj_cache.clear();
+            PFX_TRY(pfx_reserve(ctx, ctx->d_adj, adj_bytes));
+            PFX_TRY(pfx_h2d(ctx, ctx->d_adj.p, adj.data(), adj_bytes));
+            ctx->adj_cache.assign((const uint8_t*)adj.data(), (const uint8_t*)adj.data() + adj_bytes);
+        }
     }
     return PFX_OK;
 }

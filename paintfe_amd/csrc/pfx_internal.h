@@ -42,6 +42,7 @@ struct pfx_ctx {
     pfx_devbuf fx_a, fx_b; // effect-bank scratch (crystallize cell table, drop-shadow planes)
     // small parameter buffers
     pfx_devbuf d_desc, d_adj, d_chunks, d_wts, d_lut, d_pts, d_misc;
+    std::vector<uint8_t> desc_cache, adj_cache; // host copies of what d_desc / d_adj hold (build_stack skips identical uploads)
     std::map<uint32_t, pfx_layer_state> layers;
     bool timing = false;
     std::vector<pfx_timing_rec> timings;
