@@ -444,6 +444,10 @@ int pfx_contours_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t 
 /* device self-test: compares the compositor's shared-reciprocal division with the compiler's IEEE f32 divide on
  * n_millions*1e6 random operand pairs drawn from the kernel's operand range; *mismatches must come back 0 */
 int pfx_selftest_division(pfx_ctx* ctx, uint64_t seed, uint32_t n_millions, uint64_t* mismatches);
+/* device self-test: the three-instruction round-and-pack (`v.round().clamp(0.0, 255.0) as u8` of every pointwise op, resampler, effect and
+ * warp) against the step-by-step formula for ALL 2^32 f32 bit patterns; *mismatches must come back 0.  Signalling NaNs, which no
+ * arithmetic instruction produces, are counted separately (they convert to 255 instead of 0). */
+int pfx_selftest_round_pack(pfx_ctx* ctx, uint64_t* mismatches, uint64_t* signalling_nan_mismatches);
 
 /* development tuning knobs (kernel tile configurations); unknown keys return PFX_ERR_INVALID.  Results never change. */
 int pfx_tune(pfx_ctx* ctx, const char* key, int value);

@@ -408,9 +408,34 @@ __global__ __launch_bounds__(256) void rdiv_check_kernel(uint64_t seed, uint32_t
     if (bad) atomicAdd(out, bad);
 }
 
+// device-side check of pack_round_rgba (k_common.h) against the step-by-step `v.round().clamp(0, 255) as u8` for every f32 bit pattern:
+// out[0] += mismatches among the patterns arithmetic can produce, out[1] += mismatches among signalling NaNs (it cannot)
+__global__ __launch_bounds__(256) void round_pack_check_kernel(unsigned long long* out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, bad_snan = 0;
+    for (uint64_t b = tid; b < (1ull << 32); b += nth) {
+        const uint32_t bits = (uint32_t)b;
+        const float v = __builtin_bit_cast(float, bits);
+        const uint32_t fast = pack_round_rgba(v, 0.0f, 0.0f, 0.0f) & 0xffu;
+        const uint32_t ref = (v != v) ? 0u : (uint32_t)round_u8f(v); // `NaN as u8` == 0
+        if (fast != ref) {
+            const bool snan = (bits & 0x7f800000u) == 0x7f800000u && (bits & 0x007fffffu) != 0u && !(bits & 0x00400000u);
+            if (snan) ++bad_snan; else ++bad;
+        }
+    }
+    if (bad) atomicAdd(out, bad);
+    if (bad_snan) atomicAdd(out + 1, bad_snan);
+}
+
 } // namespace
 
 extern "C" void pfxk_flatten_set_variant(int v) { g_flatten_variant = v; }
+extern "C" hipError_t pfxk_round_pack_check(hipStream_t s, unsigned long long* d_out)
+{
+    round_pack_check_kernel<<<4096, 256, 0, s>>>(d_out);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out)
 {

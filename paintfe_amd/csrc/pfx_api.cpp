@@ -1102,4 +1102,19 @@ int pfx_selftest_division(pfx_ctx* ctx, uint64_t seed, uint32_t n_millions, uint
     return PFX_OK;
 }
 
+int pfx_selftest_round_pack(pfx_ctx* ctx, uint64_t* mismatches, uint64_t* signalling_nan_mismatches)
+{
+    if (!ctx || !mismatches) return PFX_ERR_INVALID;
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->d_misc, 64));
+    PFX_HIP(ctx, hipMemsetAsync(ctx->d_misc.p, 0, 16, ctx->stream));
+    PFX_HIP(ctx, pfxk_round_pack_check(ctx->stream, (unsigned long long*)ctx->d_misc.p));
+    unsigned long long bad[2] = {0, 0};
+    PFX_TRY(pfx_d2h(ctx, bad, ctx->d_misc.p, 16));
+    PFX_TRY(pfx_sync(ctx));
+    *mismatches = bad[0];
+    if (signalling_nan_mismatches) *signalling_nan_mismatches = bad[1];
+    return PFX_OK;
+}
+
 } // extern "C"

@@ -51,6 +51,7 @@ hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uin
 void       pfxk_flatten_set_variant(int v); // tuning knob: 0 = shipped kernel, 1.. = experimental pixels-per-lane / occupancy variants
 // counts (into *d_out) operand pairs for which the shared-reciprocal division differs from the IEEE divide
 hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out);
+hipError_t pfxk_round_pack_check(hipStream_t s, unsigned long long* d_out /* [2]: mismatches, signalling-NaN mismatches */);
 
 // ---- k_gauss.hip ---- (d_wts_tap0 points at tap 0 of a device array with pfxk_gauss_weight_pad() zeros on both sides)
 int        pfxk_gauss_max_radius(void);

@@ -619,6 +619,12 @@ class GpuRenderer:
         self._check(self._lib.pfx_warp_displacement_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(sw), C.c_uint32(sh),
                                                         C.c_void_p(disp_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr)))
 
+    def selftest_round_pack(self):
+        """(mismatches, signalling-NaN mismatches) of the device's round-and-pack against the step-by-step formula over all 2^32 floats"""
+        bad, snan = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.pfx_selftest_round_pack(self._h, C.byref(bad), C.byref(snan)))
+        return bad.value, snan.value
+
     def selftest_division(self, seed: int, n_millions: int) -> int:
         bad = C.c_uint64(0)
         self._check(self._lib.pfx_selftest_division(self._h, C.c_uint64(seed), C.c_uint32(n_millions), C.byref(bad)))

@@ -68,6 +68,14 @@ def test_blend_pixels_exhaustive_alpha_lattice(gpu):
             assert_same(got[::97], exp, 0, f"mode {mode} opacity {opacity}")
 
 
+def test_round_and_pack_matches_rust_rounding_for_every_float(gpu):
+    """k_common.h:pack_round_rgba (v_med3_f32, OR 1, v_cvt_pk_u8_f32) vs `v.round().clamp(0.0, 255.0) as u8` evaluated step by step, for all
+    2^32 f32 bit patterns: identical except for signalling NaNs, which no arithmetic produces"""
+    bad, snan = gpu.r.selftest_round_pack()
+    assert bad == 0
+    assert snan <= 2 * (2 ** 22 - 1)
+
+
 def test_fast_division_matches_ieee(gpu):
     """k_flatten.hip:rdiv (shared refined reciprocal) vs the compiler's IEEE f32 divide on 2^28 random operand pairs
     from the compositor's operand range — must be bit-identical."""
