@@ -74,6 +74,53 @@ __global__ __launch_bounds__(256) void box_v_kernel(const uint32_t* __restrict__
     }
 }
 
+// Both passes in one kernel for small radii: a block owns a BF_T x BF_T output tile, stages the (BF_T + 2r)^2 source pixels it reaches
+// (clamp-to-edge, blur.rs:258,290) in LDS, runs the horizontal pass for the tile's BF_T + 2r rows into a second LDS tile — the u8
+// intermediate of the reference, rounded exactly as in box_h_kernel — and the vertical pass out of that.  Same integer arithmetic,
+// bit-identical to the two kernels above; the 4 B/px intermediate never reaches HBM and the halo (1.2x at r = 3) is recomputed.
+constexpr int BF_T = 64, BF_RUN = 8, BF_MAXR = 8;
+__global__ __launch_bounds__(256) void box_fused_kernel(const uint32_t* __restrict__ src, const uint8_t* __restrict__ mask, uint32_t* __restrict__ dst,
+                                                        int r, uint32_t half, uint32_t magic, int w, int h)
+{
+    extern __shared__ uint32_t bf_lds[];
+    const int side = BF_T + 2 * r;                 // source tile is side x side, horizontal results are side rows x BF_T
+    uint32_t* s_src = bf_lds;                      // [side][side]
+    uint32_t* s_h = bf_lds + side * side;          // [side][BF_T]
+    const int bx = blockIdx.x * BF_T, by = blockIdx.y * BF_T;
+    for (int i = threadIdx.x; i < side * side; i += 256) {
+        const int ty = i / side, tx = i - ty * side;
+        s_src[i] = src[(size_t)min(max(by - r + ty, 0), h - 1) * w + min(max(bx - r + tx, 0), w - 1)];
+    }
+    __syncthreads();
+    // horizontal: runs of BF_RUN outputs, sliding window (blur.rs:262-276)
+    for (int run = threadIdx.x; run < side * (BF_T / BF_RUN); run += 256) {
+        const int ty = run / (BF_T / BF_RUN), x0 = (run - ty * (BF_T / BF_RUN)) * BF_RUN;
+        const uint32_t* row = s_src + ty * side + x0; // window of output x0 + o = row[o .. o + 2r]
+        u4 s = {{0, 0, 0, 0}};
+        for (int k = 0; k <= 2 * r; ++k) add_px(s, row[k]);
+#pragma unroll
+        for (int o = 0; o < BF_RUN; ++o) {
+            s_h[ty * BF_T + x0 + o] = avg_px(s, half, magic);
+            if (o + 1 < BF_RUN) { sub_px(s, row[o]); add_px(s, row[o + 2 * r + 1]); }
+        }
+    }
+    __syncthreads();
+    // vertical: one run of BF_T / 4 rows per lane (blur.rs:294-312)
+    const int lx = threadIdx.x & 63, y0 = (threadIdx.x >> 6) * (BF_T / 4);
+    const int x = bx + lx;
+    if (x >= w) return;
+    u4 s = {{0, 0, 0, 0}};
+    for (int k = 0; k <= 2 * r; ++k) add_px(s, s_h[(y0 + k) * BF_T + lx]);
+    for (int o = 0; o < BF_T / 4; ++o) {
+        const int y = by + y0 + o;
+        if (y >= h) break;
+        const size_t i = (size_t)y * w + x;
+        dst[i] = (mask && mask[i] == 0) ? src[i] : avg_px(s, half, magic); // blur.rs:296-303
+        sub_px(s, s_h[(y0 + o) * BF_T + lx]);
+        add_px(s, s_h[(y0 + o + 2 * r + 1 < side ? y0 + o + 2 * r + 1 : side - 1) * BF_T + lx]);
+    }
+}
+
 // ---------------------------------------------------------------- median
 constexpr int MD_TX = 32, MD_TY = 8; // outputs per block: one per lane
 
@@ -247,6 +294,8 @@ __global__ __launch_bounds__(256) void pixelate_kernel(const uint32_t* __restric
 
 } // namespace
 
+int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
+extern "C" void pfxk_box_set_two_pass(int on) { g_box_two_pass = on; }
 extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst,
                                     const uint8_t* d_mask, int radius, uint32_t w, uint32_t h)
 {
@@ -254,6 +303,15 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
     const uint32_t d = (uint32_t)(2 * radius + 1);
     if (d >= 4096u) return hipErrorInvalidValue;
     const uint32_t magic = (uint32_t)((0x100000000ull / d) + 1ull), half = d / 2u;
+    if (radius <= BF_MAXR && g_box_two_pass == 0) { // small radii: both passes in one kernel (the halo recomputation stays below 1.6x)
+        const int side = BF_T + 2 * radius;
+        const size_t lds = (size_t)(side * side + side * BF_T) * 4;
+        hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e) return e;
+        box_fused_kernel<<<dim3((w + BF_T - 1) / BF_T, (h + BF_T - 1) / BF_T), 256, lds, s>>>((const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, half, magic,
+                                                                                           (int)w, (int)h);
+        return hipGetLastError();
+    }
     dim3 gh((w + BX_TILE - 1) / BX_TILE, h);
     const size_t lds = (size_t)(BX_TILE + 2 * radius + BX_PX) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)box_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

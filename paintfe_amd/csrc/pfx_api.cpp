@@ -1083,6 +1083,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (!ctx || !key) return PFX_ERR_INVALID;
     if (std::strcmp(key, "gauss_v_cfg") == 0) { pfxk_gauss_set_v_config(value); return PFX_OK; }
     if (std::strcmp(key, "flatten_variant") == 0) { pfxk_flatten_set_variant(value); return PFX_OK; }
+    if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
     if (std::strcmp(key, "resize_two_pass") == 0) { ctx->resize_two_pass = value != 0; return PFX_OK; } // A/B and the parity test of the fused kernel
     return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_tune: unknown key %s", key);
 }

@@ -700,3 +700,22 @@ def test_resize_fused_equals_two_pass_and_oracle(gpu, filt, src, dst):
         gpu.r.tune("resize_two_pass", 0)
     assert np.array_equal(fused, two)
     assert_same(fused, O.resize(img, nw, nh, filt), 0, f"resize {filt} {src}->{dst}")
+
+
+@pytest.mark.parametrize("radius", [1.0, 2.0, 3.0, 5.5, 8.0, 9.0])
+@pytest.mark.parametrize("size", [(257, 131), (64, 64), (70, 300), (5, 3)])
+def test_box_blur_fused_equals_two_pass_and_oracle(gpu, radius, size):
+    """box_blur_core for r <= 8 runs both passes in one kernel (u8 intermediate in LDS): bit-identical to the two-pass path (pfx_tune
+    box_two_pass) and to the oracle, with and without a selection mask; r = 9 takes the two-pass path by itself"""
+    w, h = size
+    img = I.random_rgba(w, h, 4242 + w)
+    mask = (np.random.default_rng(w * h).random((h, w)) < 0.6).astype(np.uint8) * 255
+    for m in (None, mask):
+        fused = gpu.box_blur(img, radius, m)
+        gpu.r.tune("box_two_pass", 1)
+        try:
+            two = gpu.box_blur(img, radius, m)
+        finally:
+            gpu.r.tune("box_two_pass", 0)
+        assert np.array_equal(fused, two)
+        assert_same(fused, O.box_blur(img, radius, m), 0, f"box blur r={radius} {size}")
