@@ -86,29 +86,33 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
                                                     const uint8_t* __restrict__ lut, const uint8_t* __restrict__ tip_mask,
                                                     const uint8_t* __restrict__ selection, int bx0, int by0, int bx1, int by1)
 {
-    const int gx = bx0 + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    // a wave covers one 64-pixel row segment: gy and the segment's x range are wave-uniform
+    const uint32_t lane = threadIdx.x & 63u;
+    const int gx0 = bx0 + (int)(blockIdx.x * 64u), gx = gx0 + (int)lane;
     const int gy = by0 + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
-    if (gx > bx1 || gy > by1) return;
-    const size_t i = (size_t)gy * w + (size_t)gx;
-    if (selection && selection[i] == 0) return; // :312-320
-    uint32_t px = target[i];
+    if (gy > by1 || gx0 > bx1) return; // whole wave
+    const size_t i = (size_t)gy * w + (size_t)min(gx, bx1);
+    bool active = gx <= bx1;
+    if (active && selection && selection[i] == 0) active = false; // :312-320
+    uint32_t px = active ? target[i] : 0u;
     const uint32_t px_in = px;
     const uint32_t wm1 = w ? w - 1u : 0u, hm1 = h ? h - 1u : 0u;
-    for (uint32_t k = 0; k < n_pts; ++k) {
+    const uint32_t seg_lo = (uint32_t)gx0, seg_hi = (uint32_t)min(gx0 + 63, bx1);
+    auto stamp_px = [&](uint32_t k) {
         const pfxk_stamp S = stamps[k]; // uniform -> scalar loads
         if (B.tip_size) { // image tip (:533-760): max-alpha stamping or eraser only, no brush modes, no 0.01 cut-off for paint
             uint32_t g8;
-            if (!tip_coverage(B, S, tip_mask, gx, gy, wm1, hm1, g8) || g8 == 0u) continue;
+            if (!tip_coverage(B, S, tip_mask, gx, gy, wm1, hm1, g8) || g8 == 0u) return;
             const float geom_alpha = div255((float)g8);
             if (B.is_eraser) {
                 const float erase_strength = geom_alpha * B.src_a * B.flow;
-                if (erase_strength < 0.01f) continue;
+                if (erase_strength < 0.01f) return;
                 if (erase_strength > div255((float)(px >> 24))) px = (uint32_t)trunc_u8f(erase_strength * 255.0f) << 24;
             } else {
                 const uint32_t a8 = (uint32_t)trunc_u8f(geom_alpha * B.src_a * B.flow * 255.0f);
                 if (a8 >= (px >> 24)) px = S.rgb8 | (a8 << 24);
             }
-            continue;
+            return;
         }
         const float2 c = make_float2(S.cx, S.cy);
         // stamp bounding box exactly as the reference computes it (:209-215)
@@ -116,10 +120,10 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
         const uint32_t max_x = min(rs_f32_as_u32(__builtin_ceilf(c.x + B.draw_radius)), wm1);
         const uint32_t min_y = rs_f32_as_u32(__builtin_fmaxf(__builtin_floorf(c.y - B.draw_radius), 0.0f));
         const uint32_t max_y = min(rs_f32_as_u32(__builtin_ceilf(c.y + B.draw_radius)), hm1);
-        if ((uint32_t)gx < min_x || (uint32_t)gx > max_x || (uint32_t)gy < min_y || (uint32_t)gy > max_y) continue;
+        if ((uint32_t)gx < min_x || (uint32_t)gx > max_x || (uint32_t)gy < min_y || (uint32_t)gy > max_y) return;
         const float dy = (float)gy - c.y, dx = (float)gx - c.x;
         const float dist_sq = dx * dx + dy * dy;
-        if (dist_sq > B.draw_radius_sq) continue;
+        if (dist_sq > B.draw_radius_sq) return;
         uint32_t geom_u8;
         if (B.use_direct_alpha) {
             const float a = pfx_brush_alpha(__builtin_sqrtf(dist_sq), B.radius, B.hardness, B.anti_aliased != 0);
@@ -127,16 +131,16 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
         } else {
             geom_u8 = lut[rs_f32_as_u32(__builtin_fminf(dist_sq * B.inv_radius_sq * 255.0f, 255.0f))]; // :335-336
         }
-        if (geom_u8 == 0u) continue;
+        if (geom_u8 == 0u) return;
         const float geom_alpha = div255((float)geom_u8);
         if (B.is_eraser) { // :345-356
             const float erase_strength = geom_alpha * B.src_a * B.flow;
-            if (erase_strength < 0.01f) continue;
+            if (erase_strength < 0.01f) return;
             const float old_mask = div255((float)(px >> 24));
             if (erase_strength > old_mask) px = (uint32_t)trunc_u8f(erase_strength * 255.0f) << 24;
         } else {
             const float brush_alpha = geom_alpha * B.src_a * B.flow;
-            if (brush_alpha < 0.01f) continue;
+            if (brush_alpha < 0.01f) return;
             if (B.mode == 0) { // Normal: max-alpha stamping, ties overwrite (:363-373)
                 const uint32_t a8 = (uint32_t)trunc_u8f(brush_alpha * 255.0f);
                 if (a8 >= (px >> 24)) px = S.rgb8 | (a8 << 24);
@@ -158,6 +162,34 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
                 px = (px & 0xff000000u) | (uint32_t)trunc_u8f(nr * 255.0f) | ((uint32_t)trunc_u8f(ng * 255.0f) << 8) |
                      ((uint32_t)trunc_u8f(nb * 255.0f) << 16);
             }
+        }
+    };
+    // Stamp culling, 64 stamps at a time: lane j tests stamp k0 + j's bounding box — the very box the per-pixel test uses — against the
+    // wave's row segment; only the stamps some lane of the wave can see are walked, in order.  (A long diagonal stroke's bounding box is
+    // mostly empty and a row segment sees a few per cent of the stamps: without this every lane walked all of them.)
+    for (uint32_t k0 = 0; k0 < n_pts; k0 += 64u) {
+        const uint32_t kk = k0 + lane;
+        bool seen = false;
+        if (kk < n_pts) {
+            const float cx = stamps[kk].cx, cy = stamps[kk].cy;
+            uint32_t min_x, max_x, min_y, max_y;
+            if (B.tip_size) { // tip_coverage's box
+                const float half = (float)B.tip_size / 2.0f, eh = stamps[kk].rotated ? half * 1.41421356237309504880f : half;
+                min_x = rs_f32_as_u32(__builtin_fmaxf(cx - eh, 0.0f)); min_y = rs_f32_as_u32(__builtin_fmaxf(cy - eh, 0.0f));
+                max_x = min(rs_f32_as_u32(cx + eh), wm1); max_y = min(rs_f32_as_u32(cy + eh), hm1);
+            } else {          // :209-215
+                min_x = rs_f32_as_u32(__builtin_fmaxf(__builtin_floorf(cx - B.draw_radius), 0.0f));
+                max_x = min(rs_f32_as_u32(__builtin_ceilf(cx + B.draw_radius)), wm1);
+                min_y = rs_f32_as_u32(__builtin_fmaxf(__builtin_floorf(cy - B.draw_radius), 0.0f));
+                max_y = min(rs_f32_as_u32(__builtin_ceilf(cy + B.draw_radius)), hm1);
+            }
+            seen = !(seg_hi < min_x || seg_lo > max_x || (uint32_t)gy < min_y || (uint32_t)gy > max_y);
+        }
+        unsigned long long m = __ballot(seen);
+        while (m) {
+            const uint32_t k = k0 + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            if (active) stamp_px(k);
         }
     }
     if (px != px_in) target[i] = px;
