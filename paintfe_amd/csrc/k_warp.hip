@@ -262,16 +262,21 @@ extern "C" hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src
 __global__ __launch_bounds__(256) void disp_brush_kernel(float2* __restrict__ disp, uint32_t w, const pfxk_disp_dab* __restrict__ dabs, uint32_t n,
                                                          int bx0, int by0, int bx1, int by1)
 {
-    const int px = bx0 + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)), py = by0 + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
-    if (px >= bx1 || py >= by1) return;
-    float2* p = disp + (size_t)py * w + (size_t)px;
-    float2 d = *p;
-    for (uint32_t k = 0; k < n; ++k) {
+    // a wave covers one 64-pixel row segment (py and the segment's x range are wave-uniform); dabs are culled against it 64 at a time
+    // with the reference's own loop bounds, so a lane only walks the dabs its wave can see — in order, like the reference's `+=`
+    const uint32_t lane = threadIdx.x & 63u;
+    const int px0 = bx0 + (int)(blockIdx.x * 64u), px = px0 + (int)lane, py = by0 + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (py >= by1 || px0 >= bx1) return; // whole wave
+    const bool active = px < bx1;
+    float2* p = disp + (size_t)py * w + (size_t)min(px, bx1 - 1);
+    float2 d = active ? *p : make_float2(0.0f, 0.0f);
+    const int seg_hi = min(px0 + 64, bx1); // exclusive
+    auto dab_px = [&](uint32_t k) {
         const pfxk_disp_dab D = dabs[k]; // uniform -> scalar loads
-        if (px < D.x0 || px >= D.x1 || py < D.y0 || py >= D.y1) continue; // the reference's loop bounds (:1066-1069)
+        if (px < D.x0 || px >= D.x1 || py < D.y0 || py >= D.y1) return; // the reference's loop bounds (:1066-1069)
         const float dx = (float)px - D.cx, dy = (float)py - D.cy;
         const float dist_sq = dx * dx + dy * dy;
-        if (dist_sq > D.r * D.r) continue;
+        if (dist_sq > D.r * D.r) return;
         if (D.mode == 0) {        // push :1051-1085
             const float weight = (float)exp((double)(-dist_sq / D.sigma_sq_2)) * D.strength;
             d.x += D.delta_x * weight;
@@ -292,8 +297,19 @@ __global__ __launch_bounds__(256) void disp_brush_kernel(float2* __restrict__ di
             d.x += -dy * weight * 0.1f;
             d.y += dx * weight * 0.1f;
         }
+    };
+    for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
+        const uint32_t kk = k0 + lane;
+        bool seen = false;
+        if (kk < n) seen = !(seg_hi <= dabs[kk].x0 || px0 >= dabs[kk].x1 || py < dabs[kk].y0 || py >= dabs[kk].y1);
+        unsigned long long m = __ballot(seen);
+        while (m) {
+            const uint32_t k = k0 + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            if (active) dab_px(k);
+        }
     }
-    *p = d;
+    if (active) *p = d;
 }
 
 extern "C" hipError_t pfxk_disp_brushes(hipStream_t s, float* d_disp, uint32_t w, uint32_t h, const pfxk_disp_dab* d_dabs, uint32_t n, int bx0, int by0,
