@@ -451,6 +451,10 @@ int pfx_selftest_round_pack(pfx_ctx* ctx, uint64_t* mismatches, uint64_t* signal
 
 /* development tuning knobs (kernel tile configurations); unknown keys return PFX_ERR_INVALID.  Results never change. */
 int pfx_tune(pfx_ctx* ctx, const char* key, int value);
+/* work counters of the compositor's dead-layer elimination since the last reset (diagnostics for profiles/ and the tests; the call
+ * synchronises the device): out[0] compacted rounds, [1] pixels in them, [2] sum of layers over rounds, [3] natural 192-pixel units,
+ * [4] sum of layers over natural units, [5] candidate alpha reads (units), [6] units that used the queue, [7] reserved */
+int pfx_flatten_stats(pfx_ctx* ctx, uint64_t out[8], int reset);
 
 /* per-launch timing of the most recent `_dev` call family, measured with HIP events on the context stream
  * (used by bench.py for the roofline line).  Enable, run, then read the accumulated milliseconds / launches. */

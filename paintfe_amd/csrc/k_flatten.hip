@@ -15,6 +15,7 @@
 //     (this file is compiled with -ffp-contract=off); u8/255 uses the proved 2-op form (k_common.h:div255);
 //   * the three `/ out_a` of a pixel share one refined reciprocal (rdiv below): the exact operation sequence
 //     hipcc emits for an IEEE f32 divide, with the per-denominator part hoisted — bit-identical to `/`.
+#include <type_traits>
 #include "k_common.h"
 #include "pfx_kernels.h"
 
@@ -26,6 +27,7 @@ using namespace pfxk;
 typedef float pfx_v4f __attribute__((ext_vector_type(4)));
 typedef int pfx_v4i __attribute__((ext_vector_type(4)));
 __device__ pfx_v4f pfx_buffer_load_format_v4f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
+__device__ float pfx_buffer_load_format_f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.f32");
 __device__ void pfx_buffer_store_i32(int data, pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
 
 
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(256) void flatten_kernel(const pfxk_layer_desc* __r
 // gfx9-family buffer resource (V#), stride 0 => offsets and num_records are bytes
 enum : uint32_t {
     PFX_RSRC_UNORM8X4 = 0xFACu | (0u << 12) | (10u << 15), // dst_sel = x,y,z,w; num_format UNORM; data_format 8_8_8_8
-    PFX_RSRC_RAW32 = 0xFACu | (7u << 12) | (4u << 15)      // num_format FLOAT, data_format 32 (untyped dword access)
+    PFX_RSRC_RAW32 = 0xFACu | (7u << 12) | (4u << 15),     // num_format FLOAT, data_format 32 (untyped dword access)
+    PFX_RSRC_ALPHA8 = 0xFAFu | (0u << 12) | (10u << 15)    // 8_8_8_8 UNORM with dst_sel_x = A: buffer_load_format_x returns alpha / 255
 };
 PFX_DEV pfx_v4i make_rsrc(const void* base, uint32_t bytes, uint32_t word3)
 {
@@ -319,6 +322,490 @@ __global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_la
     }
 }
 
+// ---- dead-layer elimination (canvas_state.rs:1253-1281) -------------------------------------------------------------------------
+// blend_pixel_static has two results that do not depend on `base`: an Overwrite layer wherever its alpha is non-zero (:1275-1281, any
+// opacity) and a Normal layer at opacity >= 1 wherever its alpha is 255 (:1258).  For a pixel, every layer below the topmost such
+// "reset" layer L* is dead: whatever the accumulator holds is replaced at L*.  Skipping dead layers is bit-exact by construction;
+// running some of them anyway is harmless, so every decision below only has to be conservative.
+//
+// The host lists up to 4 candidate layers (mode / opacity only, topmost first kept); the kernel finds L* per pixel from the
+// candidates' alpha.  Real documents are spatially coherent (a photo layer covers a region): a 192-pixel unit whose pixels agree
+// simply starts its layer loop at min L*.  Fine-grained mixtures (BASELINE's S2 stack: an Overwrite layer at depth 14 whose alpha
+// is non-zero on a random 75 % of the pixels) need compaction, or every wave would still walk every layer for its unlucky lanes:
+//   * a wave owns a contiguous stream of U units and a private LDS slice — no workgroup barrier anywhere;
+//   * classifying a unit appends its EARLY pixels (L* below the unit's split layer r) to a FIFO of pixel offsets (ballot + mbcnt
+//     prefix: a stable partition, the queue stays in address order so a gathered wave load touches a few neighbouring lines);
+//   * whenever the queue holds 192 entries the wave runs layers [start, r) on them with full lanes (typed buffer loads with per-lane
+//     offsets), and parks the accumulators as RGBA8 — the reference's own accumulator type — in an LDS ring at the pixels' natural slots;
+//   * a unit whose early pixels are all through runs layers [r, n) in natural order (coalesced loads and stores), accumulators
+//     picked up from the ring; the carry-over queue is what keeps the compacted rounds full whatever the early fraction is.
+// HBM traffic: the candidates' alpha is read once more (+4 bytes per pixel and candidate actually inspected).
+// work counters of the last launches (pfxk_flatten_dle_stats): [0] compacted rounds, [1] pixels in them, [2] layers x rounds,
+// [3] natural units, [4] layers x natural units, [5] candidate alpha reads (units), [6] units that used the queue
+__device__ unsigned long long g_dle_stats[8];
+
+template <int PX, int NB>
+PFX_DEV void dle_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__ layers, uint32_t lb, uint32_t le, uint32_t bytes,
+                        const int (&voff)[PX], bool noblend)
+{
+    // NB register sets rotate (the loop is unrolled NB times, so set indices are compile-time): NB - 1 layers are in flight while one is
+    // blended; every fetch is unconditional (past the item's end it re-reads the last layer) so that the s_waitcnt counts stay exact
+    float t[NB][PX][4];
+    uint32_t m[NB], o[NB];
+    const uint32_t last = le - 1u;
+    const uint8_t* npx = layers[lb].pixels;
+    uint32_t nmode = layers[lb].mode;
+    uint32_t nop = __builtin_bit_cast(uint32_t, layers[lb].opacity);
+    auto fetch = [&](auto SET, uint32_t K) {
+        constexpr int S = decltype(SET)::value;
+        m[S] = nmode; o[S] = nop;
+        const pfx_v4i rs = make_rsrc(npx, bytes, PFX_RSRC_UNORM8X4);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const pfx_v4f v = pfx_buffer_load_format_v4f32(rs, voff[j], 0, 0);
+            t[S][j][0] = v.x; t[S][j][1] = v.y; t[S][j][2] = v.z; t[S][j][3] = v.w;
+        }
+        const uint32_t kn = (K + 1u < last) ? K + 1u : last;
+        npx = layers[kn].pixels; nmode = layers[kn].mode; nop = __builtin_bit_cast(uint32_t, layers[kn].opacity);
+    };
+    auto blend = [&](auto SET, uint32_t K) {
+        constexpr int S = decltype(SET)::value;
+        if (K < le) {
+            if (noblend) { // diagnostic (pfx_tune "dle_stats" = 2): the load stream without the arithmetic — results are garbage
+#pragma unroll
+                for (int j = 0; j < PX; ++j) { acc[j][0] += t[S][j][0]; acc[j][1] += t[S][j][1]; acc[j][2] += t[S][j][2]; acc[j][3] = t[S][j][3]; }
+            } else stream_layer<PX>(acc, t[S], m[S], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(o[S])));
+        }
+    };
+    if constexpr (NB == 3) {
+        fetch(std::integral_constant<int, 0>{}, lb);
+        fetch(std::integral_constant<int, 1>{}, lb + 1u);
+        for (uint32_t li = lb; li < le; li += 3) {
+            fetch(std::integral_constant<int, 2>{}, li + 2); blend(std::integral_constant<int, 0>{}, li);
+            fetch(std::integral_constant<int, 0>{}, li + 3); blend(std::integral_constant<int, 1>{}, li + 1);
+            fetch(std::integral_constant<int, 1>{}, li + 4); blend(std::integral_constant<int, 2>{}, li + 2);
+        }
+    } else {
+        static_assert(NB == 4, "three or four register sets");
+        fetch(std::integral_constant<int, 0>{}, lb);
+        fetch(std::integral_constant<int, 1>{}, lb + 1u);
+        fetch(std::integral_constant<int, 2>{}, lb + 2u);
+        for (uint32_t li = lb; li < le; li += 4) {
+            fetch(std::integral_constant<int, 3>{}, li + 3); blend(std::integral_constant<int, 0>{}, li);
+            fetch(std::integral_constant<int, 0>{}, li + 4); blend(std::integral_constant<int, 1>{}, li + 1);
+            fetch(std::integral_constant<int, 1>{}, li + 5); blend(std::integral_constant<int, 2>{}, li + 2);
+            fetch(std::integral_constant<int, 2>{}, li + 6); blend(std::integral_constant<int, 3>{}, li + 3);
+        }
+    }
+}
+
+PFX_DEV void wave_lds_sync()
+{
+    // LDS operations of one wave execute in order; this only keeps the compiler from moving them across the hand-over
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int PX, int RING_LOG2, int WPB, int NB = 3>
+__global__ __launch_bounds__(64 * WPB) void flatten_dle_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
+                                                                uint32_t n_px, uint8_t* __restrict__ dst, const pfxk_dle_cands C,
+                                                                uint32_t U)
+{
+    constexpr uint32_t UPX = 64u * PX, QCAP = PX == 2 ? 256u : 512u, RING = 1u << RING_LOG2, R = RING / UPX, NREC = 16u;
+    static_assert(R >= 2 && R <= NREC, "ring depth");
+    __shared__ uint32_t s_acc[WPB][RING];   // parked accumulators (RGBA8) at the pixels' natural slots (offset mod RING), R units deep
+    __shared__ uint16_t s_q[WPB][QCAP];     // FIFO of early pixels (offset from the wave's first pixel)
+    __shared__ uint32_t s_rec[WPB][NREC][2]; // per unit in flight: {first layer of its natural pass, queue tail after its append}
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)WPB + wid);
+    const uint32_t units_total = (n_px + UPX - 1u) / UPX;
+    const uint32_t u0 = gw * U;
+    if (u0 >= units_total) return;
+    const uint32_t nu = min(U, units_total - u0);
+    const uint32_t base_px = u0 * UPX;
+    const uint32_t bytes = n_px * 4u;
+    const pfx_v4i rs_dst = make_rsrc(dst, bytes, PFX_RSRC_RAW32);
+    uint32_t* const acc_ring = s_acc[wid];
+    uint16_t* const q = s_q[wid];
+    uint32_t (*const rec)[2] = s_rec[wid];
+
+    uint32_t cls_next = 0, nat_next = 0;          // units classified / finished so far (relative to u0)
+    uint32_t q_head = 0, q_tail = 0;              // monotone counters; entry k lives at q[k % QCAP]
+    uint32_t q_r = 0, q_start = 0;                // layers [q_start, q_r) are what the queued pixels still need
+    uint32_t st_rounds = 0, st_rpx = 0, st_rlay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0;
+    for (;;) {
+        const uint32_t q_cnt = q_tail - q_head;
+        bool run_queue = q_cnt >= UPX, run_nat = false;
+        uint32_t nat_start = 0;
+        if (!run_queue && nat_next < cls_next) {
+            const uint32_t slot = nat_next % NREC;
+            const uint32_t need = __builtin_amdgcn_readfirstlane(rec[slot][1]);
+            // `need` = queue position after this unit's entries; consumed when head has passed it (counters do not wrap: < 2^32 px)
+            if (need <= q_head) { run_nat = true; nat_start = __builtin_amdgcn_readfirstlane(rec[slot][0]); }
+        }
+        if (!run_queue && !run_nat) {
+            if (cls_next < nu && cls_next - nat_next < R) {
+                // ---- classify unit cls_next ----
+                const uint32_t u = cls_next;
+                const uint32_t o0 = u * UPX + lane;
+                uint32_t cls[PX];
+#pragma unroll
+                for (int j = 0; j < PX; ++j) cls[j] = 0u;
+                bool done = false;
+#pragma unroll
+                for (int i = 3; i >= 0; --i) {
+                    if ((uint32_t)i < C.n && !done) {
+                        const pfx_v4i ra = make_rsrc(layers[C.layer[i]].pixels, bytes, PFX_RSRC_ALPHA8);
+                        bool all_found = true;
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            const float a = pfx_buffer_load_format_f32(ra, (int)((base_px + o0 + 64u * j) * 4u), 0, 0);
+                            const bool hit = C.kind[i] ? (a == 1.0f) : (a != 0.0f);
+                            cls[j] = (cls[j] == 0u && hit) ? (uint32_t)(i + 1) : cls[j];
+                            all_found = all_found && cls[j] != 0u;
+                        }
+                        done = __all(all_found);
+                        st_reads += 1u;
+                    }
+                }
+                // cnt[i] = pixels of the unit whose reset class is >= i (cnt[0] = all); cmin = the class every pixel reaches
+                uint32_t cnt[5] = {UPX, 0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int i = 1; i <= 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) cnt[i] += (uint32_t)__popcll(__ballot(cls[j] >= (uint32_t)i));
+                uint32_t cmin = 0;
+#pragma unroll
+                for (int i = 1; i <= 4; ++i) if (cnt[i] == UPX) cmin = (uint32_t)i;
+                uint32_t lay[5] = {0u, C.layer[0], C.layer[1], C.layer[2], C.layer[3]};
+                uint32_t s_u = 0;
+#pragma unroll
+                for (int i = 1; i <= 4; ++i) if (cmin == (uint32_t)i) s_u = lay[i];
+                // split class: the candidate that saves the most layer-pixels, if at least 30 % of the unit skip something
+                uint32_t best = 0, best_sav = 0, r = s_u;
+#pragma unroll
+                for (int i = 1; i <= 4; ++i) {
+                    if ((uint32_t)i > cmin && (uint32_t)i <= C.n && cnt[i] * 10u >= UPX * 3u) {
+                        const uint32_t sav = cnt[i] * (lay[i] - s_u);
+                        if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; }
+                    }
+                }
+                if (best != 0u && q_cnt != 0u && q_r != r) { best = 0u; r = s_u; } // one split layer in the queue at a time
+                // natural slots start from the reference's initial accumulator (0,0,0,0), canvas_state.rs:573
+#pragma unroll
+                for (int j = 0; j < PX; ++j) acc_ring[(o0 + 64u * j) % RING] = 0u;
+                if (best != 0u) {
+                    st_cunits += 1u;
+                    if (q_cnt == 0u) q_start = s_u; else q_start = min(q_start, s_u);
+                    q_r = r;
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {
+                        const bool early = cls[j] < best;
+                        const uint64_t m = __ballot(early);
+                        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (early) q[(q_tail + pre) % QCAP] = (uint16_t)(o0 + 64u * j);
+                        q_tail += (uint32_t)__popcll(m);
+                    }
+                }
+                if (lane == 0) { rec[u % NREC][0] = r; rec[u % NREC][1] = best != 0u ? q_tail : 0u; }
+                wave_lds_sync();
+                cls_next = u + 1u;
+                continue;
+            }
+            if (q_cnt == 0u) {                    // everything classified, run and stored
+                if (lane == 0 && (C.stats & 1u)) {
+                    atomicAdd(&g_dle_stats[0], st_rounds); atomicAdd(&g_dle_stats[1], st_rpx); atomicAdd(&g_dle_stats[2], st_rlay);
+                    atomicAdd(&g_dle_stats[3], nat_next); atomicAdd(&g_dle_stats[4], st_nlay); atomicAdd(&g_dle_stats[5], st_reads);
+                    atomicAdd(&g_dle_stats[6], st_cunits);
+                }
+                break;
+            }
+            run_queue = true;                     // flush a partial round: the ring is full or the stream has ended
+        }
+
+        int voff[PX];
+        float acc[PX][4];
+        uint32_t lb, le;
+        if (run_queue) {
+            const uint32_t m = min(q_cnt, UPX);
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const uint32_t k = 64u * j + lane;
+                const uint32_t o = (uint32_t)q[(q_head + k) % QCAP];
+                voff[j] = k < m ? (int)((base_px + o) * 4u) : (int)bytes; // past the end: the load returns (0,0,0,0), "transparent"
+                acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
+            }
+            lb = q_start; le = q_r;
+            q_head += m;
+            st_rounds += 1u; st_rpx += m; st_rlay += le - lb;
+        } else {
+            const uint32_t o0 = nat_next * UPX + lane;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                voff[j] = (int)((base_px + o0 + 64u * j) * 4u);
+                const uint32_t p = acc_ring[(o0 + 64u * j) % RING];
+                acc[j][0] = div255(ubyte0(p)); acc[j][1] = div255(ubyte1(p)); acc[j][2] = div255(ubyte2(p)); acc[j][3] = div255(ubyte3(p));
+            }
+            lb = nat_start; le = n_layers;
+            st_nlay += le - lb;
+        }
+        dle_layers<PX, NB>(acc, layers, lb, le, bytes, voff, (C.stats & 2u) != 0u);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            // bn = RN(k / 255)  =>  bn * 255 = k (1 + e), |e| < 2^-23: adding 0.5 and truncating recovers k
+            const uint32_t px = (uint32_t)(acc[j][0] * 255.0f + 0.5f) | ((uint32_t)(acc[j][1] * 255.0f + 0.5f) << 8) |
+                                ((uint32_t)(acc[j][2] * 255.0f + 0.5f) << 16) | ((uint32_t)(acc[j][3] * 255.0f + 0.5f) << 24);
+            if (run_queue) { if (voff[j] != (int)bytes) acc_ring[((uint32_t)voff[j] / 4u - base_px) % RING] = px; }
+            else pfx_buffer_store_i32((int)px, rs_dst, voff[j], 0, 0);
+        }
+        if (run_queue) wave_lds_sync();
+        else nat_next += 1u;
+    }
+}
+
+// ---- the flow compositor: dead-layer elimination on ONE continuously prefetched load stream -----------------------------------
+// flatten_dle_kernel above restarts its load pipeline for every item (a compacted round, a natural unit) and waits for the alpha of
+// every unit it classifies: ~2.3 exposed memory latencies per 192 pixels, which cost more than the skipped layers saved
+// (profiles/r03_tuning.md).  Here the wave's work is one flat sequence of steps (item, layer): the three register sets keep rotating
+// across item boundaries, the step two ahead is always in flight, and
+//   * the NEXT item is decided ahead of need into a scalar descriptor (N); a fetch position whose item is exhausted only switches
+//     to it (a natural unit's offsets come from its index, a round's from the queue in LDS);
+//   * the alpha of the unit classified next was requested while the previous item ran (aP);
+//   * an item boundary on the blend side (FIRST / LAST flags travelling with the register set) parks or stores the finished
+//     accumulators and sets up the next item's — a wave-uniform branch, no pipeline drain.
+// Ordering rules that keep the LDS hand-overs safe without barriers (one wave, in-order LDS): the fetch side switches items only after
+// the blend side has ENTERED the current one (so at most one item boundary is in flight and voffB can be taken from voffF at entry); a
+// natural unit counts as "decided" when its rounds have been POPPED — its accumulators are picked up at entry, after the rounds'
+// LAST steps in program order; a unit is classified (its ring slots zeroed) only when every unit R slots back has been entered.
+template <int PX, int RING_LOG2, int WPB>
+__global__ __launch_bounds__(64 * WPB) void flatten_flow_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
+                                                                 uint32_t n_px, uint8_t* __restrict__ dst, const pfxk_dle_cands C,
+                                                                 uint32_t U)
+{
+    constexpr uint32_t UPX = 64u * PX, QCAP = PX == 2 ? 256u : 512u, RING = 1u << RING_LOG2, R = RING / UPX, NREC = 16u;
+    constexpr uint32_t F_VALID = 0x100u, F_FIRST = 0x200u, F_LAST = 0x400u, F_QUEUE = 0x800u;
+    static_assert(R >= 3 && R <= NREC, "ring depth");
+    __shared__ uint32_t s_acc[WPB][RING];
+    __shared__ uint16_t s_q[WPB][QCAP];
+    __shared__ uint32_t s_rec[WPB][NREC][2];
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)WPB + wid);
+    const uint32_t units_total = (n_px + UPX - 1u) / UPX;
+    const uint32_t u0 = gw * U;
+    if (u0 >= units_total) return;
+    const uint32_t nu = min(U, units_total - u0);
+    const uint32_t base_px = u0 * UPX;
+    const uint32_t bytes = n_px * 4u;
+    const pfx_v4i rs_dst = make_rsrc(dst, bytes, PFX_RSRC_RAW32);
+    uint32_t* const acc_ring = s_acc[wid];
+    uint16_t* const q = s_q[wid];
+    uint32_t (*const rec)[2] = s_rec[wid];
+
+    // classification / queue state (wave-uniform)
+    uint32_t cls_next = 0, nat_next = 0, nat_init = 0; // units classified / decided as natural items / entered by the blend side
+    uint32_t q_head = 0, q_tail = 0, q_r = 0, q_start = 0;
+    // lookahead item N: kind 0 none, 1 natural unit (nA = unit), 2 compacted round (nA = first queue position, nM = entries)
+    uint32_t nKind = 0, nA = 0, nM = 0, nLb = 0, nLe = 0;
+    // fetch side: item F (layers [fL, fE) still to request), blend side: item B
+    uint32_t fKind = 0, fL = 0, fE = 0, fFirst = 0;
+    bool bEntered = true;
+    uint32_t bQueue = 0;
+    int voffF[PX], voffB[PX];
+    float acc[PX][4];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) { voffF[j] = voffB[j] = (int)bytes; acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; }
+    uint32_t inflight = 0;
+    uint32_t st_rounds = 0, st_rpx = 0, st_rlay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_bubbles = 0;
+
+    // alpha of the topmost candidate for the unit classified next, requested ahead
+    const uint32_t top_c = C.n - 1u;
+    float aP[PX];
+    {
+        const pfx_v4i ra = make_rsrc(layers[C.layer[top_c]].pixels, bytes, PFX_RSRC_ALPHA8);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) aP[j] = pfx_buffer_load_format_f32(ra, (int)((base_px + lane + 64u * j) * 4u), 0, 0);
+    }
+    // descriptor of the layer requested next, fetched one stage ahead
+    uint32_t dL = 0;
+    const uint8_t* dpx = layers[0].pixels;
+    uint32_t dmode = layers[0].mode, dop = __builtin_bit_cast(uint32_t, layers[0].opacity);
+
+    float tA[PX][4], tB[PX][4], tC[PX][4];
+    uint32_t mA = 0, mB = 0, mC = 0, oA = 0, oB = 0, oC = 0;
+
+#define PFX_FETCHPOS(T, M, O) { \
+        if (fL == fE && nKind != 0u && bEntered) { /* switch to the lookahead item */ \
+            fKind = nKind; fL = nLb; fE = nLe; fFirst = nLb; bEntered = false; \
+            if (nKind == 1u) { \
+                _Pragma("unroll") for (int j = 0; j < PX; ++j) voffF[j] = (int)((base_px + nA * UPX + 64u * j + lane) * 4u); \
+            } else { \
+                _Pragma("unroll") for (int j = 0; j < PX; ++j) { \
+                    const uint32_t k_ = 64u * j + lane; \
+                    const uint32_t o_ = (uint32_t)q[(nA + k_) % QCAP]; \
+                    voffF[j] = k_ < nM ? (int)((base_px + o_) * 4u) : (int)bytes; } \
+            } \
+            nKind = 0u; \
+        } \
+        uint32_t lf_ = 0u, flags_ = 0u; \
+        if (fL < fE) { \
+            lf_ = fL; \
+            flags_ = F_VALID | (fL == fFirst ? F_FIRST : 0u) | (fL + 1u == fE ? F_LAST : 0u) | (fKind == 2u ? F_QUEUE : 0u); \
+            fL += 1u; inflight += 1u; \
+        } else st_bubbles += 1u; \
+        if (dL != lf_) { dpx = layers[lf_].pixels; dmode = layers[lf_].mode; dop = __builtin_bit_cast(uint32_t, layers[lf_].opacity); } \
+        M = dmode | flags_; O = dop; \
+        { const pfx_v4i rs_ = make_rsrc(dpx, bytes, PFX_RSRC_UNORM8X4); \
+          _Pragma("unroll") for (int j = 0; j < PX; ++j) { \
+              const pfx_v4f v_ = pfx_buffer_load_format_v4f32(rs_, voffF[j], 0, 0); \
+              T[j][0] = v_.x; T[j][1] = v_.y; T[j][2] = v_.z; T[j][3] = v_.w; } } \
+        dL = fL < fE ? fL : (nKind != 0u ? nLb : 0u); \
+        dpx = layers[dL].pixels; dmode = layers[dL].mode; dop = __builtin_bit_cast(uint32_t, layers[dL].opacity); }
+
+#define PFX_BLENDPOS(T, M, O) if (M & F_VALID) { \
+        if (M & F_FIRST) { /* the blend side enters item F */ \
+            bEntered = true; bQueue = M & F_QUEUE; \
+            _Pragma("unroll") for (int j = 0; j < PX; ++j) voffB[j] = voffF[j]; \
+            if (bQueue) { \
+                _Pragma("unroll") for (int j = 0; j < PX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; \
+            } else { \
+                _Pragma("unroll") for (int j = 0; j < PX; ++j) { \
+                    const uint32_t p_ = acc_ring[((uint32_t)voffB[j] / 4u - base_px) % RING]; \
+                    acc[j][0] = div255(ubyte0(p_)); acc[j][1] = div255(ubyte1(p_)); acc[j][2] = div255(ubyte2(p_)); acc[j][3] = div255(ubyte3(p_)); } \
+                nat_init += 1u; \
+            } \
+        } \
+        stream_layer<PX>(acc, T, M & 0xffu, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(O))); \
+        if (M & F_LAST) { \
+            _Pragma("unroll") for (int j = 0; j < PX; ++j) { \
+                const uint32_t px_ = (uint32_t)(acc[j][0] * 255.0f + 0.5f) | ((uint32_t)(acc[j][1] * 255.0f + 0.5f) << 8) | \
+                                     ((uint32_t)(acc[j][2] * 255.0f + 0.5f) << 16) | ((uint32_t)(acc[j][3] * 255.0f + 0.5f) << 24); \
+                if (bQueue) { if (voffB[j] != (int)bytes) acc_ring[((uint32_t)voffB[j] / 4u - base_px) % RING] = px_; } \
+                else pfx_buffer_store_i32((int)px_, rs_dst, voffB[j], 0, 0); \
+            } \
+            if (bQueue) wave_lds_sync(); \
+        } \
+        inflight -= 1u; }
+
+    for (;;) {
+        // ---- refill the lookahead item ----
+        while (nKind == 0u) {
+            const uint32_t q_cnt = q_tail - q_head;
+            if (q_cnt >= UPX) {
+                nKind = 2u; nA = q_head; nM = UPX; nLb = q_start; nLe = q_r; q_head += UPX;
+                st_rounds += 1u; st_rpx += UPX; st_rlay += nLe - nLb;
+                break;
+            }
+            if (nat_next < cls_next) {
+                const uint32_t slot = nat_next % NREC;
+                const uint32_t need = __builtin_amdgcn_readfirstlane(rec[slot][1]);
+                if (need <= q_head) {
+                    nKind = 1u; nA = nat_next; nLb = __builtin_amdgcn_readfirstlane(rec[slot][0]); nLe = n_layers; nat_next += 1u;
+                    st_nlay += nLe - nLb;
+                    break;
+                }
+            }
+            if (cls_next < nu && cls_next - nat_init < R) {
+                // ---- classify unit cls_next (its topmost candidate's alpha is in aP) ----
+                const uint32_t u = cls_next;
+                const uint32_t o0 = u * UPX + lane;
+                uint32_t cls[PX];
+                bool all_found = true;
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const bool hit = C.kind[top_c] ? (aP[j] == 1.0f) : (aP[j] != 0.0f);
+                    cls[j] = hit ? C.n : 0u;
+                    all_found = all_found && hit;
+                }
+                st_reads += 1u;
+                bool done = __all(all_found);
+#pragma unroll
+                for (int i = 2; i >= 0; --i) {
+                    if ((uint32_t)i < top_c && !done) {
+                        const pfx_v4i ra = make_rsrc(layers[C.layer[i]].pixels, bytes, PFX_RSRC_ALPHA8);
+                        all_found = true;
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            const float a = pfx_buffer_load_format_f32(ra, (int)((base_px + o0 + 64u * j) * 4u), 0, 0);
+                            const bool hit = C.kind[i] ? (a == 1.0f) : (a != 0.0f);
+                            cls[j] = (cls[j] == 0u && hit) ? (uint32_t)(i + 1) : cls[j];
+                            all_found = all_found && cls[j] != 0u;
+                        }
+                        done = __all(all_found);
+                        st_reads += 1u;
+                    }
+                }
+                if (u + 1u < nu) { // request the next unit's alpha now: it lands while the items decided below run
+                    const pfx_v4i ra = make_rsrc(layers[C.layer[top_c]].pixels, bytes, PFX_RSRC_ALPHA8);
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) aP[j] = pfx_buffer_load_format_f32(ra, (int)((base_px + o0 + UPX + 64u * j) * 4u), 0, 0);
+                }
+                uint32_t cnt[5] = {UPX, 0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int i = 1; i <= 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) cnt[i] += (uint32_t)__popcll(__ballot(cls[j] >= (uint32_t)i));
+                uint32_t cmin = 0;
+#pragma unroll
+                for (int i = 1; i <= 4; ++i) if (cnt[i] == UPX) cmin = (uint32_t)i;
+                const uint32_t lay[5] = {0u, C.layer[0], C.layer[1], C.layer[2], C.layer[3]};
+                uint32_t s_u = 0;
+#pragma unroll
+                for (int i = 1; i <= 4; ++i) if (cmin == (uint32_t)i) s_u = lay[i];
+                uint32_t best = 0, best_sav = 0, r = s_u;
+#pragma unroll
+                for (int i = 1; i <= 4; ++i) {
+                    if ((uint32_t)i > cmin && (uint32_t)i <= C.n && cnt[i] * 10u >= UPX * 3u) {
+                        const uint32_t sav = cnt[i] * (lay[i] - s_u);
+                        if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; }
+                    }
+                }
+                if (best != 0u && q_cnt != 0u && q_r != r) { best = 0u; r = s_u; } // one split layer in the queue at a time
+#pragma unroll
+                for (int j = 0; j < PX; ++j) acc_ring[(o0 + 64u * j) % RING] = 0u;  // the reference's initial accumulator, :573
+                if (best != 0u) {
+                    st_cunits += 1u;
+                    if (q_cnt == 0u) q_start = s_u; else q_start = min(q_start, s_u);
+                    q_r = r;
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {
+                        const bool early = cls[j] < best;
+                        const uint64_t m = __ballot(early);
+                        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (early) q[(q_tail + pre) % QCAP] = (uint16_t)(o0 + 64u * j);
+                        q_tail += (uint32_t)__popcll(m);
+                    }
+                }
+                if (lane == 0) { rec[u % NREC][0] = r; rec[u % NREC][1] = best != 0u ? q_tail : 0u; }
+                wave_lds_sync();
+                cls_next = u + 1u;
+                continue;
+            }
+            if (q_cnt > 0u && !(cls_next < nu && nat_init < nat_next)) {
+                // partial round: the stream has ended, or the ring is full and nothing in flight will free it
+                nKind = 2u; nA = q_head; nM = q_cnt; nLb = q_start; nLe = q_r; q_head += q_cnt;
+                st_rounds += 1u; st_rpx += q_cnt; st_rlay += nLe - nLb;
+            }
+            break;
+        }
+        if (nKind == 0u && fL == fE && inflight == 0u) break; // nothing decided, requested or pending: the stream is done
+        PFX_FETCHPOS(tC, mC, oC)
+        PFX_BLENDPOS(tA, mA, oA)
+        PFX_FETCHPOS(tA, mA, oA)
+        PFX_BLENDPOS(tB, mB, oB)
+        PFX_FETCHPOS(tB, mB, oB)
+        PFX_BLENDPOS(tC, mC, oC)
+    }
+#undef PFX_FETCHPOS
+#undef PFX_BLENDPOS
+    if (lane == 0 && (C.stats & 1u)) {
+        atomicAdd(&g_dle_stats[0], st_rounds); atomicAdd(&g_dle_stats[1], st_rpx); atomicAdd(&g_dle_stats[2], st_rlay);
+        atomicAdd(&g_dle_stats[3], nat_next); atomicAdd(&g_dle_stats[4], st_nlay); atomicAdd(&g_dle_stats[5], st_reads);
+        atomicAdd(&g_dle_stats[6], st_cunits); atomicAdd(&g_dle_stats[7], st_bubbles);
+    }
+}
+
+int g_dle_stats_on = 0, g_dle_cfg = 0;
+int g_dle_units = 0; // tuning knobs (pfxk_flatten_set_dle): units per wave (0 = default), log2 of the accumulator ring
 int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant): 0 = shipped, 1-5 = PX / occupancy variants, +10 = grid-stride launch, 9 = the general kernel
 
 // chunk activity = union over visible raster layers of "chunk has any alpha != 0" (canvas_state.rs:529-550)
@@ -431,6 +918,26 @@ __global__ __launch_bounds__(256) void round_pack_check_kernel(unsigned long lon
 } // namespace
 
 extern "C" void pfxk_flatten_set_variant(int v) { g_flatten_variant = v; }
+extern "C" hipError_t pfxk_flatten_dle_stats(unsigned long long* out8, int reset)
+{
+    hipError_t e = hipSuccess;
+    if (out8) e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dle_stats), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_dle_stats), z, sizeof z);
+    }
+    return e;
+}
+extern "C" void pfxk_flatten_set_dle(int units_per_wave, int ring_log2)
+{
+    if (units_per_wave >= 0) g_dle_units = units_per_wave;
+    (void)ring_log2;
+}
+extern "C" void pfxk_flatten_set_dle_dev(int stats_on, int cfg)
+{
+    if (stats_on >= 0) g_dle_stats_on = stats_on;
+    if (cfg >= 0) g_dle_cfg = cfg;
+}
 extern "C" hipError_t pfxk_round_pack_check(hipStream_t s, unsigned long long* d_out)
 {
     round_pack_check_kernel<<<4096, 256, 0, s>>>(d_out);
@@ -472,7 +979,8 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                                    const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
-                                   int chunk_active_ready, uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region)
+                                   int chunk_active_ready, uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region,
+                                   const pfxk_dle_cands* cands)
 {
     size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
@@ -494,6 +1002,35 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
             const size_t lim = (g_flatten_variant >= 10) ? cap : (size_t)1 << 20;
             return (uint32_t)(b > lim ? lim : b);
         };
+        // dead-layer elimination when the stack holds a reset layer above the bottom one (variant 8 switches it off)
+        if (cands && cands->n > 0 && g_flatten_variant != 8) {
+            // g_dle_cfg: 0 flow PX3 | 1 flow PX2 (ring 512) | 2 item PX3 | 3 item PX2 (ring 512) | 4 flow PX2 (ring 1024) | 5 flow PX3 (ring 2048)
+            const uint32_t px = (g_dle_cfg == 1 || g_dle_cfg == 3 || g_dle_cfg == 4 || g_dle_cfg == 6 || g_dle_cfg == 13) ? 2u : 3u;
+            const uint32_t upx = 64u * px;
+            const uint32_t units = (uint32_t)((n_px + upx - 1) / upx);
+            uint32_t U = g_dle_units > 0 ? (uint32_t)g_dle_units : 12u;
+            if (U * upx > 65535u) U = 65535u / upx; // queue entries are 16-bit pixel offsets
+            const uint32_t waves = (units + U - 1) / U;
+            pfxk_dle_cands C = *cands;
+            C.stats = (uint32_t)g_dle_stats_on;
+            // one wave per workgroup (+10: four): a wave's stream is independent of its neighbours', and a 4-wave workgroup holds its
+            // LDS and wave slots until its slowest stream ends
+#define PFX_ARGS(WPB) <<<(waves + WPB - 1) / WPB, 64 * WPB, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, U)
+            switch (g_dle_cfg) {
+            case 1: flatten_flow_kernel<2, 9, 1> PFX_ARGS(1); break;
+            case 2: flatten_dle_kernel<3, 10, 1> PFX_ARGS(1); break;
+            case 3: flatten_dle_kernel<2, 9, 1> PFX_ARGS(1); break;
+            case 4: flatten_flow_kernel<2, 10, 1> PFX_ARGS(1); break;
+            case 5: flatten_flow_kernel<3, 11, 1> PFX_ARGS(1); break;
+            case 6: flatten_dle_kernel<2, 9, 1, 4> PFX_ARGS(1); break;
+            case 7: flatten_dle_kernel<3, 10, 1, 4> PFX_ARGS(1); break;
+            case 12: flatten_dle_kernel<3, 10, 4> PFX_ARGS(4); break;
+            case 13: flatten_dle_kernel<2, 9, 4> PFX_ARGS(4); break;
+            default: flatten_flow_kernel<3, 10, 1> PFX_ARGS(1); break;
+            }
+#undef PFX_ARGS
+            return hipGetLastError();
+        }
         switch (g_flatten_variant % 10) {
 #define PFX_STREAM(PX, NB, MINW) flatten_stream_kernel<PX, NB, MINW><<<grid(64 * PX), block, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst)
         case 1: PFX_STREAM(2, 2, 1); break;

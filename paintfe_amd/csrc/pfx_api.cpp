@@ -125,7 +125,8 @@ struct preview_arg {
 
 int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
                 uint32_t n, uint32_t w, uint32_t h, bool from_store, uint32_t* n_desc, bool* general, bool* has_adj,
-                uint32_t track_info = 0xFFFFFFFFu, uint32_t* track_pos = nullptr, const uint8_t** track_pixels = nullptr)
+                uint32_t track_info = 0xFFFFFFFFu, uint32_t* track_pos = nullptr, const uint8_t** track_pixels = nullptr,
+                pfxk_dle_cands* cands = nullptr)
 {
     std::vector<pfxk_layer_desc> desc;
     std::vector<float> adj;
@@ -166,6 +167,24 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
         desc.push_back(d);
     }
     *n_desc = (uint32_t)desc.size();
+    if (cands) {
+        // reset layers (k_flatten.hip: dead-layer elimination): the topmost PFXK_DLE_MAX raster layers above the bottom one that are
+        // Overwrite (canvas_state.rs:1275) or Normal at opacity >= 1 (:1258); only used by the raster-only streaming path
+        std::memset(cands, 0, sizeof *cands);
+        std::vector<std::pair<uint32_t, uint32_t>> found;
+        for (uint32_t p = 1; p < desc.size(); ++p) {
+            const pfxk_layer_desc& d = desc[p];
+            if (d.kind != PFX_LAYER_RASTER || d.mask) continue;
+            if (d.mode == 14u) found.emplace_back(p, 0u);
+            else if (d.mode == 0u && d.opacity >= 1.0f) found.emplace_back(p, 1u);
+        }
+        const size_t first = found.size() > PFXK_DLE_MAX ? found.size() - PFXK_DLE_MAX : 0;
+        for (size_t k = first; k < found.size(); ++k) {
+            cands->layer[cands->n] = found[k].first;
+            cands->kind[cands->n] = found[k].second;
+            cands->n++;
+        }
+    }
     // the tables only travel when they differ from what the device already holds (a render loop re-composites the same stack: the
     // small pageable-memory copy in front of every launch was a ~10 us bubble on the stream)
     const size_t desc_bytes = desc.size() * sizeof(pfxk_layer_desc), adj_bytes = adj.size() * sizeof(float);
@@ -197,8 +216,9 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
     uint32_t n_desc = 0, active_pos = 0xFFFFFFFFu;
     const uint8_t* active_pixels = nullptr;
     bool general = false, has_adj = false;
+    pfxk_dle_cands cands{};
     PFX_TRY(build_stack(ctx, layer_ptrs, mask_ptrs, layers, n_layers, w, h, from_store, &n_desc, &general, &has_adj,
-                        pv ? pv->info.active_layer : 0xFFFFFFFFu, &active_pos, &active_pixels));
+                        pv ? pv->info.active_layer : 0xFFFFFFFFu, &active_pos, &active_pixels, &cands));
     const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
     uint8_t* d_chunks = nullptr;
     bool chunks_ready = false;
@@ -228,7 +248,7 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
     for (uint32_t i = 0; i < n_layers; ++i) fast_div = fast_div && opacity_allows_fast_div(layers[i].opacity);
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
-                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region));
+                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region, &cands));
     return PFX_OK;
 }
 
@@ -1091,9 +1111,22 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (!ctx || !key) return PFX_ERR_INVALID;
     if (std::strcmp(key, "gauss_v_cfg") == 0) { pfxk_gauss_set_v_config(value); return PFX_OK; }
     if (std::strcmp(key, "flatten_variant") == 0) { pfxk_flatten_set_variant(value); return PFX_OK; }
+    if (std::strcmp(key, "dle_units") == 0) { pfxk_flatten_set_dle(value, -1); return PFX_OK; }
+    if (std::strcmp(key, "dle_ring") == 0) { pfxk_flatten_set_dle(-1, value); return PFX_OK; }
+    if (std::strcmp(key, "dle_stats") == 0) { pfxk_flatten_set_dle_dev(value, -1); return PFX_OK; }
+    if (std::strcmp(key, "dle_cfg") == 0) { pfxk_flatten_set_dle_dev(-1, value); return PFX_OK; }
     if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
     if (std::strcmp(key, "resize_two_pass") == 0) { ctx->resize_two_pass = value != 0; return PFX_OK; } // A/B and the parity test of the fused kernel
     return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_tune: unknown key %s", key);
+}
+
+int pfx_flatten_stats(pfx_ctx* ctx, uint64_t out[8], int reset)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_TRY(pfx_sync(ctx));
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+    PFX_HIP(ctx, pfxk_flatten_dle_stats((unsigned long long*)out, reset));
+    return PFX_OK;
 }
 
 int pfx_selftest_division(pfx_ctx* ctx, uint64_t seed, uint32_t n_millions, uint64_t* mismatches)

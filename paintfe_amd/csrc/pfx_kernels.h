@@ -44,10 +44,18 @@ typedef struct pfxk_preview {
 } pfxk_preview;
 // dirty rectangle: composite only [x0, x0+rw) x [y0, y0+rh) into a compact rw x rh destination (rw == 0: whole canvas)
 typedef struct pfxk_region { uint32_t x0, y0, rw, rh; } pfxk_region;
+// Candidate "reset" layers of a stack (positions in the descriptor array, ascending): layers whose result does not depend on what is
+// below them wherever their alpha qualifies — kind 0: Overwrite, alpha != 0 (canvas_state.rs:1275-1281); kind 1: Normal at
+// opacity >= 1, alpha == 255 (:1258).  The compositor skips the layers below a pixel's topmost reset (k_flatten.hip, flatten_dle_kernel).
+#define PFXK_DLE_MAX 4
+typedef struct pfxk_dle_cands { uint32_t n; uint32_t layer[PFXK_DLE_MAX]; uint32_t kind[PFXK_DLE_MAX]; uint32_t stats; /* set by the launcher */ } pfxk_dle_cands;
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                         const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, int chunk_active_ready, uint32_t w,
                         uint32_t h, uint8_t* d_dst, const pfxk_preview* preview /* may be NULL */,
-                        const pfxk_region* region /* may be NULL */);
+                        const pfxk_region* region /* may be NULL */, const pfxk_dle_cands* cands /* may be NULL: no elimination */);
+void       pfxk_flatten_set_dle(int units_per_wave /* 0 = default, < 0 = keep */, int ring_log2 /* 10 | 11, else keep */);
+hipError_t pfxk_flatten_dle_stats(unsigned long long* out8 /* may be NULL */, int reset); // synchronises the device
+void       pfxk_flatten_set_dle_dev(int stats_on /* < 0 keep */, int cfg /* < 0 keep */);
 void       pfxk_flatten_set_variant(int v); // tuning knob: 0 = shipped kernel, 1.. = experimental pixels-per-lane / occupancy variants
 // counts (into *d_out) operand pairs for which the shared-reciprocal division differs from the IEEE divide
 hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out);

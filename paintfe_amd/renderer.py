@@ -633,6 +633,13 @@ class GpuRenderer:
     def tune(self, key: str, value: int):
         self._check(self._lib.pfx_tune(self._h, key.encode(), C.c_int(value)))
 
+    def flatten_stats(self, reset: bool = False):
+        """work counters of the compositor's dead-layer elimination (pfx_flatten_stats)"""
+        out = (C.c_uint64 * 8)()
+        self._check(self._lib.pfx_flatten_stats(self._h, out, C.c_int(int(reset))))
+        keys = ("rounds", "round_px", "round_layers", "nat_units", "nat_layers", "alpha_reads", "queue_units", "reserved")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def timing_enable(self, on: bool):
         self._check(self._lib.pfx_timing_enable(self._h, C.c_int(int(on))))
 

@@ -1,0 +1,201 @@
+"""Parity gate (GPU): dead-layer elimination in the streaming compositor (k_flatten.hip: flatten_dle_kernel).
+
+blend_pixel_static has two results that ignore `base` (canvas_state.rs:1258 opaque Normal at opacity >= 1, :1275-1281 Overwrite
+with non-zero alpha); the kernel skips the layers below a pixel's topmost such layer, compacting the pixels that still need them.
+Everything here must equal the oracle — which walks every layer for every pixel — bit for bit: stacks with reset layers at random
+depths, alpha = 0 holes in them, Normal layers below 100 % (must NOT reset), more candidates than the kernel tracks, spatially
+coherent and per-pixel-random coverage at every fraction, ragged sizes, every queue / ring configuration, and masks or adjustment
+layers that move the stack to the general kernel."""
+import numpy as np
+import pytest
+
+from . import inputs as I
+from . import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+OVERWRITE, NORMAL = 14, 0
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from .backends import GpuBackend
+    g = GpuBackend(0)
+    yield g
+    g.r.tune("dle_units", 0)
+    g.r.tune("dle_cfg", 0)
+    g.r.tune("flatten_variant", 0)
+
+
+def check(gpu, stack, modes, opac, what):
+    n, h, w, _ = stack.shape
+    layers = [dict(pixels=stack[k], mode=int(modes[k]), opacity=float(opac[k])) for k in range(n)]
+    got = gpu.composite(layers, w, h)
+    ref = O.flatten_stack(stack, np.asarray(modes, np.uint8), np.asarray(opac, np.float32))
+    bad = (got != ref).any(-1)
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {w * h} px differ, first at flat index {int(np.flatnonzero(bad)[0])}"
+
+
+def noise_alpha(rng, h, w, p_zero, p_opaque):
+    u = rng.random((h, w))
+    a = rng.integers(1, 255, (h, w), dtype=np.uint8)
+    return np.where(u < p_zero, 0, np.where(u < p_zero + p_opaque, 255, a)).astype(np.uint8)
+
+
+def blocky_alpha(rng, h, w, cell, p_zero, p_opaque):
+    gh, gw = (h + cell - 1) // cell, (w + cell - 1) // cell
+    coarse = noise_alpha(rng, gh, gw, p_zero, p_opaque)
+    return np.kron(coarse, np.ones((cell, cell), np.uint8))[:h, :w]
+
+
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], autouse=True)
+def every_kernel_configuration(request, gpu):
+    """every test of this file runs on every elimination kernel the library carries (pfx_tune "dle_cfg": pixels per lane, ring depth,
+    continuously prefetched or item-by-item load stream)"""
+    gpu.r.tune("dle_cfg", request.param)
+    yield request.param
+    gpu.r.tune("dle_cfg", 0)
+
+
+@pytest.mark.parametrize("units", [0, 1, 2, 5, 340])
+def test_s2_stack_every_queue_configuration(gpu, units):
+    """BASELINE's S2 stack (Overwrite at depth 14, alpha non-zero on a random 75 %) with short and long wave streams"""
+    gpu.r.tune("dle_units", units)
+    w, h, n = 517, 263, 32
+    stack, modes, opac = I.layer_stack(w, h, n, seed=1234 + units)
+    check(gpu, stack, modes, opac, f"S2 units={units}")
+    gpu.r.tune("dle_units", 0)
+
+
+@pytest.mark.parametrize("p_live", [0.0, 0.004, 0.05, 0.28, 0.32, 0.5, 0.75, 0.97, 1.0])
+@pytest.mark.parametrize("kind", ["overwrite", "normal"])
+def test_single_reset_layer_at_every_coverage(gpu, kind, p_live):
+    """one reset layer at depth 9 of 14 whose qualifying pixels are a random fraction p_live of the image: below the 30 % threshold
+    (no compaction), around it, the compacted regime, and the forced partial flushes of a nearly empty queue"""
+    w, h, n = 389, 211, 14
+    rng = np.random.default_rng(int(p_live * 1000) + (7 if kind == "normal" else 0))
+    stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    modes = [0] + [1 + (3 * k) % 24 for k in range(1, n)]
+    modes = [m if m not in (OVERWRITE, NORMAL) else 2 for m in modes]
+    opac = [1.0] + [float(np.float32(0.3 + 0.7 * rng.random())) for _ in range(1, n)]
+    for k in range(1, n):
+        stack[k, ..., 3] = noise_alpha(rng, h, w, 0.25, 0.25)
+    if kind == "overwrite":
+        modes[9], opac[9] = OVERWRITE, 0.6                       # any opacity resets
+        stack[9, ..., 3] = np.where(rng.random((h, w)) < p_live, rng.integers(1, 256, (h, w)), 0).astype(np.uint8)
+    else:
+        modes[9], opac[9] = NORMAL, 1.0                          # only alpha 255 resets
+        stack[9, ..., 3] = np.where(rng.random((h, w)) < p_live, 255, rng.integers(0, 255, (h, w))).astype(np.uint8)
+    check(gpu, stack, modes, opac, f"{kind} p_live={p_live}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_stacks_with_reset_layers_at_random_depths(gpu, seed):
+    rng = np.random.default_rng(7000 + seed)
+    w, h = int(rng.integers(40, 700)), int(rng.integers(20, 300))
+    n = int(rng.integers(2, 34))
+    stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    modes, opac = [], []
+    for k in range(n):
+        t = rng.random()
+        if t < 0.22:
+            modes.append(OVERWRITE); opac.append(float(rng.choice([1.0, 0.5, 1e-3, 0.999])))
+        elif t < 0.40:
+            modes.append(NORMAL); opac.append(float(rng.choice([1.0, 1.5, 1.0, 2.0])))         # resets where alpha is 255
+        elif t < 0.50:
+            modes.append(NORMAL); opac.append(float(rng.choice([0.999999, 0.5])))              # never resets
+        else:
+            modes.append(int(rng.integers(0, 25))); opac.append(float(np.float32(0.05 + 0.95 * rng.random())))
+        style = rng.integers(0, 6)
+        if style == 0:
+            a = noise_alpha(rng, h, w, 0.25, 0.25)
+        elif style == 1:
+            a = noise_alpha(rng, h, w, float(rng.random()), float(rng.random()) * 0.5)
+        elif style == 2:
+            a = blocky_alpha(rng, h, w, int(rng.choice([3, 16, 64, 200])), 0.3, 0.5)
+        elif style == 3:
+            a = np.full((h, w), 255, np.uint8)
+        elif style == 4:
+            a = np.zeros((h, w), np.uint8)
+        else:
+            a = np.broadcast_to((np.arange(w) * 256 // w).astype(np.uint8), (h, w)).copy()
+        stack[k, ..., 3] = a
+    gpu.r.tune("dle_units", int(rng.choice([0, 1, 3, 7, 24])))
+    check(gpu, stack, modes, opac, f"seed {seed}: {w}x{h}x{n}, modes {modes}")
+    gpu.r.tune("dle_units", 0)
+
+
+def test_more_candidates_than_the_kernel_tracks_and_bottom_or_top_position(gpu):
+    w, h, n = 300, 150, 12
+    rng = np.random.default_rng(31)
+    stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    for k in range(n):
+        stack[k, ..., 3] = noise_alpha(rng, h, w, 0.4, 0.3)
+    modes = [OVERWRITE, NORMAL, OVERWRITE, 5, NORMAL, OVERWRITE, 8, OVERWRITE, NORMAL, 16, NORMAL, OVERWRITE]
+    opac = [1.0, 1.0, 0.7, 0.5, 1.0, 1.0, 0.9, 0.2, 1.0, 1.0, 1.0, 0.8]
+    check(gpu, stack, modes, opac, "7+ candidates, reset layer at the bottom and on top")
+    # a reset layer covering everything on top: every unit starts at the last layer
+    stack[n - 1, ..., 3] = 255
+    check(gpu, stack, modes, opac, "opaque Overwrite on top")
+    modes[n - 1], opac[n - 1] = NORMAL, 1.0
+    check(gpu, stack, modes, opac, "opaque Normal on top")
+
+
+@pytest.mark.parametrize("size", [(1, 1), (191, 1), (192, 1), (193, 1), (64, 3), (5, 77), (4609, 1), (383, 13)])
+def test_tiny_and_ragged_sizes(gpu, size):
+    w, h = size
+    n = 6
+    rng = np.random.default_rng(w * 131 + h)
+    stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    for k in range(n):
+        stack[k, ..., 3] = noise_alpha(rng, h, w, 0.25, 0.25)
+    modes, opac = [0, 3, 9, OVERWRITE, 20, 1], [1.0, 0.5, 1.0, 1.0, 0.7, 0.4]
+    for units in (1, 0):
+        gpu.r.tune("dle_units", units)
+        check(gpu, stack, modes, opac, f"{w}x{h} units={units}")
+    gpu.r.tune("dle_units", 0)
+
+
+def test_coherent_documents_start_at_the_covering_layer(gpu):
+    """photo-like documents: opaque Normal layers covering rectangles (units agree on their reset layer, units on a rectangle's
+    edge are mixed), a soft-edged opaque blob, an Overwrite patch with a hole"""
+    w, h, n = 640, 256, 9
+    rng = np.random.default_rng(99)
+    stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    stack[:, ..., 3] = 0
+    stack[0, ..., 3] = 255
+    stack[1, ..., 3] = noise_alpha(rng, h, w, 0.2, 0.2)
+    stack[2, 30:200, 50:400, 3] = 255                                   # opaque photo (Normal 100 %)
+    stack[3, ..., 3] = noise_alpha(rng, h, w, 0.5, 0.1)
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = np.hypot(yy - 128, xx - 420)
+    stack[4, ..., 3] = np.clip(255 * (90 - d) / 20, 0, 255).astype(np.uint8)   # soft-edged opaque disc
+    stack[5, 100:180, 300:600, 3] = 200                                 # Overwrite patch ...
+    stack[5, 120:140, 350:380, 3] = 0                                   # ... with a hole
+    stack[6, ..., 3] = noise_alpha(rng, h, w, 0.6, 0.0)
+    stack[7, :, 600:, 3] = 255                                          # opaque strip, Normal but at 99 %: no reset
+    stack[8, ..., 3] = noise_alpha(rng, h, w, 0.7, 0.0)
+    modes = [0, 1, NORMAL, 8, NORMAL, OVERWRITE, 2, NORMAL, 16]
+    opac = [1.0, 0.8, 1.0, 0.6, 1.0, 0.75, 1.0, 0.99, 0.5]
+    check(gpu, stack, modes, opac, "coherent document")
+
+
+def test_switched_off_and_general_path_agree(gpu):
+    """the same stack through the plain streaming kernel (variant 8), the general kernel (variant 9) and with a live mask on the
+    reset layer (the mask can lower alpha to 0: the host must not list that layer)"""
+    w, h, n = 333, 120, 8
+    stack, modes, opac = I.layer_stack(w, h, n, seed=5)
+    modes = list(modes); opac = list(opac)
+    modes[5], opac[5] = OVERWRITE, 1.0
+    for v in (8, 9, 0):
+        gpu.r.tune("flatten_variant", v)
+        check(gpu, stack, modes, opac, f"variant {v}")
+    gpu.r.tune("flatten_variant", 0)
+    rng = np.random.default_rng(17)
+    mask = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    mask[:, : w // 2] = 255                                             # fully concealed half: the Overwrite layer vanishes there
+    layers = [dict(pixels=stack[k], mode=int(modes[k]), opacity=float(opac[k])) for k in range(n)]
+    layers[5]["mask"] = mask
+    got = gpu.composite(layers, w, h)
+    ref = O.composite(layers, w, h)
+    assert np.array_equal(got, ref), "masked reset layer"
