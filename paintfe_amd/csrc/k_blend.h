@@ -336,11 +336,22 @@ PFX_DEV void blend_nx(float (&acc)[4], const float (&top)[4], float opacity_raw,
     if constexpr (!(OB != 0 && M != M_XOR && M != M_OVERWRITE)) acc[3] = skip ? acc[3] : o3; // UNIT: alpha stays 1.0 either way
 }
 
+#ifndef PFX_XSKIP
+#define PFX_XSKIP 0
+#endif
 template <uint32_t M, int PX, int OB>
 PFX_DEV void blendN_nx(float (&acc)[PX][4], const float (&top)[PX][4], float opacity_raw, float opc)
 {
 #pragma unroll
-    for (int p = 0; p < PX; ++p) blend_nx<M, OB>(acc[p], top[p], opacity_raw, opc);
+    for (int p = 0; p < PX; ++p) {
+#if PFX_XSKIP
+        // lanes whose layer pixel is transparent (:1253) sit the pixel's blend out under EXEC instead of computing it and discarding the
+        // result: the kernel runs at the chip's power limit, so an idle lane is clock the others get
+        if (OB == 2 || top[p][3] != 0.0f) blend_nx<M, OB>(acc[p], top[p], opacity_raw, opc);
+#else
+        blend_nx<M, OB>(acc[p], top[p], opacity_raw, opc);
+#endif
+    }
 }
 
 template <int PX, int OB>

@@ -15,6 +15,7 @@
 //     (this file is compiled with -ffp-contract=off); u8/255 uses the proved 2-op form (k_common.h:div255);
 //   * the three `/ out_a` of a pixel share one refined reciprocal (rdiv below): the exact operation sequence
 //     hipcc emits for an IEEE f32 divide, with the per-denominator part hoisted — bit-identical to `/`.
+#include <algorithm>
 #include <type_traits>
 #include "k_common.h"
 #include "pfx_kernels.h"
@@ -344,7 +345,12 @@ __global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_la
 // [3] natural units, [4] layers x natural units, [5] candidate alpha reads (units), [6] units that used the queue
 __device__ unsigned long long g_dle_stats[8];
 
-template <int PX, int NB>
+#ifndef PFX_DLE_SGPR_ATTR
+#define PFX_DLE_SGPR_ATTR
+#endif
+struct dle_sched { uint32_t wavesA, UA, wavesB, UB, UC; }; // waves [0, wavesA) own UA units each, the next wavesB UB, the rest UC
+
+template <int PX, int NB, int AUX = 0>
 PFX_DEV void dle_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__ layers, uint32_t lb, uint32_t le, uint32_t bytes,
                         const int (&voff)[PX], bool noblend)
 {
@@ -362,7 +368,7 @@ PFX_DEV void dle_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
         const pfx_v4i rs = make_rsrc(npx, bytes, PFX_RSRC_UNORM8X4);
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            const pfx_v4f v = pfx_buffer_load_format_v4f32(rs, voff[j], 0, 0);
+            const pfx_v4f v = pfx_buffer_load_format_v4f32(rs, voff[j], 0, AUX);
             t[S][j][0] = v.x; t[S][j][1] = v.y; t[S][j][2] = v.z; t[S][j][3] = v.w;
         }
         const uint32_t kn = (K + 1u < last) ? K + 1u : last;
@@ -406,10 +412,10 @@ PFX_DEV void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int PX, int RING_LOG2, int WPB, int NB = 3>
-__global__ __launch_bounds__(64 * WPB) void flatten_dle_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
+template <int PX, int RING_LOG2, int WPB, int NB = 3, int AUX = 0>
+__global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
                                                                 uint32_t n_px, uint8_t* __restrict__ dst, const pfxk_dle_cands C,
-                                                                uint32_t U)
+                                                                const dle_sched SC)
 {
     constexpr uint32_t UPX = 64u * PX, QCAP = PX == 2 ? 256u : 512u, RING = 1u << RING_LOG2, R = RING / UPX, NREC = 16u;
     static_assert(R >= 2 && R <= NREC, "ring depth");
@@ -419,7 +425,12 @@ __global__ __launch_bounds__(64 * WPB) void flatten_dle_kernel(const pfxk_layer_
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)WPB + wid);
     const uint32_t units_total = (n_px + UPX - 1u) / UPX;
-    const uint32_t u0 = gw * U;
+    // stream lengths shrink towards the end of the launch (workgroups start in index order): long streams waste the least on their
+    // final partial round, short ones keep the tail of the launch short
+    uint32_t u0, U;
+    if (gw < SC.wavesA) { U = SC.UA; u0 = gw * SC.UA; }
+    else if (gw < SC.wavesA + SC.wavesB) { U = SC.UB; u0 = SC.wavesA * SC.UA + (gw - SC.wavesA) * SC.UB; }
+    else { U = SC.UC; u0 = SC.wavesA * SC.UA + SC.wavesB * SC.UB + (gw - SC.wavesA - SC.wavesB) * SC.UC; }
     if (u0 >= units_total) return;
     const uint32_t nu = min(U, units_total - u0);
     const uint32_t base_px = u0 * UPX;
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(64 * WPB) void flatten_dle_kernel(const pfxk_layer_
             lb = nat_start; le = n_layers;
             st_nlay += le - lb;
         }
-        dle_layers<PX, NB>(acc, layers, lb, le, bytes, voff, (C.stats & 2u) != 0u);
+        dle_layers<PX, NB, AUX>(acc, layers, lb, le, bytes, voff, (C.stats & 2u) != 0u);
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             // bn = RN(k / 255)  =>  bn * 255 = k (1 + e), |e| < 2^-23: adding 0.5 and truncating recovers k
@@ -563,248 +574,7 @@ __global__ __launch_bounds__(64 * WPB) void flatten_dle_kernel(const pfxk_layer_
     }
 }
 
-// ---- the flow compositor: dead-layer elimination on ONE continuously prefetched load stream -----------------------------------
-// flatten_dle_kernel above restarts its load pipeline for every item (a compacted round, a natural unit) and waits for the alpha of
-// every unit it classifies: ~2.3 exposed memory latencies per 192 pixels, which cost more than the skipped layers saved
-// (profiles/r03_tuning.md).  Here the wave's work is one flat sequence of steps (item, layer): the three register sets keep rotating
-// across item boundaries, the step two ahead is always in flight, and
-//   * the NEXT item is decided ahead of need into a scalar descriptor (N); a fetch position whose item is exhausted only switches
-//     to it (a natural unit's offsets come from its index, a round's from the queue in LDS);
-//   * the alpha of the unit classified next was requested while the previous item ran (aP);
-//   * an item boundary on the blend side (FIRST / LAST flags travelling with the register set) parks or stores the finished
-//     accumulators and sets up the next item's — a wave-uniform branch, no pipeline drain.
-// Ordering rules that keep the LDS hand-overs safe without barriers (one wave, in-order LDS): the fetch side switches items only after
-// the blend side has ENTERED the current one (so at most one item boundary is in flight and voffB can be taken from voffF at entry); a
-// natural unit counts as "decided" when its rounds have been POPPED — its accumulators are picked up at entry, after the rounds'
-// LAST steps in program order; a unit is classified (its ring slots zeroed) only when every unit R slots back has been entered.
-template <int PX, int RING_LOG2, int WPB>
-__global__ __launch_bounds__(64 * WPB) void flatten_flow_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
-                                                                 uint32_t n_px, uint8_t* __restrict__ dst, const pfxk_dle_cands C,
-                                                                 uint32_t U)
-{
-    constexpr uint32_t UPX = 64u * PX, QCAP = PX == 2 ? 256u : 512u, RING = 1u << RING_LOG2, R = RING / UPX, NREC = 16u;
-    constexpr uint32_t F_VALID = 0x100u, F_FIRST = 0x200u, F_LAST = 0x400u, F_QUEUE = 0x800u;
-    static_assert(R >= 3 && R <= NREC, "ring depth");
-    __shared__ uint32_t s_acc[WPB][RING];
-    __shared__ uint16_t s_q[WPB][QCAP];
-    __shared__ uint32_t s_rec[WPB][NREC][2];
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)WPB + wid);
-    const uint32_t units_total = (n_px + UPX - 1u) / UPX;
-    const uint32_t u0 = gw * U;
-    if (u0 >= units_total) return;
-    const uint32_t nu = min(U, units_total - u0);
-    const uint32_t base_px = u0 * UPX;
-    const uint32_t bytes = n_px * 4u;
-    const pfx_v4i rs_dst = make_rsrc(dst, bytes, PFX_RSRC_RAW32);
-    uint32_t* const acc_ring = s_acc[wid];
-    uint16_t* const q = s_q[wid];
-    uint32_t (*const rec)[2] = s_rec[wid];
-
-    // classification / queue state (wave-uniform)
-    uint32_t cls_next = 0, nat_next = 0, nat_init = 0; // units classified / decided as natural items / entered by the blend side
-    uint32_t q_head = 0, q_tail = 0, q_r = 0, q_start = 0;
-    // lookahead item N: kind 0 none, 1 natural unit (nA = unit), 2 compacted round (nA = first queue position, nM = entries)
-    uint32_t nKind = 0, nA = 0, nM = 0, nLb = 0, nLe = 0;
-    // fetch side: item F (layers [fL, fE) still to request), blend side: item B
-    uint32_t fKind = 0, fL = 0, fE = 0, fFirst = 0;
-    bool bEntered = true;
-    uint32_t bQueue = 0;
-    int voffF[PX], voffB[PX];
-    float acc[PX][4];
-#pragma unroll
-    for (int j = 0; j < PX; ++j) { voffF[j] = voffB[j] = (int)bytes; acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; }
-    uint32_t inflight = 0;
-    uint32_t st_rounds = 0, st_rpx = 0, st_rlay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_bubbles = 0;
-
-    // alpha of the topmost candidate for the unit classified next, requested ahead
-    const uint32_t top_c = C.n - 1u;
-    float aP[PX];
-    {
-        const pfx_v4i ra = make_rsrc(layers[C.layer[top_c]].pixels, bytes, PFX_RSRC_ALPHA8);
-#pragma unroll
-        for (int j = 0; j < PX; ++j) aP[j] = pfx_buffer_load_format_f32(ra, (int)((base_px + lane + 64u * j) * 4u), 0, 0);
-    }
-    // descriptor of the layer requested next, fetched one stage ahead
-    uint32_t dL = 0;
-    const uint8_t* dpx = layers[0].pixels;
-    uint32_t dmode = layers[0].mode, dop = __builtin_bit_cast(uint32_t, layers[0].opacity);
-
-    float tA[PX][4], tB[PX][4], tC[PX][4];
-    uint32_t mA = 0, mB = 0, mC = 0, oA = 0, oB = 0, oC = 0;
-
-#define PFX_FETCHPOS(T, M, O) { \
-        if (fL == fE && nKind != 0u && bEntered) { /* switch to the lookahead item */ \
-            fKind = nKind; fL = nLb; fE = nLe; fFirst = nLb; bEntered = false; \
-            if (nKind == 1u) { \
-                _Pragma("unroll") for (int j = 0; j < PX; ++j) voffF[j] = (int)((base_px + nA * UPX + 64u * j + lane) * 4u); \
-            } else { \
-                _Pragma("unroll") for (int j = 0; j < PX; ++j) { \
-                    const uint32_t k_ = 64u * j + lane; \
-                    const uint32_t o_ = (uint32_t)q[(nA + k_) % QCAP]; \
-                    voffF[j] = k_ < nM ? (int)((base_px + o_) * 4u) : (int)bytes; } \
-            } \
-            nKind = 0u; \
-        } \
-        uint32_t lf_ = 0u, flags_ = 0u; \
-        if (fL < fE) { \
-            lf_ = fL; \
-            flags_ = F_VALID | (fL == fFirst ? F_FIRST : 0u) | (fL + 1u == fE ? F_LAST : 0u) | (fKind == 2u ? F_QUEUE : 0u); \
-            fL += 1u; inflight += 1u; \
-        } else st_bubbles += 1u; \
-        if (dL != lf_) { dpx = layers[lf_].pixels; dmode = layers[lf_].mode; dop = __builtin_bit_cast(uint32_t, layers[lf_].opacity); } \
-        M = dmode | flags_; O = dop; \
-        { const pfx_v4i rs_ = make_rsrc(dpx, bytes, PFX_RSRC_UNORM8X4); \
-          _Pragma("unroll") for (int j = 0; j < PX; ++j) { \
-              const pfx_v4f v_ = pfx_buffer_load_format_v4f32(rs_, voffF[j], 0, 0); \
-              T[j][0] = v_.x; T[j][1] = v_.y; T[j][2] = v_.z; T[j][3] = v_.w; } } \
-        dL = fL < fE ? fL : (nKind != 0u ? nLb : 0u); \
-        dpx = layers[dL].pixels; dmode = layers[dL].mode; dop = __builtin_bit_cast(uint32_t, layers[dL].opacity); }
-
-#define PFX_BLENDPOS(T, M, O) if (M & F_VALID) { \
-        if (M & F_FIRST) { /* the blend side enters item F */ \
-            bEntered = true; bQueue = M & F_QUEUE; \
-            _Pragma("unroll") for (int j = 0; j < PX; ++j) voffB[j] = voffF[j]; \
-            if (bQueue) { \
-                _Pragma("unroll") for (int j = 0; j < PX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; \
-            } else { \
-                _Pragma("unroll") for (int j = 0; j < PX; ++j) { \
-                    const uint32_t p_ = acc_ring[((uint32_t)voffB[j] / 4u - base_px) % RING]; \
-                    acc[j][0] = div255(ubyte0(p_)); acc[j][1] = div255(ubyte1(p_)); acc[j][2] = div255(ubyte2(p_)); acc[j][3] = div255(ubyte3(p_)); } \
-                nat_init += 1u; \
-            } \
-        } \
-        stream_layer<PX>(acc, T, M & 0xffu, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(O))); \
-        if (M & F_LAST) { \
-            _Pragma("unroll") for (int j = 0; j < PX; ++j) { \
-                const uint32_t px_ = (uint32_t)(acc[j][0] * 255.0f + 0.5f) | ((uint32_t)(acc[j][1] * 255.0f + 0.5f) << 8) | \
-                                     ((uint32_t)(acc[j][2] * 255.0f + 0.5f) << 16) | ((uint32_t)(acc[j][3] * 255.0f + 0.5f) << 24); \
-                if (bQueue) { if (voffB[j] != (int)bytes) acc_ring[((uint32_t)voffB[j] / 4u - base_px) % RING] = px_; } \
-                else pfx_buffer_store_i32((int)px_, rs_dst, voffB[j], 0, 0); \
-            } \
-            if (bQueue) wave_lds_sync(); \
-        } \
-        inflight -= 1u; }
-
-    for (;;) {
-        // ---- refill the lookahead item ----
-        while (nKind == 0u) {
-            const uint32_t q_cnt = q_tail - q_head;
-            if (q_cnt >= UPX) {
-                nKind = 2u; nA = q_head; nM = UPX; nLb = q_start; nLe = q_r; q_head += UPX;
-                st_rounds += 1u; st_rpx += UPX; st_rlay += nLe - nLb;
-                break;
-            }
-            if (nat_next < cls_next) {
-                const uint32_t slot = nat_next % NREC;
-                const uint32_t need = __builtin_amdgcn_readfirstlane(rec[slot][1]);
-                if (need <= q_head) {
-                    nKind = 1u; nA = nat_next; nLb = __builtin_amdgcn_readfirstlane(rec[slot][0]); nLe = n_layers; nat_next += 1u;
-                    st_nlay += nLe - nLb;
-                    break;
-                }
-            }
-            if (cls_next < nu && cls_next - nat_init < R) {
-                // ---- classify unit cls_next (its topmost candidate's alpha is in aP) ----
-                const uint32_t u = cls_next;
-                const uint32_t o0 = u * UPX + lane;
-                uint32_t cls[PX];
-                bool all_found = true;
-#pragma unroll
-                for (int j = 0; j < PX; ++j) {
-                    const bool hit = C.kind[top_c] ? (aP[j] == 1.0f) : (aP[j] != 0.0f);
-                    cls[j] = hit ? C.n : 0u;
-                    all_found = all_found && hit;
-                }
-                st_reads += 1u;
-                bool done = __all(all_found);
-#pragma unroll
-                for (int i = 2; i >= 0; --i) {
-                    if ((uint32_t)i < top_c && !done) {
-                        const pfx_v4i ra = make_rsrc(layers[C.layer[i]].pixels, bytes, PFX_RSRC_ALPHA8);
-                        all_found = true;
-#pragma unroll
-                        for (int j = 0; j < PX; ++j) {
-                            const float a = pfx_buffer_load_format_f32(ra, (int)((base_px + o0 + 64u * j) * 4u), 0, 0);
-                            const bool hit = C.kind[i] ? (a == 1.0f) : (a != 0.0f);
-                            cls[j] = (cls[j] == 0u && hit) ? (uint32_t)(i + 1) : cls[j];
-                            all_found = all_found && cls[j] != 0u;
-                        }
-                        done = __all(all_found);
-                        st_reads += 1u;
-                    }
-                }
-                if (u + 1u < nu) { // request the next unit's alpha now: it lands while the items decided below run
-                    const pfx_v4i ra = make_rsrc(layers[C.layer[top_c]].pixels, bytes, PFX_RSRC_ALPHA8);
-#pragma unroll
-                    for (int j = 0; j < PX; ++j) aP[j] = pfx_buffer_load_format_f32(ra, (int)((base_px + o0 + UPX + 64u * j) * 4u), 0, 0);
-                }
-                uint32_t cnt[5] = {UPX, 0u, 0u, 0u, 0u};
-#pragma unroll
-                for (int i = 1; i <= 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < PX; ++j) cnt[i] += (uint32_t)__popcll(__ballot(cls[j] >= (uint32_t)i));
-                uint32_t cmin = 0;
-#pragma unroll
-                for (int i = 1; i <= 4; ++i) if (cnt[i] == UPX) cmin = (uint32_t)i;
-                const uint32_t lay[5] = {0u, C.layer[0], C.layer[1], C.layer[2], C.layer[3]};
-                uint32_t s_u = 0;
-#pragma unroll
-                for (int i = 1; i <= 4; ++i) if (cmin == (uint32_t)i) s_u = lay[i];
-                uint32_t best = 0, best_sav = 0, r = s_u;
-#pragma unroll
-                for (int i = 1; i <= 4; ++i) {
-                    if ((uint32_t)i > cmin && (uint32_t)i <= C.n && cnt[i] * 10u >= UPX * 3u) {
-                        const uint32_t sav = cnt[i] * (lay[i] - s_u);
-                        if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; }
-                    }
-                }
-                if (best != 0u && q_cnt != 0u && q_r != r) { best = 0u; r = s_u; } // one split layer in the queue at a time
-#pragma unroll
-                for (int j = 0; j < PX; ++j) acc_ring[(o0 + 64u * j) % RING] = 0u;  // the reference's initial accumulator, :573
-                if (best != 0u) {
-                    st_cunits += 1u;
-                    if (q_cnt == 0u) q_start = s_u; else q_start = min(q_start, s_u);
-                    q_r = r;
-#pragma unroll
-                    for (int j = 0; j < PX; ++j) {
-                        const bool early = cls[j] < best;
-                        const uint64_t m = __ballot(early);
-                        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (early) q[(q_tail + pre) % QCAP] = (uint16_t)(o0 + 64u * j);
-                        q_tail += (uint32_t)__popcll(m);
-                    }
-                }
-                if (lane == 0) { rec[u % NREC][0] = r; rec[u % NREC][1] = best != 0u ? q_tail : 0u; }
-                wave_lds_sync();
-                cls_next = u + 1u;
-                continue;
-            }
-            if (q_cnt > 0u && !(cls_next < nu && nat_init < nat_next)) {
-                // partial round: the stream has ended, or the ring is full and nothing in flight will free it
-                nKind = 2u; nA = q_head; nM = q_cnt; nLb = q_start; nLe = q_r; q_head += q_cnt;
-                st_rounds += 1u; st_rpx += q_cnt; st_rlay += nLe - nLb;
-            }
-            break;
-        }
-        if (nKind == 0u && fL == fE && inflight == 0u) break; // nothing decided, requested or pending: the stream is done
-        PFX_FETCHPOS(tC, mC, oC)
-        PFX_BLENDPOS(tA, mA, oA)
-        PFX_FETCHPOS(tA, mA, oA)
-        PFX_BLENDPOS(tB, mB, oB)
-        PFX_FETCHPOS(tB, mB, oB)
-        PFX_BLENDPOS(tC, mC, oC)
-    }
-#undef PFX_FETCHPOS
-#undef PFX_BLENDPOS
-    if (lane == 0 && (C.stats & 1u)) {
-        atomicAdd(&g_dle_stats[0], st_rounds); atomicAdd(&g_dle_stats[1], st_rpx); atomicAdd(&g_dle_stats[2], st_rlay);
-        atomicAdd(&g_dle_stats[3], nat_next); atomicAdd(&g_dle_stats[4], st_nlay); atomicAdd(&g_dle_stats[5], st_reads);
-        atomicAdd(&g_dle_stats[6], st_cunits); atomicAdd(&g_dle_stats[7], st_bubbles);
-    }
-}
-
-int g_dle_stats_on = 0, g_dle_cfg = 0;
+int g_dle_stats_on = 0, g_dle_cfg = 0, g_dle_sched = 1, g_dle_fracA = 75, g_dle_fracB = 20;
 int g_dle_units = 0; // tuning knobs (pfxk_flatten_set_dle): units per wave (0 = default), log2 of the accumulator ring
 int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant): 0 = shipped, 1-5 = PX / occupancy variants, +10 = grid-stride launch, 9 = the general kernel
 
@@ -938,6 +708,12 @@ extern "C" void pfxk_flatten_set_dle_dev(int stats_on, int cfg)
     if (stats_on >= 0) g_dle_stats_on = stats_on;
     if (cfg >= 0) g_dle_cfg = cfg;
 }
+extern "C" void pfxk_flatten_set_dle_sched(int sched, int fracA, int fracB)
+{
+    if (sched >= 0) g_dle_sched = sched;
+    if (fracA >= 0 && fracA <= 100) g_dle_fracA = fracA;
+    if (fracB >= 0 && fracB <= 100 - g_dle_fracA) g_dle_fracB = fracB;
+}
 extern "C" hipError_t pfxk_round_pack_check(hipStream_t s, unsigned long long* d_out)
 {
     round_pack_check_kernel<<<4096, 256, 0, s>>>(d_out);
@@ -1004,30 +780,33 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
         };
         // dead-layer elimination when the stack holds a reset layer above the bottom one (variant 8 switches it off)
         if (cands && cands->n > 0 && g_flatten_variant != 8) {
-            // g_dle_cfg: 0 flow PX3 | 1 flow PX2 (ring 512) | 2 item PX3 | 3 item PX2 (ring 512) | 4 flow PX2 (ring 1024) | 5 flow PX3 (ring 2048)
-            const uint32_t px = (g_dle_cfg == 1 || g_dle_cfg == 3 || g_dle_cfg == 4 || g_dle_cfg == 6 || g_dle_cfg == 13) ? 2u : 3u;
+            // g_dle_cfg: 0 = 2 pixels per lane (8 waves per SIMD), 1 = 3 pixels per lane; g_dle_sched 0 = equal streams of g_dle_units
+            const uint32_t px = g_dle_cfg == 1 ? 3u : 2u;
             const uint32_t upx = 64u * px;
             const uint32_t units = (uint32_t)((n_px + upx - 1) / upx);
-            uint32_t U = g_dle_units > 0 ? (uint32_t)g_dle_units : 12u;
-            if (U * upx > 65535u) U = 65535u / upx; // queue entries are 16-bit pixel offsets
-            const uint32_t waves = (units + U - 1) / U;
+            const uint32_t umax = 65535u / upx; // queue entries are 16-bit pixel offsets
+            dle_sched SC{};
+            if (g_dle_sched == 0) {
+                SC.UA = SC.UB = SC.UC = std::min(g_dle_units > 0 ? (uint32_t)g_dle_units : 8u, umax);
+                SC.wavesA = (units + SC.UA - 1) / SC.UA;
+            } else {
+                // the long streams fill the chip about once (256 CUs x 24 waves): measured best (profiles/r03_tuning.md)
+                const uint32_t ua_auto = std::max(((uint32_t)((uint64_t)units * (uint32_t)g_dle_fracA / 100u) + 6143u) / 6144u, 4u);
+                SC.UA = std::min(g_dle_units > 0 ? (uint32_t)g_dle_units : ua_auto, umax);
+                SC.UB = std::max(SC.UA / 4u, 1u);
+                SC.UC = 1u;
+                SC.wavesA = (uint32_t)((uint64_t)units * (uint32_t)g_dle_fracA / 100u) / SC.UA;
+                SC.wavesB = (uint32_t)((uint64_t)units * (uint32_t)g_dle_fracB / 100u) / SC.UB;
+            }
+            const uint32_t rest = units - std::min(units, SC.wavesA * SC.UA + SC.wavesB * SC.UB);
+            const uint32_t waves = SC.wavesA + SC.wavesB + (rest + SC.UC - 1) / SC.UC;
             pfxk_dle_cands C = *cands;
             C.stats = (uint32_t)g_dle_stats_on;
-            // one wave per workgroup (+10: four): a wave's stream is independent of its neighbours', and a 4-wave workgroup holds its
-            // LDS and wave slots until its slowest stream ends
-#define PFX_ARGS(WPB) <<<(waves + WPB - 1) / WPB, 64 * WPB, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, U)
-            switch (g_dle_cfg) {
-            case 1: flatten_flow_kernel<2, 9, 1> PFX_ARGS(1); break;
-            case 2: flatten_dle_kernel<3, 10, 1> PFX_ARGS(1); break;
-            case 3: flatten_dle_kernel<2, 9, 1> PFX_ARGS(1); break;
-            case 4: flatten_flow_kernel<2, 10, 1> PFX_ARGS(1); break;
-            case 5: flatten_flow_kernel<3, 11, 1> PFX_ARGS(1); break;
-            case 6: flatten_dle_kernel<2, 9, 1, 4> PFX_ARGS(1); break;
-            case 7: flatten_dle_kernel<3, 10, 1, 4> PFX_ARGS(1); break;
-            case 12: flatten_dle_kernel<3, 10, 4> PFX_ARGS(4); break;
-            case 13: flatten_dle_kernel<2, 9, 4> PFX_ARGS(4); break;
-            default: flatten_flow_kernel<3, 10, 1> PFX_ARGS(1); break;
-            }
+            // one wave per workgroup: a wave's stream is independent of its neighbours' (no barrier, private LDS slice), and a 4-wave
+            // workgroup would hold its LDS and wave slots until its slowest stream ends
+#define PFX_ARGS <<<waves, 64, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, SC)
+            if (g_dle_cfg == 1) flatten_dle_kernel<3, 10, 1> PFX_ARGS;
+            else flatten_dle_kernel<2, 9, 1> PFX_ARGS;
 #undef PFX_ARGS
             return hipGetLastError();
         }

@@ -56,6 +56,7 @@ hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uin
 void       pfxk_flatten_set_dle(int units_per_wave /* 0 = default, < 0 = keep */, int ring_log2 /* 10 | 11, else keep */);
 hipError_t pfxk_flatten_dle_stats(unsigned long long* out8 /* may be NULL */, int reset); // synchronises the device
 void       pfxk_flatten_set_dle_dev(int stats_on /* < 0 keep */, int cfg /* < 0 keep */);
+void       pfxk_flatten_set_dle_sched(int sched /* 0 equal streams, 1 shrinking */, int fracA, int fracB); // < 0 keeps
 void       pfxk_flatten_set_variant(int v); // tuning knob: 0 = shipped kernel, 1.. = experimental pixels-per-lane / occupancy variants
 // counts (into *d_out) operand pairs for which the shared-reciprocal division differs from the IEEE divide
 hipError_t pfxk_rdiv_check(hipStream_t s, uint64_t seed, uint32_t blocks, uint32_t iters, unsigned long long* d_out);

@@ -48,13 +48,15 @@ def blocky_alpha(rng, h, w, cell, p_zero, p_opaque):
     return np.kron(coarse, np.ones((cell, cell), np.uint8))[:h, :w]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5], autouse=True)
+@pytest.fixture(params=[(0, 1), (1, 1), (0, 0), (1, 0)], ids=["px2-shrinking", "px3-shrinking", "px2-equal", "px3-equal"], autouse=True)
 def every_kernel_configuration(request, gpu):
-    """every test of this file runs on every elimination kernel the library carries (pfx_tune "dle_cfg": pixels per lane, ring depth,
-    continuously prefetched or item-by-item load stream)"""
-    gpu.r.tune("dle_cfg", request.param)
+    """every test of this file runs on both instantiations of the elimination kernel (pfx_tune "dle_cfg": 2 or 3 pixels per lane) and
+    both stream schedules ("dle_sched": equal streams, or streams that shrink towards the end of the launch)"""
+    gpu.r.tune("dle_cfg", request.param[0])
+    gpu.r.tune("dle_sched", request.param[1])
     yield request.param
     gpu.r.tune("dle_cfg", 0)
+    gpu.r.tune("dle_sched", 1)
 
 
 @pytest.mark.parametrize("units", [0, 1, 2, 5, 340])
