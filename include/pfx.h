@@ -361,6 +361,11 @@ int pfx_tiled_roundtrip(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t
 int pfx_chunk_populated(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* populated);
 
 /* ================= device-resident tier (`_dev`): same kernels, caller-owned device memory, asynchronous ========= */
+/* Aliasing: `src_dev == dst_dev` (in place) is accepted by the pointwise calls (pfx_adjust_dev, pfx_lut_apply-style ops) and by
+ * pfx_gaussian_blur_dev / pfx_box_blur_dev, which then run their two-pass kernels through `tmp_dev` — for the Gaussian that is the
+ * f32 path, so an in-place call can differ from an out-of-place one by the +-1 LSB of the default (MFMA) mode unless the context is
+ * in exact mode.  Every other call that reads a neighbourhood or gathers (median, pixelate, warps, the effect bank) returns
+ * PFX_ERR_INVALID when the two images overlap; partially overlapping buffers are always refused. */
 int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev /* may be NULL */,
                     const pfx_layer_info* layers, uint32_t n_layers, uint32_t w, uint32_t h, void* dst_dev);
 int pfx_flatten_preview_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev, const pfx_layer_info* layers,

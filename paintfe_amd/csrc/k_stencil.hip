@@ -297,13 +297,13 @@ __global__ __launch_bounds__(256) void pixelate_kernel(const uint32_t* __restric
 int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
 extern "C" void pfxk_box_set_two_pass(int on) { g_box_two_pass = on; }
 extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst,
-                                    const uint8_t* d_mask, int radius, uint32_t w, uint32_t h)
+                                    const uint8_t* d_mask, int radius, uint32_t w, uint32_t h, int force_two_pass)
 {
     if (w == 0 || h == 0) return hipSuccess;
     const uint32_t d = (uint32_t)(2 * radius + 1);
     if (d >= 4096u) return hipErrorInvalidValue;
     const uint32_t magic = (uint32_t)((0x100000000ull / d) + 1ull), half = d / 2u;
-    if (radius <= BF_MAXR && g_box_two_pass == 0) { // small radii: both passes in one kernel (the halo recomputation stays below 1.6x)
+    if (radius <= BF_MAXR && g_box_two_pass == 0 && !force_two_pass && d_src != d_dst) { // small radii: both passes in one kernel (the halo recomputation stays below 1.6x)
         const int side = BF_T + 2 * radius;
         const size_t lds = (size_t)(side * side + side * BF_T) * 4;
         hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -37,6 +37,22 @@ int check_img(pfx_ctx* ctx, const void* src, const void* dst, uint32_t w, uint32
     return pfx_use(ctx);
 }
 
+// Aliasing rule of the `_dev` entry points (include/pfx.h): src == dst is allowed where the header says so; buffers that overlap in
+// any other way, or at all for a neighbourhood operation, are refused — a kernel that reads a halo while other workgroups write the
+// same memory would race silently.
+bool ranges_overlap(const void* a, const void* b, size_t bytes)
+{
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return x < y + bytes && y < x + bytes;
+}
+int check_disjoint(pfx_ctx* ctx, const void* src, const void* dst, uint32_t w, uint32_t h, const char* who, bool same_ok = false)
+{
+    if (src == dst) return same_ok ? PFX_OK : pfx_fail(ctx, PFX_ERR_INVALID, "%s: src and dst must be different buffers", who);
+    if (ranges_overlap(src, dst, (size_t)w * h * 4))
+        return pfx_fail(ctx, PFX_ERR_INVALID, "%s: src and dst overlap", who);
+    return PFX_OK;
+}
+
 // stage host src (+ optional mask) into the context's device buffers
 int stage_in(pfx_ctx* ctx, const uint8_t* src, const uint8_t* mask, uint32_t w, uint32_t h, const void** d_mask)
 {
@@ -310,6 +326,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
                                uint32_t first_row)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_gaussian_blur_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_gaussian_blur_dev", true)); // in place: the two-pass kernels (through tmp)
     // radius first: a huge sigma must be refused before a tap array of that size is built (the C ABI must not throw)
     const int radius = pfx_host_gaussian_radius(sigma);
     if (radius > pfxk_gauss_max_radius())
@@ -317,7 +334,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
     uint32_t sigma_bits; std::memcpy(&sigma_bits, &sigma, 4);
     if (!ctx->exact && radius >= 1 && radius <= pfxk_gauss_mfma_max_radius() && src_dev != dst_dev) {
         // default mode: fused H+V on the matrix cores, no intermediate in HBM, no scratch (k_gauss.hip:gauss_strip_kernel)
-        if (ctx->wsplit_sigma_bits != sigma_bits) {
+        if (!ctx->wsplit_valid || ctx->wsplit_sigma_bits != sigma_bits) {
             std::vector<float> k;
             pfx_host_gaussian_kernel(sigma, k);
             std::vector<uint16_t> ws;
@@ -325,6 +342,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
             PFX_TRY(pfx_reserve(ctx, ctx->d_wsplit, ws.size() * sizeof(uint16_t)));
             PFX_TRY(pfx_h2d(ctx, ctx->d_wsplit.p, ws.data(), ws.size() * sizeof(uint16_t)));
             ctx->wsplit_sigma_bits = sigma_bits;
+            ctx->wsplit_valid = true;
         }
         pfx_timer t(ctx, "gauss_mfma");
         PFX_HIP(ctx, pfxk_gauss_mfma(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint16_t*)ctx->d_wsplit.p,
@@ -332,7 +350,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
         return PFX_OK;
     }
     const int pad = pfxk_gauss_weight_pad(); // zero taps on both sides: the kernels' register blocking reads past the ends
-    if (ctx->wts_sigma_bits != sigma_bits) {
+    if (!ctx->wts_valid || ctx->wts_sigma_bits != sigma_bits) {
         std::vector<float> k;
         pfx_host_gaussian_kernel(sigma, k);
         std::vector<float> padded(k.size() + 2 * (size_t)pad, 0.0f);
@@ -340,6 +358,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
         PFX_TRY(pfx_reserve(ctx, ctx->d_wts, padded.size() * sizeof(float)));
         PFX_TRY(pfx_h2d(ctx, ctx->d_wts.p, padded.data(), padded.size() * sizeof(float)));
         ctx->wts_sigma_bits = sigma_bits;
+        ctx->wts_valid = true;
     }
     if (!tmp_dev) {
         PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 16));
@@ -361,6 +380,7 @@ int pfx_box_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t 
                      const void* mask_dev, void* tmp_dev)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_box_blur_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_box_blur_dev", true));
     if (radius < 0.5f) { // blur.rs:234: returns flat.clone()
         PFX_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, img_bytes(w, h), hipMemcpyDeviceToDevice, ctx->stream));
         return PFX_OK;
@@ -372,14 +392,17 @@ int pfx_box_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t 
         tmp_dev = ctx->st_tmp.p;
     }
     pfx_timer t(ctx, "box_blur");
+    // in place: the two-pass path (H into tmp, V reads tmp and only its own pixel of src); the fused kernel stages a halo tile from src
+    // while neighbouring workgroups write dst
     PFX_HIP(ctx, pfxk_box_blur(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)tmp_dev, (uint8_t*)dst_dev,
-                               (const uint8_t*)mask_dev, (int)rc, w, h));
+                               (const uint8_t*)mask_dev, (int)rc, w, h, src_dev == dst_dev ? 1 : 0));
     return PFX_OK;
 }
 
 int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius, const void* mask_dev)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_median_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_median_dev"));
     const uint32_t r = std::max(radius, 1u); // noise.rs:364
     if (r > PFX_MEDIAN_MAX_RADIUS) return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "median radius %u > %d", r, PFX_MEDIAN_MAX_RADIUS);
     pfx_timer t(ctx, "median");
@@ -390,6 +413,7 @@ int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w,
 int pfx_pixelate_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t block_size, const void* mask_dev)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_pixelate_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_pixelate_dev"));
     pfx_timer t(ctx, "pixelate");
     PFX_HIP(ctx, pfxk_pixelate(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint8_t*)mask_dev,
                                std::max(block_size, 2u), w, h)); // distort.rs:334
@@ -454,6 +478,7 @@ int pfx_warp_displacement_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, ui
                               uint32_t h, void* dst_dev)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_warp_displacement_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_warp_displacement_dev"));
     PFX_REQUIRE(ctx, disp_dev && sw && sh, "pfx_warp_displacement_dev: bad arguments");
     pfx_timer t(ctx, "warp_displacement");
     PFX_HIP(ctx, pfxk_warp_displacement(ctx->stream, (const uint8_t*)src_dev, sw, sh, (const float*)disp_dev, w, h, (uint8_t*)dst_dev));
@@ -529,6 +554,7 @@ int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float
                                   uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, void* dst_dev)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_warp_mesh_catmull_rom_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_warp_mesh_catmull_rom_dev"));
     const float *d_orig, *d_def;
     PFX_TRY(upload_points(ctx, orig_pts_xy, deformed_pts_xy, cols, rows, &d_orig, &d_def));
     pfx_timer t(ctx, "warp_mesh");

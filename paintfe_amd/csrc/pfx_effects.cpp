@@ -13,6 +13,10 @@ int check2(pfx_ctx* ctx, const void* a, const void* b, uint32_t w, uint32_t h, c
     if (!ctx) return PFX_ERR_INVALID;
     if (!a || !b) return pfx_fail(ctx, PFX_ERR_INVALID, "%s: null image pointer", who);
     if (w == 0 || h == 0 || (uint64_t)w * h > 256000000ull) return pfx_fail(ctx, PFX_ERR_INVALID, "%s: bad image size %ux%u", who, w, h);
+    // the effect kernels read neighbourhoods / gather from src while other workgroups write dst: the buffers must not overlap (pfx.h)
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    const size_t bytes = (size_t)w * h * 4;
+    if (x < y + bytes && y < x + bytes) return pfx_fail(ctx, PFX_ERR_INVALID, "%s: src and dst overlap", who);
     return pfx_use(ctx);
 }
 

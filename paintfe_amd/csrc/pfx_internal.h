@@ -48,7 +48,8 @@ struct pfx_ctx {
     std::vector<pfx_timing_rec> timings;
     int n_cus = 0;                  // multiProcessorCount of `device` (persistent-kernel grids)
     // Gaussian tap weights currently resident in d_wts / d_wsplit (re-uploaded only when sigma changes)
-    uint32_t wts_sigma_bits = 0xffffffffu, wsplit_sigma_bits = 0xffffffffu;
+    uint32_t wts_sigma_bits = 0, wsplit_sigma_bits = 0;
+    bool wts_valid = false, wsplit_valid = false; // explicit flags: every 32-bit pattern is some sigma (0xffffffff is a NaN)
     float wsplit_inv_scale = 1.0f, wsplit_bias = 0.0f;
     pfx_devbuf d_wsplit;
     // GpuLiquifyPipeline's cached source texture (ref: src/gpu/compute/liquify.rs:166-176); 0 x 0 = none / invalidated
