@@ -80,7 +80,9 @@ def pmc_profile(w: int, h: int, n: int):
     if not files:
         return None
     try:
-        return json.load(open(files[-1]))
+        d = json.load(open(files[-1]))
+        d["_file"] = os.path.relpath(files[-1], ROOT)
+        return d
     except Exception:
         return None
 
@@ -106,6 +108,141 @@ def usable_cores() -> int:
 
 
 PCIE_GEN5_X16_GBS = 63.0  # guides/MI355X_MICROARCH.md: host link, spec, per direction
+BATCH_MAX_LSB, BATCH_FRAC = 8, 1e-3  # parity gate of the S4 pipeline in the default Gaussian mode (derivation: tests/test_gpu_batch.py)
+PREWARM = 25  # untimed steps in front of the --warmup steps: the clock needs ~30 ms of load to settle (20 steps are 33 ms)
+
+
+def s4_inputs(w, h, n_pool=4):
+    """S4 generator: a pool of uniform-random images and three overlays with S2's alpha distribution"""
+    rng = np.random.default_rng(0x5EED0004)
+    pool = [rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) for _ in range(n_pool)]
+    overlays = []
+    for k in range(3):
+        o = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        sel = rng.integers(0, 4, size=(h, w))
+        o[..., 3] = np.where(sel == 0, 0, np.where(sel == 1, 255, o[..., 3]))
+        overlays.append(o)
+    return pool, overlays, [1, 2, 8]
+
+
+def s4_check(O, src, overlays, modes, got, exact):
+    """oracle pipeline on one image: (ok, {max_abs_diff, channels_differing})"""
+    blur = O.gaussian_blur(src, 4.0)
+    hsl = O.adjust(blur, "hsl", (30.0, -20.0, 10.0))
+    ref = O.flatten_stack(np.stack([hsl] + overlays), np.array([0] + modes, np.uint8), np.ones(4, np.float32))
+    d = np.abs(ref.astype(np.int16) - got.astype(np.int16))
+    dmax, frac = int(d.max()), float((d > 0).mean())
+    ok = (dmax == 0) if exact else (dmax <= BATCH_MAX_LSB and frac <= BATCH_FRAC)
+    return ok, {"max_abs_diff": dmax, "channels_differing": round(frac, 7), "gate": "bit-exact" if exact else f"max <= {BATCH_MAX_LSB}, fraction <= {BATCH_FRAC}"}
+
+
+def other_configs(args, torch, r, device, O, flat, blurred):
+    """The other BASELINE.json configurations on the same box, after the headline: each with the mean HIP-event kernel time, its
+    algorithmic HBM bytes, the fraction of the 8 TB/s roofline and an oracle check.  Returns (dict, failed_checks)."""
+    from tests import inputs as I
+    w, h = W8K, H8K
+    px = w * h
+    out, failed = {}, []
+
+    def kernel_ms(names, fn, iters, warm=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(); r.timing_reset(); r.timing_enable(True)
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(); r.timing_enable(False)
+        return {n: r.timing_read(n)[0] / max(r.timing_read(n)[1], 1) for n in names if r.timing_read(n)[1]}
+
+    def entry(ms, alg_bytes, **kw):
+        return {"ms": round(ms, 4), "alg_bytes": int(alg_bytes), "GBs": round(alg_bytes / ms / 1e6, 1), "frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), **kw}
+
+    # ---- config 2: 8K Gaussian sigma=16 + HSL(30, -20, 10) on the flattened frame; 8 + 8 algorithmic bytes per pixel ----
+    hsl = torch.empty_like(flat)
+    hp = (30.0, -20.0, 10.0)
+    rad = int(np.ceil(np.float32(SIGMA) * np.float32(3.0)))
+    y0, x0, wh, ww = 1000, 2000, 256, 512
+    win = flat[y0 - rad:y0 + wh + rad, x0 - rad:x0 + ww + rad].contiguous().cpu().numpy()
+    ref_blur = O.gaussian_blur(win, SIGMA)[rad:-rad, rad:-rad]
+
+    def c2():
+        r.gaussian_blur_dev(flat.data_ptr(), blurred.data_ptr(), w, h, SIGMA)
+        r.adjust_dev(blurred.data_ptr(), hsl.data_ptr(), w, h, "hsl", hp)
+    k = kernel_ms(("gauss_mfma", "adjust"), c2, 20)
+    got_blur = blurred[y0:y0 + wh, x0:x0 + ww].contiguous().cpu().numpy()
+    got_hsl = hsl[y0:y0 + wh, x0:x0 + ww].contiguous().cpu().numpy()
+    dmax = int(np.abs(ref_blur.astype(np.int16) - got_blur.astype(np.int16)).max())
+    hsl_ok = bool(np.array_equal(O.adjust(got_blur, "hsl", hp), got_hsl))
+    ms2 = k.get("gauss_mfma", 0.0) + k.get("adjust", 0.0)
+    out["config2_gaussian16_hsl_8k"] = entry(ms2, 16 * px, kernel_ms={n: round(v, 4) for n, v in k.items()},
+                                             gaussian_mode="f16-split MFMA, f32 accumulate (+-1 LSB class)",
+                                             check={"gaussian_window_max_diff_vs_oracle": dmax, "hsl_window_bitexact_on_the_gpu_blur": hsl_ok})
+    if dmax > 1: failed.append("config2_gaussian")
+    if not hsl_ok: failed.append("config2_hsl")
+    # the bit-exact Gaussian mode beside it (f32 VALU passes, intermediate in HBM: 8 + 32 bytes per pixel of traffic)
+    r.set_exact(True)
+    try:
+        k = kernel_ms(("gauss_h", "gauss_v"), lambda: r.gaussian_blur_dev(flat.data_ptr(), blurred.data_ptr(), w, h, SIGMA), 10, warm=3)
+        got = blurred[y0:y0 + wh, x0:x0 + ww].contiguous().cpu().numpy()
+    finally:
+        r.set_exact(False)
+    ex_ok = bool(np.array_equal(ref_blur, got))
+    out["config2_gaussian16_exact_mode_8k"] = entry(k.get("gauss_h", 0.0) + k.get("gauss_v", 0.0), 8 * px, kernel_ms={n: round(v, 4) for n, v in k.items()},
+                                                    check={"window_bitexact_vs_oracle": ex_ok})
+    if not ex_ok: failed.append("config2_exact_gaussian")
+    del hsl
+
+    # ---- config 4: 16K (15360 x 8640) fused 6x6 Catmull-Rom mesh warp (8 B/px) and Liquify displacement resample (16 B/px) ----
+    W16, H16 = 15360, 8640
+    g = torch.Generator(device=device); g.manual_seed(0x5EED0004)
+    img = torch.randint(0, 256, (H16, W16, 4), dtype=torch.uint8, device=device, generator=g)
+    dst = torch.empty_like(img)
+    orig, deformed = I.jittered_mesh(6, 6, W16, H16)
+    k = kernel_ms(("warp_mesh",), lambda: r.warp_mesh_catmull_rom_dev(img.data_ptr(), orig, deformed, 6, 6, W16, H16, dst.data_ptr()), 10, warm=3)
+    disp = torch.zeros((H16, W16, 2), dtype=torch.float32, device=device)
+    rng = np.random.default_rng(7)
+    dabs = [(int(rng.integers(0, 5)), float(rng.uniform(0, W16)), float(rng.uniform(0, H16)), float(rng.uniform(-40, 40)), float(rng.uniform(-40, 40)),
+             float(rng.uniform(200, 1500)), float(rng.uniform(0.2, 1.0))) for _ in range(48)]
+    r.displacement_brushes_dev(disp.data_ptr(), W16, H16, dabs)
+    k2 = kernel_ms(("warp_displacement",), lambda: r.warp_displacement_dev(img.data_ptr(), W16, H16, disp.data_ptr(), W16, H16, dst.data_ptr()), 10, warm=3)
+    # oracle check on a 2048 x 1152 document (the same kernels; the whole-frame 16K comparison is tests/test_gpu_fullsize.py)
+    cw, ch = 2048, 1152
+    small = img[:ch, :cw].contiguous()
+    sdst = torch.empty_like(small)
+    so, sd = I.jittered_mesh(6, 6, cw, ch)
+    r.warp_mesh_catmull_rom_dev(small.data_ptr(), so, sd, 6, 6, cw, ch, sdst.data_ptr())
+    torch.cuda.synchronize()
+    mesh_ok = bool(np.array_equal(O.warp_mesh_catmull_rom(small.cpu().numpy(), so, sd, 6, 6), sdst.cpu().numpy()))
+    sdisp = torch.zeros((ch, cw, 2), dtype=torch.float32, device=device)
+    r.displacement_brushes_dev(sdisp.data_ptr(), cw, ch, [(d[0], d[1] * cw / W16, d[2] * ch / H16, d[3], d[4], d[5] * cw / W16, d[6]) for d in dabs])
+    r.warp_displacement_dev(small.data_ptr(), cw, ch, sdisp.data_ptr(), cw, ch, sdst.data_ptr())
+    torch.cuda.synchronize()
+    liq_ok = bool(np.array_equal(O.warp_displacement(small.cpu().numpy(), sdisp.cpu().numpy()), sdst.cpu().numpy()))
+    out["config4_mesh_warp_16k"] = entry(k.get("warp_mesh", 0.0), 8 * W16 * H16, check={"2048x1152_whole_frame_bitexact_vs_oracle": mesh_ok})
+    out["config4_liquify_16k"] = entry(k2.get("warp_displacement", 0.0), 16 * W16 * H16, check={"2048x1152_whole_frame_bitexact_vs_oracle": liq_ok})
+    if not mesh_ok: failed.append("config4_mesh_warp")
+    if not liq_ok: failed.append("config4_liquify")
+    del img, dst, disp, small, sdst, sdisp
+    torch.cuda.empty_cache()
+
+    # ---- config 5, a 64-image slice on this GPU: 3840 x 2160 images streamed over PCIe (Gaussian 4 -> HSL -> flatten under 3 overlays) ----
+    from paintfe_amd.batch import run_batch
+    w4, h4 = 3840, 2160
+    pool, overlays, modes = s4_inputs(w4, h4)
+    dev_index = device.index or 0
+    run_batch([dev_index], 8, pool, overlays, modes, sigma=4.0, slots=args.slots)
+    res = run_batch([dev_index], 64, pool, overlays, modes, sigma=4.0, slots=args.slots, keep=[0])
+    ok, chk = s4_check(O, pool[0], overlays, modes, res["kept"][0], exact=False)
+    res_x = run_batch([dev_index], 4, pool, overlays, modes, sigma=4.0, slots=args.slots, keep=[1], exact=True)
+    ok_x, chk_x = s4_check(O, pool[1], overlays, modes, res_x["kept"][1], exact=True)
+    gbs = res["images_per_s"] * w4 * h4 * 4 / 1e9
+    out["config5_batch_4k_slice"] = {"images": 64, "images_per_s": round(res["images_per_s"], 1), "mpixels_per_s": round(res["images_per_s"] * w4 * h4 / 1e6, 1),
+                                     "resident_kernel_ms_per_image": round(res["kernel_ms_per_image"], 4), "alg_bytes_per_image": 36 * w4 * h4,
+                                     "bound": "pcie", "GBs_each_direction": round(gbs, 2), "frac": round(gbs / PCIE_GEN5_X16_GBS, 3),
+                                     "frac_of": f"PCIe Gen5 x16, {PCIE_GEN5_X16_GBS:g} GB/s per direction",
+                                     "check": {"image0_vs_oracle": chk, "exact_gaussian_image1_vs_oracle": chk_x}}
+    if not ok: failed.append("config5_image0")
+    if not ok_x: failed.append("config5_exact_image1")
+    return out, failed
 
 
 def run_batch4k(args, torch, dist, rank, world, dev_index, device) -> int:
@@ -118,15 +255,7 @@ def run_batch4k(args, torch, dist, rank, world, dev_index, device) -> int:
     w, h = (3840, 2160) if (args.width, args.height) == (W8K, H8K) else (args.width, args.height)
     n_total = args.images
     mine = len(range(rank, n_total, world))
-    rng = np.random.default_rng(0x5EED0004)
-    pool = [rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) for _ in range(4)]  # S1 generator; the batch cycles a pool of 4
-    overlays = []
-    for k in range(3):
-        o = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
-        sel = rng.integers(0, 4, size=(h, w))
-        o[..., 3] = np.where(sel == 0, 0, np.where(sel == 1, 255, o[..., 3]))
-        overlays.append(o)
-    modes = [1, 2, 8]
+    pool, overlays, modes = s4_inputs(w, h)  # S1 images; the batch cycles a pool of 4
     run_batch([dev_index], min(8, max(mine, 1)), pool, overlays, modes, sigma=4.0, slots=args.slots)  # warm-up: clocks, allocator
     if world > 1:
         dist.barrier()
@@ -164,12 +293,9 @@ def run_batch4k(args, torch, dist, rank, world, dev_index, device) -> int:
     failed = []
     if rank == 0:
         from tests import oracle_lib as O
-        blur = O.gaussian_blur(pool[0], 4.0)
-        hsl = O.adjust(blur, "hsl", (30.0, -20.0, 10.0))
-        ref = O.flatten_stack(np.stack([hsl] + overlays), np.array([0] + modes, np.uint8), np.ones(4, np.float32))
-        frac = float((ref != res["kept"][0]).mean())
-        out["check"] = {"image0_channels_differing_from_oracle": round(frac, 6)}
-        if frac > 0.02:
+        ok, chk = s4_check(O, pool[0], overlays, modes, res["kept"][0], exact=False)
+        out["check"] = {"image0_vs_oracle": chk}
+        if not ok:
             failed.append("image0_vs_oracle")
             out["value"] = None
         print(json.dumps(out), flush=True)
@@ -198,6 +324,7 @@ def main() -> int:
     ap.add_argument("--images", type=int, default=1024, help="batch4k: images in the batch (whole job)")
     ap.add_argument("--slots", type=int, default=3, help="batch4k: buffer sets in the per-GPU upload / kernels / download pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the other BASELINE configurations (development runs)")
     ap.add_argument("--tune", action="append", default=[], help="key=value kernel tuning knob (development)")
     ap.add_argument("--exact", action="store_true", help="Gaussian without FMA contraction (bit-exact with the CPU path)")
     args = ap.parse_args()
@@ -240,23 +367,30 @@ def main() -> int:
     modes, opac = synth_params(n, 0x5EED0002)
     info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
 
+    state = {}
+
     def bracket():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     def timed(step_fn):
-        for _ in range(args.warmup):
+        for _ in range(PREWARM + args.warmup):
             step_fn()
         bracket()
         r.timing_reset()
         r.timing_enable(True)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # on the stream the kernels run on (set_stream above)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for k in range(args.steps):
             step_fn()
+            marks[k + 1].record()
         bracket()
         el = time.perf_counter() - t0
         r.timing_enable(False)
+        per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+        state["step_ms"] = {"min": round(per[0], 4), "median": round(per[len(per) // 2], 4), "max": round(per[-1], 4)}
         if world > 1:
             from paintfe_amd.sharding import max_over_ranks
             el = max_over_ranks(el, device=device)  # the step time of the job is the slowest rank's
@@ -267,7 +401,6 @@ def main() -> int:
                 kern[name] = (ms / cnt, cnt)
         return el, kern
 
-    state = {}
     doc_mode = None
     if band_mode:
         # ONE document for the whole job, cut into bands of whole chunk rows (pfx_band_rows): every rank generates the same layers
@@ -365,6 +498,10 @@ def main() -> int:
             except Exception:
                 pass
         roofline["per_kernel_bound"] = pmc.get("bounds")
+        # traffic / valu_* / per_kernel_bound come from a committed counter pass, not from this run (PMC collection needs rocprofv3 around
+        # the process): say so, and which build the pass profiled
+        roofline["static"] = {"fields": ["traffic", "valu_frac", "valu_insts_per_layer_px", "valu_frac_of_sustained_fma_rate", "per_kernel_bound"],
+                              "profile": pmc.get("_file"), "profiled_commit": pmc.get("commit"), "static": True}
 
     out = {"metric": "Mpixels/sec: 8K 32-layer flatten + Gaussian sigma=16; HBM GB/s vs peak", "value": round(value, 1),
            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -377,6 +514,7 @@ def main() -> int:
                       "sharding": ("ONE document in chunk-row bands: RCCL send/recv of %d halo rows before the blur%s" %
                                    (radius, "" if args.no_gather else ", all-gather of the result bands (asynchronous: it overlaps the next step's flatten)")) if band_mode else
                                   ("one independent document per GPU, no collective" if world > 1 else "single GPU")},
+           "step_ms_hip_events": state.get("step_ms"),
            "roofline": roofline}
     if doc_mode:
         out["doc_mode"] = doc_mode
@@ -454,6 +592,12 @@ def main() -> int:
                                    "faithful": {"value": round(sw * sh / ((t5 - t4) + (t3 - t2)) / 1e6, 2), "unit": "Mpixels/s", "cores": cores,
                                                 "what": f"same sample with the reference's collect + single-threaded put_pixel write-back "
                                                         f"(canvas_state.rs:686-695): flatten {t5 - t4:.2f}s + gaussian {t3 - t2:.2f}s"}}
+        if world == 1 and not band_mode and not args.headline_only and (w, h) == (W8K, H8K):
+            del stack
+            torch.cuda.empty_cache()
+            cfgs, cfg_failed = other_configs(args, torch, r, device, O, flat, blurred)
+            out["configs"] = cfgs
+            failed += cfg_failed
         if failed:  # a wrong-but-fast kernel must not be scored
             out["value"] = None
             out["failed_checks"] = failed

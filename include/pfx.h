@@ -654,6 +654,7 @@ typedef struct pfx_batch_params {
     uint32_t n_keep;
     const uint32_t* keep_indices;
     uint8_t* const* keep_out;
+    uint32_t exact_gaussian;              /* 1 = the bit-exact f32 Gaussian (pfx_ctx_set_exact): every kept result equals the CPU path exactly */
 } pfx_batch_params;
 typedef struct pfx_batch_stats {
     double   seconds;              /* first enqueue .. last result back on the host, slowest device */

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -39,8 +40,20 @@ struct worker_result {
     std::chrono::steady_clock::time_point t_begin, t_end; // first enqueue .. last result retired (setup excluded)
 };
 
+void run_device_body(int device, uint32_t rank, uint32_t world, uint32_t n_images, const pfx_batch_params& P, const uint8_t* const* pool,
+                     uint32_t n_pool, worker_result& R);
+
+// thread entry: no C++ exception may leave a worker thread (std::terminate) or the C ABI (include/pfx.h)
 void run_device(int device, uint32_t rank, uint32_t world, uint32_t n_images, const pfx_batch_params& P, const uint8_t* const* pool,
-                uint32_t n_pool, worker_result& R)
+                uint32_t n_pool, worker_result& R) noexcept
+{
+    try { run_device_body(device, rank, world, n_images, P, pool, n_pool, R); }
+    catch (const std::bad_alloc&) { R.status = PFX_ERR_OOM; try { R.err = "out of host memory in a batch worker"; } catch (...) {} }
+    catch (...) { R.status = PFX_ERR_HIP; try { R.err = "unexpected exception in a batch worker"; } catch (...) {} }
+}
+
+void run_device_body(int device, uint32_t rank, uint32_t world, uint32_t n_images, const pfx_batch_params& P, const uint8_t* const* pool,
+                     uint32_t n_pool, worker_result& R)
 {
     const size_t bytes = (size_t)P.w * P.h * 4;
     const uint32_t n_slots = P.slots >= 2 && P.slots <= 8 ? P.slots : 3;
@@ -54,6 +67,7 @@ void run_device(int device, uint32_t rank, uint32_t world, uint32_t n_images, co
 
     if (!hip(hipSetDevice(device), "hipSetDevice")) return;
     if (pfx_ctx_create(device, &ctx) != PFX_OK) fail(PFX_ERR_HIP, "pfx_ctx_create failed");
+    else if (P.exact_gaussian) (void)pfx_ctx_set_exact(ctx, 1);
     if (R.status == PFX_OK) {
         (void)(hip(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking), "hipStreamCreate") && hip(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking), "hipStreamCreate") &&
                hip(hipMalloc(&d_a, bytes), "hipMalloc") && hip(hipMalloc(&d_b, bytes), "hipMalloc"));
@@ -146,8 +160,21 @@ void run_device(int device, uint32_t rank, uint32_t world, uint32_t n_images, co
 
 } // namespace
 
+static int batch_pipeline_impl(const int* devices, uint32_t n_devices, uint32_t n_images, const pfx_batch_params* params,
+                               const uint8_t* const* image_pool_host, uint32_t n_pool, pfx_batch_stats* stats, char* err, size_t err_cap);
+
 extern "C" int pfx_batch_pipeline(const int* devices, uint32_t n_devices, uint32_t n_images, const pfx_batch_params* params,
                                   const uint8_t* const* image_pool_host, uint32_t n_pool, pfx_batch_stats* stats, char* err, size_t err_cap)
+{
+    auto say = [&](const char* m) { if (err && err_cap) { std::strncpy(err, m, err_cap - 1); err[err_cap - 1] = 0; } };
+    try { return batch_pipeline_impl(devices, n_devices, n_images, params, image_pool_host, n_pool, stats, err, err_cap); }
+    catch (const std::bad_alloc&) { say("out of host memory"); return PFX_ERR_OOM; }
+    catch (const std::system_error& e) { say(e.what()); return PFX_ERR_HIP; } // std::thread could not start
+    catch (...) { say("unexpected exception"); return PFX_ERR_HIP; }
+}
+
+static int batch_pipeline_impl(const int* devices, uint32_t n_devices, uint32_t n_images, const pfx_batch_params* params,
+                               const uint8_t* const* image_pool_host, uint32_t n_pool, pfx_batch_stats* stats, char* err, size_t err_cap)
 {
     auto say = [&](const std::string& m) { if (err && err_cap) { std::strncpy(err, m.c_str(), err_cap - 1); err[err_cap - 1] = 0; } };
     if (!devices || n_devices == 0 || n_devices > 64 || !params || !image_pool_host || n_pool == 0 || !stats) { say("bad arguments"); return PFX_ERR_INVALID; }
@@ -167,8 +194,16 @@ extern "C" int pfx_batch_pipeline(const int* devices, uint32_t n_devices, uint32
     }
     std::vector<worker_result> R(n_devices);
     std::vector<std::thread> th;
-    for (uint32_t d = 0; d < n_devices; ++d)
-        th.emplace_back(run_device, devices[d], d, n_devices, n_images, std::cref(P), image_pool_host, n_pool, std::ref(R[d]));
+    th.reserve(n_devices);
+    try {
+        for (uint32_t d = 0; d < n_devices; ++d)
+            th.emplace_back(run_device, devices[d], d, n_devices, n_images, std::cref(P), image_pool_host, n_pool, std::ref(R[d]));
+    } catch (...) { // a thread could not start: the ones that did must be joined before the exception travels on
+        for (auto& t : th) t.join();
+        for (uint32_t k = 0; k < n_pool; ++k)
+            if (registered[k]) (void)hipHostUnregister(const_cast<uint8_t*>(image_pool_host[k]));
+        throw;
+    }
     for (auto& t : th) t.join();
     for (uint32_t k = 0; k < n_pool; ++k)
         if (registered[k]) (void)hipHostUnregister(const_cast<uint8_t*>(image_pool_host[k]));

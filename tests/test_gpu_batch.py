@@ -1,5 +1,12 @@
 """pfx_batch_pipeline (BASELINE config 5's driver): a 16-image batch streamed through the pipeline slots must give, for every
-sampled image, exactly what the single calls give and what the oracle gives within the Gaussian's +-1 LSB."""
+sampled image, exactly what the single calls give; against the oracle it is BIT-EXACT with the exact Gaussian, and in the default
+(MFMA, +-1 LSB class) mode the few channels the Gaussian rounds differently stay within a small bound after HSL and three blends.
+
+The bound: the default Gaussian differs from the CPU path by at most 1 LSB on ~1e-4 of the channels (rounding noise of the f32 sum,
+tests/test_gpu_parity.py).  HSL(30, -20, 10) is piecewise linear in RGB with channel gains below 2 (hue rotation by 30 degrees mixes
+two channels with weights <= 1, saturation 0.8, lightness +10 %) and re-quantises (+1); Multiply and Screen have gain <= 1, Overlay
+<= 2, each re-quantising (+1).  A 1 LSB input step can therefore grow to at most (1 * 2 + 1) * 2 + 3 = 9; the gate holds it to
+MAX_LSB = 8 and to FRAC = 1e-3 of the channels (measured: max 3, fraction ~1e-5)."""
 import numpy as np
 import pytest
 
@@ -7,6 +14,8 @@ from tests import inputs as I
 from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
+
+MAX_LSB, FRAC = 8, 1e-3
 
 
 def _s4_inputs(w, h, n_pool, seed=0x5EED0004):
@@ -40,8 +49,25 @@ def test_batch_of_16_matches_oracle(n_members, slots):
         ref = O.flatten_stack(stack, np.array([0] + modes, np.uint8), np.ones(4, np.float32))
         got = res["kept"][idx]
         d = np.abs(ref.astype(np.int16) - got.astype(np.int16))
-        # the Gaussian's +-1 LSB can be amplified by HSL and by the blend functions of the overlays: bound the fraction instead of the size
-        assert (d > 0).mean() < 0.02, f"image {idx}: {(d > 0).mean():.4f} of the channels differ"
+        assert int(d.max()) <= MAX_LSB, f"image {idx}: max |diff| {int(d.max())} > {MAX_LSB}"
+        assert (d > 0).mean() <= FRAC, f"image {idx}: {(d > 0).mean():.6f} of the channels differ"
+
+
+@pytest.mark.parametrize("n_members,slots", [(1, 3), (2, 2)])
+def test_batch_with_exact_gaussian_is_bitexact(n_members, slots):
+    from paintfe_amd import _lib as L
+    from paintfe_amd.batch import run_batch
+    w, h, n_images = 448, 320, 10
+    pool, overlays = _s4_inputs(w, h, 4, seed=21)
+    modes = [1, 2, 8]
+    cnt = max(L.load().pfx_device_count(), 1)
+    keep = [0, 5, 9]
+    res = run_batch([k % cnt for k in range(n_members)], n_images, pool, overlays, modes, sigma=4.0, slots=slots, keep=keep, exact=True)
+    for idx in keep:
+        blur = O.gaussian_blur(pool[idx % len(pool)], 4.0)
+        hsl = O.adjust(blur, "hsl", (30.0, -20.0, 10.0))
+        ref = O.flatten_stack(np.stack([hsl] + overlays), np.array([0] + modes, np.uint8), np.ones(4, np.float32))
+        assert np.array_equal(ref, res["kept"][idx]), f"image {idx}: {int((ref != res['kept'][idx]).any(-1).sum())} px differ"
 
 
 def test_batch_equals_single_calls_bitexact():
