@@ -21,7 +21,8 @@ namespace {
 struct hsl3 { float h, s, l; };
 struct rgb3 { float r, g, b; };
 
-// adjustments.rs:944-974 (EPS = 1e-6) / scripting.rs:980-998 (EPS = 1e-10)
+// adjustments.rs:944-974 (EPS = 1e-6).  Only ever called on k / 255 values (k a byte, div255 is exact RN): two of them are equal or
+// at least 1/255 apart, so the reference's `(a - b).abs() < 1e-6` tests are plain equality tests here.
 PFX_DEV hsl3 rgb_to_hsl(float r, float g, float b)
 {
     const float mx = __builtin_fmaxf(__builtin_fmaxf(r, g), b);
@@ -30,13 +31,13 @@ PFX_DEV hsl3 rgb_to_hsl(float r, float g, float b)
     // Branch-free on purpose (the branches of the reference are per-pixel data: a wave takes all of them, and every divergent
     // branch costs scalar exec-mask traffic on top): the same operations in the same order, operands selected before each
     // division, results selected at the end.  Lanes of the grey case divide 0 by 0; that NaN is never selected.
-    const bool gray = __builtin_fabsf(mx - mn) < 1e-6f;
+    const bool gray = mx == mn;
     // Divisions via k_common.h:rdiv (bit-identical to '/'): inputs are k/255, so d = max-min >= 1/255, the saturation
     // denominators are >= 1/255 and every numerator is 0 or >= 1/255 in magnitude — all in the normal range.
     const float d = mx - mn;
     const float s = fdiv_fast(d, (l > 0.5f) ? (2.0f - mx - mn) : (mx + mn)); // selecting the operand == selecting the quotient
     const rdiv kd = rdiv_prepare(d), k6 = rdiv_prepare(6.0f);
-    const bool is_r = __builtin_fabsf(mx - r) < 1e-6f, is_g = __builtin_fabsf(mx - g) < 1e-6f;
+    const bool is_r = mx == r, is_g = mx == g;
     const float n_rb = pin(is_g ? (b - r) : (r - g));
     const float sector = rdiv_apply(kd, is_r ? pin(g - b) : n_rb);
     // red sector: `if h < 0 { h += 6 }` (adding +0.0 otherwise leaves the value as it is); green: + 2; blue: + 4
@@ -44,18 +45,23 @@ PFX_DEV hsl3 rgb_to_hsl(float r, float g, float b)
     const float h = rdiv_apply(k6, sector + offset);
     return {gray ? 0.0f : h, gray ? 0.0f : s, l};
 }
-// adjustments.rs:995-1012, branch-free like rgb_to_hsl: both ramps are evaluated, the reference's if-chain becomes the selects
-PFX_DEV float hue_to_rgb(float p, float q, float t)
+// adjustments.rs:995-1012 / scripting.rs hue_to_rgb for a t that is already wrapped into [0, 1].  The reference's two ramps
+//   t < 1/6:        p + ((q - p) * 6) * t            1/2 <= t < 2/3:  p + ((q - p) * (2/3 - t)) * 6
+// are ONE multiply-multiply-add with the operands picked first ((q - p) * x) * y, x = 6 or 2/3 - t, y = t or 6: the same operations on
+// the same values in the same order as whichever ramp the reference evaluates; its if-chain is the three selects at the end.
+PFX_DEV float hue_seg(float p, float q, float qmp, float t)
 {
-    t = (t < 0.0f) ? t + 1.0f : t;
-    t = (t > 1.0f) ? t - 1.0f : t;
-    const float up = pin(p + (q - p) * 6.0f * t);
-    const float down = pin(p + (q - p) * (2.0f / 3.0f - t) * 6.0f);
-    float v = pin((t < 2.0f / 3.0f) ? down : p); // the if-chain read from its last test to its first: three v_cndmask
-    v = pin((t < 1.0f / 2.0f) ? q : v);
-    return (t < 1.0f / 6.0f) ? up : v;
+    const bool up = t < 1.0f / 6.0f, is_q = t < 1.0f / 2.0f, down = t < 2.0f / 3.0f;
+    const float x = up ? 6.0f : (2.0f / 3.0f - t);
+    const float y = up ? t : 6.0f;
+    const float ramp = pin(p + (qmp * x) * y);
+    float v = down ? ramp : p;
+    v = is_q ? q : v;
+    return up ? ramp : v;
 }
-// adjustments.rs:976-993
+// adjustments.rs:976-993.  h is in [0, 1] at every call site (fract() + 1 if negative; rem_euclid(1.0); rgb_to_hsl's own h), so of
+// hue_to_rgb's two wrap tests `t < 0 -> t + 1`, `t > 1 -> t - 1` only one can fire per channel: h + 1/3 lies in [1/3, 4/3], h itself
+// needs none, h - 1/3 lies in [-1/3, 2/3] (and a wrapped value never trips the other test).
 template <bool RHAI>
 PFX_DEV rgb3 hsl_to_rgb(float h, float s, float l)
 {
@@ -63,7 +69,11 @@ PFX_DEV rgb3 hsl_to_rgb(float h, float s, float l)
     const float q_lo = pin(l * (1.0f + s)), q_hi = pin(l + s - l * s);
     const float q = (l < 0.5f) ? q_lo : q_hi;
     const float p = 2.0f * l - q;
-    const float r = hue_to_rgb(p, q, h + 1.0f / 3.0f), g = hue_to_rgb(p, q, h), b = hue_to_rgb(p, q, h - 1.0f / 3.0f);
+    const float qmp = q - p;
+    float tr = h + 1.0f / 3.0f, tb = h - 1.0f / 3.0f;
+    tr = (tr > 1.0f) ? tr - 1.0f : tr;
+    tb = (tb < 0.0f) ? tb + 1.0f : tb;
+    const float r = hue_seg(p, q, qmp, tr), g = hue_seg(p, q, qmp, h), b = hue_seg(p, q, qmp, tb);
     return {gray ? l : r, gray ? l : g, gray ? l : b};
 }
 PFX_DEV float lum709(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
@@ -208,7 +218,12 @@ PFX_DEV uint32_t apply_px(const pfxk_params& P, const uint8_t* __restrict__ lut,
         return pack_rgba(o[0], o[1], o[2], o[3]);
     } else {
         adjust_px<OP>(P, lut, ubyte0(px), ubyte1(px), ubyte2(px), ubyte3(px), o);
-        return pack_round_rgba(o[0], o[1], o[2], o[3]);
+        if constexpr (OP == PFXK_OP_INVERT_ALPHA || OP == PFXK_OP_LUT_RGBA) return pack_round_rgba(o[0], o[1], o[2], o[3]);
+        else { // alpha passes through untouched: round three channels, keep the byte
+            uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[0]), 0, px);
+            q = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[1]), 1, q);
+            return __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[2]), 2, q);
+        }
     }
 }
 
@@ -232,6 +247,32 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t* __restric
     const bool vec = (w & 3u) == 0u; // rows 16-byte aligned -> one dwordx4 per row
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
     uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+
+    if (!mask && vec && bx + 64u <= w && by + 64u <= h) {
+        // interior chunk without a selection mask (every chunk of an 8K frame but the bottom row's): no per-pixel bounds or mask
+        // logic, so the 16 pixels of a lane are straight-line code — the general path below spends ~5 exec-mask branches per pixel
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(s32 + (size_t)(by + r0 + 16u * k) * w + x);
+        int any_in = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) any_in |= (int)((v[k].x | v[k].y | v[k].z | v[k].w) >> 24);
+        const bool live = sparse_mode == 2 ? __syncthreads_or(any_in) != 0 : true; // IN_PLACE: an unpopulated chunk is never visited
+        int any_out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (live) {
+                v[k].x = apply_px<OP, RHAI>(P, lut, v[k].x); v[k].y = apply_px<OP, RHAI>(P, lut, v[k].y);
+                v[k].z = apply_px<OP, RHAI>(P, lut, v[k].z); v[k].w = apply_px<OP, RHAI>(P, lut, v[k].w);
+            } else v[k] = make_uint4(0u, 0u, 0u, 0u);
+            any_out |= (int)((v[k].x | v[k].y | v[k].z | v[k].w) >> 24);
+        }
+        const bool drop = sparse_mode == 1 ? __syncthreads_or(any_out) == 0 : false; // FROM_FLAT: a chunk whose alpha is all zero is dropped
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<uint4*>(d32 + (size_t)(by + r0 + 16u * k) * w + x) = drop ? make_uint4(0u, 0u, 0u, 0u) : v[k];
+        return;
+    }
 
     uint32_t in[4][4], out[4][4];
     bool ok[4][4];
