@@ -349,6 +349,17 @@ def main() -> int:
             dist.init_process_group(backend=backend)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    if args.gpus != world:
+        # the driver's contract: `--gpus N` is launched as N ranks.  A job that silently ran on fewer ranks (or one that was started
+        # without torch.distributed.run) must not report an N-GPU number
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the job has WORLD_SIZE={world} ranks (launch with python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} ... for N > 1)")
+    if world > 1:
+        joined = dist.get_world_size()
+        if joined != world:
+            raise SystemExit(f"bench.py: {joined} ranks joined the process group, expected {world}")
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} devices are visible (one rank per GPU over RCCL)")
 
     if args.config == "batch4k":
         return run_batch4k(args, torch, dist, rank, world, dev_index, device)
@@ -393,6 +404,10 @@ def main() -> int:
         state["step_ms"] = {"min": round(per[0], 4), "median": round(per[len(per) // 2], 4), "max": round(per[-1], 4)}
         if world > 1:
             from paintfe_amd.sharding import max_over_ranks
+            mine = torch.tensor([el / args.steps * 1e3], dtype=torch.float64, device=None if backend == "gloo" else device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            state["per_rank_ms_per_step"] = [round(float(t.item()), 4) for t in every]
             el = max_over_ranks(el, device=device)  # the step time of the job is the slowest rank's
         kern = {}
         for name in ("flatten", "gauss_mfma", "gauss_h", "gauss_v"):
@@ -516,6 +531,9 @@ def main() -> int:
                                   ("one independent document per GPU, no collective" if world > 1 else "single GPU")},
            "step_ms_hip_events": state.get("step_ms"),
            "roofline": roofline}
+    if world > 1:
+        out["ranks"] = {"world_size": dist.get_world_size(), "backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend,
+                        "devices_visible": torch.cuda.device_count(), "per_rank_ms_per_step": state.get("per_rank_ms_per_step")}
     if doc_mode:
         out["doc_mode"] = doc_mode
     if band_mode and band_sharded:

@@ -378,6 +378,13 @@ int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint
  * the rows a whole-image call produces wherever the band holds the full +-ceil(3 sigma) neighbourhood (row-band sharding) */
 int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma,
                                void* tmp_dev, uint32_t first_row);
+/* box blur / median of a band with its halo rows (ceil(radius) / max(radius, 1) of them on each side that is not an image edge): the
+ * arithmetic is integer per pixel, so every row at least `radius` rows away from the buffer's first and last row equals the same row of
+ * the whole image's filter bit for bit, wherever the band was cut; `first_row` is accepted for symmetry with the Gaussian and unused. */
+int pfx_box_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius, const void* mask_dev,
+                          void* tmp_dev, uint32_t first_row);
+int pfx_median_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius, const void* mask_dev,
+                        uint32_t first_row);
 int pfx_box_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius,
                      const void* mask_dev, void* tmp_dev /* w*h*4 or NULL */);
 int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius,
@@ -628,6 +635,19 @@ void*       pfx_group_layer_band_dev(pfx_group* g, uint32_t rank, uint32_t index
 /* CanvasState::composite() of the document followed by parallel_gaussian_blur(sigma) (sigma <= 0: flatten only).
  * layers[k].layer_idx indexes the document's layers.  all_gather != 0: afterwards every member holds the whole result. */
 int         pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, float sigma, int all_gather);
+/* the same with any of the band filters behind the flatten (the Gaussian, box and median vertical passes need halo rows):
+ * PFX_BAND_GAUSSIAN param = sigma (halo ceil(3 sigma)); PFX_BAND_BOX param = radius (halo ceil(radius), ref: blur.rs:233-318);
+ * PFX_BAND_MEDIAN param = radius (halo max(radius, 1), ref: noise.rs:357-410); PFX_BAND_NONE = flatten only */
+enum { PFX_BAND_NONE = 0, PFX_BAND_GAUSSIAN = 1, PFX_BAND_BOX = 2, PFX_BAND_MEDIAN = 3 };
+int         pfx_group_flatten_filter(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, int filter, float param, int all_gather);
+/* how halo rows and gathered bands travel between the members.  PFX_GROUP_PEER (default): hipMemcpyPeerAsync over xGMI, pair by pair
+ * replaced by staged copies where peer access cannot be enabled; PFX_GROUP_STAGED: always through pinned host memory;
+ * PFX_GROUP_RCCL: one ncclSend / ncclRecv group for the halos and one ncclBroadcast group (one broadcast per ragged band) for the
+ * all-gather — librccl is loaded with dlopen on first use (PFX_ERR_UNSUPPORTED if it is missing or two members share a device).
+ * Results are identical under every transport. */
+enum { PFX_GROUP_PEER = 0, PFX_GROUP_RCCL = 1, PFX_GROUP_STAGED = 2 };
+int         pfx_group_set_transport(pfx_group* g, int transport);
+int         pfx_group_transport(const pfx_group* g);
 int         pfx_group_synchronize(pfx_group* g);
 void*       pfx_group_result_band_dev(pfx_group* g, uint32_t rank);  /* rows [y0, y1) of the last result on member `rank` */
 void*       pfx_group_gathered_dev(pfx_group* g, uint32_t rank);     /* w*h*4 on member `rank` after an all_gather call */

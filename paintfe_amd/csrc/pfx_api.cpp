@@ -399,6 +399,20 @@ int pfx_box_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t 
     return PFX_OK;
 }
 
+int pfx_box_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius, const void* mask_dev,
+                          void* tmp_dev, uint32_t first_row)
+{
+    (void)first_row; // integer window sums: a row's result does not depend on where the band was cut (pfx.h)
+    return pfx_box_blur_dev(ctx, src_dev, dst_dev, w, h, radius, mask_dev, tmp_dev);
+}
+
+int pfx_median_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius, const void* mask_dev,
+                        uint32_t first_row)
+{
+    (void)first_row;
+    return pfx_median_dev(ctx, src_dev, dst_dev, w, h, radius, mask_dev);
+}
+
 int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, uint32_t radius, const void* mask_dev)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_median_dev"));

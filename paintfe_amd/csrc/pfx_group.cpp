@@ -15,8 +15,22 @@
 //     xGMI is point-to-point, so the N-1 copies of a member travel on N-1 different links at once (no ring).  The pushes run on a
 //     copy stream per member, so the next call's flatten overlaps them (only its blur, which rewrites the source, waits).
 // Everything is asynchronous on the members' streams; the host thread only enqueues.  Nothing here touches pixels on the CPU.
+//
+// Three transports move the halo rows and the gathered bands (pfx_group_set_transport):
+//   PEER   (default) hipMemcpyPeerAsync as described above; a pair of devices whose peer access cannot be enabled falls back, pair by
+//          pair, to STAGED copies;
+//   STAGED device -> pinned host -> device, ordered by events (what a node without xGMI / with peer access disabled can do);
+//   RCCL   the halo exchange as ONE group of ncclSend / ncclRecv on the members' compute streams and the all-gather as one group of
+//          ncclBroadcast calls (one per band: bands are ragged) on the copy streams — BASELINE's "RCCL halo exchange over xGMI ... and
+//          an all-gather".  librccl is loaded at run time (dlopen) the first time this transport is selected: libpfx.so itself does
+//          not link it, and a process that already carries an RCCL (PyTorch) keeps using that copy.
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only; the functions are resolved with dlsym
+
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <new>
 #include <string>
@@ -38,6 +52,14 @@ struct pfx_group_member {
     hipStream_t s_copy = nullptr;       // the all-gather's pushes run here, behind ev_done, so that the next call's flatten overlaps them
     hipEvent_t ev_gather = nullptr;     // this member's pushes finished (s_copy)
     bool gather_pending = false;        // ev_gather was recorded and not yet waited for by the compute stream
+    // STAGED transport: pinned bounce buffers of this member as a SOURCE (its halo rows for the neighbours / its result band)
+    uint8_t* h_halo = nullptr;          // [rows it sends upwards | rows it sends downwards], 2 * halo_cap rows
+    uint8_t* h_band = nullptr;          // the member's result band
+    size_t h_halo_cap = 0, h_band_cap = 0;
+    hipEvent_t ev_staged_halo = nullptr, ev_staged_band = nullptr; // the D2H into the bounce buffer finished
+    hipEvent_t ev_gin = nullptr;        // every H2D of a gather INTO this member finished (its copy stream)
+    bool gin_pending = false;
+    ncclComm_t comm = nullptr;          // RCCL transport
 };
 
 struct pfx_group {
@@ -45,6 +67,9 @@ struct pfx_group {
     uint32_t w = 0, h = 0, n_layers = 0;
     uint32_t halo_cap = 0;              // halo rows the padded buffers were sized for
     bool have_result = false, result_blurred = false;
+    int transport = PFX_GROUP_PEER;
+    std::vector<uint8_t> peer_ok;       // [a * n + b]: device of member a may access member b's memory directly (or they share a device)
+    bool rccl_ready = false;
     std::string err;
 };
 
@@ -76,6 +101,49 @@ int gfail(pfx_group* g, int status, const char* fmt, ...)
 
 hipStream_t stream_of(const pfx_group_member& mem) { return (hipStream_t)pfx_ctx_stream(mem.ctx); }
 
+// ---- RCCL, resolved at run time ----
+struct rccl_api {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+rccl_api& rccl()
+{
+    static rccl_api R;
+    static bool tried = false;
+    if (tried) return R;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        R.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (R.lib) break;
+    }
+    if (!R.lib) return R;
+#define PFX_SYM(field, sym) R.field = (decltype(R.field))dlsym(R.lib, #sym)
+    PFX_SYM(CommInitAll, ncclCommInitAll); PFX_SYM(CommDestroy, ncclCommDestroy); PFX_SYM(GroupStart, ncclGroupStart);
+    PFX_SYM(GroupEnd, ncclGroupEnd); PFX_SYM(Send, ncclSend); PFX_SYM(Recv, ncclRecv); PFX_SYM(Broadcast, ncclBroadcast);
+    PFX_SYM(GetErrorString, ncclGetErrorString);
+#undef PFX_SYM
+    R.ok = R.CommInitAll && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv && R.Broadcast && R.GetErrorString;
+    return R;
+}
+#define PFXG_NCCL(g, call)                                                                                              \
+    do {                                                                                                                \
+        ncclResult_t _r = (call);                                                                                       \
+        if (_r != ncclSuccess) return gfail((g), PFX_ERR_HIP, "%s failed: %s", #call, rccl().GetErrorString(_r));       \
+    } while (0)
+
+bool direct(const pfx_group* g, uint32_t dst, uint32_t src)
+{
+    return g->transport != PFX_GROUP_STAGED && g->peer_ok[(size_t)dst * g->m.size() + src] != 0;
+}
+
 // device-to-device copy between two members, enqueued on `dst`'s stream
 hipError_t copy_between(const pfx_group_member& dst, void* d, const pfx_group_member& src, const void* s, size_t bytes)
 {
@@ -94,11 +162,29 @@ void free_member_buffers(pfx_group_member& mem)
     if (mem.gathered) (void)hipFree(mem.gathered);
     mem.padded = mem.blurred = mem.gathered = nullptr;
     mem.padded_cap = 0;
+    if (mem.h_halo) (void)hipHostFree(mem.h_halo);
+    if (mem.h_band) (void)hipHostFree(mem.h_band);
+    mem.h_halo = mem.h_band = nullptr;
+    mem.h_halo_cap = mem.h_band_cap = 0;
+}
+
+// every stream of every member idle: nothing in flight may still read or write a buffer that is about to be freed or re-used by hand
+void quiesce(pfx_group* g)
+{
+    for (auto& mem : g->m) {
+        if (mem.ctx) (void)pfx_ctx_synchronize(mem.ctx);
+        if (mem.s_copy) { (void)hipSetDevice(mem.device); (void)hipStreamSynchronize(mem.s_copy); }
+        mem.gather_pending = mem.gin_pending = false;
+    }
 }
 
 int ensure_padded(pfx_group* g, uint32_t halo)
 {
     if (halo <= g->halo_cap && g->m[0].padded_cap != 0) return PFX_OK;
+    // the previous call may still be pulling halo rows out of / pushing result bands out of the buffers that are about to be freed
+    // (hipFree only waits for the owning device): drain every stream first, and forget the result those buffers held
+    quiesce(g);
+    g->have_result = false;
     for (auto& mem : g->m) {
         const size_t rows = (size_t)(mem.y1 - mem.y0) + 2 * (size_t)halo;
         const size_t bytes = std::max<size_t>(rows * g->w * 4, 256);
@@ -134,7 +220,14 @@ void pfx_band_rows(uint32_t h, uint32_t world, uint32_t rank, uint32_t* y0, uint
     if (y1) *y1 = b;
 }
 
+static int group_create_impl(const int* devices, uint32_t n, pfx_group** out);
 int pfx_group_create(const int* devices, uint32_t n, pfx_group** out)
+{
+    try { return group_create_impl(devices, n, out); }
+    catch (const std::bad_alloc&) { return PFX_ERR_OOM; }
+    catch (...) { return PFX_ERR_HIP; }
+}
+static int group_create_impl(const int* devices, uint32_t n, pfx_group** out)
 {
     if (!out) return PFX_ERR_INVALID;
     *out = nullptr;
@@ -149,20 +242,29 @@ int pfx_group_create(const int* devices, uint32_t n, pfx_group** out)
         if (hipSetDevice(devices[k]) != hipSuccess || hipEventCreateWithFlags(&g->m[k].ev_flat, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->m[k].ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->m[k].ev_gather, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->m[k].ev_staged_halo, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->m[k].ev_staged_band, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->m[k].ev_gin, hipEventDisableTiming) != hipSuccess ||
             hipStreamCreateWithFlags(&g->m[k].s_copy, hipStreamNonBlocking) != hipSuccess) {
             pfx_group_destroy(g);
             return PFX_ERR_HIP;
         }
     }
-    // direct xGMI access between every pair of distinct devices (idempotent; a refusal only makes the copies staged)
+    // direct xGMI access between every pair of distinct devices.  A pair whose access cannot be enabled (no link, IOMMU / container
+    // restrictions, PFX_GROUP_DENY_PEER=1 for tests) is served by staged copies through pinned host memory instead — the calls keep
+    // working, only slower.
+    const char* deny = getenv("PFX_GROUP_DENY_PEER");
+    const bool deny_peer = deny && deny[0] == '1';
+    g->peer_ok.assign((size_t)n * n, 0);
     for (uint32_t a = 0; a < n; ++a)
         for (uint32_t b = 0; b < n; ++b) {
-            if (devices[a] == devices[b]) continue;
+            if (devices[a] == devices[b]) { g->peer_ok[(size_t)a * n + b] = deny_peer ? 0 : 1; continue; }
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+            if (!deny_peer && hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
                 (void)hipSetDevice(devices[a]);
                 const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-                if (e != hipSuccess) (void)hipGetLastError(); // hipErrorPeerAccessAlreadyEnabled et al.
+                if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) g->peer_ok[(size_t)a * n + b] = 1;
+                (void)hipGetLastError(); // clear the sticky "already enabled"
             }
         }
     *out = g;
@@ -180,6 +282,10 @@ void pfx_group_destroy(pfx_group* g)
         if (mem.ev_flat) (void)hipEventDestroy(mem.ev_flat);
         if (mem.ev_done) (void)hipEventDestroy(mem.ev_done);
         if (mem.ev_gather) (void)hipEventDestroy(mem.ev_gather);
+        if (mem.ev_staged_halo) (void)hipEventDestroy(mem.ev_staged_halo);
+        if (mem.ev_staged_band) (void)hipEventDestroy(mem.ev_staged_band);
+        if (mem.ev_gin) (void)hipEventDestroy(mem.ev_gin);
+        if (mem.comm && rccl().ok) (void)rccl().CommDestroy(mem.comm);
         if (mem.ctx) pfx_ctx_destroy(mem.ctx);
     }
     delete g;
@@ -189,16 +295,19 @@ uint32_t pfx_group_size(const pfx_group* g) { return g ? (uint32_t)g->m.size() :
 pfx_ctx* pfx_group_ctx(pfx_group* g, uint32_t rank) { return (g && rank < g->m.size()) ? g->m[rank].ctx : nullptr; }
 const char* pfx_group_last_error(const pfx_group* g) { return g ? g->err.c_str() : "null group"; }
 
+static int group_set_document_impl(pfx_group* g, uint32_t w, uint32_t h, uint32_t n_layers);
 int pfx_group_set_document(pfx_group* g, uint32_t w, uint32_t h, uint32_t n_layers)
+{
+    try { return group_set_document_impl(g, w, h, n_layers); }
+    catch (const std::bad_alloc&) { return g ? gfail(g, PFX_ERR_OOM, "out of host memory") : PFX_ERR_OOM; }
+    catch (...) { return g ? gfail(g, PFX_ERR_HIP, "unexpected exception") : PFX_ERR_HIP; }
+}
+static int group_set_document_impl(pfx_group* g, uint32_t w, uint32_t h, uint32_t n_layers)
 {
     if (!g) return PFX_ERR_INVALID;
     if (w == 0 || h == 0 || n_layers == 0 || n_layers > PFX_MAX_LAYERS) return gfail(g, PFX_ERR_INVALID, "bad document geometry");
-    for (auto& mem : g->m) {
-        if (mem.ctx) (void)pfx_ctx_synchronize(mem.ctx);
-        if (mem.s_copy) { (void)hipSetDevice(mem.device); (void)hipStreamSynchronize(mem.s_copy); }
-        mem.gather_pending = false;
-        free_member_buffers(mem);
-    }
+    quiesce(g);
+    for (auto& mem : g->m) free_member_buffers(mem);
     g->w = w; g->h = h; g->n_layers = n_layers; g->halo_cap = 0; g->have_result = false;
     const uint32_t world = (uint32_t)g->m.size();
     for (uint32_t k = 0; k < world; ++k) {
@@ -240,26 +349,66 @@ int pfx_group_band(const pfx_group* g, uint32_t rank, uint32_t* y0, uint32_t* y1
     return PFX_OK;
 }
 
-int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, float sigma, int all_gather)
+int pfx_group_set_transport(pfx_group* g, int transport)
+{
+    if (!g) return PFX_ERR_INVALID;
+    if (transport != PFX_GROUP_PEER && transport != PFX_GROUP_STAGED && transport != PFX_GROUP_RCCL)
+        return gfail(g, PFX_ERR_INVALID, "unknown transport %d", transport);
+    quiesce(g); // a transport change must not overtake copies of the old one
+    if (transport == PFX_GROUP_RCCL && !g->rccl_ready) {
+        if (!rccl().ok) return gfail(g, PFX_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+        const size_t n = g->m.size();
+        for (size_t a = 0; a < n; ++a)
+            for (size_t b2 = a + 1; b2 < n; ++b2)
+                if (g->m[a].device == g->m[b2].device)
+                    return gfail(g, PFX_ERR_UNSUPPORTED, "RCCL needs one device per member (members %zu and %zu share device %d)", a, b2, g->m[a].device);
+        std::vector<int> devs(n);
+        std::vector<ncclComm_t> comms(n, nullptr);
+        for (size_t k = 0; k < n; ++k) devs[k] = g->m[k].device;
+        PFXG_NCCL(g, rccl().CommInitAll(comms.data(), (int)n, devs.data()));
+        for (size_t k = 0; k < n; ++k) g->m[k].comm = comms[k];
+        g->rccl_ready = true;
+    }
+    g->transport = transport;
+    return PFX_OK;
+}
+
+int pfx_group_transport(const pfx_group* g) { return g ? g->transport : -1; }
+
+// halo rows of a band filter: what pfx_*_band_dev needs around a band ("halo rows of the Gaussian / box / median vertical pass")
+static int band_filter_halo(int filter, float param, uint32_t* halo)
+{
+    switch (filter) {
+    case PFX_BAND_NONE: *halo = 0; return PFX_OK;
+    case PFX_BAND_GAUSSIAN: { const int r = pfx_host_gaussian_radius(param); *halo = r >= 1 ? (uint32_t)r : 0u; return PFX_OK; }
+    case PFX_BAND_BOX: *halo = param < 0.5f ? 0u : (uint32_t)std::min(ceilf(param), 4096.0f); return PFX_OK;       // blur.rs:234,241
+    case PFX_BAND_MEDIAN: *halo = (uint32_t)std::max(std::min(param, 4096.0f), 1.0f); return PFX_OK;              // noise.rs:364
+    default: return PFX_ERR_INVALID;
+    }
+}
+
+static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, int filter, float param, int all_gather)
 {
     if (!g || !layers || n_layers == 0) return PFX_ERR_INVALID;
     if (g->n_layers == 0) return gfail(g, PFX_ERR_INVALID, "no document: call pfx_group_set_document first");
     for (uint32_t l = 0; l < n_layers; ++l)
         if (layers[l].kind == PFX_LAYER_RASTER && layers[l].layer_idx >= g->n_layers)
             return gfail(g, PFX_ERR_INVALID, "layer_idx %u outside the document", layers[l].layer_idx);
-    const int radius = pfx_host_gaussian_radius(sigma);
-    const bool blur = radius >= 1;
-    const uint32_t halo = blur ? (uint32_t)radius : 0u;
-    if (halo > g->h + 4096u) return gfail(g, PFX_ERR_UNSUPPORTED, "gaussian radius %d is not a sensible halo", radius);
+    uint32_t halo = 0;
+    if (band_filter_halo(filter, param, &halo) != PFX_OK) return gfail(g, PFX_ERR_INVALID, "unknown band filter %d", filter);
+    const bool blur = halo >= 1;
+    if (halo > g->h + 4096u) return gfail(g, PFX_ERR_UNSUPPORTED, "a halo of %u rows is not sensible", halo);
     {
         const int s = ensure_padded(g, halo);
         if (s != PFX_OK) return s;
     }
     const uint32_t world = (uint32_t)g->m.size(), w = g->w, h = g->h;
     const size_t row_bytes = (size_t)w * 4;
+    const bool use_rccl = g->transport == PFX_GROUP_RCCL;
 
     // 0. a member may not overwrite what the previous call is still reading: its neighbours' halo pulls out of its padded buffer
-    // (finished when their ev_done fires) and — when that call gathered an un-blurred result — its own pushes out of it
+    // (finished when their ev_done fires; staged pulls read the bounce buffer, whose D2H is ordered on the member's own stream) and —
+    // when that call gathered an un-filtered result — its own pushes out of it
     for (auto& mem : g->m) {
         PFXG_HIP(g, hipSetDevice(mem.device));
         for (auto& other : g->m)
@@ -286,31 +435,92 @@ int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t 
         PFXG_HIP(g, hipEventRecord(mem.ev_flat, stream_of(mem)));
     }
     if (blur) {
-        // 2. halo rows: member i pulls rows [y0 - top, y0) and [y1, y1 + bottom) from whichever members own them
+        // 2. halo rows: member i needs rows [y0 - top, y0) and [y1, y1 + bottom) from whichever members own them.
+        // Every (consumer i, producer j, image rows [s0, s1)) piece is listed once and then moved by the transport in use.
+        struct piece { uint32_t i, j, s0, s1; };
+        std::vector<piece> pieces;
+        for (uint32_t i = 0; i < world; ++i) {
+            const auto& mem = g->m[i];
+            if (mem.y1 == mem.y0) continue;
+            const uint32_t ranges[2][2] = {{mem.y0 - mem.top, mem.y0}, {mem.y1, mem.y1 + mem.bottom}};
+            for (uint32_t j = 0; j < world; ++j) {
+                if (j == i || g->m[j].y1 == g->m[j].y0) continue;
+                for (const auto& rg : ranges) {
+                    const uint32_t s0 = std::max(rg[0], g->m[j].y0), s1 = std::min(rg[1], g->m[j].y1);
+                    if (s1 > s0) pieces.push_back({i, j, s0, s1});
+                }
+            }
+        }
+        auto dst_of = [&](const piece& p) { const auto& mem = g->m[p.i]; return (uint8_t*)mem.padded + (size_t)(p.s0 - (mem.y0 - mem.top)) * row_bytes; };
+        auto src_of = [&](const piece& p) { const auto& src = g->m[p.j]; return (const uint8_t*)src.padded + (size_t)(src.top + (p.s0 - src.y0)) * row_bytes; };
+        if (use_rccl) {
+            // one group: every send sits on the producer's compute stream (behind its flatten), every receive on the consumer's (in
+            // front of its filter) — no events, RCCL pairs them up over xGMI
+            PFXG_NCCL(g, rccl().GroupStart());
+            for (const auto& p : pieces) {
+                const size_t bytes = (size_t)(p.s1 - p.s0) * row_bytes;
+                const ncclResult_t r1 = rccl().Send(src_of(p), bytes, ncclUint8, (int)p.i, g->m[p.j].comm, stream_of(g->m[p.j]));
+                const ncclResult_t r2 = rccl().Recv(dst_of(p), bytes, ncclUint8, (int)p.j, g->m[p.i].comm, stream_of(g->m[p.i]));
+                if (r1 != ncclSuccess || r2 != ncclSuccess) {
+                    (void)rccl().GroupEnd();
+                    return gfail(g, PFX_ERR_HIP, "ncclSend / ncclRecv failed: %s", rccl().GetErrorString(r1 != ncclSuccess ? r1 : r2));
+                }
+            }
+            PFXG_NCCL(g, rccl().GroupEnd());
+        } else {
+            // producers whose rows travel through the host stage them once (D2H into their pinned bounce buffer, behind their flatten)
+            std::vector<uint8_t> stages(world, 0);
+            for (const auto& p : pieces) if (!direct(g, p.i, p.j)) stages[p.j] = 1;
+            for (uint32_t j = 0; j < world; ++j) {
+                if (!stages[j]) continue;
+                auto& src = g->m[j];
+                const uint32_t rows = src.y1 - src.y0, n_up = std::min(halo, rows), n_dn = std::min(halo, rows);
+                const size_t need = (size_t)(n_up + n_dn) * row_bytes;
+                PFXG_HIP(g, hipSetDevice(src.device));
+                if (src.h_halo_cap < need) {
+                    // consumers of the old buffer were drained by step 0's waits only on the device side: their H2Ds ran on THEIR streams
+                    quiesce(g);
+                    if (src.h_halo) (void)hipHostFree(src.h_halo);
+                    src.h_halo = nullptr; src.h_halo_cap = 0;
+                    PFXG_HIP(g, hipHostMalloc((void**)&src.h_halo, need, hipHostMallocPortable));
+                    src.h_halo_cap = need;
+                }
+                const uint8_t* band0 = (const uint8_t*)src.padded + (size_t)src.top * row_bytes;
+                // [first n_up rows of the band | last n_dn rows of the band]: what the members above / below can ask for
+                PFXG_HIP(g, hipMemcpyAsync(src.h_halo, band0, (size_t)n_up * row_bytes, hipMemcpyDeviceToHost, stream_of(src)));
+                PFXG_HIP(g, hipMemcpyAsync(src.h_halo + (size_t)n_up * row_bytes, band0 + (size_t)(rows - n_dn) * row_bytes, (size_t)n_dn * row_bytes,
+                                           hipMemcpyDeviceToHost, stream_of(src)));
+                PFXG_HIP(g, hipEventRecord(src.ev_staged_halo, stream_of(src)));
+            }
+            for (const auto& p : pieces) {
+                auto& mem = g->m[p.i];
+                const auto& src = g->m[p.j];
+                const size_t bytes = (size_t)(p.s1 - p.s0) * row_bytes;
+                PFXG_HIP(g, hipSetDevice(mem.device));
+                if (direct(g, p.i, p.j)) {
+                    PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), src.ev_flat, 0));
+                    PFXG_HIP(g, copy_between(mem, dst_of(p), src, src_of(p), bytes));
+                } else {
+                    const uint32_t rows = src.y1 - src.y0, n_up = std::min(halo, rows), n_dn = std::min(halo, rows);
+                    // rows below the consumer come from the TOP of the producer's band, rows above it from the BOTTOM
+                    const bool from_top = p.s0 >= mem.y1;
+                    const size_t off = from_top ? (size_t)(p.s0 - src.y0) * row_bytes
+                                                : (size_t)n_up * row_bytes + (size_t)(p.s0 - (src.y1 - n_dn)) * row_bytes;
+                    PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), src.ev_staged_halo, 0));
+                    PFXG_HIP(g, hipMemcpyAsync(dst_of(p), src.h_halo + off, bytes, hipMemcpyHostToDevice, stream_of(mem)));
+                }
+            }
+        }
+        // 3. filter band + halo; rows [top, top + rows) of the output are the member's result (the previous call's pushes read it)
         for (uint32_t i = 0; i < world; ++i) {
             auto& mem = g->m[i];
             if (mem.y1 == mem.y0) continue;
             PFXG_HIP(g, hipSetDevice(mem.device));
-            const uint32_t lo0 = mem.y0 - mem.top, lo1 = mem.y0, hi0 = mem.y1, hi1 = mem.y1 + mem.bottom;
-            for (uint32_t j = 0; j < world; ++j) {
-                if (j == i) continue;
-                const auto& src = g->m[j];
-                if (src.y1 == src.y0) continue;
-                const uint32_t ranges[2][2] = {{lo0, lo1}, {hi0, hi1}};
-                bool waited = false;
-                for (const auto& rg : ranges) {
-                    const uint32_t s0 = std::max(rg[0], src.y0), s1 = std::min(rg[1], src.y1);
-                    if (s1 <= s0) continue;
-                    if (!waited) { PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), src.ev_flat, 0)); waited = true; }
-                    uint8_t* d = (uint8_t*)mem.padded + (size_t)(s0 - lo0) * row_bytes;                       // padded row 0 = image row lo0
-                    const uint8_t* s = (const uint8_t*)src.padded + (size_t)(src.top + (s0 - src.y0)) * row_bytes;
-                    PFXG_HIP(g, copy_between(mem, d, src, s, (size_t)(s1 - s0) * row_bytes));
-                }
-            }
-            // 3. blur band + halo; rows [top, top + rows) of the output are the member's result (the previous call's pushes read it)
             if (mem.gather_pending) { PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), mem.ev_gather, 0)); mem.gather_pending = false; }
-            const uint32_t prow = mem.top + (mem.y1 - mem.y0) + mem.bottom;
-            PFXG_CTX(g, mem, pfx_gaussian_blur_band_dev(mem.ctx, mem.padded, mem.blurred, w, prow, sigma, nullptr, lo0));
+            const uint32_t prow = mem.top + (mem.y1 - mem.y0) + mem.bottom, first = mem.y0 - mem.top;
+            if (filter == PFX_BAND_GAUSSIAN) PFXG_CTX(g, mem, pfx_gaussian_blur_band_dev(mem.ctx, mem.padded, mem.blurred, w, prow, param, nullptr, first));
+            else if (filter == PFX_BAND_BOX) PFXG_CTX(g, mem, pfx_box_blur_band_dev(mem.ctx, mem.padded, mem.blurred, w, prow, param, nullptr, nullptr, first));
+            else PFXG_CTX(g, mem, pfx_median_band_dev(mem.ctx, mem.padded, mem.blurred, w, prow, (uint32_t)halo, nullptr, first));
         }
     }
     g->result_blurred = blur;
@@ -318,32 +528,102 @@ int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t 
         PFXG_HIP(g, hipSetDevice(mem.device));
         PFXG_HIP(g, hipEventRecord(mem.ev_done, stream_of(mem)));
     }
-    // 4. all-gather: every member pushes its result band into every member's full image (one xGMI link per pair).  The pushes run on
-    // the member's copy stream behind ev_done: the next call's flatten (compute stream) overlaps them, its blur waits for them.
+    // 4. all-gather: every member's result band lands in every member's full image.  The transfers run on the members' copy streams
+    // behind ev_done: the next call's flatten (compute stream) overlaps them, its filter waits for them.
     if (all_gather) {
         for (auto& mem : g->m)
             if (!mem.gathered) {
                 PFXG_HIP(g, hipSetDevice(mem.device));
                 PFXG_HIP(g, hipMalloc(&mem.gathered, std::max<size_t>((size_t)h * row_bytes, 256)));
             }
-        for (auto& mem : g->m) {
-            const uint32_t rows = mem.y1 - mem.y0;
-            if (!rows) continue;
-            PFXG_HIP(g, hipSetDevice(mem.device));
-            PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
-            const uint8_t* band = (const uint8_t*)(blur ? mem.blurred : mem.padded) + (size_t)mem.top * row_bytes;
-            for (auto& dst : g->m) {
-                // enqueued on the PRODUCER's copy stream; hipMemcpyPeerAsync accepts any stream
-                uint8_t* d = (uint8_t*)dst.gathered + (size_t)mem.y0 * row_bytes;
-                if (dst.device == mem.device) PFXG_HIP(g, hipMemcpyAsync(d, band, (size_t)rows * row_bytes, hipMemcpyDeviceToDevice, mem.s_copy));
-                else PFXG_HIP(g, hipMemcpyPeerAsync(d, dst.device, band, mem.device, (size_t)rows * row_bytes, mem.s_copy));
+        auto band_of = [&](const pfx_group_member& mem) { return (const uint8_t*)(blur ? mem.blurred : mem.padded) + (size_t)mem.top * row_bytes; };
+        if (use_rccl) {
+            for (auto& mem : g->m) {
+                PFXG_HIP(g, hipSetDevice(mem.device));
+                PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
             }
-            PFXG_HIP(g, hipEventRecord(mem.ev_gather, mem.s_copy));
-            mem.gather_pending = true;
+            // one broadcast per band (bands are ragged by a chunk row, so ncclAllGather's equal counts do not fit), all in one group
+            PFXG_NCCL(g, rccl().GroupStart());
+            for (uint32_t k = 0; k < world; ++k) {
+                const uint32_t rows = g->m[k].y1 - g->m[k].y0;
+                if (!rows) continue;
+                for (auto& mem : g->m) {
+                    uint8_t* d = (uint8_t*)mem.gathered + (size_t)g->m[k].y0 * row_bytes;
+                    const ncclResult_t r = rccl().Broadcast(&mem == &g->m[k] ? (const void*)band_of(mem) : (const void*)d, d, (size_t)rows * row_bytes, ncclUint8,
+                                                            (int)k, mem.comm, mem.s_copy);
+                    if (r != ncclSuccess) { (void)rccl().GroupEnd(); return gfail(g, PFX_ERR_HIP, "ncclBroadcast failed: %s", rccl().GetErrorString(r)); }
+                }
+            }
+            PFXG_NCCL(g, rccl().GroupEnd());
+            for (auto& mem : g->m) {
+                PFXG_HIP(g, hipSetDevice(mem.device));
+                PFXG_HIP(g, hipEventRecord(mem.ev_gather, mem.s_copy));
+                mem.gather_pending = true;
+            }
+        } else {
+            for (uint32_t k = 0; k < world; ++k) {
+                auto& mem = g->m[k];
+                const uint32_t rows = mem.y1 - mem.y0;
+                if (!rows) continue;
+                const size_t bytes = (size_t)rows * row_bytes;
+                bool any_staged = false;
+                for (uint32_t d = 0; d < world; ++d) any_staged = any_staged || !direct(g, d, k);
+                PFXG_HIP(g, hipSetDevice(mem.device));
+                PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
+                if (any_staged) {
+                    if (mem.h_band_cap < bytes) {
+                        quiesce(g);
+                        if (mem.h_band) (void)hipHostFree(mem.h_band);
+                        mem.h_band = nullptr; mem.h_band_cap = 0;
+                        PFXG_HIP(g, hipHostMalloc((void**)&mem.h_band, bytes, hipHostMallocPortable));
+                        mem.h_band_cap = bytes;
+                        PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
+                    }
+                    // the previous gather's H2Ds out of this bounce buffer run on the destinations' copy streams
+                    for (auto& dst : g->m)
+                        if (dst.gin_pending) PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, dst.ev_gin, 0));
+                    PFXG_HIP(g, hipMemcpyAsync(mem.h_band, band_of(mem), bytes, hipMemcpyDeviceToHost, mem.s_copy));
+                    PFXG_HIP(g, hipEventRecord(mem.ev_staged_band, mem.s_copy));
+                }
+                for (uint32_t d = 0; d < world; ++d) {
+                    auto& dst = g->m[d];
+                    uint8_t* out = (uint8_t*)dst.gathered + (size_t)mem.y0 * row_bytes;
+                    if (direct(g, d, k)) {
+                        // enqueued on the PRODUCER's copy stream; hipMemcpyPeerAsync accepts any stream
+                        if (dst.device == mem.device) PFXG_HIP(g, hipMemcpyAsync(out, band_of(mem), bytes, hipMemcpyDeviceToDevice, mem.s_copy));
+                        else PFXG_HIP(g, hipMemcpyPeerAsync(out, dst.device, band_of(mem), mem.device, bytes, mem.s_copy));
+                    } else {
+                        PFXG_HIP(g, hipSetDevice(dst.device));
+                        PFXG_HIP(g, hipStreamWaitEvent(dst.s_copy, mem.ev_staged_band, 0));
+                        PFXG_HIP(g, hipMemcpyAsync(out, mem.h_band, bytes, hipMemcpyHostToDevice, dst.s_copy));
+                        PFXG_HIP(g, hipSetDevice(mem.device));
+                    }
+                }
+                PFXG_HIP(g, hipEventRecord(mem.ev_gather, mem.s_copy));
+                mem.gather_pending = true;
+            }
+            for (auto& dst : g->m) { // staged arrivals into `dst` are complete when its copy stream reaches this point
+                PFXG_HIP(g, hipSetDevice(dst.device));
+                PFXG_HIP(g, hipEventRecord(dst.ev_gin, dst.s_copy));
+                dst.gin_pending = true;
+            }
         }
     }
     g->have_result = true;
     return PFX_OK;
+}
+
+// the C ABI must not let a C++ exception (std::vector growth) escape
+int pfx_group_flatten_filter(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, int filter, float param, int all_gather)
+{
+    try { return flatten_filter_impl(g, layers, n_layers, filter, param, all_gather); }
+    catch (const std::bad_alloc&) { return g ? gfail(g, PFX_ERR_OOM, "out of host memory") : PFX_ERR_OOM; }
+    catch (...) { return g ? gfail(g, PFX_ERR_HIP, "unexpected exception") : PFX_ERR_HIP; }
+}
+
+int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, float sigma, int all_gather)
+{
+    return pfx_group_flatten_filter(g, layers, n_layers, pfx_host_gaussian_radius(sigma) >= 1 ? PFX_BAND_GAUSSIAN : PFX_BAND_NONE, sigma, all_gather);
 }
 
 int pfx_group_synchronize(pfx_group* g)

@@ -71,6 +71,22 @@ class GpuGroup:
             arr[k].layer_idx, arr[k].opacity, arr[k].visible, arr[k].blend_mode, arr[k].kind = idx, op, 1 if vis else 0, mode, 0
         self._check(self.lib.pfx_group_flatten_blur(self.g, arr, C.c_uint32(len(infos)), C.c_float(sigma), C.c_int(1 if all_gather else 0)))
 
+    BAND_NONE, BAND_GAUSSIAN, BAND_BOX, BAND_MEDIAN = 0, 1, 2, 3
+    PEER, RCCL, STAGED = 0, 1, 2
+
+    def flatten_filter(self, infos: List[Tuple[int, float, bool, int]], filt: int, param: float, all_gather: bool = False):
+        """pfx_group_flatten_filter: flatten, then a band filter (BAND_GAUSSIAN sigma | BAND_BOX radius | BAND_MEDIAN radius)"""
+        arr = (L.LayerInfo * len(infos))()
+        for k, (idx, op, vis, mode) in enumerate(infos):
+            arr[k].layer_idx, arr[k].opacity, arr[k].visible, arr[k].blend_mode, arr[k].kind = idx, op, 1 if vis else 0, mode, 0
+        self._check(self.lib.pfx_group_flatten_filter(self.g, arr, C.c_uint32(len(infos)), C.c_int(filt), C.c_float(param), C.c_int(1 if all_gather else 0)))
+
+    def set_transport(self, transport: int):
+        self._check(self.lib.pfx_group_set_transport(self.g, C.c_int(transport)))
+
+    def transport(self) -> int:
+        return int(self.lib.pfx_group_transport(self.g))
+
     def synchronize(self):
         self._check(self.lib.pfx_group_synchronize(self.g))
 

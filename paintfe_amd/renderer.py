@@ -599,6 +599,15 @@ class GpuRenderer:
         self._check(self._lib.pfx_box_blur_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
                                                C.c_float(radius), C.c_void_p(mask_ptr or None), C.c_void_p(tmp_ptr or None)))
 
+    def box_blur_band_dev(self, src_ptr, dst_ptr, w, h, radius, mask_ptr=0, tmp_ptr=0, first_row=0):
+        """pfx_box_blur_band_dev: a band with its halo rows (rows at least ceil(radius) from the buffer's ends equal the whole image's)"""
+        self._check(self._lib.pfx_box_blur_band_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h), C.c_float(radius),
+                                                    C.c_void_p(mask_ptr or None), C.c_void_p(tmp_ptr or None), C.c_uint32(first_row)))
+
+    def median_band_dev(self, src_ptr, dst_ptr, w, h, radius, mask_ptr=0, first_row=0):
+        self._check(self._lib.pfx_median_band_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h), C.c_uint32(radius),
+                                                  C.c_void_p(mask_ptr or None), C.c_uint32(first_row)))
+
     def median_dev(self, src_ptr, dst_ptr, w, h, radius, mask_ptr=0):
         self._check(self._lib.pfx_median_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
                                              C.c_uint32(radius), C.c_void_p(mask_ptr or None)))

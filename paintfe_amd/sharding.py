@@ -107,9 +107,9 @@ def gather_bands(band, height: int, group=None):
 
 
 class BandPipeline:
-    """flatten -> halo exchange -> Gaussian -> all-gather of ONE document on this rank's band, buffers allocated once.
+    """flatten -> halo exchange -> Gaussian (or box blur / median) -> all-gather of ONE document on this rank's band, buffers allocated once.
 
-    Everything is enqueued on the current stream: the flatten writes straight into the centre of [top halo | band | bottom halo]
+    Everything is enqueued on torch's current stream (the constructor points the renderer at it): the flatten writes straight into the centre of [top halo | band | bottom halo]
     (edge rows first, so that the halo exchange overlaps the flatten of the band's interior), the halo rows arrive in place through one
     batched RCCL send/recv group (no concatenation, no host synchronisation), the blur
     runs on band + halo with its tiles on the whole image's grid (pfx_gaussian_blur_band_dev: results equal the single-GPU ones bit
@@ -120,11 +120,19 @@ class BandPipeline:
 
     SETS = 2
 
-    def __init__(self, renderer, w: int, h: int, radius: int, sigma: float, device, gather: bool = True, group=None):
+    def __init__(self, renderer, w: int, h: int, radius: int, sigma: float, device, gather: bool = True, group=None, filter: str = "gaussian"):
+        """filter: "gaussian" (sigma; radius = ceil(3 sigma)), "box" (sigma carries the box radius; radius = ceil of it) or "median"
+        (sigma carries the radius) — the three stencils whose vertical pass needs halo rows"""
         import torch
         import torch.distributed as dist
 
+        assert filter in ("gaussian", "box", "median")
+        self.filter = filter
         self.r, self.w, self.h, self.radius, self.sigma, self.group, self.gather = renderer, w, h, radius, sigma, group, gather
+        # every kernel of a step and RCCL's ordering (req.wait(), the asynchronous all-gather) are relative to torch's CURRENT stream:
+        # the renderer must launch there too, or the halo exchange races the flatten and the blur races the halo's arrival
+        if getattr(device, "type", str(device)) == "cuda" or str(device).startswith("cuda"):
+            renderer.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.y0, self.y1 = band_rows(h, self.world, self.rank)
         self.rows = self.y1 - self.y0
@@ -209,7 +217,13 @@ class BandPipeline:
         blurred = self.blurred[s]
         if self.rows:
             prow = self.top + self.rows + self.bottom
-            self.r.gaussian_blur_dev(self.padded.data_ptr(), blurred.data_ptr(), self.w, prow, self.sigma, first_row=self.y0 - self.top)
+            first = self.y0 - self.top
+            if self.filter == "gaussian":
+                self.r.gaussian_blur_dev(self.padded.data_ptr(), blurred.data_ptr(), self.w, prow, self.sigma, first_row=first)
+            elif self.filter == "box":
+                self.r.box_blur_band_dev(self.padded.data_ptr(), blurred.data_ptr(), self.w, prow, self.sigma, first_row=first)
+            else:
+                self.r.median_band_dev(self.padded.data_ptr(), blurred.data_ptr(), self.w, prow, int(self.sigma), first_row=first)
         if not self.gather:
             return blurred[self.top:self.top + self.rows]
         send = blurred[self.top:self.top + self.max_rows]

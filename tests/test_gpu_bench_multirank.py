@@ -39,12 +39,22 @@ def test_doc_mode_two_ranks_contract():
 def test_band_mode_is_the_default_and_matches_single_process(nproc):
     d = _run(nproc, ["--exact"], 29630 + nproc)  # no --shard: the driver's command line
     assert d["scaling"] == "strong" and d["n_gpus"] == nproc and "all-gather" in d["config"]["sharding"]
+    assert d["ranks"]["world_size"] == nproc and len(d["ranks"]["per_rank_ms_per_step"]) == nproc and all(t > 0 for t in d["ranks"]["per_rank_ms_per_step"])
     assert d["check"]["band_blur_max_diff_vs_oracle"] == 0  # exact Gaussian: bit-identical to the unsharded pipeline
     assert abs(d["value"] - 640 * 400 / d["ms_per_step"] / 1e3) / d["value"] < 0.01  # ONE document per step for the whole job
     assert d["doc_mode"]["scaling"] == "weak" and d["doc_mode"]["value"] > 0
     assert d["band_sharded_result"]["scaling"] == "strong" and d["band_sharded_result"]["value"] > 0  # the same pipeline without the all-gather
     d = _run(nproc, [], 29640 + nproc)
     assert d["check"]["band_blur_max_diff_vs_oracle"] <= 1  # matrix-core Gaussian: the stated +-1 LSB
+
+
+def test_gpus_flag_without_that_many_ranks_fails_loudly():
+    """`--gpus 2` started as a single process must refuse to print a number (the driver launches N ranks; a job that silently ran on
+    fewer would report a wrong N-GPU value)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--width", "256", "--height", "128",
+                        "--layers", "3", "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
 
 
 def test_band_mode_with_split_flatten_matches_single_process():

@@ -28,13 +28,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+FILTERS = {  # name -> (halo rows, filter on a numpy image): the three stencils whose vertical pass needs neighbours' rows
+    "gaussian": (lambda: len(O.gaussian_kernel(SIGMA)) // 2, lambda img: O.gaussian_blur(img, SIGMA, threads=1)),
+    "box": (lambda: 3, lambda img: O.box_blur(img, 2.5)),          # ceil(2.5) rows (blur.rs:241)
+    "median": (lambda: 2, lambda img: O.median(img, 2)),
+}
+
+
+def _worker(rank, world, port, out_dir, filt="gaussian"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         stack, modes, opac = I.layer_stack(W, H, NL, seed=11)
-        radius = len(O.gaussian_kernel(SIGMA)) // 2
+        radius = FILTERS[filt][0]()
         y0, y1 = S.band_rows(H, world, rank)
         if y1 > y0:
             flat_band = O.flatten_stack(np.ascontiguousarray(stack[:, y0:y1]), modes, opac, threads=1)
@@ -42,7 +49,7 @@ def _worker(rank, world, port, out_dir):
             flat_band = np.zeros((0, W, 4), np.uint8)
         padded, top, bottom = S.exchange_halo(torch.from_numpy(flat_band), H, radius)
         if y1 > y0:
-            blurred = O.gaussian_blur(padded.numpy(), SIGMA, threads=1)[top:top + (y1 - y0)]
+            blurred = FILTERS[filt][1](padded.numpy())[top:top + (y1 - y0)]
         else:
             blurred = np.zeros((0, W, 4), np.uint8)
         full = S.gather_bands(torch.from_numpy(np.ascontiguousarray(blurred)), H).numpy()
@@ -53,12 +60,12 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_band_sharded_pipeline_matches_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,filt", [(2, "gaussian"), (3, "gaussian"), (2, "box"), (3, "box"), (2, "median"), (3, "median")])
+def test_band_sharded_pipeline_matches_single_process(tmp_path, world, filt):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), filt), nprocs=world, join=True)
     stack, modes, opac = I.layer_stack(W, H, NL, seed=11)
-    ref = O.gaussian_blur(O.flatten_stack(stack, modes, opac, threads=2), SIGMA, threads=2)
+    ref = FILTERS[filt][1](O.flatten_stack(stack, modes, opac, threads=2))
     for r in range(world):
         got = np.load(tmp_path / f"r{r}.npy")
         assert got.shape == ref.shape
