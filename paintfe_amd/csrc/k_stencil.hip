@@ -8,6 +8,7 @@
 // first output of a lane and a 2-term slide for the following ones.
 #include "k_common.h"
 #include "k_median25_net.h"
+#include "k_median_shared_net.h"
 #include "pfx_kernels.h"
 
 using namespace pfxk;
@@ -280,6 +281,88 @@ __global__ __launch_bounds__(MD_TX* MD_TY) void median_net_kernel(const uint32_t
     dst[oi] = __builtin_bit_cast(uint32_t, e[N / 2]) | (__builtin_bit_cast(uint32_t, o[N / 2]) << 8);
 }
 
+// 5x5 / 7x7 median, four adjacent windows per lane (k_median_shared_net.h, tools/gen_median_shared.py): every column is sorted once
+// and serves up to four windows, the sorted run two neighbouring windows share is merged once, and a window's median is picked out of
+// `shared run U one more column` — 83.5 (r = 2) / 199.5 (r = 3) min / max operations per window and channel pair instead of 226 / 626
+// for the single-window selection networks above.  Same integers, same element len/2 of the ascending sort (noise.rs:398-404).
+// A block is 4 rows x 64 lanes x 4 pixels; the (4 + 2r) x (256 + 2r) source tile is staged in LDS with the reference's edge clamp.
+constexpr int MS_W = 256, MS_H = 4;
+// DIRECT (w % 4 == 0, 16-byte aligned images — every real document): a lane fetches its 4 + 2r columns of a row as three aligned
+// 16-byte quads straight from global memory (the quads left and right of its own overlap the neighbouring lanes' — L1 serves them),
+// edge quads replicate the border pixel (noise.rs:389-392); no LDS tile, no barrier, all 3 (2r+1) loads in flight at once.
+// Otherwise the (4 + 2r) x (256 + 2r) source tile of the block is staged in LDS with the same clamp.
+template <int R, bool DIRECT>
+__global__ __launch_bounds__(256) void median_shared_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                            const uint8_t* __restrict__ mask, int w, int h)
+{
+    constexpr int S = 2 * R + 1, NC = 4 + 2 * R, TW = MS_W + 2 * R, TH = MS_H + 2 * R;
+    __shared__ uint32_t tile[DIRECT ? 1 : TH * TW];
+    const int bx = blockIdx.x * MS_W, by = blockIdx.y * MS_H;
+    const int lane = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x0 = bx + lane * 4, y = by + ly;
+    uint32_t px[S][NC]; // rows y-R .. y+R, columns x0-R .. x0+3+R
+    if constexpr (DIRECT) {
+        if (x0 >= w || y >= h) return;
+        const bool first = x0 == 0, last = x0 + 4 >= w;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const uint32_t* row = src + (size_t)min(max(y + k - R, 0), h - 1) * w;
+            const uint4 v = *reinterpret_cast<const uint4*>(row + x0);
+            uint4 l = *reinterpret_cast<const uint4*>(row + (first ? 0 : x0 - 4));
+            uint4 q = *reinterpret_cast<const uint4*>(row + (last ? x0 : x0 + 4));
+            if (first) l = make_uint4(v.x, v.x, v.x, v.x);
+            if (last) q = make_uint4(v.w, v.w, v.w, v.w);
+            const uint32_t a[12] = {l.x, l.y, l.z, l.w, v.x, v.y, v.z, v.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) px[k][c] = a[c + 4 - R];
+        }
+    } else {
+        for (int i = threadIdx.x; i < TW * TH; i += 256) {
+            const int ty = i / TW, tx = i - ty * TW;
+            tile[i] = src[(size_t)min(max(by - R + ty, 0), h - 1) * w + min(max(bx - R + tx, 0), w - 1)]; // noise.rs:389-392
+        }
+        __syncthreads();
+        if (x0 >= w || y >= h) return;
+#pragma unroll
+        for (int k = 0; k < S; ++k)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) px[k][c] = tile[(ly + k) * TW + lane * 4 + c];
+    }
+    uint32_t out[4] = {0u, 0u, 0u, 0u};
+#define PFX_MS_MIN(a, b) __builtin_elementwise_min(a, b)
+#define PFX_MS_MAX(a, b) __builtin_elementwise_max(a, b)
+    { // R,B in 16-bit lanes: one v_pk_min_u16 / v_pk_max_u16 handles two channels
+#define PFX_MS_IN(c, k) __builtin_bit_cast(pfx_us2, px[k][c] & 0x00ff00ffu)
+#define PFX_MS_OUT(j, v) out[j] = __builtin_bit_cast(uint32_t, v)
+        if constexpr (R == 2) { PFX_MEDIAN_SHARED_R2(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
+        else { PFX_MEDIAN_SHARED_R3(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
+#undef PFX_MS_IN
+#undef PFX_MS_OUT
+    }
+    { // G,A
+#define PFX_MS_IN(c, k) __builtin_bit_cast(pfx_us2, (px[k][c] >> 8) & 0x00ff00ffu)
+#define PFX_MS_OUT(j, v) out[j] |= __builtin_bit_cast(uint32_t, v) << 8
+        if constexpr (R == 2) { PFX_MEDIAN_SHARED_R2(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
+        else { PFX_MEDIAN_SHARED_R3(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
+#undef PFX_MS_IN
+#undef PFX_MS_OUT
+    }
+#undef PFX_MS_MIN
+#undef PFX_MS_MAX
+    const size_t o0 = (size_t)y * w + x0;
+    if (mask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < w && mask[o0 + j] == 0) out[j] = px[R][R + j];
+    }
+    if constexpr (DIRECT) *reinterpret_cast<uint4*>(dst + o0) = make_uint4(out[0], out[1], out[2], out[3]);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < w) dst[o0 + j] = out[j];
+    }
+}
+
 // ---------------------------------------------------------------- pixelate
 __global__ __launch_bounds__(256) void pixelate_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                        const uint8_t* __restrict__ mask, uint32_t bs, uint32_t w, uint32_t h)
@@ -294,6 +377,8 @@ __global__ __launch_bounds__(256) void pixelate_kernel(const uint32_t* __restric
 
 } // namespace
 
+int g_median_single = 0; // pfxk_median_set_single: the one-window-per-lane networks for radii 2 and 3
+extern "C" void pfxk_median_set_single(int on) { g_median_single = on; }
 int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
 extern "C" void pfxk_box_set_two_pass(int on) { g_box_two_pass = on; }
 extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst,
@@ -384,7 +469,16 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         else median3_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         return hipGetLastError();
     }
-    if (radius == 2 || radius == 3) { // 5x5 / 7x7: selection networks
+    if ((radius == 2 || radius == 3) && !g_median_single) { // 5x5 / 7x7: four windows per lane on shared sorted columns
+        const dim3 g((w + MS_W - 1) / MS_W, (h + MS_H - 1) / MS_H);
+        const bool direct = (w & 3u) == 0 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0;
+#define PFX_MS(R, D) median_shared_kernel<R, D><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h)
+        if (radius == 2) { if (direct) PFX_MS(2, true); else PFX_MS(2, false); }
+        else { if (direct) PFX_MS(3, true); else PFX_MS(3, false); }
+#undef PFX_MS
+        return hipGetLastError();
+    }
+    if (radius == 2 || radius == 3) { // the single-window selection networks (pfx_tune "median_single": A/B and parity of the two paths)
         const dim3 g((w + MD_TX - 1) / MD_TX, (h + MD_TY - 1) / MD_TY);
         if (radius == 2) median_net_kernel<2><<<g, MD_TX * MD_TY, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         else median_net_kernel<3><<<g, MD_TX * MD_TY, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);

@@ -255,6 +255,26 @@ def test_median_bitexact(gpu, oracle, radius):
     assert_same(gpu.median(img, radius, mask), oracle.median(img, radius, mask), 0, f"median r={radius} masked")
 
 
+@pytest.mark.parametrize("radius", [2, 3])
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (4, 9), (7, 7), (255, 5), (256, 4), (257, 6), (260, 64), (512, 3), (1031, 37)])
+def test_median_shared_column_networks(gpu, oracle, radius, size):
+    """radii 2 and 3: four windows per lane on shared sorted columns (k_median_shared_net.h) — block edges (256 x 4 pixel blocks), image
+    edges (clamped windows wider than the image), widths that are and are not multiples of 4, masks, heavy ties; the single-window
+    networks (pfx_tune "median_single") must give the same image"""
+    w, h = size
+    img = I.random_rgba(w, h, 600 + w + radius)
+    img[: h // 2] = (img[: h // 2] // 86) * 86  # three levels per channel: ties everywhere
+    mask = (np.random.default_rng(w).random((h, w)) < 0.5).astype(np.uint8)
+    ref, ref_m = oracle.median(img, radius), oracle.median(img, radius, mask)
+    for single in (0, 1):
+        gpu.r.tune("median_single", single)
+        try:
+            assert_same(gpu.median(img, radius), ref, 0, f"median r={radius} {w}x{h} single={single}")
+            assert_same(gpu.median(img, radius, mask), ref_m, 0, f"median r={radius} {w}x{h} masked single={single}")
+        finally:
+            gpu.r.tune("median_single", 0)
+
+
 @pytest.mark.parametrize("size", [(4, 1), (4, 5), (8, 3), (256, 9), (260, 64), (1024, 33), (1, 1), (3, 7), (255, 6)])
 def test_median_3x3_network_paths(gpu, oracle, size):
     """r <= 1 takes the min3/med3/max3 network: widths that are multiples of 4 use the 16-byte load + lane-exchange path
