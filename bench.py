@@ -502,6 +502,11 @@ def main() -> int:
             clk = fl.get("clock_ghz", 2.0)
             roofline["valu_frac"] = round(fl["valu_wave_insts"] * 2 / (1024 * clk * 1e9 * d_ms * 1e-3), 3)
             roofline["valu_insts_per_layer_px"] = round(fl["valu_wave_insts"] * 64 / (n * px_per_launch), 1)
+            if fl.get("valu_issue_cycles_weighted"):
+                # per-class issue costs (FMA / MUL / ADD 2 cycles, transcendental 8, compare / select / min / max / trunc / convert 4: tools/lab/
+                # valu_tput.hip) applied to the profiled instruction mix, against THIS run's kernel duration at the profiled clock
+                lo, hi = fl["valu_issue_cycles_weighted"]
+                roofline["valu_frac_weighted_by_issue_cost"] = [round(lo / (1024 * clk * 1e9 * d_ms * 1e-3), 3), round(hi / (1024 * clk * 1e9 * d_ms * 1e-3), 3)]
             # against what the chip's VALU sustains: a pure v_fma_f32 loop (tools/ubench_valu, profiles/rNN_valu_peak.json); a quarter-rate
             # (transcendental) instruction takes four plain instructions' worth of the pipe
             try:
@@ -515,7 +520,7 @@ def main() -> int:
         roofline["per_kernel_bound"] = pmc.get("bounds")
         # traffic / valu_* / per_kernel_bound come from a committed counter pass, not from this run (PMC collection needs rocprofv3 around
         # the process): say so, and which build the pass profiled
-        roofline["static"] = {"fields": ["traffic", "valu_frac", "valu_insts_per_layer_px", "valu_frac_of_sustained_fma_rate", "per_kernel_bound"],
+        roofline["static"] = {"fields": ["traffic", "valu_frac", "valu_frac_weighted_by_issue_cost", "valu_insts_per_layer_px", "valu_frac_of_sustained_fma_rate", "per_kernel_bound"],
                               "profile": pmc.get("_file"), "profiled_commit": pmc.get("commit"), "static": True}
 
     out = {"metric": "Mpixels/sec: 8K 32-layer flatten + Gaussian sigma=16; HBM GB/s vs peak", "value": round(value, 1),

@@ -31,7 +31,7 @@ def name(kernel):
 
 
 px = W * H
-fl, gs = "flatten_stream_kernel", "gauss_strip_kernel"
+fl, gs = ("flatten_dle_kernel" if "flatten_dle_kernel" in txt else "flatten_stream_kernel"), "gauss_strip_kernel"
 cyc_f, cyc_g = val(fl, "GRBM_GUI_ACTIVE") / 8, val(gs, "GRBM_GUI_ACTIVE") / 8
 d = {
     "source": "tools/prof.sh -> tools/prof_summary.py -> tools/pmc_json.py (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group; "
@@ -45,6 +45,7 @@ d = {
         "valu_issue_frac_profiled": round(val(fl, "SQ_INSTS_VALU") * 2 / (1024 * cyc_f), 3),  # 2 issue cycles per wave64 VALU, 1024 SIMDs
         "valu_insts_per_layer_px": round(val(fl, "SQ_INSTS_VALU") * 64 / (px * N), 2),
     },
+    "commit": (sys.argv[3] if len(sys.argv) > 3 else None),
     "gauss_strip": {
         "kernel": name(gs), "avg_ns_profiled": round(avg_ns(gs), 1),
         "fetch_bytes": hbm(gs, "FETCH_SIZE"), "write_bytes": hbm(gs, "WRITE_SIZE"),
@@ -57,9 +58,24 @@ d = {
     },
 }
 f, g = d["flatten"], d["gauss_strip"]
+# weighted issue cycles: FMA / MUL / ADD f32 at 2 cycles per wave64 instruction, transcendentals at 8, every other class at 4
+# (measured: tools/lab/valu_tput.hip, profiles/r03_valu_rates.txt; integer add / logic / moves are also 2-cycle, so this is an upper bound
+# for the INT32 class and the result is quoted as a range)
+mix = {k: val(fl, "SQ_INSTS_VALU_" + k) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "CVT", "INT32")}
+if all(v is not None for v in mix.values()):
+    total = val(fl, "SQ_INSTS_VALU")
+    fast = mix["ADD_F32"] + mix["MUL_F32"] + mix["FMA_F32"]
+    rest = total - fast - mix["TRANS_F32"] - mix["INT32"]
+    lo = 2 * (fast + mix["INT32"]) + 8 * mix["TRANS_F32"] + 4 * rest
+    hi = lo + 2 * mix["INT32"]
+    f["valu_class_mix"] = {k.lower(): v for k, v in mix.items()}
+    f["valu_class_mix"]["other_half_rate (compare, select, min/max, trunc, moves)"] = rest
+    f["valu_issue_cycles_weighted"] = [lo, hi]
+    f["valu_issue_frac_weighted"] = [round(lo / (1024 * cyc_f), 3), round(hi / (1024 * cyc_f), 3)]
 d["bounds"] = {
-    "flatten": f"VALU issue ({f['valu_issue_frac_profiled'] * 100:.0f} % of the issue slots at the profiled {f['clock_ghz']:.2f} GHz; HBM traffic = algorithmic, "
-               f"{f['hbm_bytes'] / f['algorithmic_bytes']:.3f}x)",
+    "flatten": f"VALU issue: {f['valu_issue_frac_profiled'] * 100:.0f} % of the issue slots if every instruction took 2 cycles, "
+               + (f"{f['valu_issue_frac_weighted'][0] * 100:.0f}-{f['valu_issue_frac_weighted'][1] * 100:.0f} % with the measured per-class issue costs " if "valu_issue_frac_weighted" in f else "")
+               + f"at the profiled {f['clock_ghz']:.2f} GHz; HBM traffic {f['hbm_bytes'] / f['algorithmic_bytes']:.3f}x algorithmic",
     "gauss_strip": f"barrier-to-barrier dependency chain of the producer / consumer wave roles (MFMA pipe {g['mfma_pipe_frac_profiled'] * 100:.0f} % busy, LDS "
                    f"{g['lds_busy_frac_profiled'] * 100:.0f} %; HBM traffic {g['hbm_bytes'] / g['algorithmic_bytes']:.2f}x algorithmic: the 4x x-halo overlap of neighbouring strips "
                    "is served by one XCD's L2 since the strip order is XCD-aware)",
