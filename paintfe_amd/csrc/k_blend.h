@@ -370,18 +370,22 @@ PFX_DEV void blend_nx_dispatch(uint32_t mode, float (&acc)[PX][4], const float (
     }
 }
 
-// one layer on PX pixels per lane: picks the opaque-accumulator specialisations wave-wide
+// one layer on PX pixels per lane: picks the opaque-accumulator specialisations wave-wide.  `opc` = the layer opacity clamped to [0, 1],
+// prepared by the host (pfxk_layer_desc::adj_off of a raster layer): clamping a wave-uniform value on the VALU cost two half-rate
+// instructions per wave and layer, and the raw value is only ever compared with 1.0 — `raw >= 1` <=> `clamp(raw) >= 1`.
 template <int PX>
-PFX_DEV void blend_layer_nx(uint32_t mode, float (&acc)[PX][4], const float (&top)[PX][4], float opacity_raw)
+PFX_DEV void blend_layer_nx(uint32_t mode, float (&acc)[PX][4], const float (&top)[PX][4], float opc)
 {
-    const float opc = rs_clamp(opacity_raw, 0.0f, 1.0f);
-    float amin = acc[0][3], tmin = top[0][3];
+    float amin = acc[0][3];
 #pragma unroll
-    for (int p = 1; p < PX; ++p) { amin = vmin(amin, acc[p][3]); tmin = vmin(tmin, top[p][3]); }
+    for (int p = 1; p < PX; ++p) amin = vmin(amin, acc[p][3]);
     if (__all(amin == 1.0f)) {
-        if (opacity_raw >= 1.0f && __all(tmin == 1.0f)) blend_nx_dispatch<PX, 2>(mode, acc, top, opacity_raw, opc);
-        else blend_nx_dispatch<PX, 1>(mode, acc, top, opacity_raw, opc);
-    } else blend_nx_dispatch<PX, 0>(mode, acc, top, opacity_raw, opc);
+        float tmin = top[0][3];
+#pragma unroll
+        for (int p = 1; p < PX; ++p) tmin = vmin(tmin, top[p][3]);
+        if (opc >= 1.0f && __all(tmin == 1.0f)) blend_nx_dispatch<PX, 2>(mode, acc, top, opc, opc);
+        else blend_nx_dispatch<PX, 1>(mode, acc, top, opc, opc);
+    } else blend_nx_dispatch<PX, 0>(mode, acc, top, opc, opc);
 }
 
 } // namespace pfxk

@@ -287,10 +287,10 @@ __global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_la
         const uint32_t last = n_layers - 1u;
         const uint8_t* npx = layers[0].pixels;
         uint32_t nmode = layers[0].mode;
-        uint32_t nop = __builtin_bit_cast(uint32_t, layers[0].opacity);
+        uint32_t nop = layers[0].adj_off; // raster layers: bits of the clamped opacity (pfx_kernels.h)
 #define PFX_FETCH(T, M, O, K) { M = nmode; O = nop; stream_fetch<PX>(T, npx, bytes, voff); \
                                 const uint32_t kn = ((K) + 1u < last) ? (K) + 1u : last; \
-                                npx = layers[kn].pixels; nmode = layers[kn].mode; nop = __builtin_bit_cast(uint32_t, layers[kn].opacity); }
+                                npx = layers[kn].pixels; nmode = layers[kn].mode; nop = layers[kn].adj_off; }
 #define PFX_LAYER(T, M, O, K) if ((K) < n_layers) stream_layer<PX>(acc, T, M, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(O)));
         PFX_FETCH(tA, mA, oA, 0u)
         if constexpr (NB == 2) {
@@ -361,7 +361,7 @@ PFX_DEV void dle_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
     const uint32_t last = le - 1u;
     const uint8_t* npx = layers[lb].pixels;
     uint32_t nmode = layers[lb].mode;
-    uint32_t nop = __builtin_bit_cast(uint32_t, layers[lb].opacity);
+    uint32_t nop = layers[lb].adj_off; // raster layers: bits of the clamped opacity (pfx_kernels.h)
     auto fetch = [&](auto SET, uint32_t K) {
         constexpr int S = decltype(SET)::value;
         m[S] = nmode; o[S] = nop;
@@ -372,7 +372,7 @@ PFX_DEV void dle_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
             t[S][j][0] = v.x; t[S][j][1] = v.y; t[S][j][2] = v.z; t[S][j][3] = v.w;
         }
         const uint32_t kn = (K + 1u < last) ? K + 1u : last;
-        npx = layers[kn].pixels; nmode = layers[kn].mode; nop = __builtin_bit_cast(uint32_t, layers[kn].opacity);
+        npx = layers[kn].pixels; nmode = layers[kn].mode; nop = layers[kn].adj_off;
     };
     auto blend = [&](auto SET, uint32_t K) {
         constexpr int S = decltype(SET)::value;

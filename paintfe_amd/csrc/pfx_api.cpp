@@ -179,6 +179,10 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
             if (!d.pixels) return pfx_fail(ctx, PFX_ERR_INVALID, "layer %u: null device pointer", i);
             if (mask_ptrs && mask_ptrs[i]) { d.mask = (const uint8_t*)mask_ptrs[i]; *general = true; }
         }
+        if (d.kind == PFX_LAYER_RASTER) { // Rust f32::clamp(0.0, 1.0); NaN stays NaN (such a stack never takes the streaming kernels)
+            const float c = d.opacity < 0.0f ? 0.0f : (d.opacity > 1.0f ? 1.0f : d.opacity);
+            std::memcpy(&d.adj_off, &c, 4);
+        }
         if (i == track_info && track_pos && d.kind == PFX_LAYER_RASTER) { *track_pos = (uint32_t)desc.size(); *track_pixels = d.pixels; }
         desc.push_back(d);
     }

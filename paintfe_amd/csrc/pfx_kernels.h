@@ -18,7 +18,8 @@ typedef struct pfxk_layer_desc {
     float    opacity;      // as stored (unclamped: the >= 1.0 fast path looks at the raw value)
     uint32_t mode;         // BlendMode::to_u8
     uint32_t kind;         // PFXK_LAYER_RASTER or PFXK_ADJ_*
-    uint32_t adj_off;      // offset (floats) of this layer's 16 parameters in the adj table
+    uint32_t adj_off;      // adjustment layers: offset (floats) of the 16 parameters in the adj table; raster layers: bit pattern of
+                           // opacity.clamp(0, 1) (the streaming compositor kernels read this instead of clamping per wave and layer)
 } pfxk_layer_desc;
 
 // parameter block of the pointwise kernels (passed by value: lands in SGPRs)

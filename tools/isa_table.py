@@ -61,7 +61,24 @@ def main():
         valu = sum(1 for i in ins if i.startswith("v_"))
         salu = sum(1 for i in ins if i.startswith("s_") and not i.startswith(("s_waitcnt", "s_nop", "s_load")))
         trans = sum(1 for i in ins if i.startswith(("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log")))
-        counts[(m, ob)] = (valu, salu, trans)
+        # issue cost per class, measured on gfx950 (tools/lab/valu_tput.hip -> profiles/r03_valu_rates.txt): FMA / MUL / ADD / SUB f32, moves, logic, shifts
+        # and integer adds 2 cycles per wave64 instruction; transcendentals 8; everything else (min / max / med3, trunc, conversions, compares, selects,
+        # bfi / perm / and_or, packed ops) 4
+        full = ("v_fma_f32", "v_fmac_f32", "v_fmaak", "v_fmamk", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_and_b32", "v_or_b32",
+                "v_xor_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32")
+        cyc = 0
+        half = 0
+        for i in ins:
+            if not i.startswith("v_"):
+                continue
+            if i.startswith(("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log")):
+                cyc += 8
+            elif i.startswith(full):
+                cyc += 2
+            else:
+                cyc += 4
+                half += 1
+        counts[(m, ob)] = (valu, salu, trans, cyc, half)
     base = counts[(-1, 0)][0] - 4  # the empty probe's own four adds
     lines = ["# Compositor pixel code: gfx950 instructions per layer-pixel, by blend mode",
              "",
@@ -70,16 +87,22 @@ def main():
              "OB 1 = wave-uniform opaque accumulator (out_a == 1), OB 2 = additionally an opaque layer at 100 % opacity.",
              "VALU/px is what bounds the kernel (one wave64 VALU instruction = 2 issue cycles on a SIMD);",
              "`trans` = quarter-rate instructions among them (v_rcp / v_sqrt).", "",
-             "| mode | OB0 VALU/px | OB0 trans/px | OB0 SALU/quad | OB1 VALU/px | OB2 VALU/px |", "|---|---|---|---|---|---|"]
-    tot = [0.0, 0.0, 0.0]
+             "`cycles` = the same instructions weighted by their measured issue cost (2 / 4 / 8 cycles per wave64 instruction, profiles/r03_valu_rates.txt);",
+             "`half` = how many of them are 4-cycle instructions (compare, select, min / max, trunc, convert).", "",
+             "| mode | OB0 VALU/px | OB0 cycles/px | OB0 half-rate/px | OB0 trans/px | OB0 SALU/quad | OB1 VALU/px | OB1 cycles/px | OB2 VALU/px | OB2 cycles/px |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
+    tot = [0.0] * 6
+    base_c = counts[(-1, 0)][3] - 8
     for m in range(25):
-        v0, s0, t0 = counts[(m, 0)]
-        v1 = counts[(m, 1)][0]
-        v2 = counts[(m, 2)][0]
+        v0, s0, t0, c0, h0 = counts[(m, 0)]
+        v1, _, _, c1, _ = counts[(m, 1)]
+        v2, _, _, c2, _ = counts[(m, 2)]
         a, b, c = (v0 - base) / 4, (v1 - base) / 4, (v2 - base) / 4
-        tot[0] += a; tot[1] += b; tot[2] += c
-        lines.append(f"| {m} {MODES[m]} | {a:.2f} | {t0 / 4:.2f} | {s0} | {b:.2f} | {c:.2f} |")
-    lines.append(f"| **mean of 25** | **{tot[0] / 25:.2f}** | | | **{tot[1] / 25:.2f}** | **{tot[2] / 25:.2f}** |")
+        ca, cb, cc = (c0 - base_c) / 4, (c1 - base_c) / 4, (c2 - base_c) / 4
+        for k, v in enumerate((a, b, c, ca, cb, cc)):
+            tot[k] += v
+        lines.append(f"| {m} {MODES[m]} | {a:.2f} | {ca:.1f} | {(h0 - counts[(-1, 0)][4]) / 4:.1f} | {t0 / 4:.2f} | {s0} | {b:.2f} | {cb:.1f} | {c:.2f} | {cc:.1f} |")
+    lines.append(f"| **mean of 25** | **{tot[0] / 25:.2f}** | **{tot[3] / 25:.1f}** | | | | **{tot[1] / 25:.2f}** | **{tot[4] / 25:.1f}** | **{tot[2] / 25:.2f}** | **{tot[5] / 25:.1f}** |")
     txt = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(txt)
