@@ -444,6 +444,7 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
     uint32_t q_head = 0, q_tail = 0;              // monotone counters; entry k lives at q[k % QCAP]
     uint32_t q_r = 0, q_start = 0;                // layers [q_start, q_r) are what the queued pixels still need
     uint32_t st_rounds = 0, st_rpx = 0, st_rlay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0;
+    uint32_t probe_fail = 0, skip_left = 0;      // classification back-off (below)
     for (;;) {
         const uint32_t q_cnt = q_tail - q_head;
         bool run_queue = q_cnt >= UPX, run_nat = false;
@@ -462,7 +463,12 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
                 uint32_t cls[PX];
 #pragma unroll
                 for (int j = 0; j < PX; ++j) cls[j] = 0u;
-                bool done = false;
+                // Reading a candidate's alpha costs as much HBM traffic as a layer: where the reset layers do not pay (say Normal layers at
+                // 100 % whose pixels are mostly translucent) the stream stops asking — after two units in a row that saved nothing the next
+                // 14 start at layer 0 unexamined, then two more are probed
+                const bool probe = skip_left == 0u;
+                if (!probe) skip_left -= 1u;
+                bool done = !probe;
 #pragma unroll
                 for (int i = 3; i >= 0; --i) {
                     if ((uint32_t)i < C.n && !done) {
@@ -502,6 +508,10 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
                     }
                 }
                 if (best != 0u && q_cnt != 0u && q_r != r) { best = 0u; r = s_u; } // one split layer in the queue at a time
+                if (probe) {
+                    if (best != 0u || s_u != 0u) probe_fail = 0u;
+                    else if (++probe_fail >= 2u) { probe_fail = 0u; skip_left = 14u; }
+                }
                 // natural slots start from the reference's initial accumulator (0,0,0,0), canvas_state.rs:573
 #pragma unroll
                 for (int j = 0; j < PX; ++j) acc_ring[(o0 + 64u * j) % RING] = 0u;

@@ -198,7 +198,13 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
             if (d.mode == 14u) found.emplace_back(p, 0u);
             else if (d.mode == 0u && d.opacity >= 1.0f) found.emplace_back(p, 1u);
         }
-        const size_t first = found.size() > PFXK_DLE_MAX ? found.size() - PFXK_DLE_MAX : 0;
+        // Every candidate the kernel inspects costs a layer's worth of reads for the units it examines, and the elimination kernel's load
+        // stream is less efficient than the plain streaming kernel's (4.7 against 5+ TB/s with the arithmetic taken out): it pays where the
+        // blend arithmetic dominates — deep stacks — and loses up to 30 % on shallow, memory-bound ones (tools/ab_docs_dle.py: nine Normal
+        // layers with S2's alpha 0.43 against 0.33 ms).  Stacks below 16 layers keep the plain kernel (pfx_tune "dle_min_layers").
+        if (desc.size() < (size_t)ctx->dle_min_layers) found.clear();
+        const size_t kmax = std::min<size_t>(PFXK_DLE_MAX, std::max<size_t>(1, desc.size() / 6));
+        const size_t first = found.size() > kmax ? found.size() - kmax : 0;
         for (size_t k = first; k < found.size(); ++k) {
             cands->layer[cands->n] = found[k].first;
             cands->kind[cands->n] = found[k].second;
@@ -1158,6 +1164,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "dle_units") == 0) { pfxk_flatten_set_dle(value, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_ring") == 0) { pfxk_flatten_set_dle(-1, value); return PFX_OK; }
     if (std::strcmp(key, "dle_stats") == 0) { pfxk_flatten_set_dle_dev(value, -1); return PFX_OK; }
+    if (std::strcmp(key, "dle_min_layers") == 0) { ctx->dle_min_layers = value; return PFX_OK; }
     if (std::strcmp(key, "dle_sched") == 0) { pfxk_flatten_set_dle_sched(value, -1, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_frac_a") == 0) { pfxk_flatten_set_dle_sched(-1, value, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_frac_b") == 0) { pfxk_flatten_set_dle_sched(-1, -1, value); return PFX_OK; }

@@ -49,6 +49,7 @@ struct pfx_ctx {
     int n_cus = 0;                  // multiProcessorCount of `device` (persistent-kernel grids)
     // Gaussian tap weights currently resident in d_wts / d_wsplit (re-uploaded only when sigma changes)
     uint32_t wts_sigma_bits = 0, wsplit_sigma_bits = 0;
+    int dle_min_layers = 16;  // stacks at least this deep may take the compositor's dead-layer elimination kernel (pfx_api.cpp:build_stack)
     bool wts_valid = false, wsplit_valid = false; // explicit flags: every 32-bit pattern is some sigma (0xffffffff is a NaN)
     float wsplit_inv_scale = 1.0f, wsplit_bias = 0.0f;
     pfx_devbuf d_wsplit;

@@ -21,7 +21,9 @@ OVERWRITE, NORMAL = 14, 0
 def gpu():
     from .backends import GpuBackend
     g = GpuBackend(0)
+    g.r.tune("dle_min_layers", 0)  # the library only takes the elimination kernel for stacks of 16+ layers; here every stack must
     yield g
+    g.r.tune("dle_min_layers", 16)
     g.r.tune("dle_units", 0)
     g.r.tune("dle_cfg", 0)
     g.r.tune("flatten_variant", 0)
