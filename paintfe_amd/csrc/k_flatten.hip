@@ -261,7 +261,8 @@ PFX_DEV void stream_layer(float (&acc)[PX][4], const float (&t)[PX][4], uint32_t
 
 template <int PX, int NB, int MINW>
 __global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
-                                                                   uint32_t n_px, uint8_t* __restrict__ dst)
+                                                                   uint32_t n_px, uint8_t* __restrict__ dst,
+                                                                   const uint8_t* __restrict__ chunk_start, uint32_t w)
 {
     // NB register sets hold the layer pixels of NB consecutive layers: while layer k is blended, layers k+1 .. k+NB-1 are in
     // flight (the typed load lands 16 bytes of registers per 4 bytes read, so the in-flight volume a CU needs to cover HBM
@@ -285,24 +286,41 @@ __global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_la
         // instead of the vmcnt(0) it falls back to when a prefetch sits behind a branch.  The descriptor (scalar loads) of the layer
         // fetched NEXT is requested one stage ahead, so no fetch waits for it either.
         const uint32_t last = n_layers - 1u;
-        const uint8_t* npx = layers[0].pixels;
-        uint32_t nmode = layers[0].mode;
-        uint32_t nop = layers[0].adj_off; // raster layers: bits of the clamped opacity (pfx_kernels.h)
+        // Layers of the layer store carry per-chunk alpha summaries (pfxk_chunk_alpha_flags): `chunk_start[c]` is the topmost layer that
+        // resets every pixel of 64 x 64 chunk c (an opaque Normal layer at 100 %, canvas_state.rs:1258, or an Overwrite layer without a
+        // transparent pixel there, :1275) — whatever is below it cannot show.  The tile starts at the lowest such layer of the chunks it
+        // touches: a photo layer over a stack costs nothing below the photo, and no pixel is read to find that out.
+        uint32_t first = 0u;
+        if (chunk_start) {
+            const uint32_t cxn = (w + 63u) / 64u;
+            uint32_t s = 255u;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const uint32_t p = tile * (64u * PX) + 64u * j + lane;
+                if (p < n_px) { const uint32_t y = p / w, x = p - y * w; s = min(s, (uint32_t)chunk_start[(y >> 6) * cxn + (x >> 6)]); }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s = min(s, (uint32_t)__shfl_xor((int)s, off));
+            first = min((uint32_t)__builtin_amdgcn_readfirstlane((int)s), last);
+        }
+        const uint8_t* npx = layers[first].pixels;
+        uint32_t nmode = layers[first].mode;
+        uint32_t nop = layers[first].adj_off; // raster layers: bits of the clamped opacity (pfx_kernels.h)
 #define PFX_FETCH(T, M, O, K) { M = nmode; O = nop; stream_fetch<PX>(T, npx, bytes, voff); \
                                 const uint32_t kn = ((K) + 1u < last) ? (K) + 1u : last; \
                                 npx = layers[kn].pixels; nmode = layers[kn].mode; nop = layers[kn].adj_off; }
 #define PFX_LAYER(T, M, O, K) if ((K) < n_layers) stream_layer<PX>(acc, T, M, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(O)));
-        PFX_FETCH(tA, mA, oA, 0u)
+        PFX_FETCH(tA, mA, oA, first)
         if constexpr (NB == 2) {
-            for (uint32_t li = 0; li < n_layers; li += 2) {
+            for (uint32_t li = first; li < n_layers; li += 2) {
                 PFX_FETCH(tB, mB, oB, li + 1)
                 PFX_LAYER(tA, mA, oA, li)
                 PFX_FETCH(tA, mA, oA, li + 2)
                 PFX_LAYER(tB, mB, oB, li + 1)
             }
         } else {
-            PFX_FETCH(tB, mB, oB, 1u)
-            for (uint32_t li = 0; li < n_layers; li += 3) { // at the top: layers li (A) and li + 1 (B) are in flight or landed
+            PFX_FETCH(tB, mB, oB, first + 1u)
+            for (uint32_t li = first; li < n_layers; li += 3) { // at the top: layers li (A) and li + 1 (B) are in flight or landed
                 PFX_FETCH(tC, mC, oC, li + 2)
                 PFX_LAYER(tA, mA, oA, li)
                 PFX_FETCH(tA, mA, oA, li + 3)
@@ -588,6 +606,39 @@ int g_dle_stats_on = 0, g_dle_cfg = 0, g_dle_sched = 1, g_dle_fracA = 75, g_dle_
 int g_dle_units = 0; // tuning knobs (pfxk_flatten_set_dle): units per wave (0 = default), log2 of the accumulator ring
 int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant): 0 = shipped, 1-5 = PX / occupancy variants, +10 = grid-stride launch, 9 = the general kernel
 
+// per 64 x 64 chunk of a layer: bit 0 = every alpha is 255, bit 1 = no alpha is 0 (computed when a layer enters the layer store)
+__global__ __launch_bounds__(256) void chunk_alpha_flags_kernel(const uint8_t* __restrict__ px, uint32_t w, uint32_t h, uint32_t cx0, uint32_t cy0,
+                                                                uint32_t ncx, uint8_t* __restrict__ flags)
+{
+    const uint32_t cxn = (w + 63u) / 64u;
+    const uint32_t cx = cx0 + blockIdx.x % ncx, cy = cy0 + blockIdx.x / ncx;
+    const uint32_t bx = cx * 64u, by = cy * 64u;
+    const uint32_t cw = min(64u, w - bx), ch = min(64u, h - by);
+    int not_opaque = 0, has_zero = 0;
+    for (uint32_t i = threadIdx.x; i < cw * ch; i += blockDim.x) {
+        const uint32_t a = px[((size_t)(by + i / cw) * w + bx + i % cw) * 4 + 3];
+        not_opaque |= a != 255u;
+        has_zero |= a == 0u;
+    }
+    const int any_no = __syncthreads_or(not_opaque), any_zero = __syncthreads_or(has_zero);
+    if (threadIdx.x == 0) flags[cy * cxn + cx] = (uint8_t)((any_no ? 0u : 1u) | (any_zero ? 0u : 2u));
+}
+
+// start[c] = topmost layer that resets the whole chunk c (0 if none): want[k] = which flag bit layer k needs (0: never), flags[k] = its summary
+__global__ __launch_bounds__(256) void chunk_start_kernel(const uint8_t* const* __restrict__ flags, const uint8_t* __restrict__ want, uint32_t n_layers,
+                                                          uint32_t n_chunks, uint8_t* __restrict__ start, uint32_t* __restrict__ useful, uint32_t tag)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    uint32_t s = 0u;
+    for (uint32_t k = 1; k < n_layers; ++k)
+        if (want[k] && flags[k] && (flags[k][c] & want[k])) s = k;
+    start[c] = (uint8_t)min(s, 254u);
+    // tells the host (pinned memory, read on a LATER call) whether the table skips anything at all: a stack whose table is all zeros
+    // is composited without it from then on (the lookup costs the plain kernel ~7 %)
+    if (s != 0u && useful) *useful = tag;
+}
+
 // chunk activity = union over visible raster layers of "chunk has any alpha != 0" (canvas_state.rs:529-550)
 __global__ __launch_bounds__(256) void chunk_active_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers,
                                                            uint32_t w, uint32_t h, uint8_t* __restrict__ chunk_active,
@@ -698,6 +749,20 @@ __global__ __launch_bounds__(256) void round_pack_check_kernel(unsigned long lon
 } // namespace
 
 extern "C" void pfxk_flatten_set_variant(int v) { g_flatten_variant = v; }
+extern "C" hipError_t pfxk_chunk_alpha_flags(hipStream_t s, const uint8_t* d_px, uint32_t w, uint32_t h, uint32_t cx0, uint32_t cy0, uint32_t ncx, uint32_t ncy,
+                                             uint8_t* d_flags)
+{
+    if (ncx == 0 || ncy == 0) return hipSuccess;
+    chunk_alpha_flags_kernel<<<ncx * ncy, 256, 0, s>>>(d_px, w, h, cx0, cy0, ncx, d_flags);
+    return hipGetLastError();
+}
+extern "C" hipError_t pfxk_chunk_start(hipStream_t s, const uint8_t* const* d_flag_ptrs, const uint8_t* d_want, uint32_t n_layers, uint32_t n_chunks,
+                                       uint8_t* d_start, uint32_t* useful_pinned, uint32_t tag)
+{
+    if (n_chunks == 0) return hipSuccess;
+    chunk_start_kernel<<<(n_chunks + 255) / 256, 256, 0, s>>>(d_flag_ptrs, d_want, n_layers, n_chunks, d_start, useful_pinned, tag);
+    return hipGetLastError();
+}
 extern "C" hipError_t pfxk_flatten_dle_stats(unsigned long long* out8, int reset)
 {
     hipError_t e = hipSuccess;
@@ -766,7 +831,7 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                                    const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
                                    int chunk_active_ready, uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region,
-                                   const pfxk_dle_cands* cands)
+                                   const pfxk_dle_cands* cands, const uint8_t* d_chunk_start)
 {
     size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
@@ -821,7 +886,7 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
             return hipGetLastError();
         }
         switch (g_flatten_variant % 10) {
-#define PFX_STREAM(PX, NB, MINW) flatten_stream_kernel<PX, NB, MINW><<<grid(64 * PX), block, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst)
+#define PFX_STREAM(PX, NB, MINW) flatten_stream_kernel<PX, NB, MINW><<<grid(64 * PX), block, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, d_chunk_start, w)
         case 1: PFX_STREAM(2, 2, 1); break;
         case 2: PFX_STREAM(2, 3, 1); break;
         case 3: PFX_STREAM(4, 2, 1); break;

@@ -142,8 +142,9 @@ struct preview_arg {
 int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
                 uint32_t n, uint32_t w, uint32_t h, bool from_store, uint32_t* n_desc, bool* general, bool* has_adj,
                 uint32_t track_info = 0xFFFFFFFFu, uint32_t* track_pos = nullptr, const uint8_t** track_pixels = nullptr,
-                pfxk_dle_cands* cands = nullptr)
+                pfxk_dle_cands* cands = nullptr, std::vector<uint8_t>* chunk_meta = nullptr)
 {
+    std::vector<const uint8_t*> flag_ptrs; // per descriptor: the stored layer's chunk alpha summary (NULL: none)
     std::vector<pfxk_layer_desc> desc;
     std::vector<float> adj;
     desc.reserve(n);
@@ -174,6 +175,8 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
                 return pfx_fail(ctx, PFX_ERR_INVALID, "layer %u is %ux%u, canvas is %ux%u", L.layer_idx, it->second.w, it->second.h, w, h);
             d.pixels = (const uint8_t*)it->second.pixels.p;
             if (it->second.has_mask) { d.mask = (const uint8_t*)it->second.mask.p; *general = true; }
+            flag_ptrs.resize(desc.size() + 1, nullptr);
+            flag_ptrs[desc.size()] = it->second.has_mask ? nullptr : (const uint8_t*)it->second.chunk_flags.p;
         } else {
             d.pixels = (const uint8_t*)layer_ptrs[i];
             if (!d.pixels) return pfx_fail(ctx, PFX_ERR_INVALID, "layer %u: null device pointer", i);
@@ -187,6 +190,25 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
         desc.push_back(d);
     }
     *n_desc = (uint32_t)desc.size();
+    if (chunk_meta) {
+        // [n_desc summary pointers | n_desc wanted bits]: Normal at opacity >= 1 resets a chunk whose alpha is all 255 (canvas_state.rs:1258),
+        // Overwrite one without a zero alpha (:1275); layer 0 has nothing below it
+        chunk_meta->clear();
+        flag_ptrs.resize(desc.size(), nullptr);
+        std::vector<uint8_t> want(desc.size(), 0);
+        bool any = false;
+        for (size_t p = 1; p < desc.size(); ++p) {
+            if (desc[p].kind != PFX_LAYER_RASTER || desc[p].mask || !flag_ptrs[p]) continue;
+            if (desc[p].mode == 14u) want[p] = 2;
+            else if (desc[p].mode == 0u && desc[p].opacity >= 1.0f) want[p] = 1;
+            any = any || want[p] != 0;
+        }
+        if (any) {
+            chunk_meta->resize(desc.size() * sizeof(void*) + desc.size());
+            std::memcpy(chunk_meta->data(), flag_ptrs.data(), desc.size() * sizeof(void*));
+            std::memcpy(chunk_meta->data() + desc.size() * sizeof(void*), want.data(), desc.size());
+        }
+    }
     if (cands) {
         // reset layers (k_flatten.hip: dead-layer elimination): the topmost PFXK_DLE_MAX raster layers above the bottom one that are
         // Overwrite (canvas_state.rs:1275) or Normal at opacity >= 1 (:1258); only used by the raster-only streaming path
@@ -243,8 +265,9 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
     const uint8_t* active_pixels = nullptr;
     bool general = false, has_adj = false;
     pfxk_dle_cands cands{};
+    std::vector<uint8_t> chunk_meta;
     PFX_TRY(build_stack(ctx, layer_ptrs, mask_ptrs, layers, n_layers, w, h, from_store, &n_desc, &general, &has_adj,
-                        pv ? pv->info.active_layer : 0xFFFFFFFFu, &active_pos, &active_pixels, &cands));
+                        pv ? pv->info.active_layer : 0xFFFFFFFFu, &active_pos, &active_pixels, &cands, from_store ? &chunk_meta : nullptr));
     const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
     uint8_t* d_chunks = nullptr;
     bool chunks_ready = false;
@@ -272,9 +295,37 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
     }
     bool fast_div = true; // k_flatten.hip:rdiv is bit-identical to '/' unless an opacity is a positive value < 2^-40
     for (uint32_t i = 0; i < n_layers; ++i) fast_div = fast_div && opacity_allows_fast_div(layers[i].opacity);
+    // stored layers: the per-chunk start table (which layer is the first that can show in a 64 x 64 chunk) from their alpha summaries —
+    // only the plain streaming kernel takes it (whole-frame, raster-only stacks)
+    const uint8_t* d_chunk_start = nullptr;
+    if (ctx->use_chunk_start && !chunk_meta.empty() && !general && fast_div && !region && !PV.pixels && cands.n == 0 && n_desc < 255) {
+        if (!ctx->h_chunk_useful) {
+            PFX_HIP(ctx, hipHostMalloc((void**)&ctx->h_chunk_useful, sizeof(uint32_t), hipHostMallocDefault));
+            *ctx->h_chunk_useful = 0;
+            PFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_chunk_useful, hipEventDisableTiming));
+        }
+        const bool same = ctx->chunk_state != 0 && ctx->chunk_epoch == ctx->store_epoch && ctx->chunk_meta_cache == chunk_meta &&
+                          ctx->d_chunk_start.cap >= nchunks;
+        if (same && ctx->chunk_state == 1 && hipEventQuery(ctx->ev_chunk_useful) == hipSuccess)
+            ctx->chunk_state = (*ctx->h_chunk_useful == ctx->chunk_tag) ? 2 : 3; // the table kernel of an earlier call has finished: its verdict is in
+        if (!same) {
+            ctx->chunk_meta_cache.clear();
+            PFX_TRY(pfx_reserve(ctx, ctx->d_chunk_meta, chunk_meta.size()));
+            PFX_TRY(pfx_h2d(ctx, ctx->d_chunk_meta.p, chunk_meta.data(), chunk_meta.size()));
+            ctx->chunk_meta_cache = chunk_meta;
+            PFX_TRY(pfx_reserve(ctx, ctx->d_chunk_start, nchunks));
+            ctx->chunk_tag += 1u;
+            PFX_HIP(ctx, pfxk_chunk_start(ctx->stream, (const uint8_t* const*)ctx->d_chunk_meta.p, (const uint8_t*)ctx->d_chunk_meta.p + (size_t)n_desc * sizeof(void*),
+                                          n_desc, (uint32_t)nchunks, (uint8_t*)ctx->d_chunk_start.p, ctx->h_chunk_useful, ctx->chunk_tag));
+            PFX_HIP(ctx, hipEventRecord(ctx->ev_chunk_useful, ctx->stream));
+            ctx->chunk_state = 1;
+            ctx->chunk_epoch = ctx->store_epoch;
+        }
+        if (ctx->chunk_state != 3) d_chunk_start = (const uint8_t*)ctx->d_chunk_start.p; // pending or useful: the table of THIS stack is in the buffer
+    }
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
-                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region, &cands));
+                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region, &cands, d_chunk_start));
     return PFX_OK;
 }
 
@@ -1164,6 +1215,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "dle_units") == 0) { pfxk_flatten_set_dle(value, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_ring") == 0) { pfxk_flatten_set_dle(-1, value); return PFX_OK; }
     if (std::strcmp(key, "dle_stats") == 0) { pfxk_flatten_set_dle_dev(value, -1); return PFX_OK; }
+    if (std::strcmp(key, "chunk_start") == 0) { ctx->use_chunk_start = value != 0; return PFX_OK; }
     if (std::strcmp(key, "dle_min_layers") == 0) { ctx->dle_min_layers = value; return PFX_OK; }
     if (std::strcmp(key, "dle_sched") == 0) { pfxk_flatten_set_dle_sched(value, -1, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_frac_a") == 0) { pfxk_flatten_set_dle_sched(-1, value, -1); return PFX_OK; }

@@ -6,6 +6,7 @@
 #include <cstdio>
 
 #include "pfx_internal.h"
+#include "pfx_kernels.h"
 
 static thread_local std::string g_no_ctx_error;
 
@@ -122,10 +123,12 @@ void pfx_ctx_destroy(pfx_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& t : ctx->timings) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    for (auto& kv : ctx->layers) { free_buf(kv.second.pixels); free_buf(kv.second.mask); }
+    for (auto& kv : ctx->layers) { free_buf(kv.second.pixels); free_buf(kv.second.mask); free_buf(kv.second.chunk_flags); }
     pfx_devbuf* bufs[] = {&ctx->st_in, &ctx->st_out, &ctx->st_mask, &ctx->st_tmp, &ctx->st_aux, &ctx->st_aux2, &ctx->fx_a, &ctx->fx_b, &ctx->d_desc,
-                          &ctx->d_adj, &ctx->d_chunks, &ctx->d_wts, &ctx->d_wsplit, &ctx->warp_src, &ctx->d_lut, &ctx->d_pts, &ctx->d_misc};
+                          &ctx->d_adj, &ctx->d_chunks, &ctx->d_chunk_meta, &ctx->d_chunk_start, &ctx->d_wts, &ctx->d_wsplit, &ctx->warp_src, &ctx->d_lut, &ctx->d_pts, &ctx->d_misc};
     for (auto* b : bufs) free_buf(*b);
+    if (ctx->h_chunk_useful) (void)hipHostFree(ctx->h_chunk_useful);
+    if (ctx->ev_chunk_useful) (void)hipEventDestroy(ctx->ev_chunk_useful);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -216,7 +219,12 @@ int pfx_layer_upload(pfx_ctx* ctx, uint32_t idx, uint32_t w, uint32_t h, const u
     if (st != PFX_OK) { if (!L.pixels.p) ctx->layers.erase(idx); return st; }
     if (L.w != w || L.h != h) L.has_mask = false;
     L.w = w; L.h = h; L.generation = generation;
+    ctx->store_epoch++;
     PFX_TRY(pfx_h2d(ctx, L.pixels.p, rgba, bytes));
+    // per-chunk alpha summary for the compositor's start table (k_flatten.hip: a tile starts at the topmost layer that covers its chunks)
+    const uint32_t cxn = (w + 63u) / 64u, cyn = (h + 63u) / 64u;
+    PFX_TRY(pfx_reserve(ctx, L.chunk_flags, (size_t)cxn * cyn));
+    PFX_HIP(ctx, pfxk_chunk_alpha_flags(ctx->stream, (const uint8_t*)L.pixels.p, w, h, 0, 0, cxn, cyn, (uint8_t*)L.chunk_flags.p));
     return pfx_sync(ctx);
 }
 
@@ -228,8 +236,13 @@ int pfx_layer_update_rect(pfx_ctx* ctx, uint32_t idx, uint32_t x, uint32_t y, ui
     pfx_layer_state& L = it->second;
     PFX_REQUIRE(ctx, rgba && rw && rh && x + rw <= L.w && y + rh <= L.h, "pfx_layer_update_rect: region out of bounds");
     PFX_TRY(pfx_use(ctx));
+    ctx->store_epoch++;
     PFX_HIP(ctx, hipMemcpy2DAsync((uint8_t*)L.pixels.p + ((size_t)y * L.w + x) * 4, (size_t)L.w * 4, rgba, (size_t)rw * 4,
                                   (size_t)rw * 4, rh, hipMemcpyHostToDevice, ctx->stream));
+    if (L.chunk_flags.p) { // the chunks the rectangle touches get their summary refreshed
+        const uint32_t cx0 = x / 64u, cy0 = y / 64u, cx1 = (x + rw - 1u) / 64u, cy1 = (y + rh - 1u) / 64u;
+        PFX_HIP(ctx, pfxk_chunk_alpha_flags(ctx->stream, (const uint8_t*)L.pixels.p, L.w, L.h, cx0, cy0, cx1 - cx0 + 1u, cy1 - cy0 + 1u, (uint8_t*)L.chunk_flags.p));
+    }
     return pfx_sync(ctx);
 }
 
@@ -239,6 +252,7 @@ int pfx_layer_set_mask(pfx_ctx* ctx, uint32_t idx, const uint8_t* conceal)
     auto it = ctx->layers.find(idx);
     PFX_REQUIRE(ctx, it != ctx->layers.end(), "pfx_layer_set_mask: layer not uploaded");
     pfx_layer_state& L = it->second;
+    ctx->store_epoch++;
     if (!conceal) { L.has_mask = false; return PFX_OK; }
     PFX_TRY(pfx_use(ctx));
     PFX_TRY(pfx_reserve(ctx, L.mask, (size_t)L.w * L.h));
@@ -256,7 +270,9 @@ int pfx_layer_remove(pfx_ctx* ctx, uint32_t idx)
     PFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_buf(it->second.pixels);
     free_buf(it->second.mask);
+    free_buf(it->second.chunk_flags);
     ctx->layers.erase(it);
+    ctx->store_epoch++;
     return PFX_OK;
 }
 
@@ -265,8 +281,9 @@ int pfx_layer_clear(pfx_ctx* ctx)
     if (!ctx) return PFX_ERR_INVALID;
     PFX_TRY(pfx_use(ctx));
     PFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto& kv : ctx->layers) { free_buf(kv.second.pixels); free_buf(kv.second.mask); }
+    for (auto& kv : ctx->layers) { free_buf(kv.second.pixels); free_buf(kv.second.mask); free_buf(kv.second.chunk_flags); }
     ctx->layers.clear();
+    ctx->store_epoch++;
     return PFX_OK;
 }
 

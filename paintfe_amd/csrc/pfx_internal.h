@@ -19,6 +19,7 @@ struct pfx_devbuf { // grow-on-demand device allocation (never shrinks; freed wi
 struct pfx_layer_state { // GpuLayerState (ref: src/gpu/renderer.rs:206-209): device-resident, versioned
     pfx_devbuf pixels;
     pfx_devbuf mask;
+    pfx_devbuf chunk_flags; // per 64 x 64 chunk: bit 0 = every alpha 255, bit 1 = no alpha 0 (pfxk_chunk_alpha_flags; refreshed with the pixels)
     bool has_mask = false;
     uint32_t w = 0, h = 0;
     uint64_t generation = 0;
@@ -42,6 +43,15 @@ struct pfx_ctx {
     pfx_devbuf fx_a, fx_b; // effect-bank scratch (crystallize cell table, drop-shadow planes)
     // small parameter buffers
     pfx_devbuf d_desc, d_adj, d_chunks, d_wts, d_lut, d_pts, d_misc;
+    pfx_devbuf d_chunk_meta, d_chunk_start;     // per-layer summary pointers + wanted bits, and the per-chunk start table built from them
+    std::vector<uint8_t> chunk_meta_cache;
+    // whether the table of the stack in chunk_meta_cache skips anything: written by the table kernel into pinned memory (tag), read on a later
+    // composite of the same stack once `ev_chunk_useful` has fired — 0 = not built, 1 = pending, 2 = useful (table kept), 3 = useless (no table)
+    uint32_t* h_chunk_useful = nullptr;
+    hipEvent_t ev_chunk_useful = nullptr;
+    uint32_t chunk_tag = 0;
+    int chunk_state = 0;
+    uint64_t store_epoch = 0, chunk_epoch = 0;  // store_epoch moves whenever a stored layer's pixels or mask change
     std::vector<uint8_t> desc_cache, adj_cache; // host copies of what d_desc / d_adj hold (build_stack skips identical uploads)
     std::map<uint32_t, pfx_layer_state> layers;
     bool timing = false;
@@ -49,6 +59,7 @@ struct pfx_ctx {
     int n_cus = 0;                  // multiProcessorCount of `device` (persistent-kernel grids)
     // Gaussian tap weights currently resident in d_wts / d_wsplit (re-uploaded only when sigma changes)
     uint32_t wts_sigma_bits = 0, wsplit_sigma_bits = 0;
+    bool use_chunk_start = true; // stored layers: per-chunk start table from their alpha summaries (pfx_tune "chunk_start")
     int dle_min_layers = 16;  // stacks at least this deep may take the compositor's dead-layer elimination kernel (pfx_api.cpp:build_stack)
     bool wts_valid = false, wsplit_valid = false; // explicit flags: every 32-bit pattern is some sigma (0xffffffff is a NaN)
     float wsplit_inv_scale = 1.0f, wsplit_bias = 0.0f;

@@ -53,7 +53,14 @@ typedef struct pfxk_dle_cands { uint32_t n; uint32_t layer[PFXK_DLE_MAX]; uint32
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                         const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, int chunk_active_ready, uint32_t w,
                         uint32_t h, uint8_t* d_dst, const pfxk_preview* preview /* may be NULL */,
-                        const pfxk_region* region /* may be NULL */, const pfxk_dle_cands* cands /* may be NULL: no elimination */);
+                        const pfxk_region* region /* may be NULL */, const pfxk_dle_cands* cands /* may be NULL: no elimination */,
+                        const uint8_t* d_chunk_start /* may be NULL: per-chunk first layer that can show (pfxk_chunk_start) */);
+// per-chunk alpha summary of a stored layer (bit 0: all 255, bit 1: none 0) over the chunk rectangle [cx0, cx0+ncx) x [cy0, cy0+ncy), and the
+// per-chunk start table of a stack (want[k]: 1 = Normal at opacity >= 1 needs bit 0, 2 = Overwrite needs bit 1, 0 = layer k never resets)
+hipError_t pfxk_chunk_alpha_flags(hipStream_t s, const uint8_t* d_px, uint32_t w, uint32_t h, uint32_t cx0, uint32_t cy0, uint32_t ncx, uint32_t ncy,
+                                  uint8_t* d_flags);
+hipError_t pfxk_chunk_start(hipStream_t s, const uint8_t* const* d_flag_ptrs, const uint8_t* d_want, uint32_t n_layers, uint32_t n_chunks,
+                            uint8_t* d_start, uint32_t* useful_pinned /* may be NULL: receives `tag` if any chunk starts above layer 0 */, uint32_t tag);
 void       pfxk_flatten_set_dle(int units_per_wave /* 0 = default, < 0 = keep */, int ring_log2 /* 10 | 11, else keep */);
 hipError_t pfxk_flatten_dle_stats(unsigned long long* out8 /* may be NULL */, int reset); // synchronises the device
 void       pfxk_flatten_set_dle_dev(int stats_on /* < 0 keep */, int cfg /* < 0 keep */);

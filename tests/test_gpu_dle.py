@@ -203,3 +203,41 @@ def test_switched_off_and_general_path_agree(gpu):
     got = gpu.composite(layers, w, h)
     ref = O.composite(layers, w, h)
     assert np.array_equal(got, ref), "masked reset layer"
+
+
+def test_stored_layers_start_at_the_covering_layer_per_chunk(gpu):
+    """layers of the layer store carry per-chunk alpha summaries: a tile of the plain streaming kernel starts at the topmost layer that
+    resets all the chunks it touches (opaque Normal at 100 %, Overwrite without a hole).  Chunk-aligned and unaligned opaque regions,
+    a one-pixel hole in an otherwise opaque chunk, a Normal layer at 99 %, a rectangle update that opens and closes a hole"""
+    gpu.r.tune("dle_min_layers", 16)   # shallow stack: the plain kernel + the chunk table, not the elimination kernel
+    try:
+        w, h, n = 448, 200, 7
+        rng = np.random.default_rng(4)
+        stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+        for k in range(1, n):
+            stack[k, ..., 3] = noise_alpha(rng, h, w, 0.3, 0.2)
+        stack[0, ..., 3] = 255
+        stack[2, :, :, 3] = 255                       # opaque photo over everything (Normal 100 %): every tile may start at layer 2
+        stack[4, 64:128, 128:320, 3] = 255            # chunk-aligned opaque patch
+        stack[4, 100, 200, 3] = 254                   # ... with a one-pixel dent in chunk (1, 3)
+        stack[5, 30:170, 50:400, 3] = 200             # Overwrite patch covering whole chunks and partial ones
+        stack[5, 70, 300, 3] = 0                      # ... with a hole
+        stack[6, :64, :, 3] = 255                     # opaque strip at 99 %: never a reset
+        modes = [0, 7, NORMAL, 3, NORMAL, OVERWRITE, NORMAL]
+        opac = [1.0, 0.8, 1.0, 0.5, 1.0, 0.6, 0.99]
+        check(gpu, stack, modes, opac, "stored layers with covering chunks")
+        # the same through update_rect: close the dent and the hole, open a new hole — the summaries must follow the pixels
+        layers = [dict(pixels=stack[k], mode=int(modes[k]), opacity=float(opac[k])) for k in range(n)]
+        gpu.composite(layers, w, h)                   # uploads (generation 1)
+        patch = stack[4, 96:104, 196:204].copy(); patch[..., 3] = 255
+        gpu.r.update_layer_rect(4, 196, 96, patch)
+        stack[4, 96:104, 196:204] = patch
+        hole = stack[2, 10:12, 300:303].copy(); hole[..., 3] = 0
+        gpu.r.update_layer_rect(2, 300, 10, hole)
+        stack[2, 10:12, 300:303] = hole
+        info = [(k, float(opac[k]), True, int(modes[k]), 0, ()) for k in range(n)]
+        got = gpu.r.composite(w, h, info)
+        ref = O.flatten_stack(stack, np.asarray(modes, np.uint8), np.asarray(opac, np.float32))
+        assert np.array_equal(got, ref), f"after update_rect: {int((got != ref).any(-1).sum())} px differ"
+    finally:
+        gpu.r.tune("dle_min_layers", 0)
