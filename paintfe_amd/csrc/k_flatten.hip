@@ -409,8 +409,14 @@ PFX_DEV void dle_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
             fetch(std::integral_constant<int, 0>{}, li + 3); blend(std::integral_constant<int, 1>{}, li + 1);
             fetch(std::integral_constant<int, 1>{}, li + 4); blend(std::integral_constant<int, 2>{}, li + 2);
         }
+    } else if constexpr (NB == 2) {
+        fetch(std::integral_constant<int, 0>{}, lb);
+        for (uint32_t li = lb; li < le; li += 2) {
+            fetch(std::integral_constant<int, 1>{}, li + 1); blend(std::integral_constant<int, 0>{}, li);
+            fetch(std::integral_constant<int, 0>{}, li + 2); blend(std::integral_constant<int, 1>{}, li + 1);
+        }
     } else {
-        static_assert(NB == 4, "three or four register sets");
+        static_assert(NB == 4, "two, three or four register sets");
         fetch(std::integral_constant<int, 0>{}, lb);
         fetch(std::integral_constant<int, 1>{}, lb + 1u);
         fetch(std::integral_constant<int, 2>{}, lb + 2u);
@@ -855,8 +861,9 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
         };
         // dead-layer elimination when the stack holds a reset layer above the bottom one (variant 8 switches it off)
         if (cands && cands->n > 0 && g_flatten_variant != 8) {
-            // g_dle_cfg: 0 = 2 pixels per lane (8 waves per SIMD), 1 = 3 pixels per lane; g_dle_sched 0 = equal streams of g_dle_units
-            const uint32_t px = g_dle_cfg == 1 ? 3u : 2u;
+            // g_dle_cfg: 0 = 3 pixels per lane, 2 register sets (78 VGPRs: 6 waves per SIMD; measured best), 1 = 2 pixels per lane, 3 sets (61 VGPRs),
+            // 2 = 3 pixels per lane, 3 sets (90 VGPRs: 5 waves); g_dle_sched 0 = equal streams of g_dle_units
+            const uint32_t px = g_dle_cfg == 1 ? 2u : 3u;
             const uint32_t upx = 64u * px;
             const uint32_t units = (uint32_t)((n_px + upx - 1) / upx);
             const uint32_t umax = 65535u / upx; // queue entries are 16-bit pixel offsets
@@ -880,8 +887,9 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
             // one wave per workgroup: a wave's stream is independent of its neighbours' (no barrier, private LDS slice), and a 4-wave
             // workgroup would hold its LDS and wave slots until its slowest stream ends
 #define PFX_ARGS <<<waves, 64, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, SC)
-            if (g_dle_cfg == 1) flatten_dle_kernel<3, 10, 1> PFX_ARGS;
-            else flatten_dle_kernel<2, 9, 1> PFX_ARGS;
+            if (g_dle_cfg == 2) flatten_dle_kernel<3, 10, 1, 3> PFX_ARGS;
+            else if (g_dle_cfg == 1) flatten_dle_kernel<2, 9, 1, 3> PFX_ARGS;
+            else flatten_dle_kernel<3, 10, 1, 2> PFX_ARGS;
 #undef PFX_ARGS
             return hipGetLastError();
         }

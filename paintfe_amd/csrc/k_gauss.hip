@@ -181,6 +181,7 @@ hipError_t launch_v_cfg(hipStream_t stream, const float4* tmp, uint8_t* d_dst, c
 
 unsigned long long* g_dbg_buf = nullptr; // development: phase timestamps of gauss_strip_kernel (pfxk_gauss_set_dbg_buf)
 int g_v_cfg = 0; // tuning knob (pfxk_gauss_set_v_config); 0 is the shipped configuration
+int g_mfma_seg = 0; // tuning knob (pfxk_gauss_set_mfma_segments): row segments per strip of the matrix-core kernel, 0 = automatic
 
 template <bool EXACT>
 hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const float* wts, int radius, uint32_t w, uint32_t h)
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 // LDS bounds: H tile (1024 + 2r + 12) x 20 B and the narrowest V tile (256 + 2r + 4) rows x 5 x 16 B <= 160 KiB
 extern "C" int pfxk_gauss_max_radius(void) { return 850; }
 extern "C" void pfxk_gauss_set_v_config(int cfg) { g_v_cfg = cfg; }
+extern "C" void pfxk_gauss_set_mfma_segments(int n) { g_mfma_seg = n > 0 && n < 256 ? n : 0; }
 extern "C" void pfxk_gauss_set_dbg_buf(unsigned long long* p) { g_dbg_buf = p; }
 extern "C" int pfxk_gauss_weight_pad(void) { return W_PAD; }
 
@@ -618,7 +620,7 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
         // cut every strip into n_seg row segments so that the launch has just under two workgroups per CU (one is resident per CU,
         // LDS-bound; measured at 8K: 1 / 2 / 3 segments per strip = 0.359 / 0.340 / 0.341 ms); a segment pays NK/2 - 1 run-in steps
         int n_seg = (int)((18L * n_cus / 10 + tiles_x - 1) / tiles_x);
-        if (g_v_cfg & 0xff) n_seg = g_v_cfg & 0xff; // tuning override
+        if (g_mfma_seg > 0) n_seg = g_mfma_seg; // tuning override (its own key: "gauss_v_cfg" only configures the VALU vertical pass)
         if (n_seg < 1) n_seg = 1;
         int per = (n_steps + n_seg - 1) / n_seg;
         if (per < 4) per = n_steps < 4 ? n_steps : 4;

@@ -1211,6 +1211,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
 {
     if (!ctx || !key) return PFX_ERR_INVALID;
     if (std::strcmp(key, "gauss_v_cfg") == 0) { pfxk_gauss_set_v_config(value); return PFX_OK; }
+    if (std::strcmp(key, "gauss_mfma_segments") == 0) { pfxk_gauss_set_mfma_segments(value); return PFX_OK; }
     if (std::strcmp(key, "flatten_variant") == 0) { pfxk_flatten_set_variant(value); return PFX_OK; }
     if (std::strcmp(key, "dle_units") == 0) { pfxk_flatten_set_dle(value, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_ring") == 0) { pfxk_flatten_set_dle(-1, value); return PFX_OK; }

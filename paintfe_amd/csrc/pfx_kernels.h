@@ -74,6 +74,7 @@ hipError_t pfxk_round_pack_check(hipStream_t s, unsigned long long* d_out /* [2]
 int        pfxk_gauss_max_radius(void);
 int        pfxk_gauss_weight_pad(void);
 void       pfxk_gauss_set_v_config(int cfg); // tuning knob, 0 = shipped
+void       pfxk_gauss_set_mfma_segments(int n); // tuning knob of the matrix-core kernel, 0 = automatic
 hipError_t pfxk_gauss_h(hipStream_t stream, const uint8_t* d_src, float* d_tmp, const float* d_wts_tap0, int radius,
                         uint32_t w, uint32_t h, int exact);
 int        pfxk_gauss_mfma_max_radius(void);

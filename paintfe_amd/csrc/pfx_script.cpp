@@ -371,9 +371,19 @@ int pfx_cli_main(int argc, char** argv)
     } else {
         std::vector<file_report> reports(total);
         std::vector<std::thread> th;
-        for (size_t k = 0; k < workers; ++k)
-            th.emplace_back([&, k] { for (size_t idx = k; idx < total; idx += workers) reports[idx] = process(ctxs[k], idx); });
+        th.reserve(workers);
+        // no exception may leave a worker thread (std::terminate): a file whose processing throws is reported as failed
+        auto work = [&](size_t k) noexcept {
+            for (size_t idx = k; idx < total; idx += workers) {
+                try { reports[idx] = process(ctxs[k], idx); }
+                catch (...) { reports[idx].failed = true; try { reports[idx].err_text = "error: out of memory or internal error while processing the file\n"; } catch (...) {} }
+            }
+        };
+        size_t started = 0;
+        try { for (; started < workers; ++started) th.emplace_back(work, started); }
+        catch (...) { std::fprintf(stderr, "warning: only %zu of %zu worker threads could start\n", started, workers); }
         for (auto& t : th) t.join();
+        for (size_t k = started; k < workers; ++k) work(k); // the shares of threads that did not start run here
         for (const auto& rep : reports) emit(rep);
     }
     for (pfx_ctx* c : ctxs) pfx_ctx_destroy(c);

@@ -50,9 +50,9 @@ def blocky_alpha(rng, h, w, cell, p_zero, p_opaque):
     return np.kron(coarse, np.ones((cell, cell), np.uint8))[:h, :w]
 
 
-@pytest.fixture(params=[(0, 1), (1, 1), (0, 0), (1, 0)], ids=["px2-shrinking", "px3-shrinking", "px2-equal", "px3-equal"], autouse=True)
+@pytest.fixture(params=[(0, 1), (1, 1), (2, 1), (0, 0), (1, 0)], ids=["px3x2sets-shrinking", "px2-shrinking", "px3x3sets-shrinking", "px3x2sets-equal", "px2-equal"], autouse=True)
 def every_kernel_configuration(request, gpu):
-    """every test of this file runs on both instantiations of the elimination kernel (pfx_tune "dle_cfg": 2 or 3 pixels per lane) and
+    """every test of this file runs on the three instantiations of the elimination kernel (pfx_tune "dle_cfg": pixels per lane, register sets) and
     both stream schedules ("dle_sched": equal streams, or streams that shrink towards the end of the launch)"""
     gpu.r.tune("dle_cfg", request.param[0])
     gpu.r.tune("dle_sched", request.param[1])
