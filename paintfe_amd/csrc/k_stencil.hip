@@ -281,7 +281,7 @@ __global__ __launch_bounds__(MD_TX* MD_TY) void median_net_kernel(const uint32_t
     dst[oi] = __builtin_bit_cast(uint32_t, e[N / 2]) | (__builtin_bit_cast(uint32_t, o[N / 2]) << 8);
 }
 
-// 5x5 / 7x7 median, four adjacent windows per lane (k_median_shared_net.h, tools/gen_median_shared.py): every column is sorted once
+// 5x5 / 7x7 / 9x9 median, four adjacent windows per lane (k_median_shared_net.h, tools/gen_median_shared.py): every column is sorted once
 // and serves up to four windows, the sorted run two neighbouring windows share is merged once, and a window's median is picked out of
 // `shared run U one more column` — 83.5 (r = 2) / 199.5 (r = 3) min / max operations per window and channel pair instead of 226 / 626
 // for the single-window selection networks above.  Same integers, same element len/2 of the ascending sort (noise.rs:398-404).
@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void median_shared_kernel(const uint32_t* __re
 #define PFX_MS_IN(c, k) __builtin_bit_cast(pfx_us2, px[k][c] & 0x00ff00ffu)
 #define PFX_MS_OUT(j, v) out[j] = __builtin_bit_cast(uint32_t, v)
         if constexpr (R == 2) { PFX_MEDIAN_SHARED_R2(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
-        else { PFX_MEDIAN_SHARED_R3(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
+        else if constexpr (R == 3) { PFX_MEDIAN_SHARED_R3(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
+        else { PFX_MEDIAN_SHARED_R4(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
 #undef PFX_MS_IN
 #undef PFX_MS_OUT
     }
@@ -343,7 +344,8 @@ __global__ __launch_bounds__(256) void median_shared_kernel(const uint32_t* __re
 #define PFX_MS_IN(c, k) __builtin_bit_cast(pfx_us2, (px[k][c] >> 8) & 0x00ff00ffu)
 #define PFX_MS_OUT(j, v) out[j] |= __builtin_bit_cast(uint32_t, v) << 8
         if constexpr (R == 2) { PFX_MEDIAN_SHARED_R2(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
-        else { PFX_MEDIAN_SHARED_R3(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
+        else if constexpr (R == 3) { PFX_MEDIAN_SHARED_R3(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
+        else { PFX_MEDIAN_SHARED_R4(pfx_us2, PFX_MS_IN, PFX_MS_MIN, PFX_MS_MAX, PFX_MS_OUT) }
 #undef PFX_MS_IN
 #undef PFX_MS_OUT
     }
@@ -469,12 +471,13 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         else median3_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         return hipGetLastError();
     }
-    if ((radius == 2 || radius == 3) && !g_median_single) { // 5x5 / 7x7: four windows per lane on shared sorted columns
+    if (radius >= 2 && radius <= 4 && !g_median_single) { // 5x5 / 7x7 / 9x9: four windows per lane on shared sorted columns
         const dim3 g((w + MS_W - 1) / MS_W, (h + MS_H - 1) / MS_H);
         const bool direct = (w & 3u) == 0 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0;
 #define PFX_MS(R, D) median_shared_kernel<R, D><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h)
         if (radius == 2) { if (direct) PFX_MS(2, true); else PFX_MS(2, false); }
-        else { if (direct) PFX_MS(3, true); else PFX_MS(3, false); }
+        else if (radius == 3) { if (direct) PFX_MS(3, true); else PFX_MS(3, false); }
+        else { if (direct) PFX_MS(4, true); else PFX_MS(4, false); }
 #undef PFX_MS
         return hipGetLastError();
     }

@@ -255,12 +255,12 @@ def test_median_bitexact(gpu, oracle, radius):
     assert_same(gpu.median(img, radius, mask), oracle.median(img, radius, mask), 0, f"median r={radius} masked")
 
 
-@pytest.mark.parametrize("radius", [2, 3])
+@pytest.mark.parametrize("radius", [2, 3, 4])
 @pytest.mark.parametrize("size", [(1, 1), (3, 2), (4, 9), (7, 7), (255, 5), (256, 4), (257, 6), (260, 64), (512, 3), (1031, 37)])
 def test_median_shared_column_networks(gpu, oracle, radius, size):
-    """radii 2 and 3: four windows per lane on shared sorted columns (k_median_shared_net.h) — block edges (256 x 4 pixel blocks), image
+    """radii 2, 3 and 4: four windows per lane on shared sorted columns (k_median_shared_net.h) — block edges (256 x 4 pixel blocks), image
     edges (clamped windows wider than the image), widths that are and are not multiples of 4, masks, heavy ties; the single-window
-    networks (pfx_tune "median_single") must give the same image"""
+    networks / the value search (pfx_tune "median_single") must give the same image"""
     w, h = size
     img = I.random_rgba(w, h, 600 + w + radius)
     img[: h // 2] = (img[: h // 2] // 86) * 86  # three levels per channel: ties everywhere

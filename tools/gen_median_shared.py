@@ -23,6 +23,9 @@ import numpy as np
 
 SORT5 = [(0, 1), (3, 4), (2, 4), (2, 3), (0, 3), (0, 2), (1, 4), (1, 3), (1, 2)]
 SORT7 = [(1, 2), (3, 4), (5, 6), (0, 2), (3, 5), (4, 6), (0, 1), (4, 5), (2, 6), (0, 4), (1, 5), (0, 3), (2, 5), (1, 3), (2, 4), (2, 3)]
+SORT9 = [(0, 1), (3, 4), (6, 7), (1, 2), (4, 5), (7, 8), (0, 1), (3, 4), (6, 7), (0, 3), (3, 6), (0, 3), (1, 4), (4, 7), (1, 4), (2, 5), (5, 8), (2, 5),
+         (1, 3), (5, 7), (2, 6), (4, 6), (2, 4), (2, 3), (5, 6)]  # 25 comparators (Floyd)
+SORTERS = {2: SORT5, 3: SORT7, 4: SORT9}
 
 
 class Graph:
@@ -95,10 +98,15 @@ class Graph:
 def build(r):
     s, ncol = 2 * r + 1, 4 + 2 * r
     g = Graph(ncol * s)  # input id = column * s + row
-    net = SORT5 if r == 2 else SORT7
+    net = SORTERS[r]
     col = [g.sort([c * s + k for k in range(s)], net) for c in range(ncol)]
     K = (s * s) // 2 + 1  # 1-based rank of element len/2
-    if r == 2:
+    if r == 4:  # X = c1..c8 (W0, W1), Y = c3..c10 (W2, W3); the six columns c3..c8 all four windows share are merged once
+        core = g.merge(g.merge(g.merge(col[3], col[4]), g.merge(col[5], col[6])), g.merge(col[7], col[8]))
+        X = g.merge(g.merge(col[1], col[2]), core)
+        Y = g.merge(core, g.merge(col[9], col[10]))
+        outs = [g.kth_of_union(X, col[0], K), g.kth_of_union(X, col[9], K), g.kth_of_union(Y, col[2], K), g.kth_of_union(Y, col[11], K)]
+    elif r == 2:
         m34 = g.merge(col[3], col[4])
         X = g.merge(g.merge(col[1], col[2]), m34)
         Y = g.merge(m34, g.merge(col[5], col[6]))
@@ -111,9 +119,35 @@ def build(r):
     return g, outs, g.prune(outs)
 
 
+def verify_pieces():
+    """Batcher's merge and the k-th-of-union formula on every pair of sorted 0/1 lists up to the lengths used (72 + 9): with the column sorters
+    correct, a graph composed of correct merges computes correct order statistics, and pruning only removes nodes no output depends on"""
+    for la in range(1, 73):
+        for lb in (1, 2, 5, 7, 9, 10, 14, 18, 27, 28, 36, 54):
+            if la + lb > 81 or lb > la:
+                continue
+            g = Graph(la + lb)
+            M = g.merge(list(range(la)), list(range(la, la + lb)))
+            na, nb = np.meshgrid(np.arange(la + 1), np.arange(lb + 1), indexing="ij")
+            na, nb = na.reshape(-1), nb.reshape(-1)
+            ins = [(na > (la - 1 - k)).astype(np.uint8) for k in range(la)] + [(nb > (lb - 1 - k)).astype(np.uint8) for k in range(lb)]
+            v = g.evaluate(ins, [True] * len(g.ops))
+            tot = na + nb
+            for k, m in enumerate(M):
+                if not np.array_equal(v[m], (tot > (la + lb - 1 - k)).astype(np.uint8)):
+                    return f"merge({la},{lb}) output {k}"
+            for K in {(la + lb) // 2 + 1, 1, la + lb}:
+                g2 = Graph(la + lb)
+                o = g2.kth_of_union(list(range(la)), list(range(la, la + lb)), K)
+                v2 = g2.evaluate(ins, [True] * len(g2.ops))
+                if not np.array_equal(v2[o], (tot > (la + lb - K)).astype(np.uint8)):
+                    return f"kth_of_union({la},{lb},{K})"
+    return None
+
+
 def verify(r, g, outs, keep):
     s, ncol = 2 * r + 1, 4 + 2 * r
-    net = SORT5 if r == 2 else SORT7
+    net = SORTERS[r]
     # the column sorter on every 0/1 input
     for bits in range(1 << s):
         w = [(bits >> k) & 1 for k in range(s)]
@@ -123,7 +157,10 @@ def verify(r, g, outs, keep):
             return f"sort{s} fails on {bits:b}"
     # every window on every combination of ones-counts of its columns (the other columns do not reach it: all zeros)
     need_ones = s * s - (s * s) // 2  # element len/2 of the ascending sort is 1 iff at least this many ones
-    grids = np.meshgrid(*[np.arange(s + 1, dtype=np.int8)] * s, indexing="ij")
+    # r <= 3: every combination of ones-counts; r = 4 (10^9 combinations): the combinations of counts from {0, 1, 2, 7, 8, 9} (10^7, every
+    # all-low / all-high mix around the median), on top of verify_pieces()
+    levels = np.arange(s + 1, dtype=np.int8) if r <= 3 else np.array([0, 1, 2, 7, 8, 9], np.int8)
+    grids = np.meshgrid(*[levels] * s, indexing="ij")
     counts = [x.reshape(-1) for x in grids]
     for j in range(4):
         inputs = []
@@ -152,7 +189,7 @@ def verify(r, g, outs, keep):
 def emit(r, g, outs, keep):
     s = 2 * r + 1
     lines = [f"// median of four adjacent {s}x{s} windows: {sum(keep)} min / max operations ({sum(keep) / 4:.1f} per window; the single-window network "
-             f"needs {2 * (113 if r == 2 else 313)})\n// IN(c, k) = row k of column c (columns x0-{r} .. x0+{3 + r}); OUT(j, v) receives window j's median\n"
+             f"needs {2 * {2: 113, 3: 313}[r] if r in (2, 3) else 'none exists here'})\n// IN(c, k) = row k of column c (columns x0-{r} .. x0+{3 + r}); OUT(j, v) receives window j's median\n"
              f"#define PFX_MEDIAN_SHARED_R{r}(T, IN, MIN, MAX, OUT) \\\n"]
     name = lambda i: f"IN({i // s}, {i % s})" if i < g.n_inputs else f"n{i - g.n_inputs}"
     for k, (kind, a, b) in enumerate(g.ops):
@@ -166,7 +203,12 @@ def main():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "paintfe_amd", "csrc", "k_median_shared_net.h")
     text = ["// k_median_shared_net.h — generated by tools/gen_median_shared.py (do not edit): shared-column median selection, verified\n"
             "// exhaustively on 0/1 inputs (every window, every combination of its sorted columns) and on random bytes with ties.\n#pragma once\n"]
-    for r in (2, 3):
+    if "--no-verify" not in sys.argv:
+        err = verify_pieces()
+        if err:
+            print("VERIFICATION FAILED:", err, file=sys.stderr)
+            return 1
+    for r in (2, 3, 4):
         g, outs, keep = build(r)
         print(f"r={r}: {len(g.ops)} operations built, {sum(keep)} after pruning = {sum(keep) / 4:.1f} per window", file=sys.stderr)
         if "--no-verify" not in sys.argv:
