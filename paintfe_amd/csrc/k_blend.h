@@ -48,6 +48,19 @@ template <bool F> PFX_DEV float reflect_channel(float base, float top)
 // it cannot prove that values read from memory are not signalling NaNs; the blend operands are bytes / 255.
 PFX_DEV float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 PFX_DEV float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// three-operand forms: min / max instructions issue in 4 cycles whatever their operand count (profiles/r03_valu_rates.txt)
+PFX_DEV float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+PFX_DEV float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+template <int PX> PFX_DEV float alpha_min(const float (&v)[PX][4])
+{
+    if constexpr (PX == 3) return vmin3(v[0][3], v[1][3], v[2][3]);
+    else { float m = v[0][3]; for (int p = 1; p < PX; ++p) m = vmin(m, v[p][3]); return m; }
+}
+template <int PX> PFX_DEV float alpha_max(const float (&v)[PX][4])
+{
+    if constexpr (PX == 3) return vmax3(v[0][3], v[1][3], v[2][3]);
+    else { float m = v[0][3]; for (int p = 1; p < PX; ++p) m = vmax(m, v[p][3]); return m; }
+}
 
 // Correctly rounded sqrt for a normal positive argument: the core of the sequence hipcc emits for sqrtf
 // (-fhip-fp32-correctly-rounded-divide-sqrt) — hardware estimate, its two neighbours, two exact residuals, two selects — without the
@@ -376,13 +389,9 @@ PFX_DEV void blend_nx_dispatch(uint32_t mode, float (&acc)[PX][4], const float (
 template <int PX>
 PFX_DEV void blend_layer_nx(uint32_t mode, float (&acc)[PX][4], const float (&top)[PX][4], float opc)
 {
-    float amin = acc[0][3];
-#pragma unroll
-    for (int p = 1; p < PX; ++p) amin = vmin(amin, acc[p][3]);
+    const float amin = alpha_min<PX>(acc);
     if (__all(amin == 1.0f)) {
-        float tmin = top[0][3];
-#pragma unroll
-        for (int p = 1; p < PX; ++p) tmin = vmin(tmin, top[p][3]);
+        const float tmin = alpha_min<PX>(top);
         if (opc >= 1.0f && __all(tmin == 1.0f)) blend_nx_dispatch<PX, 2>(mode, acc, top, opc, opc);
         else blend_nx_dispatch<PX, 1>(mode, acc, top, opc, opc);
     } else blend_nx_dispatch<PX, 0>(mode, acc, top, opc, opc);

@@ -251,9 +251,7 @@ PFX_DEV void stream_fetch(float (&t)[PX][4], const uint8_t* pixels, uint32_t byt
 template <int PX>
 PFX_DEV void stream_layer(float (&acc)[PX][4], const float (&t)[PX][4], uint32_t mode, float opacity)
 {
-    float amax = t[0][3];
-#pragma unroll
-    for (int j = 1; j < PX; ++j) amax = vmax(amax, t[j][3]);
+    const float amax = alpha_max<PX>(t);
     // a wave whose 64*PX pixels are all transparent in this layer (sparse layers of real documents; the TiledImage analogue
     // is a missing chunk, canvas_state.rs:600) skips the blend entirely
     if (__any(amax != 0.0f)) blend_layer_nx<PX>(mode, acc, t, opacity);
