@@ -180,6 +180,85 @@ __global__ __launch_bounds__(MD_TX* MD_TY) void median_kernel(const uint32_t* __
     dst[oi] = (te & 0x00ff00ffu) | ((to & 0x00ff00ffu) << 8);
 }
 
+// The same search with FOUR horizontally adjacent pixels per lane: median_kernel above reads the whole window from LDS once per bit — 8 x (2r+1)^2
+// ds_read_b64 per pixel, which is what bounds it (r = 7: 1 800 reads, 28.8 k LDS cycles per four waves against 20 k VALU cycles each) — while the
+// windows of neighbouring pixels share all but one column.  A lane walks the 2r + 4 columns its four pixels reach and tests every element
+// it loads against the thresholds of the pixels whose window holds it: 0.3 x the LDS reads per pixel, the same arithmetic per pixel.
+constexpr int MQ_P = 4, MQ_TX = 32 * MQ_P, MQ_TY = 8;
+__global__ __launch_bounds__(256) void median_search4_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                             const uint8_t* __restrict__ mask, int r, int w, int h)
+{
+    extern __shared__ uint2 win_tile[]; // (MQ_TY + 2r) x (MQ_TX + 2r), {R,B | G,A}
+    const int tw = MQ_TX + 2 * r, th = MQ_TY + 2 * r;
+    const int bx = blockIdx.x * MQ_TX, by = blockIdx.y * MQ_TY;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const int sx = min(max(bx - r + tx, 0), w - 1), sy = min(max(by - r + ty, 0), h - 1); // noise.rs:389-392
+        const uint32_t px = src[(size_t)sy * w + sx];
+        win_tile[i] = make_uint2(px & 0x00ff00ffu, (px >> 8) & 0x00ff00ffu);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x0 = bx + lx * MQ_P, y = by + ly;
+    if (x0 >= w || y >= h) return;
+    const int side = 2 * r + 1;
+    const uint32_t n = (uint32_t)(side * side);
+    const uint32_t need = n - n / 2; // elements >= the median (element len/2 of the ascending sort)
+    constexpr uint32_t M = 0x01000100u;
+    uint32_t te[MQ_P], to[MQ_P];
+#pragma unroll
+    for (int p = 0; p < MQ_P; ++p) te[p] = to[p] = 0u;
+    for (int bit = 7; bit >= 0; --bit) {
+        uint32_t tce[MQ_P], tco[MQ_P], ce[MQ_P], co[MQ_P];
+#pragma unroll
+        for (int p = 0; p < MQ_P; ++p) {
+            tce[p] = M - (te[p] | (0x00010001u << bit));
+            tco[p] = M - (to[p] | (0x00010001u << bit));
+            ce[p] = co[p] = 0u;
+        }
+        for (int dy = 0; dy < side; ++dy) {
+            const uint2* rowp = win_tile + (ly + dy) * tw + lx * MQ_P; // rowp[dx]: column x0 - r + dx; pixel p's window is dx in [p, p + side)
+            uint32_t re[MQ_P], ro[MQ_P]; // one row's flags, left at bit 8 of each 16-bit lane (<= 49 of them)
+#pragma unroll
+            for (int p = 0; p < MQ_P; ++p) re[p] = ro[p] = 0u;
+#pragma unroll
+            for (int dx = 0; dx < MQ_P - 1; ++dx) { // leading columns: only the pixels p <= dx
+                const uint2 a = rowp[dx];
+#pragma unroll
+                for (int p = 0; p <= dx; ++p) { re[p] += (a.x + tce[p]) & M; ro[p] += (a.y + tco[p]) & M; }
+            }
+            for (int dx = MQ_P - 1; dx < side; ++dx) { // every pixel's window holds these
+                const uint2 a = rowp[dx];
+#pragma unroll
+                for (int p = 0; p < MQ_P; ++p) { re[p] += (a.x + tce[p]) & M; ro[p] += (a.y + tco[p]) & M; }
+            }
+#pragma unroll
+            for (int k = 0; k < MQ_P - 1; ++k) { // trailing columns side + k: only the pixels p > k
+                const uint2 a = rowp[side + k];
+#pragma unroll
+                for (int p = k + 1; p < MQ_P; ++p) { re[p] += (a.x + tce[p]) & M; ro[p] += (a.y + tco[p]) & M; }
+            }
+#pragma unroll
+            for (int p = 0; p < MQ_P; ++p) { ce[p] += (re[p] >> 8) & 0x00ff00ffu; co[p] += (ro[p] >> 8) & 0x00ff00ffu; } // totals up to 49^2 per 16-bit lane
+        }
+        const uint32_t b = 1u << bit;
+#pragma unroll
+        for (int p = 0; p < MQ_P; ++p) {
+            if ((ce[p] & 0xffffu) >= need) te[p] |= b;
+            if ((ce[p] >> 16) >= need) te[p] |= b << 16;
+            if ((co[p] & 0xffffu) >= need) to[p] |= b;
+            if ((co[p] >> 16) >= need) to[p] |= b << 16;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < MQ_P; ++p) {
+        if (x0 + p >= w) break;
+        const size_t oi = (size_t)y * w + x0 + p;
+        const uint32_t out = (te[p] & 0x00ff00ffu) | ((to[p] & 0x00ff00ffu) << 8);
+        dst[oi] = (mask && mask[oi] == 0) ? src[oi] : out;
+    }
+}
+
 // 3x3 median (the radius most callers use) without a search: sort each 3-pixel column once with v_min3 / v_med3 / v_max3, then
 // median9 = med3(max of the three column minima, med of the column medians, min of the column maxima).  A lane produces 4
 // adjacent pixels from 6 sorted columns, so a column sort is shared by up to three windows: ~55 VALU ops per pixel against
@@ -379,6 +458,8 @@ __global__ __launch_bounds__(256) void pixelate_kernel(const uint32_t* __restric
 
 } // namespace
 
+int g_median_search1 = 0; // pfxk_median_set_search1: the value search with one pixel per lane (the pre-sharing kernel)
+extern "C" void pfxk_median_set_search1(int on) { g_median_search1 = on; }
 int g_median_single = 0; // pfxk_median_set_single: the one-window-per-lane networks for radii 2 and 3
 extern "C" void pfxk_median_set_single(int on) { g_median_single = on; }
 int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
@@ -493,6 +574,13 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         if (eh) return eh;
         const size_t runs = (size_t)((w + MH_RUN - 1) / MH_RUN) * h;
         median_hist_kernel<<<(uint32_t)((runs + 63) / 64), 64, lds_h, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, (int)w, (int)h);
+        return hipGetLastError();
+    }
+    if (!g_median_search1) { // four pixels per lane: a third of the LDS reads per pixel
+        const size_t lds4 = (size_t)(MQ_TX + 2 * radius) * (MQ_TY + 2 * radius) * 8;
+        hipError_t e4 = hipFuncSetAttribute((const void*)median_search4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        if (e4) return e4;
+        median_search4_kernel<<<dim3((w + MQ_TX - 1) / MQ_TX, (h + MQ_TY - 1) / MQ_TY), 256, lds4, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, (int)w, (int)h);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(MD_TX + 2 * radius) * (MD_TY + 2 * radius) * 8;

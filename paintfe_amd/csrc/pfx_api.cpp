@@ -1222,6 +1222,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "dle_frac_a") == 0) { pfxk_flatten_set_dle_sched(-1, value, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_frac_b") == 0) { pfxk_flatten_set_dle_sched(-1, -1, value); return PFX_OK; }
     if (std::strcmp(key, "dle_cfg") == 0) { pfxk_flatten_set_dle_dev(-1, value); return PFX_OK; }
+    if (std::strcmp(key, "median_search1") == 0) { pfxk_median_set_search1(value); return PFX_OK; }
     if (std::strcmp(key, "median_single") == 0) { pfxk_median_set_single(value); return PFX_OK; }
     if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
     if (std::strcmp(key, "resize_two_pass") == 0) { ctx->resize_two_pass = value != 0; return PFX_OK; } // A/B and the parity test of the fused kernel

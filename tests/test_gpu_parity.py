@@ -275,6 +275,28 @@ def test_median_shared_column_networks(gpu, oracle, radius, size):
             gpu.r.tune("median_single", 0)
 
 
+@pytest.mark.parametrize("radius", [4, 5, 7, 12, 24])
+@pytest.mark.parametrize("size", [(1, 1), (6, 3), (127, 9), (128, 8), (131, 23), (390, 41)])
+def test_median_value_search_four_pixels_per_lane(gpu, oracle, radius, size):
+    """radii 5..24 (and 4 when the networks are switched off): the value search with four pixels per lane sharing the columns they load —
+    block edges every 128 x 8 pixels, widths that are not multiples of 4, windows wider than the image, masks, ties; the one-pixel-per-lane
+    search (pfx_tune "median_search1") must give the same image"""
+    w, h = size
+    img = I.random_rgba(w, h, 1200 + w + radius)
+    img[: h // 2] = (img[: h // 2] // 100) * 100
+    mask = (np.random.default_rng(w + 3).random((h, w)) < 0.5).astype(np.uint8)
+    ref, ref_m = oracle.median(img, radius), oracle.median(img, radius, mask)
+    gpu.r.tune("median_single", 1)   # radius 4 takes the search too
+    try:
+        for one in (0, 1):
+            gpu.r.tune("median_search1", one)
+            assert_same(gpu.median(img, radius), ref, 0, f"median r={radius} {w}x{h} search1={one}")
+            assert_same(gpu.median(img, radius, mask), ref_m, 0, f"median r={radius} {w}x{h} masked search1={one}")
+    finally:
+        gpu.r.tune("median_search1", 0)
+        gpu.r.tune("median_single", 0)
+
+
 @pytest.mark.parametrize("size", [(4, 1), (4, 5), (8, 3), (256, 9), (260, 64), (1024, 33), (1, 1), (3, 7), (255, 6)])
 def test_median_3x3_network_paths(gpu, oracle, size):
     """r <= 1 takes the min3/med3/max3 network: widths that are multiples of 4 use the 16-byte load + lane-exchange path
