@@ -126,3 +126,25 @@ def test_cli_errors_before_device_creation():
     assert r.returncode == 2 and "--input" in r.stderr                 # clap: required argument
     r = subprocess.run([exe, "-i", __file__, os.path.join(ROOT, "bench.py"), "-o", "/tmp/x.png"], capture_output=True, text=True)
     assert r.returncode == 1 and "--output-dir" in r.stderr           # ref: src/cli.rs:114-121
+
+
+def test_shared_column_median_networks_are_what_the_generator_emits_and_select_the_median():
+    """k_median_shared_net.h must be the generator's current output (tools/gen_median_shared.py), and the r = 2 graph must pick element len/2
+    of every window on random bytes with ties (the exhaustive 0/1 verification runs when the header is generated; this pins header and tool together
+    in the CPU gate)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_median_shared", os.path.join(ROOT, "tools", "gen_median_shared.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    header = open(os.path.join(ROOT, "paintfe_amd", "csrc", "k_median_shared_net.h")).read()
+    for r in (2, 3, 4):
+        g, outs, keep = G.build(r)
+        assert G.emit(r, g, outs, keep) in header, f"k_median_shared_net.h is stale for r = {r}: run tools/gen_median_shared.py"
+    g, outs, keep = G.build(2)
+    rng = np.random.default_rng(5)
+    for levels in (256, 3):
+        px = rng.integers(0, levels, (5, 8, 4096), dtype=np.uint8)  # [row][column][sample]
+        v = g.evaluate([px[k, c] for c in range(8) for k in range(5)], keep)
+        for j in range(4):
+            want = np.sort(px[:, j:j + 5].reshape(25, -1), axis=0)[12]
+            assert np.array_equal(v[outs[j]], want), f"window {j}, {levels} levels"
