@@ -219,7 +219,14 @@ PFX_DEV uint32_t apply_px(const pfxk_params& P, const uint8_t* __restrict__ lut,
     } else {
         adjust_px<OP>(P, lut, ubyte0(px), ubyte1(px), ubyte2(px), ubyte3(px), o);
         if constexpr (OP == PFXK_OP_INVERT_ALPHA || OP == PFXK_OP_LUT_RGBA) return pack_round_rgba(o[0], o[1], o[2], o[3]);
-        else { // alpha passes through untouched: round three channels, keep the byte
+        else if ((OP == PFXK_OP_HSL || OP == PFXK_OP_VIBRANCE) && P.p[11] != 0.0f) { // wave-uniform: the host found every parameter finite
+            // hsl_to_rgb returns finite values for finite h, s, l (sums and products of numbers in [0, 2]; the grey lanes' 0 / 0 never leaves
+            // rgb_to_hsl): no +inf to keep away from the tie bit, so the v_med3 of round_tie_prep (a half-rate instruction) is not needed
+            auto tie = [](float v) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) | 1u); };
+            uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32(tie(o[0]), 0, px);
+            q = __builtin_amdgcn_cvt_pk_u8_f32(tie(o[1]), 1, q);
+            return __builtin_amdgcn_cvt_pk_u8_f32(tie(o[2]), 2, q);
+        } else { // alpha passes through untouched: round three channels, keep the byte
             uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[0]), 0, px);
             q = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[1]), 1, q);
             return __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(o[2]), 2, q);

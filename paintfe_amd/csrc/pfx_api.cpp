@@ -91,6 +91,8 @@ int prepare_adjust(pfx_ctx* ctx, int op, const float* p, uint32_t n, pfxk_params
         P.p[0] = p[0] / 360.0f;            // hue_shift / 360.0   (adjustments.rs:310)
         P.p[1] = 1.0f + p[1] / 100.0f;     // sat_factor          (:307)
         P.p[2] = p[2] * 255.0f / 100.0f;   // light_offset        (:308)
+        // p[11] != 0: every parameter is finite, so the kernel's results are finite and its cheaper round-and-pack applies (k_pointwise.hip)
+        P.p[11] = (std::isfinite(P.p[0]) && std::isfinite(P.p[1]) && std::isfinite(P.p[2])) ? 1.0f : 0.0f;
         return PFX_OK;
     case PFX_OP_EXPOSURE:
         if (!need(1)) break;
@@ -116,7 +118,9 @@ int prepare_adjust(pfx_ctx* ctx, int op, const float* p, uint32_t n, pfxk_params
         P.p[0] = p[0]; P.p[1] = p[1]; P.p[2] = p[2]; return PFX_OK;
     case PFX_OP_VIBRANCE:
         if (!need(1)) break;
-        P.p[0] = p[0] / 100.0f; return PFX_OK;
+        P.p[0] = p[0] / 100.0f;
+        P.p[11] = std::isfinite(P.p[0]) ? 1.0f : 0.0f; // as for HSL
+        return PFX_OK;
     case PFX_OP_GRADIENT_MAP: case PFX_OP_LUT_RGBA: needs_lut = true; return PFX_OK;
     default: return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_adjust: unknown op %d", op);
     }

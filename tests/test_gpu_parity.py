@@ -761,3 +761,14 @@ def test_box_blur_fused_equals_two_pass_and_oracle(gpu, radius, size):
             gpu.r.tune("box_two_pass", 0)
         assert np.array_equal(fused, two)
         assert_same(fused, O.box_blur(img, radius, m), 0, f"box blur r={radius} {size}")
+
+
+@pytest.mark.parametrize("params", [(30.0, -20.0, float("inf")), (30.0, -20.0, float("-inf")), (float("nan"), 10.0, 5.0), (10.0, float("inf"), 0.0),
+                                    (0.0, 0.0, 3.0e38), (720.0, 1.0e30, -1.0e30)])
+def test_hsl_with_non_finite_and_huge_parameters(gpu, oracle, params):
+    """the HSL / vibrance kernels use a cheaper round-and-pack when the host found every parameter finite; infinities and NaNs must still
+    round like Rust's `.round().clamp(0, 255) as u8` (inf -> 255, NaN -> 0), huge finite values saturate"""
+    img = I.random_rgba(130, 70, 321)
+    assert_same(gpu.adjust(img, "hsl", params), oracle.adjust(img, "hsl", params), 0, f"hsl {params}")
+    v = (params[2],) if np.isfinite(params[0]) else (params[0],)
+    assert_same(gpu.adjust(img, "vibrance", v), oracle.adjust(img, "vibrance", v), 0, f"vibrance {v}")
