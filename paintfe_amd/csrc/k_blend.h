@@ -82,6 +82,25 @@ PFX_DEV float soft_light_channel(float base, float top)
     float d = (base <= 0.25f) ? ((16.0f * base - 12.0f) * base + 4.0f) * base : sqrt_normal(base);
     return base + (2.0f * top - 1.0f) * (d - base);
 }
+// Soft Light's d(base) depends on the accumulator channel alone, and that is one of 256 values RN(k / 255): the streaming compositor
+// keeps the 256 results in LDS (1 KB per workgroup, filled by the kernel's own lanes with the very expression above, so the bits are
+// those the lanes would compute) and replaces v_sqrt + refinement + polynomial + select — about 50 issue cycles per channel — by
+// one fma, one and, one ds_read_b32.  bn * 1020 is 4k(1 +- 2^-24), so fl(bn * 1020 + 2^23) is exactly 2^23 + 4k: the byte offset.
+__shared__ float s_soft_d[256];
+PFX_DEV void soft_d_fill(uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t k = tid; k < 256u; k += nthreads) {
+        const float base = div255((float)k);
+        s_soft_d[k] = (base <= 0.25f) ? ((16.0f * base - 12.0f) * base + 4.0f) * base : sqrt_normal(base);
+    }
+}
+PFX_DEV float soft_light_channel_lds(float base, float top)
+{
+    const uint32_t off = __builtin_bit_cast(uint32_t, __builtin_fmaf(base, 1020.0f, 8388608.0f)) & 0x3fcu;
+    const float d = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_soft_d) + off);
+    if (top <= 0.5f) return base - (1.0f - 2.0f * top) * base * (1.0f - base);
+    return base + (2.0f * top - 1.0f) * (d - base);
+}
 template <bool F> PFX_DEV float divide_channel(float base, float top)
 {
     return (top <= 0.0f) ? 1.0f : clamp01(fdiv<F>(base, top));
@@ -279,6 +298,13 @@ PFX_DEV void blend_layer_fast(uint32_t mode, float (&acc)[PX][4], const uint32_t
 // pixel; re-quantisation `k = (q * 255) as u8` followed by `k / 255` of the next blend is requant() below.
 PFX_DEV float requant(float q) { return div255(__builtin_truncf(q * 255.0f)); }
 
+// blend function of the normalised form: Soft Light through the LDS table (the kernel must have run soft_d_fill + a barrier)
+template <uint32_t M> PFX_DEV float blend_fn_nx(float b, float t)
+{
+    if constexpr (M == M_SOFT_LIGHT) return soft_light_channel_lds(b, t);
+    else return blend_fn<M, true>(b, t);
+}
+
 template <uint32_t M, int OB>
 PFX_DEV void blend_nx(float (&acc)[4], const float (&top)[4], float opacity_raw, float opc)
 {
@@ -286,9 +312,9 @@ PFX_DEV void blend_nx(float (&acc)[4], const float (&top)[4], float opacity_raw,
     if constexpr (OB == 2 && M != M_XOR && M != M_OVERWRITE) { // opaque accumulator, opaque layer pixel, opacity >= 1 (wave-uniform)
         if constexpr (M == M_NORMAL) { acc[0] = top[0]; acc[1] = top[1]; acc[2] = top[2]; }
         else {
-            const float r = blend_fn<M, F>(acc[0], top[0]);
-            const float g = blend_fn<M, F>(acc[1], top[1]);
-            const float b = blend_fn<M, F>(acc[2], top[2]);
+            const float r = blend_fn_nx<M>(acc[0], top[0]);
+            const float g = blend_fn_nx<M>(acc[1], top[1]);
+            const float b = blend_fn_nx<M>(acc[2], top[2]);
             acc[0] = requant(r); acc[1] = requant(g); acc[2] = requant(b);
         }
         acc[3] = 1.0f;
@@ -307,9 +333,9 @@ PFX_DEV void blend_nx(float (&acc)[4], const float (&top)[4], float opacity_raw,
         const float ita = 1.0f - top_a;
         float den, nr, ng, nb;
         if constexpr (UNIT) {
-            const float r = blend_fn<M, F>(base_r, top_r);
-            const float g = blend_fn<M, F>(base_g, top_g);
-            const float b = blend_fn<M, F>(base_b, top_b);
+            const float r = blend_fn_nx<M>(base_r, top_r);
+            const float g = blend_fn_nx<M>(base_g, top_g);
+            const float b = blend_fn_nx<M>(base_b, top_b);
             den = 1.0f;
             nr = r * top_a + base_r * ita;
             ng = g * top_a + base_g * ita;
@@ -321,9 +347,9 @@ PFX_DEV void blend_nx(float (&acc)[4], const float (&top)[4], float opacity_raw,
             ng = base_g * base_a * ita + top_g * top_a * iba;
             nb = base_b * base_a * ita + top_b * top_a * iba;
         } else {
-            const float r = blend_fn<M, F>(base_r, top_r);
-            const float g = blend_fn<M, F>(base_g, top_g);
-            const float b = blend_fn<M, F>(base_b, top_b);
+            const float r = blend_fn_nx<M>(base_r, top_r);
+            const float g = blend_fn_nx<M>(base_g, top_g);
+            const float b = blend_fn_nx<M>(base_b, top_b);
             den = top_a + base_a * ita;                                // :1407
             nr = r * top_a + base_r * base_a * ita;                    // :1412
             ng = g * top_a + base_g * base_a * ita;

@@ -266,6 +266,8 @@ __global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_la
     // flight (the typed load lands 16 bytes of registers per 4 bytes read, so the in-flight volume a CU needs to cover HBM
     // latency — ~32 KB — is bought with registers: PX * NB * 4 VGPRs per lane)
     static_assert(NB == 2 || NB == 3, "two or three layer register sets");
+    soft_d_fill(threadIdx.x, 256u);
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4u;
@@ -444,6 +446,8 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
     __shared__ uint32_t s_acc[WPB][RING];   // parked accumulators (RGBA8) at the pixels' natural slots (offset mod RING), R units deep
     __shared__ uint16_t s_q[WPB][QCAP];     // FIFO of early pixels (offset from the wave's first pixel)
     __shared__ uint32_t s_rec[WPB][NREC][2]; // per unit in flight: {first layer of its natural pass, queue tail after its append}
+    soft_d_fill(threadIdx.x, 64u * WPB);
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)WPB + wid);
     const uint32_t units_total = (n_px + UPX - 1u) / UPX;
