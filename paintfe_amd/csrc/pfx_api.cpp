@@ -484,6 +484,12 @@ int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w,
     PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_median_dev"));
     const uint32_t r = std::max(radius, 1u); // noise.rs:364
     if (r > PFX_MEDIAN_MAX_RADIUS) return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "median radius %u > %d", r, PFX_MEDIAN_MAX_RADIUS);
+    if ((int)r >= ctx->median_bits_min && r <= 7u) { // bit-sliced radix select (k_median_bits.hip); scratch ~ the image size
+        PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, pfxk_median_bits_scratch((int)r, w, h)));
+        pfx_timer t(ctx, "median");
+        PFX_HIP(ctx, pfxk_median_bits(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint8_t*)mask_dev, (uint32_t*)ctx->st_tmp.p, (int)r, w, h));
+        return PFX_OK;
+    }
     pfx_timer t(ctx, "median");
     PFX_HIP(ctx, pfxk_median(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint8_t*)mask_dev, (int)r, w, h));
     return PFX_OK;
@@ -1227,6 +1233,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "dle_frac_b") == 0) { pfxk_flatten_set_dle_sched(-1, -1, value); return PFX_OK; }
     if (std::strcmp(key, "dle_cfg") == 0) { pfxk_flatten_set_dle_dev(-1, value); return PFX_OK; }
     if (std::strcmp(key, "median_search1") == 0) { pfxk_median_set_search1(value); return PFX_OK; }
+    if (std::strcmp(key, "median_bits_min") == 0) { ctx->median_bits_min = value; return PFX_OK; } // smallest radius on the bit-plane kernel (8: never)
     if (std::strcmp(key, "median_single") == 0) { pfxk_median_set_single(value); return PFX_OK; }
     if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
     if (std::strcmp(key, "resize_two_pass") == 0) { ctx->resize_two_pass = value != 0; return PFX_OK; } // A/B and the parity test of the fused kernel

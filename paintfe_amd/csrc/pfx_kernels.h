@@ -113,6 +113,10 @@ hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, ui
 #define PFXK_MEDIAN_TILE_MAX_RADIUS 24 /* beyond: sliding histograms */
 hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, int radius,
                        uint32_t w, uint32_t h);
+// ---- k_median_bits.hip ---- radii 2..7 as a bit-sliced radix select over bit planes of the image (scratch: pfxk_median_bits_scratch bytes)
+size_t pfxk_median_bits_scratch(int radius, uint32_t w, uint32_t h);
+hipError_t pfxk_median_bits(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, uint32_t* d_planes, int radius,
+                            uint32_t w, uint32_t h);
 hipError_t pfxk_pixelate(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, uint32_t bs,
                          uint32_t w, uint32_t h);
 

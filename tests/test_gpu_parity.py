@@ -246,6 +246,9 @@ def test_box_blur_bitexact(gpu, oracle, radius):
     assert_same(gpu.box_blur(img, radius, mask), oracle.box_blur(img, radius, mask), 0, f"box r={radius} masked")
 
 
+MEDIAN_BITS_MIN = 4  # pfx_ctx default (pfx_internal.h): radii 4..7 take the bit-plane select
+
+
 @pytest.mark.parametrize("radius", [0, 1, 2, 3, 7, 12])
 def test_median_bitexact(gpu, oracle, radius):
     img = I.random_rgba(131, 77, 40 + radius)
@@ -266,13 +269,15 @@ def test_median_shared_column_networks(gpu, oracle, radius, size):
     img[: h // 2] = (img[: h // 2] // 86) * 86  # three levels per channel: ties everywhere
     mask = (np.random.default_rng(w).random((h, w)) < 0.5).astype(np.uint8)
     ref, ref_m = oracle.median(img, radius), oracle.median(img, radius, mask)
-    for single in (0, 1):
-        gpu.r.tune("median_single", single)
-        try:
+    gpu.r.tune("median_bits_min", 8)  # the network kernels, not the bit-plane select
+    try:
+        for single in (0, 1):
+            gpu.r.tune("median_single", single)
             assert_same(gpu.median(img, radius), ref, 0, f"median r={radius} {w}x{h} single={single}")
             assert_same(gpu.median(img, radius, mask), ref_m, 0, f"median r={radius} {w}x{h} masked single={single}")
-        finally:
-            gpu.r.tune("median_single", 0)
+    finally:
+        gpu.r.tune("median_single", 0)
+        gpu.r.tune("median_bits_min", MEDIAN_BITS_MIN)
 
 
 @pytest.mark.parametrize("radius", [4, 5, 7, 12, 24])
@@ -287,6 +292,7 @@ def test_median_value_search_four_pixels_per_lane(gpu, oracle, radius, size):
     mask = (np.random.default_rng(w + 3).random((h, w)) < 0.5).astype(np.uint8)
     ref, ref_m = oracle.median(img, radius), oracle.median(img, radius, mask)
     gpu.r.tune("median_single", 1)   # radius 4 takes the search too
+    gpu.r.tune("median_bits_min", 8)  # ... and radii 4..7 do not take the bit-plane select
     try:
         for one in (0, 1):
             gpu.r.tune("median_search1", one)
@@ -295,6 +301,27 @@ def test_median_value_search_four_pixels_per_lane(gpu, oracle, radius, size):
     finally:
         gpu.r.tune("median_search1", 0)
         gpu.r.tune("median_single", 0)
+        gpu.r.tune("median_bits_min", MEDIAN_BITS_MIN)
+
+
+@pytest.mark.parametrize("radius", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("size", [(1, 1), (5, 3), (16, 40), (31, 33), (32, 32), (33, 31), (63, 70), (64, 16), (65, 97), (131, 23), (390, 41), (1031, 37)])
+def test_median_bit_plane_radix_select(gpu, oracle, radius, size):
+    """k_median_bits.hip: the window as bit planes, rank select from the top plane down.  Sizes cross the 32-pixel dwords of a plane row,
+    the 16-column waves, the 32-row bands and the 2r+1-row ring (several turns), windows wider / taller than the image, masks, heavy ties
+    (the select must count equal elements exactly like the sort)"""
+    w, h = size
+    img = I.random_rgba(w, h, 2100 + 7 * w + radius)
+    img[: h // 2] = (img[: h // 2] // 100) * 100
+    img[:, : w // 3, 1] = 255
+    img[:, w // 2:, 2] = 0
+    mask = (np.random.default_rng(w + 5).random((h, w)) < 0.5).astype(np.uint8)
+    gpu.r.tune("median_bits_min", 2)
+    try:
+        assert_same(gpu.median(img, radius), oracle.median(img, radius), 0, f"median bits r={radius} {w}x{h}")
+        assert_same(gpu.median(img, radius, mask), oracle.median(img, radius, mask), 0, f"median bits r={radius} {w}x{h} masked")
+    finally:
+        gpu.r.tune("median_bits_min", MEDIAN_BITS_MIN)
 
 
 @pytest.mark.parametrize("size", [(4, 1), (4, 5), (8, 3), (256, 9), (260, 64), (1024, 33), (1, 1), (3, 7), (255, 6)])

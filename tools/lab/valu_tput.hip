@@ -52,6 +52,11 @@
 #define OP_XOR(n) "v_xor_b32 %" #n ", %" #n ", %8\n"
 #define OP_MED3CLAMP(n) "v_add_f32 %" #n ", %" #n ", %8 clamp\n"
 #define OP_SAD(n) "v_sad_u8 %" #n ", %" #n ", %8, %9\n"
+#define OP_BCNT(n) "v_bcnt_u32_b32 %" #n ", %8, %" #n "\n"
+#define OP_BITOP3(n) "v_bitop3_b32 %" #n ", %" #n ", %8, %9 bitop3:0x28\n"
+#define OP_ALIGNBIT(n) "v_alignbit_b32 %" #n ", %" #n ", %8, %9\n"
+#define OP_LSHLOR(n) "v_lshl_or_b32 %" #n ", %" #n ", 3, %9\n"
+#define OP_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n"
 #define KERNEL(NAME, OP) __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) { BODY(OP) }
 KERNEL(k_fma, OP_FMA) KERNEL(k_minu32, OP_MINU32) KERNEL(k_pkmin, OP_PKMIN) KERNEL(k_pkmax, OP_PKMAX) KERNEL(k_minu16, OP_MINU16)
 KERNEL(k_min3, OP_MIN3) KERNEL(k_med3, OP_MED3) KERNEL(k_pkadd, OP_PKADD) KERNEL(k_and, OP_AND) KERNEL(k_perm, OP_PERM) KERNEL(k_mini16, OP_MINI16)
@@ -60,6 +65,7 @@ KERNEL(k_mulf32, OP_MULF32) KERNEL(k_addf32, OP_ADDF32) KERNEL(k_subf32, OP_SUBF
 KERNEL(k_cmp, OP_CMP) KERNEL(k_mov, OP_MOV) KERNEL(k_rcp, OP_RCP) KERNEL(k_cvtub, OP_CVTUB) KERNEL(k_cvtpk, OP_CVTPK) KERNEL(k_addu32, OP_ADDU32) KERNEL(k_lshr, OP_LSHR)
 KERNEL(k_andor, OP_ANDOR) KERNEL(k_bfi, OP_BFI) KERNEL(k_xor, OP_XOR) KERNEL(k_addclamp, OP_MED3CLAMP)
 KERNEL(k_med3f32, OP_MED3F32) KERNEL(k_min3f32, OP_MIN3F32) KERNEL(k_pkmulf16, OP_PKMULF16)
+KERNEL(k_bcnt, OP_BCNT) KERNEL(k_bitop3, OP_BITOP3) KERNEL(k_alignbit, OP_ALIGNBIT) KERNEL(k_lshlor, OP_LSHLOR) KERNEL(k_add3, OP_ADD3)
 template <class K> double run(K k, uint32_t* out)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -86,5 +92,6 @@ int main()
     REPORT("v_cvt_pk_u8_f32", k_cvtpk) REPORT("v_add_u32", k_addu32) REPORT("v_lshrrev_b32", k_lshr) REPORT("v_and_or_b32", k_andor) REPORT("v_bfi_b32", k_bfi)
     REPORT("v_xor_b32", k_xor) REPORT("v_add_f32 clamp", k_addclamp)
     REPORT("v_med3_f32", k_med3f32) REPORT("v_min3_f32", k_min3f32) REPORT("v_pk_mul_f16", k_pkmulf16)
+    REPORT("v_bcnt_u32_b32", k_bcnt) REPORT("v_bitop3_b32", k_bitop3) REPORT("v_alignbit_b32", k_alignbit) REPORT("v_lshl_or_b32", k_lshlor) REPORT("v_add3_u32", k_add3)
     return 0;
 }
