@@ -27,19 +27,22 @@ constexpr int MB_ROWS = 32;   // output rows per wave
 __host__ __device__ inline uint32_t mb_dwords(uint32_t w, int r) { return (w + 2u * (uint32_t)r + 31u) / 32u + 1u; } // + the funnel shift's high dword
 
 // planes[((y * 4 + c) * ND + j) * 8 + b]: bit t = NOT bit b of channel c of pixel (clamp(32 j + t - r), y)
+constexpr int MP_ROWS = 4; // rows per wave: that many loads in flight (one pixel per lane and load; the kernel is a pure stream)
 __global__ __launch_bounds__(256) void median_planes_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ planes, int r, int w, int h,
                                                            uint32_t nd)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = blockIdx.x * 4u + (threadIdx.x >> 6); // 64 padded positions = dword columns 2 wv, 2 wv + 1
-    const uint32_t y = blockIdx.y;
+    const uint32_t y0 = blockIdx.y * MP_ROWS;
     if (2u * wv >= nd) return;
     const int x = min(max((int)(wv * 64u + lane) - r, 0), w - 1);
-    const uint32_t nv = ~src[(size_t)y * w + x];
+    uint32_t v[MP_ROWS];
+#pragma unroll
+    for (int i = 0; i < MP_ROWS; ++i) v[i] = ~src[(size_t)min(y0 + i, (uint32_t)h - 1u) * w + x];
+    const uint32_t hh = lane >> 5, c = (lane >> 3) & 3u, b = lane & 7u, j = 2u * wv + hh;
     // 32 x 32 bit-matrix transpose inside each half of the wave (lane t holds pixel t's 32 bits -> lane i holds bit i of 32 pixels): five
     // butterfly stages, each exchanging with lane ^ j (ds_swizzle, no memory) the off-diagonal j x j blocks; a rotation brings the partner's
     // block under the mask on either side of the exchange
-    uint32_t out = nv;
 #define PFX_TR_STAGE(J, M)                                                                                       \
     {                                                                                                            \
         const uint32_t other = (uint32_t)__builtin_amdgcn_ds_swizzle((int)out, ((J) << 10) | 0x1f);              \
@@ -48,10 +51,13 @@ __global__ __launch_bounds__(256) void median_planes_kernel(const uint32_t* __re
         const uint32_t keep = lo ? (M) : ~(M);                                                                   \
         out = (out & keep) | (rot & ~keep);                                                                      \
     }
-    PFX_TR_STAGE(16u, 0x0000ffffu) PFX_TR_STAGE(8u, 0x00ff00ffu) PFX_TR_STAGE(4u, 0x0f0f0f0fu) PFX_TR_STAGE(2u, 0x33333333u) PFX_TR_STAGE(1u, 0x55555555u)
+#pragma unroll
+    for (int i = 0; i < MP_ROWS; ++i) {
+        uint32_t out = v[i];
+        PFX_TR_STAGE(16u, 0x0000ffffu) PFX_TR_STAGE(8u, 0x00ff00ffu) PFX_TR_STAGE(4u, 0x0f0f0f0fu) PFX_TR_STAGE(2u, 0x33333333u) PFX_TR_STAGE(1u, 0x55555555u)
+        if (j < nd && y0 + i < (uint32_t)h) planes[(((size_t)(y0 + i) * 4u + c) * nd + j) * 8u + b] = out;
+    }
 #undef PFX_TR_STAGE
-    const uint32_t hh = lane >> 5, c = (lane >> 3) & 3u, b = lane & 7u, j = 2u * wv + hh;
-    if (j < nd) planes[(((size_t)y * 4u + c) * nd + j) * 8u + b] = out;
 }
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f)
@@ -202,7 +208,7 @@ extern "C" hipError_t pfxk_median_bits(hipStream_t s, const uint8_t* d_src, uint
     if (w == 0 || h == 0) return hipSuccess;
     if (radius < 2 || radius > 7) return hipErrorInvalidValue;
     const uint32_t nd = mb_dwords(w, radius);
-    median_planes_kernel<<<dim3((nd + 7u) / 8u, h), 256, 0, s>>>((const uint32_t*)d_src, d_planes, radius, (int)w, (int)h, nd);
+    median_planes_kernel<<<dim3((nd + 7u) / 8u, (h + MP_ROWS - 1) / MP_ROWS), 256, 0, s>>>((const uint32_t*)d_src, d_planes, radius, (int)w, (int)h, nd);
     const dim3 g((w + 4 * MB_COLS - 1) / (4 * MB_COLS), (h + MB_ROWS - 1) / MB_ROWS);
 #define PFX_MB(R) case R: median_bits_kernel<R><<<g, 256, 0, s>>>(d_src, d_planes, d_dst, d_mask, (int)w, (int)h, nd); break;
     switch (radius) { PFX_MB(2) PFX_MB(3) PFX_MB(4) PFX_MB(5) PFX_MB(6) PFX_MB(7) }

@@ -246,7 +246,7 @@ def test_box_blur_bitexact(gpu, oracle, radius):
     assert_same(gpu.box_blur(img, radius, mask), oracle.box_blur(img, radius, mask), 0, f"box r={radius} masked")
 
 
-MEDIAN_BITS_MIN = 4  # pfx_ctx default (pfx_internal.h): radii 4..7 take the bit-plane select
+MEDIAN_BITS_MIN = 3  # pfx_ctx default (pfx_internal.h): radii 3..7 take the bit-plane select
 
 
 @pytest.mark.parametrize("radius", [0, 1, 2, 3, 7, 12])

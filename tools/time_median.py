@@ -8,7 +8,7 @@ r = GpuRenderer(0); r.set_stream(torch.cuda.current_stream().cuda_stream)
 w, h = 7680, 4320
 src = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
 import sys as _s
-mins = [int(a) for a in _s.argv[1:]] or [4]
+mins = [int(a) for a in _s.argv[1:]] or [3]
 for bits_min in mins:
     r.tune("median_bits_min", bits_min)
     for rad in (1, 2, 3, 4, 5, 6, 7):
