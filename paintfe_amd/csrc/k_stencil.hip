@@ -7,6 +7,7 @@
 // Integer sums are order-independent, so the reference's serial sliding sums become direct window sums for the
 // first output of a lane and a 2-term slide for the following ones.
 #include "k_common.h"
+#include <type_traits>
 #include "k_median25_net.h"
 #include "k_median_shared_net.h"
 #include "pfx_kernels.h"
@@ -31,46 +32,70 @@ PFX_DEV uint32_t avg_px(const u4& s, uint32_t half, uint32_t magic)
            (div_round(s.c[2], half, magic) << 16) | (div_round(s.c[3], half, magic) << 24);
 }
 
+// LDS index of tile element i: one pad word per 32, so that lanes PX (a power of two) elements apart start in different banks —
+// unpadded, the 64 lanes' windows (stride 8 words) met in 4 of the 32 banks: 16-way conflicts on every read, 3x the kernel's time
+PFX_DEV int bx_pad(int i) { return i + (i >> 5); }
+template <int PX>
 __global__ __launch_bounds__(BX_THREADS) void box_h_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                           int r, uint32_t half, uint32_t magic, int w, int h)
 {
-    extern __shared__ uint32_t row_tile[]; // BX_TILE + 2r
-    const int y = blockIdx.y, x_tile = blockIdx.x * BX_TILE;
-    const int n_in = min(BX_TILE, w - x_tile) + 2 * r;
+    extern __shared__ uint32_t row_tile[]; // bx_pad(BX_THREADS * PX + 2r)
+    constexpr int TILE = BX_THREADS * PX;
+    const int y = blockIdx.y, x_tile = blockIdx.x * TILE;
+    const int n_in = min(TILE, w - x_tile) + 2 * r;
     const uint32_t* row = src + (size_t)y * w;
-    for (int i = threadIdx.x; i < n_in; i += BX_THREADS) row_tile[i] = row[min(max(x_tile - r + i, 0), w - 1)];
+    for (int i = threadIdx.x; i < n_in; i += BX_THREADS) row_tile[bx_pad(i)] = row[min(max(x_tile - r + i, 0), w - 1)];
     __syncthreads();
-    const int lx0 = threadIdx.x * BX_PX, x0 = x_tile + lx0;
-    if (x0 >= w) return;
-    u4 s = {{0, 0, 0, 0}};
-    for (int k = 0; k <= 2 * r; ++k) add_px(s, row_tile[lx0 + k]);
-    uint32_t* out = dst + (size_t)y * w + x0;
-#pragma unroll
-    for (int o = 0; o < BX_PX; ++o) {
-        if (x0 + o >= w) break;
-        out[o] = avg_px(s, half, magic);
-        if (x0 + o + 1 < w) { sub_px(s, row_tile[lx0 + o]); add_px(s, row_tile[lx0 + o + 2 * r + 1]); }
+    const int lx0 = threadIdx.x * PX, x0 = x_tile + lx0;
+    // results leave through a second LDS tile: a lane's PX outputs are consecutive words, so direct stores would touch 64 sectors per
+    // instruction, 4 bytes each (measured: the kernel ran at a third of the copy rate on its write transactions alone)
+    uint32_t* const out_tile = row_tile + bx_pad(TILE + 2 * r) + 1;
+    if (x0 < w) {
+        u4 s = {{0, 0, 0, 0}};
+        for (int k = 0; k <= 2 * r; ++k) add_px(s, row_tile[bx_pad(lx0 + k)]);
+#pragma unroll 8
+        for (int o = 0; o < PX; ++o) {
+            out_tile[bx_pad(lx0 + o)] = avg_px(s, half, magic);
+            sub_px(s, row_tile[bx_pad(lx0 + o)]);                       // past the row's end these read clamped or stale words: never stored
+            add_px(s, row_tile[bx_pad(min(lx0 + o + 2 * r + 1, n_in - 1))]);
+        }
     }
+    __syncthreads();
+    const int n_out = min(TILE, w - x_tile);
+    uint32_t* const out = dst + (size_t)y * w + x_tile;
+    for (int i = threadIdx.x; i < n_out; i += BX_THREADS) out[i] = out_tile[bx_pad(i)];
 }
 
-constexpr int BV_PY = 16; // consecutive rows per lane
+// Vertical pass: a lane owns PY consecutive rows of one column.  The rows entering and leaving the window are requested eight outputs ahead
+// (16 loads in flight per lane): with the loads inside the per-output loop every iteration waited out a memory round trip
+constexpr int BV_U = 8;
+template <int PY>
 __global__ __launch_bounds__(256) void box_v_kernel(const uint32_t* __restrict__ hbuf, const uint32_t* __restrict__ src,
                                                     const uint8_t* __restrict__ mask, uint32_t* __restrict__ dst, int r,
                                                     uint32_t half, uint32_t magic, int w, int h)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * BV_PY;
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PY;
     if (x >= w || y0 >= h) return;
+    const uint32_t* const col = hbuf + x;
+    auto at = [&](int y) { return col[(size_t)min(max(y, 0), h - 1) * w]; };
     u4 s = {{0, 0, 0, 0}};
-    for (int k = -r; k <= r; ++k) add_px(s, hbuf[(size_t)min(max(y0 + k, 0), h - 1) * w + x]);
-    for (int o = 0; o < BV_PY; ++o) {
-        const int y = y0 + o;
-        if (y >= h) break;
-        const size_t i = (size_t)y * w + x;
-        dst[i] = (mask && mask[i] == 0) ? src[i] : avg_px(s, half, magic); // blur.rs:296-303
-        if (y + 1 < h) {
-            sub_px(s, hbuf[(size_t)min(max(y - r, 0), h - 1) * w + x]);
-            add_px(s, hbuf[(size_t)min(max(y + r + 1, 0), h - 1) * w + x]);
+#pragma unroll 8
+    for (int k = -r; k <= r; ++k) add_px(s, at(y0 + k));
+    for (int o = 0; o < PY; o += BV_U) {
+        if (y0 + o >= h) break;
+        uint32_t in[BV_U], out[BV_U];
+#pragma unroll
+        for (int j = 0; j < BV_U; ++j) { in[j] = at(y0 + o + j + r + 1); out[j] = at(y0 + o + j - r); }
+#pragma unroll
+        for (int j = 0; j < BV_U; ++j) {
+            const int y = y0 + o + j;
+            if (y < h) {
+                const size_t i = (size_t)y * w + x;
+                dst[i] = (mask && mask[i] == 0) ? src[i] : avg_px(s, half, magic); // blur.rs:296-303
+            }
+            sub_px(s, out[j]);
+            add_px(s, in[j]);
         }
     }
 }
@@ -79,29 +104,31 @@ __global__ __launch_bounds__(256) void box_v_kernel(const uint32_t* __restrict__
 // (clamp-to-edge, blur.rs:258,290) in LDS, runs the horizontal pass for the tile's BF_T + 2r rows into a second LDS tile — the u8
 // intermediate of the reference, rounded exactly as in box_h_kernel — and the vertical pass out of that.  Same integer arithmetic,
 // bit-identical to the two kernels above; the 4 B/px intermediate never reaches HBM and the halo (1.2x at r = 3) is recomputed.
-constexpr int BF_T = 64, BF_RUN = 8, BF_MAXR = 8;
+constexpr int BF_T = 64, BF_RUN = 8, BF_MAXR = 4; // r >= 5: the two passes (0.145 ms at 8K) beat the fused tile (0.16 .. 0.17 ms, 1.3x halo)
 __global__ __launch_bounds__(256) void box_fused_kernel(const uint32_t* __restrict__ src, const uint8_t* __restrict__ mask, uint32_t* __restrict__ dst,
                                                         int r, uint32_t half, uint32_t magic, int w, int h)
 {
     extern __shared__ uint32_t bf_lds[];
     const int side = BF_T + 2 * r;                 // source tile is side x side, horizontal results are side rows x BF_T
-    uint32_t* s_src = bf_lds;                      // [side][side]
-    uint32_t* s_h = bf_lds + side * side;          // [side][BF_T]
+    const int sp = side | 1;                       // odd row pitches: the runs of 8 lanes working on consecutive rows start in different banks
+    constexpr int HP = BF_T + 1;                   // (even pitches put them in 16 of 32 banks on the reads and ONE bank per column on the writes)
+    uint32_t* s_src = bf_lds;                      // [side][sp]
+    uint32_t* s_h = bf_lds + side * sp;            // [side][HP]
     const int bx = blockIdx.x * BF_T, by = blockIdx.y * BF_T;
     for (int i = threadIdx.x; i < side * side; i += 256) {
         const int ty = i / side, tx = i - ty * side;
-        s_src[i] = src[(size_t)min(max(by - r + ty, 0), h - 1) * w + min(max(bx - r + tx, 0), w - 1)];
+        s_src[ty * sp + tx] = src[(size_t)min(max(by - r + ty, 0), h - 1) * w + min(max(bx - r + tx, 0), w - 1)];
     }
     __syncthreads();
     // horizontal: runs of BF_RUN outputs, sliding window (blur.rs:262-276)
     for (int run = threadIdx.x; run < side * (BF_T / BF_RUN); run += 256) {
         const int ty = run / (BF_T / BF_RUN), x0 = (run - ty * (BF_T / BF_RUN)) * BF_RUN;
-        const uint32_t* row = s_src + ty * side + x0; // window of output x0 + o = row[o .. o + 2r]
+        const uint32_t* row = s_src + ty * sp + x0; // window of output x0 + o = row[o .. o + 2r]
         u4 s = {{0, 0, 0, 0}};
         for (int k = 0; k <= 2 * r; ++k) add_px(s, row[k]);
 #pragma unroll
         for (int o = 0; o < BF_RUN; ++o) {
-            s_h[ty * BF_T + x0 + o] = avg_px(s, half, magic);
+            s_h[ty * HP + x0 + o] = avg_px(s, half, magic);
             if (o + 1 < BF_RUN) { sub_px(s, row[o]); add_px(s, row[o + 2 * r + 1]); }
         }
     }
@@ -111,14 +138,14 @@ __global__ __launch_bounds__(256) void box_fused_kernel(const uint32_t* __restri
     const int x = bx + lx;
     if (x >= w) return;
     u4 s = {{0, 0, 0, 0}};
-    for (int k = 0; k <= 2 * r; ++k) add_px(s, s_h[(y0 + k) * BF_T + lx]);
+    for (int k = 0; k <= 2 * r; ++k) add_px(s, s_h[(y0 + k) * HP + lx]);
     for (int o = 0; o < BF_T / 4; ++o) {
         const int y = by + y0 + o;
         if (y >= h) break;
         const size_t i = (size_t)y * w + x;
         dst[i] = (mask && mask[i] == 0) ? src[i] : avg_px(s, half, magic); // blur.rs:296-303
-        sub_px(s, s_h[(y0 + o) * BF_T + lx]);
-        add_px(s, s_h[(y0 + o + 2 * r + 1 < side ? y0 + o + 2 * r + 1 : side - 1) * BF_T + lx]);
+        sub_px(s, s_h[(y0 + o) * HP + lx]);
+        add_px(s, s_h[(y0 + o + 2 * r + 1 < side ? y0 + o + 2 * r + 1 : side - 1) * HP + lx]);
     }
 }
 
@@ -462,6 +489,8 @@ int g_median_search1 = 0; // pfxk_median_set_search1: the value search with one 
 extern "C" void pfxk_median_set_search1(int on) { g_median_search1 = on; }
 int g_median_single = 0; // pfxk_median_set_single: the one-window-per-lane networks for radii 2 and 3
 extern "C" void pfxk_median_set_single(int on) { g_median_single = on; }
+int g_box_px_switch = 24, g_box_py_switch = 24; // radii from which a lane takes 16 columns / 128 rows instead of 8 / 32
+extern "C" void pfxk_box_set_switch(int px, int py) { if (px >= 0) g_box_px_switch = px; if (py >= 0) g_box_py_switch = py; }
 int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
 extern "C" void pfxk_box_set_two_pass(int on) { g_box_two_pass = on; }
 extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst,
@@ -473,21 +502,28 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
     const uint32_t magic = (uint32_t)((0x100000000ull / d) + 1ull), half = d / 2u;
     if (radius <= BF_MAXR && g_box_two_pass == 0 && !force_two_pass && d_src != d_dst) { // small radii: both passes in one kernel (the halo recomputation stays below 1.6x)
         const int side = BF_T + 2 * radius;
-        const size_t lds = (size_t)(side * side + side * BF_T) * 4;
+        const size_t lds = (size_t)(side * (side | 1) + side * (BF_T + 1)) * 4;
         hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e) return e;
         box_fused_kernel<<<dim3((w + BF_T - 1) / BF_T, (h + BF_T - 1) / BF_T), 256, lds, s>>>((const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, half, magic,
                                                                                            (int)w, (int)h);
         return hipGetLastError();
     }
-    dim3 gh((w + BX_TILE - 1) / BX_TILE, h);
-    const size_t lds = (size_t)(BX_TILE + 2 * radius + BX_PX) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)box_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // outputs per lane grow with the radius: a lane's first window costs 2r + 1 reads whatever it is followed by
+    auto launch_h = [&](auto px_c) -> hipError_t {
+        constexpr int PX = decltype(px_c)::value;
+        const int n = BX_THREADS * PX + 2 * radius, n2 = BX_THREADS * PX;
+        const size_t lds = (size_t)((n + (n >> 5) + 1) + (n2 + (n2 >> 5) + 1)) * 4;
+        hipError_t e = hipFuncSetAttribute((const void*)box_h_kernel<PX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e) return e;
+        box_h_kernel<PX><<<dim3((w + BX_THREADS * PX - 1) / (BX_THREADS * PX), h), BX_THREADS, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_tmp, radius, half, magic, (int)w, (int)h);
+        return hipGetLastError();
+    };
+    hipError_t e = radius < g_box_px_switch ? launch_h(std::integral_constant<int, 8>{}) : launch_h(std::integral_constant<int, 16>{});
     if (e) return e;
-    box_h_kernel<<<gh, BX_THREADS, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_tmp, radius, half, magic, (int)w, (int)h);
-    dim3 gv((w + 63) / 64, (h + 4 * BV_PY - 1) / (4 * BV_PY));
-    box_v_kernel<<<gv, 256, 0, s>>>((const uint32_t*)d_tmp, (const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, half,
-                                    magic, (int)w, (int)h);
+#define PFX_BV(PY) box_v_kernel<PY><<<dim3((w + 63) / 64, (h + 4 * PY - 1) / (4 * PY)), 256, 0, s>>>((const uint32_t*)d_tmp, (const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, half, magic, (int)w, (int)h)
+    if (radius < g_box_py_switch) PFX_BV(32); else PFX_BV(128);
+#undef PFX_BV
     return hipGetLastError();
 }
 

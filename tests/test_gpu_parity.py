@@ -771,11 +771,11 @@ def test_resize_fused_equals_two_pass_and_oracle(gpu, filt, src, dst):
     assert_same(fused, O.resize(img, nw, nh, filt), 0, f"resize {filt} {src}->{dst}")
 
 
-@pytest.mark.parametrize("radius", [1.0, 2.0, 3.0, 5.5, 8.0, 9.0])
+@pytest.mark.parametrize("radius", [1.0, 2.0, 3.0, 4.0, 5.5, 8.0, 9.0])
 @pytest.mark.parametrize("size", [(257, 131), (64, 64), (70, 300), (5, 3)])
 def test_box_blur_fused_equals_two_pass_and_oracle(gpu, radius, size):
-    """box_blur_core for r <= 8 runs both passes in one kernel (u8 intermediate in LDS): bit-identical to the two-pass path (pfx_tune
-    box_two_pass) and to the oracle, with and without a selection mask; r = 9 takes the two-pass path by itself"""
+    """box_blur_core for r <= 4 runs both passes in one kernel (u8 intermediate in LDS): bit-identical to the two-pass path (pfx_tune
+    box_two_pass) and to the oracle, with and without a selection mask; larger radii take the two-pass path by themselves"""
     w, h = size
     img = I.random_rgba(w, h, 4242 + w)
     mask = (np.random.default_rng(w * h).random((h, w)) < 0.6).astype(np.uint8) * 255
@@ -788,6 +788,25 @@ def test_box_blur_fused_equals_two_pass_and_oracle(gpu, radius, size):
             gpu.r.tune("box_two_pass", 0)
         assert np.array_equal(fused, two)
         assert_same(fused, O.box_blur(img, radius, m), 0, f"box blur r={radius} {size}")
+
+
+@pytest.mark.parametrize("radius", [5.0, 23.0, 24.0, 60.0, 130.0])
+@pytest.mark.parametrize("size", [(2049, 40), (4100, 9), (300, 300), (33, 1), (1, 70)])
+def test_box_blur_two_pass_lane_runs(gpu, radius, size):
+    """the two-pass kernels: 8 / 16 columns per lane in the horizontal pass (2048- and 4096-pixel row tiles: widths either side of one and
+    two tiles), 32 / 128 rows per lane in the vertical pass with the window's rows requested eight outputs ahead (heights below one run,
+    bands that end inside an 8-row group), both run lengths forced on every radius through pfx_tune"""
+    w, h = size
+    img = I.random_rgba(w, h, 777 + w + int(radius))
+    ref = O.box_blur(img, radius)
+    for px_sw, py_sw in ((24, 24), (0, 0), (4000, 4000)):
+        gpu.r.tune("box_px_switch", px_sw)
+        gpu.r.tune("box_py_switch", py_sw)
+        try:
+            assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} switches {px_sw}/{py_sw}")
+        finally:
+            gpu.r.tune("box_px_switch", 24)
+            gpu.r.tune("box_py_switch", 24)
 
 
 @pytest.mark.parametrize("params", [(30.0, -20.0, float("inf")), (30.0, -20.0, float("-inf")), (float("nan"), 10.0, 5.0), (10.0, float("inf"), 0.0),

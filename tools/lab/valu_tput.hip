@@ -57,6 +57,14 @@
 #define OP_ALIGNBIT(n) "v_alignbit_b32 %" #n ", %" #n ", %8, %9\n"
 #define OP_LSHLOR(n) "v_lshl_or_b32 %" #n ", %" #n ", 3, %9\n"
 #define OP_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n"
+#define OP_MULHI(n) "v_mul_hi_u32 %" #n ", %" #n ", %8\n"
+#define OP_MULLO(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\n"
+#define OP_MULHI24(n) "v_mul_hi_u32_u24 %" #n ", %" #n ", %8\n"
+#define OP_MUL24(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n"
+#define OP_MAD24(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %9\n"
+#define OP_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 8, 8\n"
+#define OP_CVTU32(n) "v_cvt_f32_u32 %" #n ", %" #n "\n"
+#define OP_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 3, %9\n"
 #define KERNEL(NAME, OP) __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) { BODY(OP) }
 KERNEL(k_fma, OP_FMA) KERNEL(k_minu32, OP_MINU32) KERNEL(k_pkmin, OP_PKMIN) KERNEL(k_pkmax, OP_PKMAX) KERNEL(k_minu16, OP_MINU16)
 KERNEL(k_min3, OP_MIN3) KERNEL(k_med3, OP_MED3) KERNEL(k_pkadd, OP_PKADD) KERNEL(k_and, OP_AND) KERNEL(k_perm, OP_PERM) KERNEL(k_mini16, OP_MINI16)
@@ -66,6 +74,7 @@ KERNEL(k_cmp, OP_CMP) KERNEL(k_mov, OP_MOV) KERNEL(k_rcp, OP_RCP) KERNEL(k_cvtub
 KERNEL(k_andor, OP_ANDOR) KERNEL(k_bfi, OP_BFI) KERNEL(k_xor, OP_XOR) KERNEL(k_addclamp, OP_MED3CLAMP)
 KERNEL(k_med3f32, OP_MED3F32) KERNEL(k_min3f32, OP_MIN3F32) KERNEL(k_pkmulf16, OP_PKMULF16)
 KERNEL(k_bcnt, OP_BCNT) KERNEL(k_bitop3, OP_BITOP3) KERNEL(k_alignbit, OP_ALIGNBIT) KERNEL(k_lshlor, OP_LSHLOR) KERNEL(k_add3, OP_ADD3)
+KERNEL(k_mulhi, OP_MULHI) KERNEL(k_mullo, OP_MULLO) KERNEL(k_mulhi24, OP_MULHI24) KERNEL(k_mul24, OP_MUL24) KERNEL(k_mad24, OP_MAD24) KERNEL(k_bfe, OP_BFE) KERNEL(k_cvtu32, OP_CVTU32) KERNEL(k_lshladd, OP_LSHLADD)
 template <class K> double run(K k, uint32_t* out)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -93,5 +102,6 @@ int main()
     REPORT("v_xor_b32", k_xor) REPORT("v_add_f32 clamp", k_addclamp)
     REPORT("v_med3_f32", k_med3f32) REPORT("v_min3_f32", k_min3f32) REPORT("v_pk_mul_f16", k_pkmulf16)
     REPORT("v_bcnt_u32_b32", k_bcnt) REPORT("v_bitop3_b32", k_bitop3) REPORT("v_alignbit_b32", k_alignbit) REPORT("v_lshl_or_b32", k_lshlor) REPORT("v_add3_u32", k_add3)
+    REPORT("v_mul_hi_u32", k_mulhi) REPORT("v_mul_lo_u32", k_mullo) REPORT("v_mul_hi_u32_u24", k_mulhi24) REPORT("v_mul_u32_u24", k_mul24) REPORT("v_mad_u32_u24", k_mad24) REPORT("v_bfe_u32", k_bfe) REPORT("v_cvt_f32_u32", k_cvtu32) REPORT("v_lshl_add_u32", k_lshladd)
     return 0;
 }
