@@ -423,40 +423,68 @@ PFX_DEV int nearest_seed(const float2* __restrict__ seeds, int cells_x, int cell
 }
 
 // acc: per cell 5 x u64 {sum r, g, b, a, count}.  Integer sums == the reference's f64 sums of integers (exact below 2^53).
-// A 64x4 tile touches a handful of cells: the block first accumulates per cell in an LDS hash table (u32 sums: <= 256 px * 255),
-// then flushes one set of global u64 atomics per (block, cell) instead of five per pixel.
+// A wave holds 64 consecutive pixels of a row, which fall into a handful of cells: the runs of lanes with the same cell are summed with one
+// wave scan (r | b << 16 and g | a << 16, the sums stay below 64 * 255) and the first lane of each run adds it to the block's LDS table.
+// (Round 2 had every lane add its own pixel to the table: 64 lanes on the same five words serialised, 78 % of the kernel's LDS cycles were
+// bank conflicts.)
 __global__ __launch_bounds__(256) void crystal_accum_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ seeds,
                                                             unsigned long long* __restrict__ acc, int cells_x, int cells_y, float cs,
-                                                            int w, int h)
+                                                            int w, int h, int tile_rows)
 {
+    // the block's four waves (a 64 x 4 tile) meet in an LDS hash table — one entry per (wave, cell), a few dozen inserts per block — and
+    // the table is flushed with one set of global u64 atomics per (block, cell)
     constexpr int SLOTS = 512; // >= 2 x the 256 keys a block can insert: open addressing always finds a slot
     __shared__ int keys[SLOTS];
     __shared__ uint32_t vals[SLOTS][5];
     for (int i = threadIdx.x; i < SLOTS; i += 256) { keys[i] = -1; vals[i][0] = vals[i][1] = vals[i][2] = vals[i][3] = vals[i][4] = 0u; }
     __syncthreads();
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < w && y < h) {
-        const uint32_t p = src[(size_t)y * w + x];
-        const int cell = nearest_seed(seeds, cells_x, cells_y, cs, x, y);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    for (int it = 0; it < tile_rows / 4; ++it) { // 64 x tile_rows pixels per block: the global atomics per pixel fall with the tile's area / perimeter
+    const int y = blockIdx.y * tile_rows + it * 4 + (threadIdx.x >> 6);
+    const bool live = x < w && y < h;
+    uint32_t p = 0;
+    int cell = -1;
+    if (live) {
+        p = src[(size_t)y * w + x];
+        cell = nearest_seed(seeds, cells_x, cells_y, cs, x, y);
+    }
+    // A cell meets a row in one or a few runs of consecutive lanes.  One inclusive scan of the wave's packed channels serves every run of the
+    // row: the first lane of each run takes the difference of the scan at the run's two ends (two ds_bpermute per value) and adds the run to
+    // the block's table — all runs of the wave at once, no loop over cells.
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t pre_rb = live ? (p & 0x00ff00ffu) : 0u, pre_ga = live ? ((p >> 8) & 0x00ff00ffu) : 0u; // 64 * 255 < 2^16: the fields do not carry
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = (uint32_t)__shfl_up((int)pre_rb, off, 64), b = (uint32_t)__shfl_up((int)pre_ga, off, 64);
+        if (lane >= off) { pre_rb += a; pre_ga += b; }
+    }
+    const int prev_cell = __shfl_up(cell, 1, 64);
+    const bool first = lane == 0 || prev_cell != cell;
+    const unsigned long long firsts = __ballot(first);
+    const unsigned long long above = lane == 63 ? 0ull : (firsts >> (lane + 1));
+    const int last = above ? lane + __builtin_ctzll(above) : 63;            // last lane of the run this lane would lead
+    const uint32_t end_rb = (uint32_t)__shfl((int)pre_rb, last, 64), end_ga = (uint32_t)__shfl((int)pre_ga, last, 64);
+    const uint32_t beg_rb = (uint32_t)__shfl_up((int)pre_rb, 1, 64), beg_ga = (uint32_t)__shfl_up((int)pre_ga, 1, 64);
+    if (first && cell >= 0) {
+        const uint32_t rb = end_rb - (lane ? beg_rb : 0u), ga = end_ga - (lane ? beg_ga : 0u);
         int slot = (int)(((uint32_t)cell * 2654435761u) >> 23); // 9 bits
         for (;;) {
             const int prev = atomicCAS(&keys[slot], -1, cell);
             if (prev == -1 || prev == cell) break;
             slot = (slot + 1) & (SLOTS - 1);
         }
-        atomicAdd(&vals[slot][0], p & 0xffu);
-        atomicAdd(&vals[slot][1], (p >> 8) & 0xffu);
-        atomicAdd(&vals[slot][2], (p >> 16) & 0xffu);
-        atomicAdd(&vals[slot][3], p >> 24);
-        atomicAdd(&vals[slot][4], 1u);
+        atomicAdd(&vals[slot][0], rb & 0xffffu); atomicAdd(&vals[slot][1], ga & 0xffffu);
+        atomicAdd(&vals[slot][2], rb >> 16);     atomicAdd(&vals[slot][3], ga >> 16);
+        atomicAdd(&vals[slot][4], (uint32_t)(last - lane + 1));
+    }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SLOTS; i += 256) {
-        const int cell = keys[i];
-        if (cell < 0) continue;
-        unsigned long long* a = acc + (size_t)cell * 5;
+        const int c = keys[i];
+        if (c < 0) continue;
+        unsigned long long* a = acc + (size_t)c * 5;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) atomicAdd(a + c, (unsigned long long)vals[i][c]);
+        for (int k = 0; k < 5; ++k) atomicAdd(a + k, (unsigned long long)vals[i][k]);
     }
 }
 
@@ -586,7 +614,8 @@ extern "C" hipError_t pfxk_crystallize(hipStream_t s, const uint8_t* d_src, uint
     const int n = cells_x * cells_y;
     hipError_t e = hipMemsetAsync(d_acc, 0, (size_t)n * 5 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    crystal_accum_kernel<<<tile_grid(w, h), 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_seeds_xy, d_acc, cells_x, cells_y, cs, (int)w, (int)h);
+    const int tile_rows = cs >= 8.0f ? 64 : 4; // distinct cells per block stay below half the table: (64 / 8 + 2)^2 = 100, or one per pixel of 64 x 4
+    crystal_accum_kernel<<<dim3((w + 63) / 64, (h + tile_rows - 1) / tile_rows), 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_seeds_xy, d_acc, cells_x, cells_y, cs, (int)w, (int)h, tile_rows);
     crystal_avg_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_acc, d_avg, n);
     crystal_assign_kernel<<<tile_grid(w, h), 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (const float2*)d_seeds_xy, d_avg, cells_x,
                                                           cells_y, cs, (int)w, (int)h);

@@ -23,6 +23,7 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="", help="run only the rows whose name contains this text")
     args = ap.parse_args()
     import torch
 
@@ -37,6 +38,8 @@ def main() -> int:
     rows = []
 
     def timed(name, timer_names, fn, px, alg_bytes_per_px, note=""):
+        if args.only and args.only not in name:
+            return
         for _ in range(5):  # clocks ramp over the first launches
             fn()
         torch.cuda.synchronize()
