@@ -521,41 +521,54 @@ __global__ __launch_bounds__(256) void crystal_assign_kernel(const uint32_t* __r
 // bins[levels][lanes] u64, one word per bin: count << 51 | sum_b << 34 | sum_g << 17 | sum_r (count <= 441, each sum <= 112455 < 2^17),
 // so a window element is ONE fire-and-forget ds_add_u64 (no read-modify-write round trip in the dependency chain; the
 // [level][lane] layout keeps a wave's 64 adds on distinct banks whatever the levels are).
+// A lane owns a column and walks OIL_ROWS rows down: the histogram persists, a step adds the window's new bottom row and removes the row that
+// left it (2 (2r+1) updates instead of (2r+1)^2 — and a source pixel's level is computed twice, not (2r+1)^2 times).  Subtracting the packed
+// word that was added restores every field (the 64-bit adds form a group; no field ever goes below what the window holds).
+constexpr int OIL_ROWS = 32;
 __global__ void oil_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint8_t* __restrict__ mask, int radius,
                            int levels, int w, int h)
 {
     extern __shared__ unsigned long long obins[];
     const int lanes = blockDim.x, t = threadIdx.x;
-    const int x = blockIdx.x * lanes + t, y = blockIdx.y;
+    const int x = blockIdx.x * lanes + t, y0 = blockIdx.y * OIL_ROWS;
     if (x >= w) return;
-    const size_t oi = (size_t)y * w + x;
-    const uint32_t s = src[oi];
-    if (mask && mask[oi] == 0) { dst[oi] = s; return; }
     unsigned long long* b0 = obins + t;
     for (int k = 0; k < levels; ++k) b0[k * lanes] = 0ull;
-    for (int dy = -radius; dy <= radius; ++dy) {
-        const uint32_t* row = src + (size_t)clampi(y + dy, 0, h - 1) * w;
+    auto row_update = [&](int yy, bool add) {
+        const uint32_t* row = src + (size_t)clampi(yy, 0, h - 1) * w;
         for (int dx = -radius; dx <= radius; ++dx) {
             const uint32_t p = row[clampi(x + dx, 0, w - 1)];
             const uint32_t pr = p & 0xffu, pg = (p >> 8) & 0xffu, pb = (p >> 16) & 0xffu;
             uint32_t k = (pr + pg + pb) / 3u * (uint32_t)levels / 256u;
             k = min(k, (uint32_t)levels - 1u);
-            atomicAdd(b0 + k * lanes, (1ull << 51) | ((unsigned long long)pb << 34) | ((unsigned long long)pg << 17) | (unsigned long long)pr);
+            const unsigned long long word = (1ull << 51) | ((unsigned long long)pb << 34) | ((unsigned long long)pg << 17) | (unsigned long long)pr;
+            atomicAdd(b0 + k * lanes, add ? word : 0ull - word);
         }
+    };
+    for (int dy = -radius; dy < radius; ++dy) row_update(y0 + dy, true);
+    const int y1 = min(y0 + OIL_ROWS, h);
+    for (int y = y0; y < y1; ++y) {
+        row_update(y + radius, true);
+        const size_t oi = (size_t)y * w + x;
+        const uint32_t s = src[oi];
+        uint32_t out = s;
+        if (!(mask && mask[oi] == 0)) {
+            uint32_t max_count = 0;
+            unsigned long long best = 0ull;
+            for (int k = 0; k < levels; ++k) {
+                const unsigned long long v = b0[k * lanes];
+                const uint32_t c = (uint32_t)(v >> 51);
+                if (c > max_count) { max_count = c; best = v; } // first level with the largest count (artistic.rs:186-195)
+            }
+            out = s & 0xff000000u;
+            if (max_count > 0) {
+                const uint32_t sr = (uint32_t)best & 0x1ffffu, sg = (uint32_t)(best >> 17) & 0x1ffffu, sb = (uint32_t)(best >> 34) & 0x1ffffu;
+                out |= (sr / max_count) | ((sg / max_count) << 8) | ((sb / max_count) << 16);
+            }
+        }
+        dst[oi] = out;
+        row_update(y - radius, false);
     }
-    uint32_t max_count = 0;
-    unsigned long long best = 0ull;
-    for (int k = 0; k < levels; ++k) {
-        const unsigned long long v = b0[k * lanes];
-        const uint32_t c = (uint32_t)(v >> 51);
-        if (c > max_count) { max_count = c; best = v; } // first level with the largest count (artistic.rs:186-195)
-    }
-    uint32_t out = s & 0xff000000u;
-    if (max_count > 0) {
-        const uint32_t sr = (uint32_t)best & 0x1ffffu, sg = (uint32_t)(best >> 17) & 0x1ffffu, sb = (uint32_t)(best >> 34) & 0x1ffffu;
-        out |= (sr / max_count) | ((sg / max_count) << 8) | ((sb / max_count) << 16);
-    }
-    dst[oi] = out;
 }
 
 // ---- drop shadow helpers (render.rs:233-301): offset alpha plane, separable max "widen", expand to RGBA ---------
@@ -628,7 +641,7 @@ extern "C" hipError_t pfxk_oil_painting(hipStream_t s, const uint8_t* d_src, uin
     if (w == 0 || h == 0) return hipSuccess;
     const int lanes = levels <= 32 ? 256 : (levels <= 64 ? 128 : 64); // 8 B per level per lane, <= 64 KiB of LDS per block
     const size_t lds = (size_t)lanes * levels * 8;
-    oil_kernel<<<dim3((w + lanes - 1) / lanes, h), lanes, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, levels, (int)w, (int)h);
+    oil_kernel<<<dim3((w + lanes - 1) / lanes, (h + OIL_ROWS - 1) / OIL_ROWS), lanes, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, levels, (int)w, (int)h);
     return hipGetLastError();
 }
 
