@@ -120,6 +120,43 @@ def test_gaussian_8k_sigma16_windows(env, stack8k, exact):
         assert d.max() <= tol, f"window at ({x},{y}) exact={exact}: max diff {int(d.max())}"
 
 
+@pytest.mark.parametrize("radius", [3, 5, 7])
+def test_median_8k_windows_bitexact(env, stack8k, radius):
+    """the bit-plane radix select (k_median_bits.hip) at the full 8K frame: plane rows of 242 dwords, 135 row bands, the last band and the last
+    64-column block ragged — corner windows (clamped borders) and interior windows against the oracle run on window + halo crops"""
+    torch, r, device = env
+    flat = stack8k[4]
+    out = torch.empty_like(flat)
+    r.median_dev(flat.data_ptr(), out.data_ptr(), W8K, H8K, radius)
+    torch.cuda.synchronize()
+    ww, wh = 200, 120
+    for (x, y) in windows(W8K, H8K, ww, wh, seed=10 + radius):
+        x0, y0 = max(x - radius, 0), max(y - radius, 0)
+        x1, y1 = min(x + ww + radius, W8K), min(y + wh + radius, H8K)
+        ref = O.median(host(flat[y0:y1, x0:x1, :]), radius)[y - y0:y - y0 + wh, x - x0:x - x0 + ww]
+        assert np.array_equal(ref, host(out[y:y + wh, x:x + ww, :])), f"median r={radius} window at ({x},{y})"
+
+
+@pytest.mark.parametrize("radius", [3.0, 9.0, 48.0])
+def test_box_blur_8k_windows_bitexact(env, stack8k, radius):
+    """box blur at the full 8K frame: the fused tile (r = 3), the two-pass kernels with 8 / 16 columns and 32 / 128 rows per lane (r = 9, 48;
+    a row is 3.75 tiles of 2048 and 1.875 of 4096 pixels, the last row band ragged)"""
+    torch, r, device = env
+    flat = stack8k[4]
+    out = torch.empty_like(flat)
+    r.box_blur_dev(flat.data_ptr(), out.data_ptr(), W8K, H8K, radius)
+    torch.cuda.synchronize()
+    rad = int(np.ceil(radius))
+    ww, wh = 300, 160
+    for (x, y) in windows(W8K, H8K, ww, wh, seed=20 + rad):
+        x0, y0 = max(x - rad, 0), max(y - rad, 0)
+        x1, y1 = min(x + ww + rad, W8K), min(y + wh + rad, H8K)
+        # the vertical pass reads horizontal results of rows up to `rad` away, whose own windows reach `rad` columns further: the crop's
+        # left / right halo only has to cover the horizontal reach, its rows carry the vertical one
+        ref = O.box_blur(host(flat[y0:y1, x0:x1, :]), radius)[y - y0:y - y0 + wh, x - x0:x - x0 + ww]
+        assert np.array_equal(ref, host(out[y:y + wh, x:x + ww, :])), f"box blur r={radius} window at ({x},{y})"
+
+
 def test_gaussian_8k_constant_is_a_fixed_point(env):
     torch, r, device = env
     img = torch.empty((H8K, W8K, 4), dtype=torch.uint8, device=device)

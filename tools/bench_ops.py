@@ -79,11 +79,15 @@ def main() -> int:
     lut = np.tile(np.arange(255, -1, -1, dtype=np.uint8), (4, 1))
     timed("levels/curves LUT apply", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "lut_rgba", lut=lut), px, 8)
     timed("vibrance", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "vibrance", [50.0]), px, 8)
-    timed("box blur r=3", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 3.0), px, 8, "two passes, u8 intermediate (+8 B/px)")
-    timed("box blur r=48", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 48.0), px, 8)
+    timed("box blur r=3", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 3.0), px, 8, "both passes in one kernel on 64 x 64 tiles (r <= 4)")
+    timed("box blur r=9", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 9.0), px, 8, "two passes, u8 intermediate (+8 B/px)")
+    timed("box blur r=48", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 48.0), px, 8, "two passes")
     timed("median r=1", ["median"], lambda: r.median_dev(s, d, w, h, 1), px, 8)
     timed("median r=2", ["median"], lambda: r.median_dev(s, d, w, h, 2), px, 8)
-    timed("median r=7", ["median"], lambda: r.median_dev(s, d, w, h, 7), px, 8, "225-element windows")
+    timed("median r=3", ["median"], lambda: r.median_dev(s, d, w, h, 3), px, 8, "bit-plane radix select (k_median_bits.hip), incl. the planes pre-pass")
+    timed("median r=4", ["median"], lambda: r.median_dev(s, d, w, h, 4), px, 8, "bit-plane radix select")
+    timed("median r=5", ["median"], lambda: r.median_dev(s, d, w, h, 5), px, 8, "bit-plane radix select")
+    timed("median r=7", ["median"], lambda: r.median_dev(s, d, w, h, 7), px, 8, "225-element windows, bit-plane radix select")
     # ---------------- the rest of the effect bank (k_effects2.hip), script VM, resamplers
     timed("vignette", ["vignette"], lambda: r.vignette_dev(s, d, w, h, 0.8, 0.5), px, 8)
     timed("add_noise gaussian mono", ["add_noise"], lambda: r.add_noise_dev(s, d, w, h, 30.0, "gaussian", True, 42, 1.0, 1), px, 8, "f64 ln + cos per pixel")
@@ -91,8 +95,8 @@ def main() -> int:
     timed("reduce_noise r=2", ["reduce_noise"], lambda: r.reduce_noise_dev(s, d, w, h, 10.0, 2), px, 8, "25 exp per pixel (glibc expf algorithm in f64)")
     timed("halftone", ["halftone"], lambda: r.halftone_dev(s, d, w, h, 4.0, 45.0, "circle"), px, 8)
     timed("ink (sobel)", ["ink"], lambda: r.ink_dev(s, d, w, h, 1.0, 0.5), px, 8)
-    timed("oil_painting r=3 levels=20", ["oil_painting"], lambda: r.oil_painting_dev(s, d, w, h, 3, 20), px, 8, "per-lane LDS histogram")
-    timed("crystallize cell=16", ["crystallize"], lambda: r.crystallize_dev(s, d, w, h, 16.0, 42), px, 8, "global u64 atomics + assign")
+    timed("oil_painting r=3 levels=20", ["oil_painting"], lambda: r.oil_painting_dev(s, d, w, h, 3, 20), px, 8, "per-lane LDS histogram sliding down a column")
+    timed("crystallize cell=16", ["crystallize"], lambda: r.crystallize_dev(s, d, w, h, 16.0, 42), px, 8, "wave-scanned cell sums -> LDS table -> u64 atomics, + assign")
     timed("bulge", ["bulge"], lambda: r.bulge_dev(s, d, w, h, 0.5), px, 8)
     timed("twist 45", ["twist"], lambda: r.twist_dev(s, d, w, h, 45.0), px, 8, "f64 sin + cos per pixel")
     timed("zoom_blur 16 samples", ["zoom_blur"], lambda: r.zoom_blur_dev(s, d, w, h, 0.5, 0.5, 0.3, 16), px, 8)
