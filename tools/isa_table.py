@@ -65,7 +65,7 @@ def main():
         # and integer adds 2 cycles per wave64 instruction; transcendentals 8; everything else (min / max / med3, trunc, conversions, compares, selects,
         # bfi / perm / and_or, packed ops) 4
         full = ("v_fma_f32", "v_fmac_f32", "v_fmaak", "v_fmamk", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_and_b32", "v_or_b32",
-                "v_xor_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32")
+                "v_xor_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32", "v_bitop3_b32")
         cyc = 0
         half = 0
         for i in ins:

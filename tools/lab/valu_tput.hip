@@ -75,6 +75,45 @@ KERNEL(k_andor, OP_ANDOR) KERNEL(k_bfi, OP_BFI) KERNEL(k_xor, OP_XOR) KERNEL(k_a
 KERNEL(k_med3f32, OP_MED3F32) KERNEL(k_min3f32, OP_MIN3F32) KERNEL(k_pkmulf16, OP_PKMULF16)
 KERNEL(k_bcnt, OP_BCNT) KERNEL(k_bitop3, OP_BITOP3) KERNEL(k_alignbit, OP_ALIGNBIT) KERNEL(k_lshlor, OP_LSHLOR) KERNEL(k_add3, OP_ADD3)
 KERNEL(k_mulhi, OP_MULHI) KERNEL(k_mullo, OP_MULLO) KERNEL(k_mulhi24, OP_MULHI24) KERNEL(k_mul24, OP_MUL24) KERNEL(k_mad24, OP_MAD24) KERNEL(k_bfe, OP_BFE) KERNEL(k_cvtu32, OP_CVTU32) KERNEL(k_lshladd, OP_LSHLADD)
+__global__ __launch_bounds__(256) void k_bitop3_mixed(uint32_t* out, uint32_t seed)
+{
+    uint32_t x[8];
+    for (int j = 0; j < 8; ++j) x[j] = threadIdx.x * 2654435761u + j + seed;
+    for (int it = 0; it < 512; ++it) {
+        asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca\nv_bitop3_b32 %1, %2, %3, %4 bitop3:0xca\nv_bitop3_b32 %2, %3, %4, %5 bitop3:0xca\nv_bitop3_b32 %3, %4, %5, %6 bitop3:0xca\n"
+                     "v_bitop3_b32 %4, %5, %6, %7 bitop3:0xca\nv_bitop3_b32 %5, %6, %7, %0 bitop3:0xca\nv_bitop3_b32 %6, %7, %0, %1 bitop3:0xca\nv_bitop3_b32 %7, %0, %1, %2 bitop3:0xca\n"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    }
+    uint32_t s = 0;
+    for (int j = 0; j < 8; ++j) s ^= x[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_fma_mixed(uint32_t* out, uint32_t seed)
+{
+    uint32_t x[8];
+    for (int j = 0; j < 8; ++j) x[j] = threadIdx.x * 2654435761u + j + seed;
+    for (int it = 0; it < 512; ++it) {
+        asm volatile("v_fma_f32 %0, %1, %2, %3\nv_fma_f32 %1, %2, %3, %4\nv_fma_f32 %2, %3, %4, %5\nv_fma_f32 %3, %4, %5, %6\n"
+                     "v_fma_f32 %4, %5, %6, %7\nv_fma_f32 %5, %6, %7, %0\nv_fma_f32 %6, %7, %0, %1\nv_fma_f32 %7, %0, %1, %2\n"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    }
+    uint32_t s = 0;
+    for (int j = 0; j < 8; ++j) s ^= x[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_cnd_mixed(uint32_t* out, uint32_t seed)
+{
+    uint32_t x[8];
+    for (int j = 0; j < 8; ++j) x[j] = threadIdx.x * 2654435761u + j + seed;
+    for (int it = 0; it < 512; ++it) {
+        asm volatile("v_cmp_lt_u32 vcc, %0, %4\nv_cndmask_b32 %0, %1, %2, vcc\nv_cndmask_b32 %1, %2, %3, vcc\nv_cndmask_b32 %2, %3, %4, vcc\nv_cndmask_b32 %3, %4, %5, vcc\n"
+                     "v_cndmask_b32 %4, %5, %6, vcc\nv_cndmask_b32 %5, %6, %7, vcc\nv_cndmask_b32 %6, %7, %0, vcc\nv_cndmask_b32 %7, %0, %1, vcc\n"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : : "vcc");
+    }
+    uint32_t s = 0;
+    for (int j = 0; j < 8; ++j) s ^= x[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 template <class K> double run(K k, uint32_t* out)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -103,5 +142,6 @@ int main()
     REPORT("v_med3_f32", k_med3f32) REPORT("v_min3_f32", k_min3f32) REPORT("v_pk_mul_f16", k_pkmulf16)
     REPORT("v_bcnt_u32_b32", k_bcnt) REPORT("v_bitop3_b32", k_bitop3) REPORT("v_alignbit_b32", k_alignbit) REPORT("v_lshl_or_b32", k_lshlor) REPORT("v_add3_u32", k_add3)
     REPORT("v_mul_hi_u32", k_mulhi) REPORT("v_mul_lo_u32", k_mullo) REPORT("v_mul_hi_u32_u24", k_mulhi24) REPORT("v_mul_u32_u24", k_mul24) REPORT("v_mad_u32_u24", k_mad24) REPORT("v_bfe_u32", k_bfe) REPORT("v_cvt_f32_u32", k_cvtu32) REPORT("v_lshl_add_u32", k_lshladd)
+    REPORT("v_bitop3 mixed regs (8 per iteration)", k_bitop3_mixed) REPORT("v_fma mixed regs", k_fma_mixed) REPORT("v_cmp + 8 v_cndmask mixed regs (9 insts counted as 8)", k_cnd_mixed)
     return 0;
 }
