@@ -1,4 +1,4 @@
-// k_median_bits.hip — median_core (src/ops/effects/noise.rs:357-410) for radii 3..7 as a bit-sliced radix select.
+// k_median_bits.hip — median_core (src/ops/effects/noise.rs:357-410) for radii 3..8 as a bit-sliced radix select.
 //
 // The reference sorts the (2r+1)^2 clamped window of every channel and takes element len/2.  The value search of k_stencil.hip
 // (median_search4_kernel) finds the same element with 8 threshold counts over the whole window: 8 x 225 byte compares per channel
@@ -66,13 +66,19 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 }
 
 template <int R> struct mb_geom {
-    static constexpr int S = 2 * R + 1;                                  // window side: rows, and bits per row field
-    static constexpr int RPR = S <= 5 ? 6 : S <= 7 ? 4 : S <= 9 ? 3 : 2; // rows per register
-    static constexpr int FO = 32 / RPR;                                  // field pitch inside a register (>= S)
-    static constexpr int NR = (S + RPR - 1) / RPR;                       // registers per plane
-    static constexpr uint32_t FM = (1u << S) - 1u;
+    static constexpr int S = 2 * R + 1;                                  // window side: rows, and bits per row
+    // r = 8 (the reference dialog's maximum, ui/dialogs/effects/noise.rs): a 17-bit row does not pack two to a register — its first 16 columns
+    // do, and the 17th column of all 17 rows gets a register of its own (the order of the elements is irrelevant to a popcount)
+    static constexpr bool XCOL = S > 16;
+    static constexpr int MW = XCOL ? 16 : S;                             // bits of a row that go into the packed fields
+    static constexpr int RPR = MW <= 5 ? 6 : MW <= 7 ? 4 : MW <= 9 ? 3 : 2; // rows per register
+    static constexpr int FO = 32 / RPR;                                  // field pitch inside a register (>= MW)
+    static constexpr int NRM = (S + RPR - 1) / RPR;                      // registers of packed fields per plane
+    static constexpr int NR = NRM + (XCOL ? 1 : 0);                      // registers per plane
+    static constexpr uint32_t FM = MW == 32 ? ~0u : (1u << MW) - 1u;
     static constexpr uint32_t cand_init(int reg)
     {
+        if (reg >= NRM) return (1u << S) - 1u;                           // the extra column: one bit per row
         uint32_t m = 0;
         for (int f = 0; f < RPR; ++f) if (reg * RPR + f < S) m |= FM << (f * FO);
         return m;
@@ -134,6 +140,11 @@ __global__ __launch_bounds__(256) void median_bits_kernel(const uint8_t* __restr
         // (np & ~fm) | (f << off & fm) as one full-rate v_bitop3 (v_bfi issues at half rate); unused register bits stay 0
 #pragma unroll
         for (int b = 0; b < 8; ++b) np[b][reg] = __builtin_amdgcn_bitop3_b32(np[b][reg], f[b] << off, fm, 0xd8);
+        if constexpr (G::XCOL) { // bit 16 of the row's field -> bit s of the column register
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                np[b][NR - 1] = __builtin_amdgcn_bitop3_b32(np[b][NR - 1], s < 16 ? f[b] >> (16 - s) : f[b] << (s - 16), 1u << s, 0xd8);
+        }
     };
     // The select's instruction sequence is pinned with inline asm: per register and plane one v_and (zeros among the candidates), one
     // accumulating v_bcnt, one v_bitop3 (cand &= plane ^ ones).  Left to itself hipcc re-derives the candidate sets from the planes with
@@ -206,12 +217,12 @@ extern "C" hipError_t pfxk_median_bits(hipStream_t s, const uint8_t* d_src, uint
                                        uint32_t w, uint32_t h)
 {
     if (w == 0 || h == 0) return hipSuccess;
-    if (radius < 2 || radius > 7) return hipErrorInvalidValue;
+    if (radius < 2 || radius > 8) return hipErrorInvalidValue;
     const uint32_t nd = mb_dwords(w, radius);
     median_planes_kernel<<<dim3((nd + 7u) / 8u, (h + MP_ROWS - 1) / MP_ROWS), 256, 0, s>>>((const uint32_t*)d_src, d_planes, radius, (int)w, (int)h, nd);
     const dim3 g((w + 4 * MB_COLS - 1) / (4 * MB_COLS), (h + MB_ROWS - 1) / MB_ROWS);
 #define PFX_MB(R) case R: median_bits_kernel<R><<<g, 256, 0, s>>>(d_src, d_planes, d_dst, d_mask, (int)w, (int)h, nd); break;
-    switch (radius) { PFX_MB(2) PFX_MB(3) PFX_MB(4) PFX_MB(5) PFX_MB(6) PFX_MB(7) }
+    switch (radius) { PFX_MB(2) PFX_MB(3) PFX_MB(4) PFX_MB(5) PFX_MB(6) PFX_MB(7) PFX_MB(8) }
 #undef PFX_MB
     return hipGetLastError();
 }

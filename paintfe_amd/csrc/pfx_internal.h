@@ -40,7 +40,7 @@ struct pfx_ctx {
     // staging for the host-buffer tier (the reference keeps cached staging/ping-pong textures the same way,
     // ref: src/gpu/renderer.rs:232-236)
     pfx_devbuf st_in, st_out, st_mask, st_tmp, st_aux, st_aux2;
-    int median_bits_min = 3;   // pfx_tune "median_bits_min": radii >= this (and <= 7) take k_median_bits.hip (r = 2: 0.35 ms against the networks' 0.22)
+    int median_bits_min = 3;   // pfx_tune "median_bits_min": radii >= this (and <= 8) take k_median_bits.hip (r = 2: 0.35 ms against the networks' 0.22)
     pfx_devbuf fx_a, fx_b; // effect-bank scratch (crystallize cell table, drop-shadow planes)
     // small parameter buffers
     pfx_devbuf d_desc, d_adj, d_chunks, d_wts, d_lut, d_pts, d_misc;

@@ -120,7 +120,7 @@ def test_gaussian_8k_sigma16_windows(env, stack8k, exact):
         assert d.max() <= tol, f"window at ({x},{y}) exact={exact}: max diff {int(d.max())}"
 
 
-@pytest.mark.parametrize("radius", [3, 5, 7])
+@pytest.mark.parametrize("radius", [3, 5, 7, 8])
 def test_median_8k_windows_bitexact(env, stack8k, radius):
     """the bit-plane radix select (k_median_bits.hip) at the full 8K frame: plane rows of 242 dwords, 135 row bands, the last band and the last
     64-column block ragged — corner windows (clamped borders) and interior windows against the oracle run on window + halo crops"""

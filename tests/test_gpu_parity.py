@@ -269,7 +269,7 @@ def test_median_shared_column_networks(gpu, oracle, radius, size):
     img[: h // 2] = (img[: h // 2] // 86) * 86  # three levels per channel: ties everywhere
     mask = (np.random.default_rng(w).random((h, w)) < 0.5).astype(np.uint8)
     ref, ref_m = oracle.median(img, radius), oracle.median(img, radius, mask)
-    gpu.r.tune("median_bits_min", 8)  # the network kernels, not the bit-plane select
+    gpu.r.tune("median_bits_min", 9)  # the network kernels, not the bit-plane select
     try:
         for single in (0, 1):
             gpu.r.tune("median_single", single)
@@ -292,7 +292,7 @@ def test_median_value_search_four_pixels_per_lane(gpu, oracle, radius, size):
     mask = (np.random.default_rng(w + 3).random((h, w)) < 0.5).astype(np.uint8)
     ref, ref_m = oracle.median(img, radius), oracle.median(img, radius, mask)
     gpu.r.tune("median_single", 1)   # radius 4 takes the search too
-    gpu.r.tune("median_bits_min", 8)  # ... and radii 4..7 do not take the bit-plane select
+    gpu.r.tune("median_bits_min", 9)  # ... and radii 4..8 do not take the bit-plane select
     try:
         for one in (0, 1):
             gpu.r.tune("median_search1", one)
@@ -304,7 +304,7 @@ def test_median_value_search_four_pixels_per_lane(gpu, oracle, radius, size):
         gpu.r.tune("median_bits_min", MEDIAN_BITS_MIN)
 
 
-@pytest.mark.parametrize("radius", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("radius", [2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("size", [(1, 1), (5, 3), (16, 40), (31, 33), (32, 32), (33, 31), (63, 70), (64, 16), (65, 97), (131, 23), (390, 41), (1031, 37)])
 def test_median_bit_plane_radix_select(gpu, oracle, radius, size):
     """k_median_bits.hip: the window as bit planes, rank select from the top plane down.  Sizes cross the 32-pixel dwords of a plane row,

@@ -11,7 +11,7 @@ import sys as _s
 mins = [int(a) for a in _s.argv[1:]] or [3]
 for bits_min in mins:
     r.tune("median_bits_min", bits_min)
-    for rad in (1, 2, 3, 4, 5, 6, 7):
+    for rad in (1, 2, 3, 4, 5, 6, 7, 8):
         for _ in range(3): r.median_dev(src.data_ptr(), dst.data_ptr(), w, h, rad)
         torch.cuda.synchronize(); r.timing_reset(); r.timing_enable(True)
         for _ in range(10): r.median_dev(src.data_ptr(), dst.data_ptr(), w, h, rad)
