@@ -187,11 +187,16 @@ template <bool EXACT>
 hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const float* wts, int radius, uint32_t w, uint32_t h)
 {
     int cfg = g_v_cfg & 0xff;
+    // The tile's halo (2r rows) is reloaded by every tile: beyond the matrix-core kernel's radii (sigma 16 .. 100 in the reference's advanced
+    // dialog) taller tiles pay — measured at 8K: sigma 50 1.06 -> 0.92 ms with 16 x 256, sigma 64 2.2 -> 1.1 with 8 x 512, sigma 100 3.3 -> 2.0 with 8 x 256
+    if (cfg == 0 && radius > 110) cfg = radius <= 160 ? 1 : (radius <= 240 ? 4 : 3); // 16 x 256, 8 x 512, 8 x 256 (what still fits 160 KB of LDS)
+    if (radius > 340) cfg = 0;
     if (radius > 380) cfg = 2; // narrowest tile for huge radii (LDS bound)
     switch (cfg) {
     case 1: return launch_v_cfg<EXACT, 16, 64, 16>(stream, tmp, d_dst, wts, radius, w, h);
     case 2: return launch_v_cfg<EXACT, 4, 64, 5>(stream, tmp, d_dst, wts, radius, w, h);
     case 3: return launch_v_cfg<EXACT, 8, 64, 10>(stream, tmp, d_dst, wts, radius, w, h);
+    case 4: return launch_v_cfg<EXACT, 8, 128, 10>(stream, tmp, d_dst, wts, radius, w, h);
     // shipped: 8 columns x 128 rows, 256 threads.  Measured at 8K, sigma=16 (profiles/r01_tuning.md): 0.344 ms vs
     // 0.368 (8x256 rows), 0.350 (4x256), 0.446 (16x256)
     default: return launch_v_cfg<EXACT, 8, 32, 10>(stream, tmp, d_dst, wts, radius, w, h);

@@ -216,6 +216,23 @@ def test_gaussian_vs_oracle(gpu, sigma, size):
     gpu.r.set_exact(False)
 
 
+@pytest.mark.parametrize("sigma", [17.0, 40.0, 60.0, 75.0, 100.0, 120.0])
+def test_gaussian_advanced_dialog_sigmas(gpu, sigma):
+    """sigma 16 .. 100 (the reference's advanced blur dialog, ui/dialogs/core/image.rs) is beyond the matrix-core kernel: the VALU passes with
+    the vertical tile chosen by radius — 8 x 128 (r <= 110), 16 x 256 (<= 160), 8 x 512 (<= 240), 8 x 256 (<= 340), 8 x 128 again beyond;
+    exact mode bit-exact, default mode within the stated 1 LSB.  The image is shorter than the window at the large radii (all rows clamp)."""
+    w, h = 150, 330
+    img = I.random_rgba(w, h, int(sigma))
+    ref = O.gaussian_blur(img, sigma)
+    gpu.r.set_exact(False)
+    assert_same(gpu.gaussian_blur(img, sigma), ref, 1, f"fma sigma={sigma}")
+    gpu.r.set_exact(True)
+    try:
+        assert_same(gpu.gaussian_blur(img, sigma), ref, 0, f"exact sigma={sigma}")
+    finally:
+        gpu.r.set_exact(False)
+
+
 def test_gaussian_fma_mismatch_rate_is_float_noise(gpu):
     img = I.random_rgba(1024, 512, 5)
     ref = O.gaussian_blur(img, 16.0)
