@@ -612,7 +612,7 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
 
 int g_dle_stats_on = 0, g_dle_cfg = 0, g_dle_sched = 1, g_dle_fracA = 75, g_dle_fracB = 20;
 int g_dle_units = 0; // tuning knobs (pfxk_flatten_set_dle): units per wave (0 = default), log2 of the accumulator ring
-int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant): 0 = shipped, 1-5 = PX / occupancy variants, +10 = grid-stride launch, 9 = the general kernel
+int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant): 0 = shipped (2 px x 2 sets, grid stride up to 16 layers), 1-5 = PX / register-set variants, 6 = 3 px x 3 sets (the round-2 shape), +10 = grid-stride launch, 8 = no elimination kernel, 9 = the general kernel
 
 // per 64 x 64 chunk of a layer: bit 0 = every alpha is 255, bit 1 = no alpha is 0 (computed when a layer enters the layer store)
 __global__ __launch_bounds__(256) void chunk_alpha_flags_kernel(const uint8_t* __restrict__ px, uint32_t w, uint32_t h, uint32_t cx0, uint32_t cy0,
@@ -856,9 +856,15 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
     const size_t n_px = (size_t)w * h;
     if (!general && fast_div && n_layers > 0 && n_px < (1u << 30) && g_flatten_variant != 9) {
         // one 64*PX-pixel tile per wave while that stays below the cap (the dispatcher balances the tail), grid-stride beyond
+        // Shipped shape (variant 0), from tools/ab_shallow.py at 8K on stacks of 2 .. 32 layers, with and without an opaque background: 2 pixels
+        // per lane and 2 register sets everywhere (against 3 x 3: -2 % at 32 layers, -8 % at 9, -20 % at 4); up to 16 layers the waves also
+        // walk the image with a grid stride instead of taking one tile each (a 4-layer tile is over before its launch cost is: -5 .. -10 % more)
+        int variant = g_flatten_variant % 10;
+        bool stride = g_flatten_variant >= 10;
+        if (g_flatten_variant == 0 || g_flatten_variant == 8) { variant = 1; stride = n_layers <= 16; }
         auto grid = [&](uint32_t px_per_wave) {
             size_t tiles = (n_px + px_per_wave - 1) / px_per_wave, b = (tiles + 3) / 4;
-            const size_t lim = (g_flatten_variant >= 10) ? cap : (size_t)1 << 20;
+            const size_t lim = stride ? cap : (size_t)1 << 20;
             return (uint32_t)(b > lim ? lim : b);
         };
         // dead-layer elimination when the stack holds a reset layer above the bottom one (variant 8 switches it off)
@@ -895,7 +901,7 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
 #undef PFX_ARGS
             return hipGetLastError();
         }
-        switch (g_flatten_variant % 10) {
+        switch (variant) {
 #define PFX_STREAM(PX, NB, MINW) flatten_stream_kernel<PX, NB, MINW><<<grid(64 * PX), block, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, d_chunk_start, w)
         case 1: PFX_STREAM(2, 2, 1); break;
         case 2: PFX_STREAM(2, 3, 1); break;

@@ -184,6 +184,22 @@ def test_coherent_documents_start_at_the_covering_layer(gpu):
     check(gpu, stack, modes, opac, "coherent document")
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 16, 17, 23])
+def test_streaming_kernel_shapes_agree_with_the_oracle(gpu, n):
+    """the plain streaming kernel's launch / register shapes (pfx_tune flatten_variant): the shipped one (2 pixels per lane, 2 register sets, grid stride
+    up to 16 layers), the other pixels-per-lane x set combinations, the round-2 shape (6), each with one tile per wave and with a grid stride (+10) —
+    stacks shorter than the register sets, at the stride switch (16 / 17 layers) and a width that leaves a ragged last tile"""
+    w, h = 389, 67
+    stack, modes, opac = I.layer_stack(w, h, n, seed=40 + n)
+    modes = [m if m != OVERWRITE else 1 for m in modes]                 # no reset layer: the elimination kernel stays out of it
+    for v in (0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16):
+        gpu.r.tune("flatten_variant", v)
+        try:
+            check(gpu, stack, modes, list(opac), f"{n} layers, variant {v}")
+        finally:
+            gpu.r.tune("flatten_variant", 0)
+
+
 def test_switched_off_and_general_path_agree(gpu):
     """the same stack through the plain streaming kernel (variant 8), the general kernel (variant 9) and with a live mask on the
     reset layer (the mask can lower alpha to 0: the host must not list that layer)"""
