@@ -341,6 +341,24 @@ def test_median_bit_plane_radix_select(gpu, oracle, radius, size):
         gpu.r.tune("median_bits_min", MEDIAN_BITS_MIN)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_median_and_box_blur_random_shapes(gpu, oracle, seed):
+    """seeded random sizes and radii through every median / box blur kernel family (3x3 network, shared-column networks, bit-plane select for
+    r = 3..8, value search, sliding histogram; fused and two-pass box blur at both lane-run sizes), with and without a selection mask"""
+    rng = np.random.default_rng(9000 + seed)
+    w, h = int(rng.integers(1, 700)), int(rng.integers(1, 260))
+    img = I.random_rgba(w, h, 9100 + seed)
+    if seed % 3 == 0:
+        img[..., :3] = (img[..., :3] // 64) * 64                      # few levels: ties in every window
+    mask = (rng.random((h, w)) < 0.5).astype(np.uint8) * 255
+    for radius in sorted({int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(9, 26))}):
+        assert_same(gpu.median(img, radius), oracle.median(img, radius), 0, f"median r={radius} {w}x{h}")
+        assert_same(gpu.median(img, radius, mask), oracle.median(img, radius, mask), 0, f"median r={radius} {w}x{h} masked")
+    for radius in (float(rng.integers(1, 5)), float(rng.integers(5, 24)) + 0.5, float(rng.integers(24, 140))):
+        assert_same(gpu.box_blur(img, radius), oracle.box_blur(img, radius), 0, f"box r={radius} {w}x{h}")
+        assert_same(gpu.box_blur(img, radius, mask), oracle.box_blur(img, radius, mask), 0, f"box r={radius} {w}x{h} masked")
+
+
 @pytest.mark.parametrize("size", [(4, 1), (4, 5), (8, 3), (256, 9), (260, 64), (1024, 33), (1, 1), (3, 7), (255, 6)])
 def test_median_3x3_network_paths(gpu, oracle, size):
     """r <= 1 takes the min3/med3/max3 network: widths that are multiples of 4 use the 16-byte load + lane-exchange path
