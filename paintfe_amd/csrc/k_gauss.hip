@@ -251,17 +251,17 @@ typedef float pfx_f32x16 __attribute__((ext_vector_type(16)));
 PFX_DEV pfx_f16x2 pkrtz(float a, float b) { return __builtin_bit_cast(pfx_f16x2, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 
 constexpr int GM_COLS = 32;             // output columns per strip (one MFMA N block)
-constexpr int GM_MAXR = 48;             // largest radius (sigma <= 16)
+constexpr int GM_MAXR = 80;             // largest radius (sigma <= 26.6: 12 K blocks; the ring + patches then fill 155 of the 160 KB of LDS)
 constexpr int GM_OUT_PITCH = 36;        // dwords per staged output row (16-byte aligned rows: the block leaves as ds_read_b128)
 constexpr int GM_WOFF = 48;             // wsplit[GM_WOFF + t] = tap t; zeros elsewhere
-constexpr int GM_WLEN = 192;            // entries per weight part
+constexpr int GM_WLEN = 256;            // entries per weight part
 constexpr int GS_DEPTH = 3;             // register sets of source pixels in flight per producer lane
-constexpr int GS_XROW = 16 * 8 + 16;    // bytes per (channel, row) line of the de-interleave patch: 16 NKB samples + 16 (bank spread)
+constexpr int gs_xrow(int nkb) { return 16 * (nkb > 8 ? nkb : 8) + 16; } // bytes per (channel, row) line of the de-interleave patch: 16 NKB samples + 16 (bank spread)
 
 inline size_t gauss_strip_lds_bytes(int nkb)
 {
     const int ring = 16 * nkb + 32;
-    return (size_t)8 * (GM_COLS * (ring + 8) + 32) * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * GS_XROW;
+    return (size_t)8 * (GM_COLS * (ring + 8) + 32) * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * gs_xrow(nkb);
 }
 
 // DBG: the development instantiation (switchable parts, s_memtime stamps); the shipped one has none of those branches — a dozen
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                                                              float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg, int dbg_arg,
                                                              unsigned long long* __restrict__ dbg_buf)
 {
+    constexpr int GS_XROW = gs_xrow(NKB);
     constexpr int RING = 16 * NKB + 32, YP = RING + 8, PLANE = GM_COLS * YP + 32, HALF = NKB / 2, PPL = 2 * NKB; // PPL: pixels per producer lane
     extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
     _Float16* HR = reinterpret_cast<_Float16*>(gm_lds);                            // [part][c][x][YP], rows = ring slots
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
         const _Float16* w2 = w1 + GM_WLEN;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const int t0 = 16 * kb + 8 * hh - i - (R8 - r); // in [-46, 120]
+            const int t0 = 16 * kb + 8 * hh - i - (R8 - r); // in [-46, 16 NKB - 8]
 #pragma unroll
             for (int j = 0; j < 8; ++j) { B1[kb][j] = w1[t0 + j]; B2[kb][j] = w2[t0 + j]; }
         }
@@ -611,7 +612,7 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     if (w == 0 || h == 0) return hipSuccess;
     if (radius < 1 || radius > GM_MAXR) return hipErrorInvalidValue;
     const int R8 = (radius + 15) & ~15;                    // window start x0 - R8: pieces of 4 pixels stay 16-byte aligned
-    const int nkb = (GM_COLS + R8 + radius + 15) / 16;      // 4, 6 or 8
+    const int nkb = ((GM_COLS + R8 + radius + 15) / 16 + 1) & ~1; // 4, 6, 8, 10 or 12
     const int tiles_x = ((int)w + GM_COLS - 1) / GM_COLS;
     // `first_row` = index of the buffer's row 0 in the whole image when the buffer is a band of it: the 32-row output blocks lie on
     // the whole image's grid, so every output sees the same K-block grouping (the same f32 summation order) as in a whole-image call
@@ -644,7 +645,9 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     switch (nkb) {
     case 4: launch_s(std::integral_constant<int, 4>{}); break;
     case 6: launch_s(std::integral_constant<int, 6>{}); break;
-    default: launch_s(std::integral_constant<int, 8>{}); break;
+    case 8: launch_s(std::integral_constant<int, 8>{}); break;
+    case 10: launch_s(std::integral_constant<int, 10>{}); break;
+    default: launch_s(std::integral_constant<int, 12>{}); break;
     }
     if (errs) return errs;
     return hipGetLastError();

@@ -216,7 +216,7 @@ def test_gaussian_vs_oracle(gpu, sigma, size):
     gpu.r.set_exact(False)
 
 
-@pytest.mark.parametrize("sigma", [17.0, 40.0, 60.0, 75.0, 100.0, 120.0])
+@pytest.mark.parametrize("sigma", [17.0, 20.0, 24.0, 26.6, 26.7, 40.0, 60.0, 75.0, 100.0, 120.0])
 def test_gaussian_advanced_dialog_sigmas(gpu, sigma):
     """sigma 16 .. 100 (the reference's advanced blur dialog, ui/dialogs/core/image.rs) is beyond the matrix-core kernel: the VALU passes with
     the vertical tile chosen by radius — 8 x 128 (r <= 110), 16 x 256 (<= 160), 8 x 512 (<= 240), 8 x 256 (<= 340), 8 x 128 again beyond;
