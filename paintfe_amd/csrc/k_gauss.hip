@@ -623,9 +623,12 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     auto launch_s = [&](auto nkb_c) {
         constexpr int NK = decltype(nkb_c)::value;
         const size_t lds = gauss_strip_lds_bytes(NK);
-        // cut every strip into n_seg row segments so that the launch has just under two workgroups per CU (one is resident per CU,
-        // LDS-bound; measured at 8K: 1 / 2 / 3 segments per strip = 0.359 / 0.340 / 0.341 ms); a segment pays NK/2 - 1 run-in steps
-        int n_seg = (int)((18L * n_cus / 10 + tiles_x - 1) / tiles_x);
+        // cut every strip into n_seg row segments so that the launch is ONE round of resident workgroups (LDS-bound: two per CU with 4 K blocks,
+        // one from 6 up): every workgroup starts at once and none waits for a second round, and a segment pays NK/2 - 1 run-in steps.  Measured
+        // (tools/lab/gauss_seg.py, sigma 16): 8K 1 / 2 / 3 segments = 0.166 / 0.175 / 0.184 ms, 4K 0.080 / 0.053 / 0.070, 1080p 4 segments 0.023
+        // against 0.033 for the 7 the previous rule ("just under two workgroups per CU") chose
+        const int resident = n_cus * (int)std::max<size_t>(1, (size_t)160 * 1024 / lds);
+        int n_seg = resident / tiles_x;
         if (g_mfma_seg > 0) n_seg = g_mfma_seg; // tuning override (its own key: "gauss_v_cfg" only configures the VALU vertical pass)
         if (n_seg < 1) n_seg = 1;
         int per = (n_steps + n_seg - 1) / n_seg;
