@@ -242,6 +242,32 @@ def other_configs(args, torch, r, device, O, flat, blurred):
                                      "check": {"image0_vs_oracle": chk, "exact_gaussian_image1_vs_oracle": chk_x}}
     if not ok: failed.append("config5_image0")
     if not ok_x: failed.append("config5_exact_image1")
+
+    # ---- config 1 (BASELINE configs[0], the reference's own CPU-runnable case): the batch tool on a 1024 x 1024 PNG with `apply_blur(4.0);` —
+    # process start, context creation, PNG decode, script, PNG encode; wall clock of the whole process (src/cli.rs:105-215) ----
+    try:
+        import subprocess, tempfile, time
+        from PIL import Image
+        exe = os.path.join(ROOT, "paintfe_amd", "pfx")
+        with tempfile.TemporaryDirectory() as td:
+            src_png, out_png, script = os.path.join(td, "in.png"), os.path.join(td, "out.png"), os.path.join(td, "blur.rhai")
+            img1 = I.create_test_gradient(1024, 1024)
+            Image.fromarray(img1, "RGBA").save(src_png)
+            open(script, "w").write("apply_blur(4.0);\n")
+            walls = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                rc = subprocess.run([exe, "-i", src_png, "-s", script, "-o", out_png], capture_output=True, timeout=120).returncode
+                walls.append((time.perf_counter() - t0) * 1e3)
+            got1 = np.asarray(Image.open(out_png).convert("RGBA"))
+        d1 = int(np.abs(got1.astype(np.int16) - O.gaussian_blur(img1, 4.0).astype(np.int16)).max())
+        out["config1_cli_png_1024_apply_blur4"] = {"wall_ms_per_process": [round(v, 1) for v in walls], "exit_code": rc, "mpixels_per_s_wall": round(1024 * 1024 / min(walls) / 1e3, 1),
+                                                   "what": "paintfe_amd/pfx -i in.png -s blur.rhai -o out.png: process start + HIP context + PNG decode + script + PNG encode",
+                                                   "check": {"max_diff_vs_oracle_gaussian": d1}}
+        if rc != 0 or d1 > 1: failed.append("config1_cli")
+    except Exception as e:  # the tool or PIL missing is a failure of this entry, not of the bench line
+        out["config1_cli_png_1024_apply_blur4"] = {"error": str(e)}
+        failed.append("config1_cli")
     return out, failed
 
 

@@ -11,9 +11,9 @@ dev = torch.device("cuda", 0)
 stack, modes, opac = bench.synth_stack(torch, dev, w, h, 32, seed=0x5EED0002)
 flat = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
 for _ in range(100): r.flatten_dev([stack[k].data_ptr() for k in range(9)], [(k, 1.0, True, 1) for k in range(9)], w, h, flat.data_ptr())
-for n in (15, 16, 18, 20, 24, 28, 32):
+for n, allnormal in [(n, a) for a in (False, True) for n in (10, 12, 14, 15, 16, 20, 32)]:
     ptrs = [stack[k].data_ptr() for k in range(n)]
-    info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+    info = [(k, float(opac[k]), True, 0 if allnormal else int(modes[k])) for k in range(n)]
     res = []
     for gate in (0, 99):
         r.tune("dle_min_layers", gate)
@@ -23,4 +23,5 @@ for n in (15, 16, 18, 20, 24, 28, 32):
         torch.cuda.synchronize(); r.timing_enable(False)
         res.append(r.timing_read("flatten")[0] / 20)
     r.tune("dle_min_layers", 16)
-    print(f"{n} layers: elimination {res[0]:.4f} ms   plain {res[1]:.4f} ms   ratio {res[0] / res[1]:.3f}")
+    tag = " all Normal" if allnormal else ""
+    print(f"{n} layers{tag}: elimination {res[0]:.4f} ms   plain {res[1]:.4f} ms   ratio {res[0] / res[1]:.3f}")
