@@ -291,6 +291,30 @@ PFX_DEV uint32_t fx_pixel(const uint32_t* __restrict__ src, uint32_t s, int x, i
         const int sr = P.i[0];
         // min d^2 over the window to a filled (alpha > 0) and to an empty texel; the reference's pruned scan returns the same minimum
         int best_f = 0x7fffffff, best_e = 0x7fffffff;
+        if (P.aux0 != nullptr) {
+            // the "filled" bit of every pixel comes from a bit plane (alpha_bits_kernel: one bit per pixel, rows padded with 16 zero bits on either
+            // side): a window row is one funnel shift, and its nearest filled / empty texel is a count of trailing / leading zeros on either side of
+            // the centre — per window ROW what the loop below does per window ELEMENT (search radii up to 15: 31-bit rows)
+            const uint32_t* bits = static_cast<const uint32_t*>(P.aux0);
+            const int stride = P.i[3], p0 = x + 16 - sr;
+            const uint32_t wmask = (2u << (2 * sr)) - 1u;                       // 2 sr + 1 bits
+            const int lo = max(0, sr - x), hi = min(2 * sr, sr + (w - 1 - x)); // window columns inside the image (render.rs:472-475)
+            const uint32_t valid = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+            auto nearest = [&](uint32_t W, int dy, int& best) {
+                const uint32_t right = W >> sr, left = W << (31 - sr);          // bit 0 / bit 31 = the centre column
+                const int dr = right ? __builtin_ctz(right) : 64, dl = left ? __builtin_clz(left) : 64;
+                const int dx = min(dr, dl);
+                if (dx <= sr) best = min(best, dx * dx + dy * dy);
+            };
+            for (int dy = -sr; dy <= sr; ++dy) {
+                const int sy = y + dy;
+                if (sy < 0 || sy >= h) continue;
+                const uint32_t* row = bits + (size_t)sy * stride + (p0 >> 5);
+                const uint32_t Wf = __builtin_amdgcn_alignbit(row[1], row[0], (uint32_t)(p0 & 31)) & wmask;
+                nearest(Wf, dy, best_f);
+                nearest(~Wf & valid, dy, best_e);
+            }
+        } else
         for (int dy = -sr; dy <= sr; ++dy) {
             const int sy = y + dy;
             if (sy < 0 || sy >= h) continue;
@@ -389,6 +413,17 @@ PFX_DEV uint32_t fx_pixel(const uint32_t* __restrict__ src, uint32_t s, int x, i
         return pack_round(r * ia + P.f[5] * alpha, g * ia + P.f[6] * alpha, b * ia + P.f[7] * alpha, a);
     }
     return s;
+}
+
+// one bit per pixel: alpha != 0.  Row layout: bit (x + 16) of the row's bit string (16 zero bits of padding on either side, one spare dword)
+__global__ __launch_bounds__(256) void alpha_bits_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ bits, int w, int h, int stride)
+{
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), y = blockIdx.y;
+    if (2 * wv >= stride) return;
+    const int x = wv * 64 + lane - 16;
+    const bool filled = x >= 0 && x < w && (src[(size_t)y * w + x] >> 24) != 0u;
+    const unsigned long long m = __ballot(filled);
+    if (lane < 2 && 2 * wv + lane < stride) bits[(size_t)y * stride + 2 * wv + lane] = (uint32_t)(m >> (32 * lane));
 }
 
 template <int FX>
@@ -616,6 +651,15 @@ extern "C" hipError_t pfxk_fx(hipStream_t s, int fx, const uint8_t* d_src, uint8
         FX_CASE(PFXK_FX2_COLOR_FILTER) FX_CASE(PFXK_FX2_CONTOURS)
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+extern "C" uint32_t pfxk_alpha_bits_stride(uint32_t w) { return 2u * ((w + 32u + 63u) / 64u) + 1u; } // dwords per row
+extern "C" hipError_t pfxk_alpha_bits(hipStream_t s, const uint8_t* d_src, uint32_t* d_bits, uint32_t w, uint32_t h)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    const int stride = (int)pfxk_alpha_bits_stride(w);
+    alpha_bits_kernel<<<dim3((uint32_t)((stride / 2 + 1 + 3) / 4), h), 256, 0, s>>>((const uint32_t*)d_src, d_bits, (int)w, (int)h, stride);
     return hipGetLastError();
 }
 

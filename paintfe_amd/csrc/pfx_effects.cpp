@@ -400,6 +400,13 @@ int pfx_outline_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w
     P.f[0] = radius;
     P.i[0] = f32_as_i32(ceilf(radius)) + 1; P.i[1] = mode; P.i[2] = anti_alias ? 1 : 0;
     P.u[0] = pack4(color);
+    if (P.i[0] <= 15 && ctx->outline_bits) { // search windows up to 31 columns: nearest filled / empty texel from a bit plane of alpha != 0
+        const uint32_t stride = pfxk_alpha_bits_stride(w);
+        PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)h * stride * 4));
+        PFX_HIP(ctx, pfxk_alpha_bits(ctx->stream, (const uint8_t*)src_dev, (uint32_t*)ctx->st_tmp.p, w, h));
+        P.aux0 = ctx->st_tmp.p;
+        P.i[3] = (int32_t)stride;
+    }
     return launch_fx(ctx, PFXK_FX2_OUTLINE, "outline", src_dev, dst_dev, mask_dev, P, w, h);
 }
 

@@ -138,6 +138,9 @@ enum { PFXK_FX2_ZOOM = 0, PFXK_FX2_DENTS, PFXK_FX2_BULGE, PFXK_FX2_TWIST, PFXK_F
        PFXK_FX2_INK, PFXK_FX2_COLOR_FILTER, PFXK_FX2_CONTOURS };
 hipError_t pfxk_fx(hipStream_t s, int fx, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, const pfxk_fx_params* P,
                    uint32_t w, uint32_t h);
+// outline: one bit per pixel (alpha != 0), rows of pfxk_alpha_bits_stride(w) dwords; fx params aux0 = the plane, i[3] = the stride
+uint32_t pfxk_alpha_bits_stride(uint32_t w);
+hipError_t pfxk_alpha_bits(hipStream_t s, const uint8_t* d_src, uint32_t* d_bits, uint32_t w, uint32_t h);
 hipError_t pfxk_crystallize(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, const float* d_seeds_xy,
                             unsigned long long* d_acc /* cells*5 */, uint32_t* d_avg /* cells */, int cells_x, int cells_y, float cs,
                             uint32_t w, uint32_t h);

@@ -155,6 +155,28 @@ def test_outline_on_empty_and_full_canvas(gpu, oracle):
     check(gpu.effect("outline", full, **kw), oracle.effect("outline", full, **kw), EXACT, "outline of a full layer")
 
 
+@pytest.mark.parametrize("width", [1, 2, 6, 8, 14, 15, 20])
+@pytest.mark.parametrize("size", [(97, 61), (64, 64), (33, 5), (1, 1), (200, 2)])
+def test_outline_bit_plane_search_equals_the_scan_and_the_oracle(gpu, oracle, width, size):
+    """the outline's nearest filled / empty texel from a bit plane of alpha != 0 (search radius = width + 1 <= 15; wider windows keep the per-element
+    scan): every mode, with and without anti-aliasing, shapes touching the borders (window columns and rows outside the image are skipped, not
+    clamped), plane rows of 2 .. 9 dwords; the scan (pfx_tune outline_bits = 0) must give the same image"""
+    w, h = size
+    img = shapes_image(w, h, 31 * w + width)
+    img[0, :, 3] = 255                                                 # a filled top row: windows hanging over the border
+    img[:, w - 1, 3] = 0
+    for mode in ("outside", "inside", "center"):
+        for aa in (False, True):
+            kw = dict(width=width, color=(20, 200, 250, 200), mode=mode, anti_alias=aa)
+            ref = oracle.effect("outline", img, **kw)
+            check(gpu.effect("outline", img, **kw), ref, EXACT, f"outline bits {kw} {size}")
+            gpu.r.tune("outline_bits", 0)
+            try:
+                check(gpu.effect("outline", img, **kw), ref, EXACT, f"outline scan {kw} {size}")
+            finally:
+                gpu.r.tune("outline_bits", 1)
+
+
 def test_effects_small_and_wide_images(gpu, oracle):
     """1-pixel-high / 1-pixel-wide / single-pixel images hit every clamp"""
     for (w, h) in ((1, 1), (300, 1), (1, 77), (65, 3)):
