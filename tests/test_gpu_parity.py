@@ -233,6 +233,16 @@ def test_gaussian_advanced_dialog_sigmas(gpu, sigma):
         gpu.r.set_exact(False)
 
 
+@pytest.mark.parametrize("size", [(1, 1), (5, 3), (33, 2), (2, 70), (31, 31), (64, 1), (4, 200), (129, 7)])
+def test_gaussian_wide_kernels_on_small_images(gpu, size):
+    """10 / 12 K-block instantiations of the matrix-core kernel (sigma 17 .. 26.6) on images far smaller than their 160 / 192-sample windows and
+    than one 32 x 32 output block: every sample clamps, strips and row segments are partial"""
+    w, h = size
+    img = I.random_rgba(w, h, 7 * w + h)
+    for sigma in (17.0, 20.0, 26.6):
+        assert_same(gpu.gaussian_blur(img, sigma), O.gaussian_blur(img, sigma), 1, f"sigma={sigma} {w}x{h}")
+
+
 def test_gaussian_fma_mismatch_rate_is_float_noise(gpu):
     img = I.random_rgba(1024, 512, 5)
     ref = O.gaussian_blur(img, 16.0)
