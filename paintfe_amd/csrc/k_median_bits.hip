@@ -11,7 +11,7 @@
 // (2r+1)-bit field per plane — eight funnel shifts out of the image row's bit planes — written over the slot of the row that left
 // (the slot order inside the registers is irrelevant to a popcount).
 //
-// The bit planes of the whole image are produced by a pre-pass (median_planes_kernel): 32 wave ballots per 64 pixels, rows padded by
+// The bit planes of the whole image are produced by a pre-pass (median_planes_kernel): a 32 x 32 bit transpose per half wave, rows padded by
 // r replicated pixels on either side (the reference's clamp-to-edge, noise.rs:383), stored inverted (the select wants ~plane).
 // Scratch: 128 bytes per row and 32 padded columns, ~ the image size.
 #include "k_common.h"
