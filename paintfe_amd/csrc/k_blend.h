@@ -365,14 +365,20 @@ PFX_DEV void blend_nx(float (&acc)[4], const float (&top)[4], float opacity_raw,
             o0 = zero ? 0.0f : o0; o1 = zero ? 0.0f : o1; o2 = zero ? 0.0f : o2; o3 = zero ? 0.0f : o3;
         }
     }
-    if constexpr (M == M_NORMAL) {
-        if (opacity_raw >= 1.0f) {                                     // uniform; :1258 opaque overwrite
-            const bool opaque = (top[3] == 1.0f);
-            o0 = opaque ? top_r : o0; o1 = opaque ? top_g : o1; o2 = opaque ? top_b : o2; o3 = opaque ? 1.0f : o3;
-        }
+    // :1258, Normal at opacity >= 1 over an opaque layer pixel returns `top`.  No select is needed for it in this representation: top_a =
+    // 1.0 * 1.0, ita = 0, so n = top_c * 1 + x * 0 = top_c, den = 1 + base_a * 0 = 1, n / 1 = n (rdiv: y = 1, residual 0) and
+    // requant(RN(k / 255)) = RN(k / 255) for all 256 k (tests/test_host_logic.py::test_requant_is_identity_on_byte_values): the general
+    // formula already yields the layer pixel, bit for bit.
+    (void)opacity_raw;
+    if constexpr (OB != 0 && M != M_XOR && M != M_OVERWRITE) {
+        // Opaque accumulator: the :1253 early-out needs no select either.  A transparent layer pixel has top_a = 0 * opc = 0, ita = 1, so
+        // n = r * 0 + base_c * 1 = base_c for every finite r (all 23 blend functions return finite values in [0, 1], rare sides included),
+        // and requant(base_c) = base_c as above; alpha stays 1.0 in this path anyway.
+        (void)skip;
+        acc[0] = o0; acc[1] = o1; acc[2] = o2;
+    } else {
+        acc[0] = skip ? acc[0] : o0; acc[1] = skip ? acc[1] : o1; acc[2] = skip ? acc[2] : o2; acc[3] = skip ? acc[3] : o3;
     }
-    acc[0] = skip ? acc[0] : o0; acc[1] = skip ? acc[1] : o1; acc[2] = skip ? acc[2] : o2;
-    if constexpr (!(OB != 0 && M != M_XOR && M != M_OVERWRITE)) acc[3] = skip ? acc[3] : o3; // UNIT: alpha stays 1.0 either way
 }
 
 #ifndef PFX_XSKIP

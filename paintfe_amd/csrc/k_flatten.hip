@@ -16,6 +16,7 @@
 //   * the three `/ out_a` of a pixel share one refined reciprocal (rdiv below): the exact operation sequence
 //     hipcc emits for an IEEE f32 divide, with the per-denominator part hoisted — bit-identical to `/`.
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include "k_common.h"
 #include "pfx_kernels.h"
@@ -30,6 +31,7 @@ typedef int pfx_v4i __attribute__((ext_vector_type(4)));
 __device__ pfx_v4f pfx_buffer_load_format_v4f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
 __device__ float pfx_buffer_load_format_f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.f32");
 __device__ void pfx_buffer_store_i32(int data, pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
+__device__ void pfx_buffer_store_format_v4f32(pfx_v4f data, pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.format.v4f32");
 
 
 namespace {
@@ -429,6 +431,14 @@ PFX_DEV void dle_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
     }
 }
 
+// v with lane `idx` replaced by `val` (both wave-uniform).  hipcc has no builtin for v_writelane_b32 here; inline asm sits outside the compiler's hazard
+// bookkeeping, so the wait states a VALU-written SGPR needs before it may select a lane are spelled out (rare instruction: once per round).
+PFX_DEV uint32_t lane_write(uint32_t v, uint32_t val, uint32_t idx)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(idx) : "m0"); // one SGPR per VALU instruction: the lane select travels in M0
+    return v;
+}
+
 PFX_DEV void wave_lds_sync()
 {
     // LDS operations of one wave execute in order; this only keeps the compiler from moving them across the hand-over
@@ -610,9 +620,260 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
     }
 }
 
-int g_dle_stats_on = 0, g_dle_cfg = 0, g_dle_sched = 1, g_dle_fracA = 75, g_dle_fracB = 20;
-int g_dle_units = 0; // tuning knobs (pfxk_flatten_set_dle): units per wave (0 = default), log2 of the accumulator ring
-int g_flatten_variant = 0; // tuning knob (pfxk_flatten_set_variant): 0 = shipped (2 px x 2 sets, grid stride up to 16 layers), 1-5 = PX / register-set variants, 6 = 3 px x 3 sets (the round-2 shape), +10 = grid-stride launch, 8 = no elimination kernel, 9 = the general kernel
+
+// ---- class queues: accumulators parked in the destination image, pixels routed by accumulator class (round 4) -------------------
+// The blend of a layer pixel over an OPAQUE accumulator costs about 60 % of the general one (out_a == 1: no division, no base-alpha
+// products, no alpha re-quantisation, no select for a transparent layer pixel: k_blend.h, OB = 1), but the specialisation only runs when a
+// whole wave's accumulators are opaque.  On per-pixel-random alpha (BASELINE's S2) that never happens above the reset layer although 30 ..
+// 90 % of the pixels are opaque there.  This kernel makes the class wave-uniform by routing pixels through FIFOs:
+//   * queue 0 (E) is flatten_dle_kernel's queue of EARLY pixels (layers [q_start, q_r) below the unit's split layer);
+//   * a unit's natural pass runs layers [start, s1) only (s1 = one above the topmost reset candidate), then appends every pixel to queue 2 (O2,
+//     accumulator alpha == 255) or queue 1 (N2, the rest);  N2 rounds run [s1, s2) and re-partition into N3 (3) / O3 (4);  O2 rounds run
+//     [s1, n), N3 / O3 rounds [s2, n) and produce the result.  Opaque pixels stay opaque (Xor / Overwrite above s1 only make the dynamic
+//     class test in blend_layer_nx fail for that wave: the classes are a performance hint, never a correctness condition);
+//   * an accumulator that leaves the registers is parked IN THE DESTINATION IMAGE at its own pixel — RGBA8 is the reference's accumulator
+//     type (canvas_state.rs:573) — with a typed buffer store (float -> UNORM8 in the texture path) and comes back with a typed load: no
+//     pack / unpack arithmetic, no LDS ring, and the final result is the last such store.  Store -> load of one address by one wave is
+//     ordered by the memory pipeline like any spill.  A pixel whose accumulator does not matter (its reset layer is still ahead) may load
+//     whatever the destination holds: UNORM8 loads are finite values in [0, 1] and the reset layer replaces them.
+// Requires: dst overlaps no layer (the launcher checks; otherwise flatten_dle_kernel runs), and the device's float -> UNORM8 store
+// conversion returns k for RN(k / 255) (pfxk_unorm_store_check, verified once per context).
+struct dle_plan { uint32_t s1, s2, min_units; };
+
+template <int PX, int NB = 2>
+__global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_cls_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers, uint32_t n_px,
+                                                                         uint8_t* __restrict__ dst, const pfxk_dle_cands C, const dle_sched SC,
+                                                                         const dle_plan P)
+{
+    constexpr uint32_t UPX = 64u * PX, QCAP = PX == 2 ? 256u : 512u, NQ = 5u, NREC = 16u;
+    static_assert(QCAP >= 2u * UPX, "a queue holds a full round plus what one round can append");
+    __shared__ uint16_t s_q[NQ][QCAP];      // FIFOs of pixel offsets (from the wave's first pixel): 0 = E, 1 = N2, 2 = O2, 3 = N3, 4 = O3
+    __shared__ uint32_t s_rec[NREC][2];     // per unit in flight: {first layer of its natural pass, E's tail after its append (0: no early pixels)}
+    soft_d_fill(threadIdx.x, 64u);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    const uint32_t units_total = (n_px + UPX - 1u) / UPX;
+    uint32_t u0, U;
+    if (gw < SC.wavesA) { U = SC.UA; u0 = gw * SC.UA; }
+    else if (gw < SC.wavesA + SC.wavesB) { U = SC.UB; u0 = SC.wavesA * SC.UA + (gw - SC.wavesA) * SC.UB; }
+    else { U = SC.UC; u0 = SC.wavesA * SC.UA + SC.wavesB * SC.UB + (gw - SC.wavesA - SC.wavesB) * SC.UC; }
+    if (u0 >= units_total) return;
+    const uint32_t nu = min(U, units_total - u0);
+    const uint32_t base_px = u0 * UPX;
+    const uint32_t bytes = n_px * 4u;
+    const pfx_v4i rs_acc = make_rsrc(dst, bytes, PFX_RSRC_UNORM8X4);
+    // short streams (the tail of the launch) would flush every queue half empty: they keep the single natural pass
+    const bool split = P.s1 != 0u && nu >= P.min_units;
+    const uint32_t s1 = split ? P.s1 : n_layers, s2 = (split && P.s2 != 0u) ? P.s2 : n_layers;
+    uint16_t (*const q)[QCAP] = s_q;
+    uint32_t (*const rec)[2] = s_rec;
+
+    uint32_t qh = 0u, qt = 0u;                    // lane i: head / tail of queue i (monotone counters; entry k lives at q[i][k % QCAP])
+    uint32_t cls_next = 0, nat_next = 0;          // units classified / through their natural pass (relative to u0)
+    uint32_t q_r = 0, q_start = 0;                // layers [q_start, q_r) are what the pixels in E still need
+    uint32_t st_rounds = 0, st_rpx = 0, st_rlay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_urounds = 0;
+    uint32_t probe_fail = 0, skip_left = 0;
+    for (;;) {
+        const uint32_t cnt = qt - qh;
+        const uint32_t full = (uint32_t)__ballot(cnt >= UPX);
+        int qi = -1;
+        bool run_nat = false, nat_split = false;
+        uint32_t nat_start = 0;
+        if (full != 0u) qi = 31 - __builtin_clz(full);          // the deepest full queue first: work drains towards the result
+        else {
+            if (nat_next < cls_next) {
+                const uint32_t slot = nat_next % NREC;
+                const uint32_t need = __builtin_amdgcn_readfirstlane(rec[slot][1]);
+                if (need <= (uint32_t)__builtin_amdgcn_readlane((int)qh, 0)) {
+                    run_nat = true; nat_split = need != 0u; nat_start = __builtin_amdgcn_readfirstlane(rec[slot][0]);
+                }
+            }
+            if (!run_nat) {
+                if (cls_next < nu && cls_next - nat_next < NREC) {
+                    // ---- classify unit cls_next (as in flatten_dle_kernel) ----
+                    const uint32_t u = cls_next;
+                    const uint32_t o0 = u * UPX + lane;
+                    const uint32_t e_tail0 = (uint32_t)__builtin_amdgcn_readlane((int)qt, 0);
+                    const uint32_t q_cnt = e_tail0 - (uint32_t)__builtin_amdgcn_readlane((int)qh, 0);
+                    uint32_t cls[PX];
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) cls[j] = 0u;
+                    const bool probe = skip_left == 0u;
+                    if (!probe) skip_left -= 1u;
+                    bool done = !probe;
+#pragma unroll
+                    for (int i = 3; i >= 0; --i) {
+                        if ((uint32_t)i < C.n && !done) {
+                            const pfx_v4i ra = make_rsrc(layers[C.layer[i]].pixels, bytes, PFX_RSRC_ALPHA8);
+                            bool all_found = true;
+#pragma unroll
+                            for (int j = 0; j < PX; ++j) {
+                                const float a = pfx_buffer_load_format_f32(ra, (int)((base_px + o0 + 64u * j) * 4u), 0, 0);
+                                const bool hit = C.kind[i] ? (a == 1.0f) : (a != 0.0f);
+                                cls[j] = (cls[j] == 0u && hit) ? (uint32_t)(i + 1) : cls[j];
+                                all_found = all_found && cls[j] != 0u;
+                            }
+                            done = __all(all_found);
+                            st_reads += 1u;
+                        }
+                    }
+                    uint32_t cn[5] = {UPX, 0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int i = 1; i <= 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) cn[i] += (uint32_t)__popcll(__ballot(cls[j] >= (uint32_t)i));
+                    uint32_t cmin = 0;
+#pragma unroll
+                    for (int i = 1; i <= 4; ++i) if (cn[i] == UPX) cmin = (uint32_t)i;
+                    const uint32_t lay[5] = {0u, C.layer[0], C.layer[1], C.layer[2], C.layer[3]};
+                    uint32_t s_u = 0;
+#pragma unroll
+                    for (int i = 1; i <= 4; ++i) if (cmin == (uint32_t)i) s_u = lay[i];
+                    uint32_t best = 0, best_sav = 0, r = s_u;
+#pragma unroll
+                    for (int i = 1; i <= 4; ++i) {
+                        if ((uint32_t)i > cmin && (uint32_t)i <= C.n && cn[i] * 10u >= UPX * 3u) {
+                            const uint32_t sav = cn[i] * (lay[i] - s_u);
+                            if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; }
+                        }
+                    }
+                    if (best != 0u && q_cnt != 0u && q_r != r) { best = 0u; r = s_u; } // one split layer in E at a time
+                    if (probe) {
+                        if (best != 0u || s_u != 0u) probe_fail = 0u;
+                        else if (++probe_fail >= 2u) { probe_fail = 0u; skip_left = 14u; }
+                    }
+                    uint32_t e_tail = e_tail0;
+                    if (best != 0u) {
+                        st_cunits += 1u;
+                        if (q_cnt == 0u) q_start = s_u; else q_start = min(q_start, s_u);
+                        q_r = r;
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            const bool early = cls[j] < best;
+                            const uint64_t m = __ballot(early);
+                            const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            if (early) q[0][(e_tail + pre) % QCAP] = (uint16_t)(o0 + 64u * j);
+                            e_tail += (uint32_t)__popcll(m);
+                        }
+                        qt = lane_write(qt, e_tail, 0u);
+                    }
+                    if (lane == 0) { rec[u % NREC][0] = r; rec[u % NREC][1] = best != 0u ? e_tail : 0u; }
+                    wave_lds_sync();
+                    cls_next = u + 1u;
+                    continue;
+                }
+                const uint32_t nonempty = (uint32_t)__ballot(cnt != 0u);
+                if (nonempty == 0u) {                 // every unit classified and through, every queue drained
+                    if (lane == 0 && (C.stats & 1u)) {
+                        atomicAdd(&g_dle_stats[0], st_rounds); atomicAdd(&g_dle_stats[1], st_rpx); atomicAdd(&g_dle_stats[2], st_rlay);
+                        atomicAdd(&g_dle_stats[3], nat_next); atomicAdd(&g_dle_stats[4], st_nlay); atomicAdd(&g_dle_stats[5], st_reads);
+                        atomicAdd(&g_dle_stats[6], st_cunits); atomicAdd(&g_dle_stats[7], st_urounds);
+                    }
+                    break;
+                }
+                qi = __builtin_ctz(nonempty);         // flush a partial round, upstream queues first (they feed the ones behind them)
+            }
+        }
+
+        int voff[PX];
+        float acc[PX][4];
+        uint32_t lb, le;
+        int push_n = -1, push_o = -1;
+        bool load_acc, opaque_class = false;
+        if (qi >= 0) {
+            const uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)qh, qi);
+            const uint32_t m = min((uint32_t)__builtin_amdgcn_readlane((int)qt, qi) - head, UPX);
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const uint32_t k = 64u * j + lane;
+                const uint32_t o = (uint32_t)q[qi][(head + k) % QCAP];
+                voff[j] = k < m ? (int)((base_px + o) * 4u) : (int)bytes; // past the end: loads return (0,0,0,0) = transparent, stores are dropped
+            }
+            qh = lane_write(qh, head + m, (uint32_t)qi);
+            if (qi == 0) { lb = q_start; le = q_r; load_acc = false; }
+            else {
+                lb = qi <= 2 ? s1 : s2;
+                le = qi == 1 ? s2 : n_layers;
+                load_acc = true;
+                opaque_class = qi == 2 || qi == 4;
+                if (qi == 1 && s2 < n_layers) { push_n = 3; push_o = 4; }
+                st_urounds += 1u;
+            }
+            st_rounds += 1u; st_rpx += m; st_rlay += le - lb;
+        } else {
+            const uint32_t o0 = nat_next * UPX + lane;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) voff[j] = (int)((base_px + o0 + 64u * j) * 4u);
+            lb = nat_start; le = s1;
+            load_acc = nat_split;                     // early pixels come back from the destination; a unit without any starts from (0,0,0,0), :573
+            if (s1 < n_layers) { push_n = 1; push_o = 2; }
+            st_nlay += le - lb;
+            nat_next += 1u;
+        }
+        if (load_acc) {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const pfx_v4f v = pfx_buffer_load_format_v4f32(rs_acc, voff[j], 0, 0);
+                acc[j][0] = v.x; acc[j][1] = v.y; acc[j][2] = v.z; acc[j][3] = opaque_class ? 1.0f : v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
+        }
+        dle_layers<PX, NB, 0>(acc, layers, lb, le, bytes, voff, (C.stats & 2u) != 0u);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            pfx_v4f v; v.x = acc[j][0]; v.y = acc[j][1]; v.z = acc[j][2]; v.w = acc[j][3];
+            pfx_buffer_store_format_v4f32(v, rs_acc, voff[j], 0, 0);   // parks the accumulator, or is the result
+        }
+        if (push_n >= 0) {
+            uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)qt, push_n), to = (uint32_t)__builtin_amdgcn_readlane((int)qt, push_o);
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const bool valid = (uint32_t)voff[j] < bytes;
+                const bool is_o = valid && acc[j][3] == 1.0f, is_n = valid && !is_o;
+                const uint64_t mo = __ballot(is_o), mn = __ballot(is_n);
+                const uint32_t pre_o = __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u));
+                const uint32_t pre_n = __builtin_amdgcn_mbcnt_hi((uint32_t)(mn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mn, 0u));
+                const uint16_t off = (uint16_t)((uint32_t)voff[j] / 4u - base_px);
+                if (is_o) q[push_o][(to + pre_o) % QCAP] = off;
+                if (is_n) q[push_n][(tn + pre_n) % QCAP] = off;
+                to += (uint32_t)__popcll(mo); tn += (uint32_t)__popcll(mn);
+            }
+            qt = lane_write(qt, tn, (uint32_t)push_n);
+            qt = lane_write(qt, to, (uint32_t)push_o);
+        }
+        wave_lds_sync();
+    }
+}
+
+// float -> UNORM8 conversion of the typed store / UNORM8 -> float of the typed load against the arithmetic the kernels assume: for every byte
+// value k and channel, storing RN(k / 255) must write k and loading k must return RN(k / 255).  out[0] += mismatches
+__global__ __launch_bounds__(256) void unorm_store_check_kernel(uint8_t* __restrict__ scratch /* 1024 bytes */, unsigned long long* out)
+{
+    const uint32_t k = threadIdx.x;
+    const float bn = div255((float)k);
+    const pfx_v4i rs = make_rsrc(scratch, 1024u, PFX_RSRC_UNORM8X4);
+    pfx_v4f v; v.x = bn; v.y = div255((float)(255u - k)); v.z = div255((float)((k * 7u) & 255u)); v.w = bn;
+    pfx_buffer_store_format_v4f32(v, rs, (int)(k * 4u), 0, 0);
+    __syncthreads();
+    const uint32_t raw = reinterpret_cast<const volatile uint32_t*>(scratch)[k];
+    const uint32_t want = k | ((255u - k) << 8) | (((k * 7u) & 255u) << 16) | (k << 24);
+    const pfx_v4f b = pfx_buffer_load_format_v4f32(rs, (int)(k * 4u), 0, 0);
+    const bool ok = raw == want && __builtin_bit_cast(uint32_t, b.x) == __builtin_bit_cast(uint32_t, v.x) &&
+                    __builtin_bit_cast(uint32_t, b.y) == __builtin_bit_cast(uint32_t, v.y) &&
+                    __builtin_bit_cast(uint32_t, b.z) == __builtin_bit_cast(uint32_t, v.z) && __builtin_bit_cast(uint32_t, b.w) == __builtin_bit_cast(uint32_t, v.w);
+    if (!ok) atomicAdd(out, 1ull);
+}
+
+// Development knobs (pfx_tune): PROCESS-WIDE on purpose — they select among bit-identical kernel shapes for A/B runs and tests, not
+// per-document behaviour; atomics because batch workers and device groups run one context per thread.
+std::atomic<int> g_dle_stats_on{0}, g_dle_cfg{0}, g_dle_sched{1}, g_dle_fracA{75}, g_dle_fracB{20};
+std::atomic<int> g_dle_units{0}; // units per wave (0 = default)
+std::atomic<int> g_dle_kernel{0}; // 0 = class queues (flatten_cls_kernel), 1 = round 3's flatten_dle_kernel
+std::atomic<int> g_dle_s1{-1}, g_dle_s2{-1}, g_dle_split_units{8}; // class-queue plan: layers above the topmost candidate of the two split points (-1: automatic; 0: none)
+std::atomic<int> g_flatten_variant{0}; // tuning knob (pfxk_flatten_set_variant): 0 = shipped (2 px x 2 sets, grid stride up to 16 layers), 1-5 = PX / register-set variants, 6 = 3 px x 3 sets (the round-2 shape), +10 = grid-stride launch, 8 = no elimination kernel, 9 = the general kernel
 
 // per 64 x 64 chunk of a layer: bit 0 = every alpha is 255, bit 1 = no alpha is 0 (computed when a layer enters the layer store)
 __global__ __launch_bounds__(256) void chunk_alpha_flags_kernel(const uint8_t* __restrict__ px, uint32_t w, uint32_t h, uint32_t cx0, uint32_t cy0,
@@ -797,6 +1058,18 @@ extern "C" void pfxk_flatten_set_dle_sched(int sched, int fracA, int fracB)
     if (fracA >= 0 && fracA <= 100) g_dle_fracA = fracA;
     if (fracB >= 0 && fracB <= 100 - g_dle_fracA) g_dle_fracB = fracB;
 }
+extern "C" void pfxk_flatten_set_dle_plan(int kernel, int s1, int s2, int split_units)
+{
+    if (kernel >= 0) g_dle_kernel = kernel;
+    if (s1 >= -1) g_dle_s1 = s1;
+    if (s2 >= -1) g_dle_s2 = s2;
+    if (split_units >= 1) g_dle_split_units = split_units;
+}
+extern "C" hipError_t pfxk_unorm_store_check(hipStream_t s, uint8_t* d_scratch1k, unsigned long long* d_out)
+{
+    unorm_store_check_kernel<<<1, 256, 0, s>>>(d_scratch1k, d_out);
+    return hipGetLastError();
+}
 extern "C" hipError_t pfxk_round_pack_check(hipStream_t s, unsigned long long* d_out)
 {
     round_pack_check_kernel<<<4096, 256, 0, s>>>(d_out);
@@ -839,7 +1112,7 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                                    const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
                                    int chunk_active_ready, uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region,
-                                   const pfxk_dle_cands* cands, const uint8_t* d_chunk_start)
+                                   const pfxk_dle_cands* cands, const uint8_t* d_chunk_start, int dst_parking_ok)
 {
     size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
@@ -854,49 +1127,73 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
     const uint32_t block = 256;
     const size_t cap = 256u * 8u * 4u; // 256 CUs x 8 blocks, x4 waves of grid-stride work granularity
     const size_t n_px = (size_t)w * h;
-    if (!general && fast_div && n_layers > 0 && n_px < (1u << 30) && g_flatten_variant != 9) {
+    const int flatten_variant = g_flatten_variant, dle_cfg = g_dle_cfg, dle_units = g_dle_units, dle_sched_mode = g_dle_sched, fracA = g_dle_fracA, fracB = g_dle_fracB;
+    if (!general && fast_div && n_layers > 0 && n_px < (1u << 30) && flatten_variant != 9) {
         // one 64*PX-pixel tile per wave while that stays below the cap (the dispatcher balances the tail), grid-stride beyond
         // Shipped shape (variant 0), from tools/ab_shallow.py at 8K on stacks of 2 .. 32 layers, with and without an opaque background: 2 pixels
         // per lane and 2 register sets everywhere (against 3 x 3: -2 % at 32 layers, -8 % at 9, -20 % at 4); up to 16 layers the waves also
         // walk the image with a grid stride instead of taking one tile each (a 4-layer tile is over before its launch cost is: -5 .. -10 % more)
-        int variant = g_flatten_variant % 10;
-        bool stride = g_flatten_variant >= 10;
-        if (g_flatten_variant == 0 || g_flatten_variant == 8) { variant = 1; stride = n_layers <= 16; }
+        int variant = flatten_variant % 10;
+        bool stride = flatten_variant >= 10;
+        if (flatten_variant == 0 || flatten_variant == 8) { variant = 1; stride = n_layers <= 16; }
         auto grid = [&](uint32_t px_per_wave) {
             size_t tiles = (n_px + px_per_wave - 1) / px_per_wave, b = (tiles + 3) / 4;
             const size_t lim = stride ? cap : (size_t)1 << 20;
             return (uint32_t)(b > lim ? lim : b);
         };
         // dead-layer elimination when the stack holds a reset layer above the bottom one (variant 8 switches it off)
-        if (cands && cands->n > 0 && g_flatten_variant != 8) {
-            // g_dle_cfg: 0 = 3 pixels per lane, 2 register sets (78 VGPRs: 6 waves per SIMD; measured best), 1 = 2 pixels per lane, 3 sets (61 VGPRs),
-            // 2 = 3 pixels per lane, 3 sets (90 VGPRs: 5 waves); g_dle_sched 0 = equal streams of g_dle_units
-            const uint32_t px = g_dle_cfg == 1 ? 2u : 3u;
+        if (cands && cands->n > 0 && flatten_variant != 8) {
+            // dle_cfg: 0 = 3 pixels per lane, 2 register sets (6 waves per SIMD; measured best), 1 = 2 pixels per lane, 2 = 3 pixels per lane, 3 sets (old kernel only);
+            // dle_sched 0 = equal streams of dle_units
+            const bool cls_kernel = g_dle_kernel == 0 && dst_parking_ok;
+            const uint32_t px = dle_cfg == 1 ? 2u : 3u;
             const uint32_t upx = 64u * px;
             const uint32_t units = (uint32_t)((n_px + upx - 1) / upx);
             const uint32_t umax = 65535u / upx; // queue entries are 16-bit pixel offsets
             dle_sched SC{};
-            if (g_dle_sched == 0) {
-                SC.UA = SC.UB = SC.UC = std::min(g_dle_units > 0 ? (uint32_t)g_dle_units : 8u, umax);
+            if (dle_sched_mode == 0) {
+                SC.UA = SC.UB = SC.UC = std::min(dle_units > 0 ? (uint32_t)dle_units : 8u, umax);
                 SC.wavesA = (units + SC.UA - 1) / SC.UA;
             } else {
                 // the long streams fill the chip about once (256 CUs x 24 waves): measured best (profiles/r03_tuning.md)
-                const uint32_t ua_auto = std::max(((uint32_t)((uint64_t)units * (uint32_t)g_dle_fracA / 100u) + 6143u) / 6144u, 4u);
-                SC.UA = std::min(g_dle_units > 0 ? (uint32_t)g_dle_units : ua_auto, umax);
+                const uint32_t ua_auto = std::max(((uint32_t)((uint64_t)units * (uint32_t)fracA / 100u) + 6143u) / 6144u, 4u);
+                SC.UA = std::min(dle_units > 0 ? (uint32_t)dle_units : ua_auto, umax);
                 SC.UB = std::max(SC.UA / 4u, 1u);
                 SC.UC = 1u;
-                SC.wavesA = (uint32_t)((uint64_t)units * (uint32_t)g_dle_fracA / 100u) / SC.UA;
-                SC.wavesB = (uint32_t)((uint64_t)units * (uint32_t)g_dle_fracB / 100u) / SC.UB;
+                SC.wavesA = (uint32_t)((uint64_t)units * (uint32_t)fracA / 100u) / SC.UA;
+                SC.wavesB = (uint32_t)((uint64_t)units * (uint32_t)fracB / 100u) / SC.UB;
             }
             const uint32_t rest = units - std::min(units, SC.wavesA * SC.UA + SC.wavesB * SC.UB);
             const uint32_t waves = SC.wavesA + SC.wavesB + (rest + SC.UC - 1) / SC.UC;
             pfxk_dle_cands C = *cands;
             C.stats = (uint32_t)g_dle_stats_on;
+            if (cls_kernel) {
+                // class-queue plan: s1 = the layer above the topmost candidate (everything below it is the natural pass), s2 = s1 + about a third of
+                // what is left — by then most pixels that will ever be opaque are (S2: the non-opaque share falls 0.69 -> 0.29 over six layers)
+                dle_plan P{};
+                const uint32_t top = C.layer[C.n - 1u];
+                const uint32_t above = n_layers - (top + 1u);
+                const int o1 = g_dle_s1, o2 = g_dle_s2;
+                if (o1 > 0 || (o1 < 0 && above >= 6u)) {           // automatic: only where enough layers follow to repay the two transitions
+                    P.s1 = top + (o1 > 0 ? (uint32_t)o1 : 1u);
+                    if (P.s1 >= n_layers) P.s1 = 0u;
+                }
+                if (P.s1 != 0u && (o2 > 0 || (o2 < 0 && n_layers - P.s1 >= 10u))) {
+                    P.s2 = P.s1 + (o2 > 0 ? (uint32_t)o2 : (n_layers - P.s1) / 3u);
+                    if (P.s2 >= n_layers) P.s2 = 0u;
+                }
+                P.min_units = (uint32_t)g_dle_split_units;
+#define PFX_ARGS <<<waves, 64, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, SC, P)
+                if (dle_cfg == 1) flatten_cls_kernel<2, 2> PFX_ARGS;
+                else flatten_cls_kernel<3, 2> PFX_ARGS;
+#undef PFX_ARGS
+                return hipGetLastError();
+            }
             // one wave per workgroup: a wave's stream is independent of its neighbours' (no barrier, private LDS slice), and a 4-wave
             // workgroup would hold its LDS and wave slots until its slowest stream ends
 #define PFX_ARGS <<<waves, 64, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, SC)
-            if (g_dle_cfg == 2) flatten_dle_kernel<3, 10, 1, 3> PFX_ARGS;
-            else if (g_dle_cfg == 1) flatten_dle_kernel<2, 9, 1, 3> PFX_ARGS;
+            if (dle_cfg == 2) flatten_dle_kernel<3, 10, 1, 3> PFX_ARGS;
+            else if (dle_cfg == 1) flatten_dle_kernel<2, 9, 1, 3> PFX_ARGS;
             else flatten_dle_kernel<3, 10, 1, 2> PFX_ARGS;
 #undef PFX_ARGS
             return hipGetLastError();

@@ -327,9 +327,30 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
         }
         if (ctx->chunk_state != 3) d_chunk_start = (const uint8_t*)ctx->d_chunk_start.p; // pending or useful: the table of THIS stack is in the buffer
     }
+    // The class-queue compositor parks accumulators in the destination between its passes (k_flatten.hip: flatten_cls_kernel): the destination
+    // must not overlap a layer it still has to read, and the device's float -> UNORM8 store conversion must round-trip RN(k / 255) (checked once
+    // per context on the device itself).  Otherwise the round-3 kernel, which keeps them in LDS, runs.
+    int parking_ok = 0;
+    if (cands.n > 0 && !general && fast_div && !region && !PV.pixels) {
+        parking_ok = 1;
+        const pfxk_layer_desc* hd = (const pfxk_layer_desc*)ctx->desc_cache.data();
+        for (uint32_t k = 0; k < n_desc && parking_ok; ++k)
+            if (hd[k].pixels && ranges_overlap(hd[k].pixels, dst_dev, img_bytes(w, h))) parking_ok = 0;
+        if (parking_ok && ctx->unorm_store_ok < 0) {
+            PFX_TRY(pfx_reserve(ctx, ctx->d_misc, 2048));
+            PFX_HIP(ctx, hipMemsetAsync(ctx->d_misc.p, 0, 2048, ctx->stream));
+            PFX_HIP(ctx, pfxk_unorm_store_check(ctx->stream, (uint8_t*)ctx->d_misc.p, (unsigned long long*)((uint8_t*)ctx->d_misc.p + 1024)));
+            unsigned long long bad = 1;
+            PFX_TRY(pfx_d2h(ctx, &bad, (uint8_t*)ctx->d_misc.p + 1024, sizeof bad));
+            PFX_TRY(pfx_sync(ctx)); // once per context
+            ctx->unorm_store_ok = bad == 0 ? 1 : 0;
+        }
+        if (parking_ok && ctx->unorm_store_ok != 1) parking_ok = 0;
+    }
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
-                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region, &cands, d_chunk_start));
+                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region, &cands, d_chunk_start,
+                              parking_ok));
     return PFX_OK;
 }
 
@@ -1232,6 +1253,10 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "dle_frac_a") == 0) { pfxk_flatten_set_dle_sched(-1, value, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_frac_b") == 0) { pfxk_flatten_set_dle_sched(-1, -1, value); return PFX_OK; }
     if (std::strcmp(key, "dle_cfg") == 0) { pfxk_flatten_set_dle_dev(-1, value); return PFX_OK; }
+    if (std::strcmp(key, "dle_kernel") == 0) { pfxk_flatten_set_dle_plan(value, -2, -2, 0); return PFX_OK; }   // 0 = class queues, 1 = round-3 kernel
+    if (std::strcmp(key, "dle_s1") == 0) { pfxk_flatten_set_dle_plan(-1, value, -2, 0); return PFX_OK; }       // split points of the class queues (-1 auto, 0 none)
+    if (std::strcmp(key, "dle_s2") == 0) { pfxk_flatten_set_dle_plan(-1, -2, value, 0); return PFX_OK; }
+    if (std::strcmp(key, "dle_split_units") == 0) { pfxk_flatten_set_dle_plan(-1, -2, -2, value); return PFX_OK; }
     if (std::strcmp(key, "median_search1") == 0) { pfxk_median_set_search1(value); return PFX_OK; }
     if (std::strcmp(key, "outline_bits") == 0) { ctx->outline_bits = value != 0; return PFX_OK; }
     if (std::strcmp(key, "median_bits_min") == 0) { ctx->median_bits_min = value; return PFX_OK; } // smallest radius on the bit-plane kernel (8: never)
@@ -1262,6 +1287,20 @@ int pfx_selftest_division(pfx_ctx* ctx, uint64_t seed, uint32_t n_millions, uint
     PFX_HIP(ctx, pfxk_rdiv_check(ctx->stream, seed, blocks, iters, (unsigned long long*)ctx->d_misc.p));
     unsigned long long bad = 0;
     PFX_TRY(pfx_d2h(ctx, &bad, ctx->d_misc.p, 8));
+    PFX_TRY(pfx_sync(ctx));
+    *mismatches = bad;
+    return PFX_OK;
+}
+
+int pfx_selftest_unorm_store(pfx_ctx* ctx, uint64_t* mismatches)
+{
+    if (!ctx || !mismatches) return PFX_ERR_INVALID;
+    PFX_TRY(pfx_use(ctx));
+    PFX_TRY(pfx_reserve(ctx, ctx->d_misc, 2048));
+    PFX_HIP(ctx, hipMemsetAsync(ctx->d_misc.p, 0, 2048, ctx->stream));
+    PFX_HIP(ctx, pfxk_unorm_store_check(ctx->stream, (uint8_t*)ctx->d_misc.p, (unsigned long long*)((uint8_t*)ctx->d_misc.p + 1024)));
+    unsigned long long bad = 0;
+    PFX_TRY(pfx_d2h(ctx, &bad, (uint8_t*)ctx->d_misc.p + 1024, sizeof bad));
     PFX_TRY(pfx_sync(ctx));
     *mismatches = bad;
     return PFX_OK;

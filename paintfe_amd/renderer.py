@@ -634,6 +634,11 @@ class GpuRenderer:
         self._check(self._lib.pfx_selftest_round_pack(self._h, C.byref(bad), C.byref(snan)))
         return bad.value, snan.value
 
+    def selftest_unorm_store(self) -> int:
+        bad = C.c_uint64(0)
+        self._check(self._lib.pfx_selftest_unorm_store(self._h, C.byref(bad)))
+        return int(bad.value)
+
     def selftest_division(self, seed: int, n_millions: int) -> int:
         bad = C.c_uint64(0)
         self._check(self._lib.pfx_selftest_division(self._h, C.c_uint64(seed), C.c_uint32(n_millions), C.byref(bad)))

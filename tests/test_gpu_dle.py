@@ -27,6 +27,7 @@ def gpu():
     g.r.tune("dle_units", 0)
     g.r.tune("dle_cfg", 0)
     g.r.tune("flatten_variant", 0)
+    set_config(g, (0, 0, 1, 8, -1, -1))
 
 
 def check(gpu, stack, modes, opac, what):
@@ -50,15 +51,40 @@ def blocky_alpha(rng, h, w, cell, p_zero, p_opaque):
     return np.kron(coarse, np.ones((cell, cell), np.uint8))[:h, :w]
 
 
-@pytest.fixture(params=[(0, 1), (1, 1), (2, 1), (0, 0), (1, 0)], ids=["px3x2sets-shrinking", "px2-shrinking", "px3x3sets-shrinking", "px3x2sets-equal", "px2-equal"], autouse=True)
+# (dle_kernel, dle_cfg, dle_sched, dle_split_units, dle_s1, dle_s2): kernel 0 = class queues (flatten_cls_kernel: accumulators parked in the destination,
+# pixels routed by "accumulator opaque?" above the topmost reset layer), 1 = round 3's kernel (accumulators parked in an LDS ring).  dle_s1 / dle_s2: layers
+# between the topmost candidate and the first split / between the splits (-1 automatic, 0 none); dle_split_units 1 = even one-unit streams split.
+CONFIGS = {
+    "cls-px3-split-auto": (0, 0, 1, 1, -1, -1),
+    "cls-px3-split-1-1": (0, 0, 1, 1, 1, 1),
+    "cls-px3-split-2-3-equal": (0, 0, 0, 1, 2, 3),
+    "cls-px3-single-level": (0, 0, 1, 1, 1, 0),
+    "cls-px3-default-thresholds": (0, 0, 1, 8, -1, -1),
+    "cls-px2-split-1-2": (0, 1, 1, 1, 1, 2),
+    "cls-px2-equal-nosplit": (0, 1, 0, 1, 0, 0),
+    "r3-px3x2sets-shrinking": (1, 0, 1, 8, -1, -1),
+    "r3-px2-shrinking": (1, 1, 1, 8, -1, -1),
+    "r3-px3x3sets-equal": (1, 2, 0, 8, -1, -1),
+}
+
+
+def set_config(gpu, cfg):
+    kernel, dcfg, sched, split_units, s1, s2 = cfg
+    gpu.r.tune("dle_kernel", kernel)
+    gpu.r.tune("dle_cfg", dcfg)
+    gpu.r.tune("dle_sched", sched)
+    gpu.r.tune("dle_split_units", split_units)
+    gpu.r.tune("dle_s1", s1)
+    gpu.r.tune("dle_s2", s2)
+
+
+@pytest.fixture(params=list(CONFIGS.values()), ids=list(CONFIGS.keys()), autouse=True)
 def every_kernel_configuration(request, gpu):
-    """every test of this file runs on the three instantiations of the elimination kernel (pfx_tune "dle_cfg": pixels per lane, register sets) and
-    both stream schedules ("dle_sched": equal streams, or streams that shrink towards the end of the launch)"""
-    gpu.r.tune("dle_cfg", request.param[0])
-    gpu.r.tune("dle_sched", request.param[1])
+    """every test of this file runs on both elimination kernels, their instantiations (pfx_tune "dle_cfg": pixels per lane, register sets), both stream
+    schedules ("dle_sched": equal streams, or streams that shrink towards the end of the launch) and several class-queue plans"""
+    set_config(gpu, request.param)
     yield request.param
-    gpu.r.tune("dle_cfg", 0)
-    gpu.r.tune("dle_sched", 1)
+    set_config(gpu, (0, 0, 1, 8, -1, -1))
 
 
 @pytest.mark.parametrize("units", [0, 1, 2, 5, 340])
@@ -257,3 +283,78 @@ def test_stored_layers_start_at_the_covering_layer_per_chunk(gpu):
         assert np.array_equal(got, ref), f"after update_rect: {int((got != ref).any(-1).sum())} px differ"
     finally:
         gpu.r.tune("dle_min_layers", 0)
+
+
+def class_stack(rng, w, h, n, reset_at, p_opaque_top, modes_above):
+    """a stack with an Overwrite reset layer at `reset_at` (alpha non-zero on 75 %) and, above it, layers whose alpha is 255 with probability
+    p_opaque_top at 100 % opacity on even positions (what turns an accumulator opaque) and translucent elsewhere"""
+    stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    modes = [0] + [1 + (5 * k) % 24 for k in range(1, n)]
+    modes = [m if m not in (OVERWRITE, NORMAL, 13) else 2 for m in modes]
+    opac = [1.0 if k % 2 == 0 else float(np.float32(0.25 + 0.75 * rng.random())) for k in range(n)]
+    for k in range(1, n):
+        stack[k, ..., 3] = noise_alpha(rng, h, w, 0.25, p_opaque_top)
+    stack[0, ..., 3] = 255
+    modes[reset_at], opac[reset_at] = OVERWRITE, 1.0
+    stack[reset_at, ..., 3] = noise_alpha(rng, h, w, 0.25, 0.25)
+    for k, m in modes_above.items():
+        modes[k] = m
+    return stack, modes, opac
+
+
+@pytest.mark.parametrize("p_opaque_top", [0.0, 0.02, 0.25, 0.6, 1.0])
+def test_accumulator_classes_at_every_mixture(gpu, p_opaque_top):
+    """above the reset layer the accumulators turn opaque at a rate set by p_opaque_top: never (the opaque queues stay empty), rarely (they are only
+    ever flushed partly filled), S2's rate, mostly, and at once (the general queues stay empty)"""
+    rng = np.random.default_rng(int(p_opaque_top * 100) + 900)
+    w, h, n = 451, 233, 20
+    stack, modes, opac = class_stack(rng, w, h, n, 6, p_opaque_top, {})
+    check(gpu, stack, modes, opac, f"class mixture p_opaque_top={p_opaque_top}")
+
+
+@pytest.mark.parametrize("breaker", [13, OVERWRITE])
+@pytest.mark.parametrize("pos", [8, 10, 14, 19])
+def test_xor_or_overwrite_above_the_split_resets_the_classes(gpu, breaker, pos):
+    """an Xor layer (canvas_state.rs:1283: lowers alpha, to zero where both are opaque) or a translucent Overwrite layer above the split points makes opaque
+    accumulators non-opaque again INSIDE the opaque queues' layer range: the class is only a hint, the per-layer test must notice"""
+    rng = np.random.default_rng(breaker * 100 + pos)
+    w, h, n = 333, 197, 20
+    stack, modes, opac = class_stack(rng, w, h, n, 5, 0.4, {pos: breaker})
+    opac[pos] = 0.7 if breaker == OVERWRITE else 1.0
+    if breaker == OVERWRITE and pos == 19:
+        stack[pos, ..., 3] = noise_alpha(rng, h, w, 0.5, 0.1)       # a second candidate on top, with holes
+    check(gpu, stack, modes, opac, f"mode {breaker} at layer {pos}")
+
+
+def test_opaque_bottom_without_early_pixels_and_all_early_pixels(gpu):
+    """the reset layer covers everything (no early pixel anywhere: the natural pass starts from scratch) / nothing (every pixel is early)"""
+    rng = np.random.default_rng(77)
+    w, h, n = 300, 211, 18
+    stack, modes, opac = class_stack(rng, w, h, n, 7, 0.25, {})
+    stack[7, ..., 3] = rng.integers(1, 256, (h, w), dtype=np.uint8)
+    check(gpu, stack, modes, opac, "reset layer without holes")
+    stack[7, ..., 3] = 0
+    check(gpu, stack, modes, opac, "reset layer all holes")
+    stack[7, ..., 3] = np.where(np.arange(w)[None, :] < w // 2, 255, 0).astype(np.uint8)
+    check(gpu, stack, modes, opac, "reset layer covering the left half")
+
+
+def test_destination_that_aliases_a_layer_takes_the_ring_kernel(gpu):
+    """the class-queue kernel parks accumulators in the destination; a destination that IS one of the layers must not be used that way (the library
+    falls back to the kernel that parks in LDS): compositing in place over layer 9 still equals the oracle"""
+    rng = np.random.default_rng(5)
+    w, h, n = 384, 96, 18
+    stack, modes, opac = class_stack(rng, w, h, n, 6, 0.3, {})
+    ref = O.flatten_stack(stack, np.asarray(modes, np.uint8), np.asarray(opac, np.float32))
+    r = gpu.r
+    bufs = [r.dev_alloc(w * h * 4) for _ in range(n)]
+    try:
+        for k in range(n):
+            r.dev_upload(bufs[k], stack[k])
+        info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+        r.flatten_dev([b for b in bufs], info, w, h, bufs[9])
+        got = r.dev_download(bufs[9], (h, w, 4))
+        assert np.array_equal(got, ref)
+    finally:
+        for b in bufs:
+            r.dev_free(b)

@@ -68,6 +68,12 @@ def test_blend_pixels_exhaustive_alpha_lattice(gpu):
             assert_same(got[::97], exp, 0, f"mode {mode} opacity {opacity}")
 
 
+def test_typed_unorm8_store_and_load_round_trip_every_byte_value(gpu):
+    """the class-queue compositor parks accumulators RN(k / 255) in the destination with typed UNORM8 buffer stores and reads them back with typed
+    loads (k_flatten.hip: flatten_cls_kernel): both conversions must be exact for all 256 byte values on every channel"""
+    assert gpu.r.selftest_unorm_store() == 0
+
+
 def test_round_and_pack_matches_rust_rounding_for_every_float(gpu):
     """k_common.h:pack_round_rgba (v_med3_f32, OR 1, v_cvt_pk_u8_f32) vs `v.round().clamp(0.0, 255.0) as u8` evaluated step by step, for all
     2^32 f32 bit patterns: identical except for signalling NaNs, which no arithmetic produces"""

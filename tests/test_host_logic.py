@@ -97,6 +97,23 @@ def test_div255_two_op_form_is_exact():
     assert (x * c_hi != x / np.float32(255.0)).sum() > 100  # a plain multiply by 1/255 is NOT enough
 
 
+def test_requant_is_identity_on_byte_values():
+    """k_blend.h:requant — `(q * 255) as u8` followed by `/ 255` of the next blend maps RN(k / 255) to itself for all 256 k.  That is why the
+    streaming compositor needs no select for a transparent layer pixel over an opaque accumulator (n = r * 0 + base * 1 = base) nor for the
+    opaque-Normal early-out (n = top * 1 + x * 0 = top): the general formula reproduces base / top bit for bit (canvas_state.rs:1253,1258)."""
+    k = np.arange(256, dtype=np.float32)
+    bn = k / np.float32(255.0)
+    assert bn.dtype == np.float32
+    t = np.trunc(bn * np.float32(255.0))
+    assert np.array_equal(t, k)
+    assert np.array_equal(t / np.float32(255.0), bn)
+    # the two products the identities rest on, for every finite blend result r in [0, 1]: r * 0 + b * 1 == b and t * 1 + x * 0 == t
+    r = np.linspace(0, 1, 4097, dtype=np.float32)
+    for b in bn[::5]:
+        assert ((r * np.float32(0.0) + b * np.float32(1.0)) == b).all()
+        assert ((b * np.float32(1.0) + r * np.float32(0.0)) == b).all()
+
+
 def test_opaque_base_out_alpha_is_exactly_one():
     """k_flatten.hip blend_px<.., OB>: over an opaque base, out_a = fl(top_a + fl(1 - top_a)) == 1.0 for EVERY f32 top_a in [0, 1]
     (all 1 065 353 217 of them), so the division by out_a, the base-alpha products and the alpha re-quantisation drop out."""
