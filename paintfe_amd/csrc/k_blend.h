@@ -429,4 +429,62 @@ PFX_DEV void blend_layer_nx(uint32_t mode, float (&acc)[PX][4], const float (&to
     } else blend_nx_dispatch<PX, 0>(mode, acc, top, opc, opc);
 }
 
+// ---- per-group classes (k_flatten.hip: flatten_srt_kernel) ----
+// The class-sorting compositor deals a unit's opaque accumulators to the leading 64-pixel groups (pixel p of every lane = group p).  LEAD = how many
+// leading groups are opaque wave-wide: those take the OB = 1 arithmetic, the rest the general one.  (LEAD == PX is blend_nx_dispatch<PX, 1 | 2>.)
+// One dispatch per value of LEAD: a scalar branch per group INSIDE each mode's case (every (mode, class) body once, 40 % less code) was measured
+// too — 93 VGPRs instead of 80 and 7 % more executed VALU instructions, 4.6 % slower than round 3's kernel (profiles/r04_tuning.md).
+template <uint32_t M, int PX, int LEAD>
+PFX_DEV void blendN_nx_lead(float (&acc)[PX][4], const float (&top)[PX][4], float opacity_raw, float opc)
+{
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        if (p < LEAD) blend_nx<M, 1>(acc[p], top[p], opacity_raw, opc);
+        else blend_nx<M, 0>(acc[p], top[p], opacity_raw, opc);
+    }
+}
+template <int PX, int LEAD>
+PFX_DEV void blend_nx_dispatch_lead(uint32_t mode, float (&acc)[PX][4], const float (&top)[PX][4], float opacity_raw, float opc)
+{
+    switch (mode) { // wave-uniform: one scalar branch per layer
+#define PFX_CASE(M) case M: blendN_nx_lead<M, PX, LEAD>(acc, top, opacity_raw, opc); break;
+        PFX_CASE(M_NORMAL) PFX_CASE(M_MULTIPLY) PFX_CASE(M_SCREEN) PFX_CASE(M_ADDITIVE) PFX_CASE(M_REFLECT)
+        PFX_CASE(M_GLOW) PFX_CASE(M_COLOR_BURN) PFX_CASE(M_COLOR_DODGE) PFX_CASE(M_OVERLAY) PFX_CASE(M_DIFFERENCE)
+        PFX_CASE(M_NEGATION) PFX_CASE(M_LIGHTEN) PFX_CASE(M_DARKEN) PFX_CASE(M_XOR) PFX_CASE(M_OVERWRITE)
+        PFX_CASE(M_HARD_LIGHT) PFX_CASE(M_SOFT_LIGHT) PFX_CASE(M_EXCLUSION) PFX_CASE(M_SUBTRACT) PFX_CASE(M_DIVIDE)
+        PFX_CASE(M_LINEAR_BURN) PFX_CASE(M_VIVID_LIGHT) PFX_CASE(M_LINEAR_LIGHT) PFX_CASE(M_PIN_LIGHT)
+        PFX_CASE(M_HARD_MIX)
+#undef PFX_CASE
+    default: blendN_nx_lead<M_NORMAL, PX, LEAD>(acc, top, opacity_raw, opc); break; // BlendMode::from_u8 fallback, layers.rs:183
+    }
+}
+// `lead` = leading groups known to be opaque wave-wide (k_flatten.hip: srt_layers keeps the count up to date: an opaque accumulator stays opaque under
+// every mode but Xor and Overwrite, so the count is only re-taken behind those, at re-deal attempts and at the start of a pass; a stale-low count is
+// merely conservative)
+template <int PX>
+PFX_DEV void blend_layer_nx_groups(uint32_t mode, float (&acc)[PX][4], const float (&top)[PX][4], float opc, uint32_t lead)
+{
+    static_assert(PX == 2 || PX == 3, "two or three groups");
+    if (lead == 0u) blend_nx_dispatch<PX, 0>(mode, acc, top, opc, opc);
+    else if (lead == (uint32_t)PX) {
+        const float tmin = alpha_min<PX>(top);
+        if (opc >= 1.0f && __all(tmin == 1.0f)) blend_nx_dispatch<PX, 2>(mode, acc, top, opc, opc);
+        else blend_nx_dispatch<PX, 1>(mode, acc, top, opc, opc);
+    } else if (PX == 3 && lead == 2u) blend_nx_dispatch_lead<PX, (PX == 3 ? 2 : 1)>(mode, acc, top, opc, opc);
+    else blend_nx_dispatch_lead<PX, 1>(mode, acc, top, opc, opc);
+}
+// number of leading groups whose accumulators are all opaque (three compares and scalar counting)
+template <int PX>
+PFX_DEV uint32_t count_lead(const float (&acc)[PX][4])
+{
+    uint32_t lead = 0u;
+    bool run = true;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        run = run && __popcll(__ballot(acc[p][3] == 1.0f)) == 64;
+        lead += run ? 1u : 0u;
+    }
+    return lead;
+}
+
 } // namespace pfxk

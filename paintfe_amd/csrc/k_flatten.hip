@@ -621,34 +621,153 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
 }
 
 
-// ---- class queues: accumulators parked in the destination image, pixels routed by accumulator class (round 4) -------------------
+#ifndef PFX_SRT_GROUPS
+#define PFX_SRT_GROUPS 1   // development A/B (tools/build_variant.sh): 0 = the per-unit class test of round 3
+#endif
+#ifndef PFX_SRT_REDEAL
+#define PFX_SRT_REDEAL 1   // development A/B: 0 = no re-deal code in the layer loop
+#endif
+template <int PX>
+PFX_DEV void stream_layer_groups(float (&acc)[PX][4], const float (&t)[PX][4], uint32_t mode, float opacity, uint32_t lead)
+{
+    const float amax = alpha_max<PX>(t);
+#if PFX_SRT_GROUPS
+    if (__any(amax != 0.0f)) blend_layer_nx_groups<PX>(mode, acc, t, opacity, lead);
+#else
+    if (__any(amax != 0.0f)) blend_layer_nx<PX>(mode, acc, t, opacity);
+#endif
+}
+
+// dle_layers for the class-sorting kernel (two register sets): blends layers [lb, le) and, in front of layers s1, s1 + seg, ..., re-deals the unit's
+// pixels to the lanes when that completes another wave-uniform opaque group.  A re-deal moves the accumulators, the pixel offsets and the one layer
+// that is already in flight (requested with the old offsets) through the LDS tile; the next request uses the new offsets.
+template <int PX>
+PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__ layers, uint32_t lb, uint32_t le, uint32_t bytes, int (&voff)[PX],
+                        uint32_t s1, uint32_t seg, float4* s_x, uint32_t* s_v, uint32_t& st_moves, bool noblend)
+{
+    float t[2][PX][4];
+    uint32_t m[2], o[2];
+    const uint32_t last = le - 1u;
+    const uint8_t* npx = layers[lb].pixels;
+    uint32_t nmode = layers[lb].mode;
+    uint32_t nop = layers[lb].adj_off; // raster layers: bits of the clamped opacity (pfx_kernels.h)
+    uint32_t next_attempt = lb < s1 ? s1 : lb + 1u;
+    uint32_t lead = 0u;            // leading groups known to be opaque wave-wide
+    bool recount = true;           // ... to be re-taken in front of the next blend (start of the pass; behind Xor / Overwrite, which can lower alpha)
+    auto fetch = [&](auto SET, uint32_t K) {
+        constexpr int S = decltype(SET)::value;
+        m[S] = nmode; o[S] = nop;
+        const pfx_v4i rs = make_rsrc(npx, bytes, PFX_RSRC_UNORM8X4);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const pfx_v4f v = pfx_buffer_load_format_v4f32(rs, voff[j], 0, 0);
+            t[S][j][0] = v.x; t[S][j][1] = v.y; t[S][j][2] = v.z; t[S][j][3] = v.w;
+        }
+        const uint32_t kn = (K + 1u < last) ? K + 1u : last;
+        npx = layers[kn].pixels; nmode = layers[kn].mode; nop = layers[kn].adj_off;
+    };
+    auto blend = [&](auto SET, uint32_t K) {
+        constexpr int S = decltype(SET)::value;
+        if (K < le) {
+            if (noblend) { // diagnostic (pfx_tune "dle_stats" = 2): the load stream without the arithmetic — results are garbage
+#pragma unroll
+                for (int j = 0; j < PX; ++j) { acc[j][0] += t[S][j][0]; acc[j][1] += t[S][j][1]; acc[j][2] += t[S][j][2]; acc[j][3] = t[S][j][3]; }
+            } else {
+                if (recount) { lead = count_lead<PX>(acc); recount = false; }
+                stream_layer_groups<PX>(acc, t[S], m[S], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(o[S])), lead);
+                recount = m[S] == M_XOR || m[S] == M_OVERWRITE;
+            }
+        }
+    };
+    auto redeal = [&](auto SET, uint32_t K) {          // in front of layer K, whose pixels are in flight in set SET
+        constexpr int S = decltype(SET)::value;
+#if !PFX_SRT_REDEAL
+        return;
+#endif
+        if (K != next_attempt || K >= le) return;
+        next_attempt = K + seg;
+        uint64_t mo[PX];
+        uint32_t co[PX], total_o = 0u, now = 0u;
+        bool run = true;
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            mo[j] = __ballot(acc[j][3] == 1.0f);
+            co[j] = (uint32_t)__popcll(mo[j]);
+            total_o += co[j];
+            run = run && co[j] == 64u;
+            now += run ? 1u : 0u;
+        }
+        lead = now; recount = false;                   // the count is a by-product of the attempt
+        if (total_o / 64u <= now) return;              // grouping the opaque accumulators would not complete another leading group
+        lead = total_o / 64u;
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); // recomputed: not worth a register across the blends
+        uint32_t slot[PX], pre_o = 0u, pre_n = total_o;
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const uint32_t rank_o = __builtin_amdgcn_mbcnt_hi((uint32_t)(mo[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo[j], 0u));
+            slot[j] = acc[j][3] == 1.0f ? pre_o + rank_o : pre_n + (lane - rank_o);
+            pre_o += co[j]; pre_n += 64u - co[j];
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) { s_x[slot[j]] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]); s_v[slot[j]] = (uint32_t)voff[j]; }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const float4 a = s_x[64u * j + lane];
+            acc[j][0] = a.x; acc[j][1] = a.y; acc[j][2] = a.z; acc[j][3] = a.w;
+            voff[j] = (int)s_v[64u * j + lane];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < PX; ++j) s_x[slot[j]] = make_float4(t[S][j][0], t[S][j][1], t[S][j][2], t[S][j][3]);
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const float4 a = s_x[64u * j + lane];
+            t[S][j][0] = a.x; t[S][j][1] = a.y; t[S][j][2] = a.z; t[S][j][3] = a.w;
+        }
+        wave_lds_sync();
+        st_moves += 1u;
+    };
+    fetch(std::integral_constant<int, 0>{}, lb);
+    for (uint32_t li = lb; li < le; li += 2) {
+        fetch(std::integral_constant<int, 1>{}, li + 1); blend(std::integral_constant<int, 0>{}, li); redeal(std::integral_constant<int, 1>{}, li + 1);
+        fetch(std::integral_constant<int, 0>{}, li + 2); blend(std::integral_constant<int, 1>{}, li + 1); redeal(std::integral_constant<int, 0>{}, li + 2);
+    }
+}
+
+// ---- class sorting inside a unit: accumulators parked in the destination image, a unit's pixels grouped by accumulator class (round 4) ----
 // The blend of a layer pixel over an OPAQUE accumulator costs about 60 % of the general one (out_a == 1: no division, no base-alpha
-// products, no alpha re-quantisation, no select for a transparent layer pixel: k_blend.h, OB = 1), but the specialisation only runs when a
-// whole wave's accumulators are opaque.  On per-pixel-random alpha (BASELINE's S2) that never happens above the reset layer although 30 ..
-// 90 % of the pixels are opaque there.  This kernel makes the class wave-uniform by routing pixels through FIFOs:
-//   * queue 0 (E) is flatten_dle_kernel's queue of EARLY pixels (layers [q_start, q_r) below the unit's split layer);
-//   * a unit's natural pass runs layers [start, s1) only (s1 = one above the topmost reset candidate), then appends every pixel to queue 2 (O2,
-//     accumulator alpha == 255) or queue 1 (N2, the rest);  N2 rounds run [s1, s2) and re-partition into N3 (3) / O3 (4);  O2 rounds run
-//     [s1, n), N3 / O3 rounds [s2, n) and produce the result.  Opaque pixels stay opaque (Xor / Overwrite above s1 only make the dynamic
-//     class test in blend_layer_nx fail for that wave: the classes are a performance hint, never a correctness condition);
-//   * an accumulator that leaves the registers is parked IN THE DESTINATION IMAGE at its own pixel — RGBA8 is the reference's accumulator
-//     type (canvas_state.rs:573) — with a typed buffer store (float -> UNORM8 in the texture path) and comes back with a typed load: no
-//     pack / unpack arithmetic, no LDS ring, and the final result is the last such store.  Store -> load of one address by one wave is
-//     ordered by the memory pipeline like any spill.  A pixel whose accumulator does not matter (its reset layer is still ahead) may load
-//     whatever the destination holds: UNORM8 loads are finite values in [0, 1] and the reset layer replaces them.
-// Requires: dst overlaps no layer (the launcher checks; otherwise flatten_dle_kernel runs), and the device's float -> UNORM8 store
-// conversion returns k for RN(k / 255) (pfxk_unorm_store_check, verified once per context).
-struct dle_plan { uint32_t s1, s2, min_units; };
+// products, no alpha re-quantisation, no select for a transparent layer pixel: k_blend.h, OB = 1), but the specialisation only runs when all the
+// accumulators a wave holds are opaque.  On per-pixel-random alpha (BASELINE's S2) that never happens above the reset layer although 30 .. 90 % of
+// the pixels are opaque there.  This kernel is flatten_dle_kernel with two changes:
+//   * in front of some layers of a unit's natural pass (srt_layers) the unit's pixels are re-dealt to the lanes so that opaque accumulators
+//     fill whole 64-pixel groups first (a stable partition: ballot + mbcnt ranks; accumulators and pixel offsets move through a 3.75 KB LDS tile as
+//     16-byte and 4-byte items, no arithmetic), and blend_layer_nx_groups' per-group class test then finds wave-uniform opaque groups.  Lane l, group j
+//     afterwards holds SOME pixel of the same 64 PX-pixel unit: the wave's loads touch the same cache lines in another lane order, which the texture
+//     path serves at 98 % of the lane-order rate (tools/lab/perm_load.hip: 4.62 against 4.72 TB/s; gathering across 4 units instead: 2.55 — what
+//     made a FIFO-per-class version of this kernel, with twice the HBM traffic, slower than round 3's).  A re-deal only happens when it completes
+//     another group (the attempt costs three compares and scalar counting); opaque accumulators stay opaque, so at most PX re-deals per unit.
+//     Xor / Overwrite above only make the per-group test fail again: the grouping is a performance hint, never a correctness condition;
+//   * an accumulator that leaves the registers (an early pixel between its compacted round and its unit's natural pass) is parked IN THE
+//     DESTINATION IMAGE at its own pixel — RGBA8 is the reference's accumulator type (canvas_state.rs:573) — with a typed buffer store (float ->
+//     UNORM8 in the texture path) and comes back with a typed load: no pack / unpack arithmetic, no LDS ring, and the result is written the same
+//     way.  Store -> load of one address by one wave is ordered by the memory pipeline like any spill.  A pixel whose accumulator does not matter
+//     (its reset layer is still ahead) loads whatever the destination holds: UNORM8 loads are finite values in [0, 1], the reset layer replaces them.
+// Requires: dst overlaps no layer (the launcher checks; otherwise flatten_dle_kernel runs), and the device's float -> UNORM8 store conversion
+// returns k for RN(k / 255) (pfxk_unorm_store_check, verified once per context).
+struct dle_plan { uint32_t s1, seg; }; // re-deal attempts in front of layers s1, s1 + seg, s1 + 2 seg, ... (seg == 0: none)
 
 template <int PX, int NB = 2>
-__global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_cls_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers, uint32_t n_px,
+__global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers, uint32_t n_px,
                                                                          uint8_t* __restrict__ dst, const pfxk_dle_cands C, const dle_sched SC,
                                                                          const dle_plan P)
 {
-    constexpr uint32_t UPX = 64u * PX, QCAP = PX == 2 ? 256u : 512u, NQ = 5u, NREC = 16u;
-    static_assert(QCAP >= 2u * UPX, "a queue holds a full round plus what one round can append");
-    __shared__ uint16_t s_q[NQ][QCAP];      // FIFOs of pixel offsets (from the wave's first pixel): 0 = E, 1 = N2, 2 = O2, 3 = N3, 4 = O3
-    __shared__ uint32_t s_rec[NREC][2];     // per unit in flight: {first layer of its natural pass, E's tail after its append (0: no early pixels)}
+    constexpr uint32_t UPX = 64u * PX, QCAP = PX == 2 ? 256u : 512u, NREC = 16u;
+    __shared__ uint16_t s_q[QCAP];          // FIFO of early pixels (offset from the wave's first pixel)
+    __shared__ uint32_t s_rec[NREC][2];     // per unit in flight: {first layer of its natural pass, queue tail after its append (0: no early pixels)}
+    __shared__ float4 s_x[UPX];             // re-deal tile: accumulators ...
+    __shared__ uint32_t s_v[UPX];           // ... and pixel byte offsets, at their new slots
     soft_d_fill(threadIdx.x, 64u);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -663,39 +782,35 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_cls_kernel(const
     const uint32_t base_px = u0 * UPX;
     const uint32_t bytes = n_px * 4u;
     const pfx_v4i rs_acc = make_rsrc(dst, bytes, PFX_RSRC_UNORM8X4);
-    // short streams (the tail of the launch) would flush every queue half empty: they keep the single natural pass
-    const bool split = P.s1 != 0u && nu >= P.min_units;
-    const uint32_t s1 = split ? P.s1 : n_layers, s2 = (split && P.s2 != 0u) ? P.s2 : n_layers;
-    uint16_t (*const q)[QCAP] = s_q;
+    uint16_t* const q = s_q;
     uint32_t (*const rec)[2] = s_rec;
 
-    uint32_t qh = 0u, qt = 0u;                    // lane i: head / tail of queue i (monotone counters; entry k lives at q[i][k % QCAP])
-    uint32_t cls_next = 0, nat_next = 0;          // units classified / through their natural pass (relative to u0)
-    uint32_t q_r = 0, q_start = 0;                // layers [q_start, q_r) are what the pixels in E still need
-    uint32_t st_rounds = 0, st_rpx = 0, st_rlay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_urounds = 0;
+    uint32_t cls_next = 0, nat_next = 0;          // units classified / finished so far (relative to u0)
+    uint32_t q_head = 0, q_tail = 0;              // monotone counters; entry k lives at q[k % QCAP]
+    uint32_t q_r = 0, q_start = 0;                // layers [q_start, q_r) are what the queued pixels still need
+    uint32_t st_rounds = 0, st_rpx = 0, st_rlay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_moves = 0;
     uint32_t probe_fail = 0, skip_left = 0;
+    const uint32_t s1 = P.seg != 0u ? P.s1 : 0xFFFFFFFFu;
     for (;;) {
-        const uint32_t cnt = qt - qh;
-        const uint32_t full = (uint32_t)__ballot(cnt >= UPX);
-        int qi = -1;
-        bool run_nat = false, nat_split = false;
-        uint32_t nat_start = 0;
-        if (full != 0u) qi = 31 - __builtin_clz(full);          // the deepest full queue first: work drains towards the result
-        else {
-            if (nat_next < cls_next) {
+        int voff[PX];
+        float acc[PX][4];
+        uint32_t lb, le;
+        bool run_queue = false;
+        {
+            const uint32_t q_cnt = q_tail - q_head;
+            bool run_nat = false, nat_split = false;
+            uint32_t nat_start = 0;
+            run_queue = q_cnt >= UPX;
+            if (!run_queue && nat_next < cls_next) {
                 const uint32_t slot = nat_next % NREC;
                 const uint32_t need = __builtin_amdgcn_readfirstlane(rec[slot][1]);
-                if (need <= (uint32_t)__builtin_amdgcn_readlane((int)qh, 0)) {
-                    run_nat = true; nat_split = need != 0u; nat_start = __builtin_amdgcn_readfirstlane(rec[slot][0]);
-                }
+                if (need <= q_head) { run_nat = true; nat_split = need != 0u; nat_start = __builtin_amdgcn_readfirstlane(rec[slot][0]); }
             }
-            if (!run_nat) {
+            if (!run_queue && !run_nat) {
                 if (cls_next < nu && cls_next - nat_next < NREC) {
-                    // ---- classify unit cls_next (as in flatten_dle_kernel) ----
+                    // ---- classify unit cls_next (flatten_dle_kernel's rules) ----
                     const uint32_t u = cls_next;
                     const uint32_t o0 = u * UPX + lane;
-                    const uint32_t e_tail0 = (uint32_t)__builtin_amdgcn_readlane((int)qt, 0);
-                    const uint32_t q_cnt = e_tail0 - (uint32_t)__builtin_amdgcn_readlane((int)qh, 0);
                     uint32_t cls[PX];
 #pragma unroll
                     for (int j = 0; j < PX; ++j) cls[j] = 0u;
@@ -738,12 +853,11 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_cls_kernel(const
                             if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; }
                         }
                     }
-                    if (best != 0u && q_cnt != 0u && q_r != r) { best = 0u; r = s_u; } // one split layer in E at a time
+                    if (best != 0u && q_cnt != 0u && q_r != r) { best = 0u; r = s_u; } // one split layer in the queue at a time
                     if (probe) {
                         if (best != 0u || s_u != 0u) probe_fail = 0u;
                         else if (++probe_fail >= 2u) { probe_fail = 0u; skip_left = 14u; }
                     }
-                    uint32_t e_tail = e_tail0;
                     if (best != 0u) {
                         st_cunits += 1u;
                         if (q_cnt == 0u) q_start = s_u; else q_start = min(q_start, s_u);
@@ -753,98 +867,62 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_cls_kernel(const
                             const bool early = cls[j] < best;
                             const uint64_t m = __ballot(early);
                             const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (early) q[0][(e_tail + pre) % QCAP] = (uint16_t)(o0 + 64u * j);
-                            e_tail += (uint32_t)__popcll(m);
+                            if (early) q[(q_tail + pre) % QCAP] = (uint16_t)(o0 + 64u * j);
+                            q_tail += (uint32_t)__popcll(m);
                         }
-                        qt = lane_write(qt, e_tail, 0u);
                     }
-                    if (lane == 0) { rec[u % NREC][0] = r; rec[u % NREC][1] = best != 0u ? e_tail : 0u; }
+                    if (lane == 0) { rec[u % NREC][0] = r; rec[u % NREC][1] = best != 0u ? q_tail : 0u; }
                     wave_lds_sync();
                     cls_next = u + 1u;
                     continue;
                 }
-                const uint32_t nonempty = (uint32_t)__ballot(cnt != 0u);
-                if (nonempty == 0u) {                 // every unit classified and through, every queue drained
+                if (q_cnt == 0u) {                    // everything classified, run and stored
                     if (lane == 0 && (C.stats & 1u)) {
                         atomicAdd(&g_dle_stats[0], st_rounds); atomicAdd(&g_dle_stats[1], st_rpx); atomicAdd(&g_dle_stats[2], st_rlay);
                         atomicAdd(&g_dle_stats[3], nat_next); atomicAdd(&g_dle_stats[4], st_nlay); atomicAdd(&g_dle_stats[5], st_reads);
-                        atomicAdd(&g_dle_stats[6], st_cunits); atomicAdd(&g_dle_stats[7], st_urounds);
+                        atomicAdd(&g_dle_stats[6], st_cunits); atomicAdd(&g_dle_stats[7], st_moves);
                     }
                     break;
                 }
-                qi = __builtin_ctz(nonempty);         // flush a partial round, upstream queues first (they feed the ones behind them)
+                run_queue = true;                     // flush a partial round: the window is full or the stream has ended
+            }
+            if (run_queue) {
+                const uint32_t m = min(q_cnt, UPX);
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const uint32_t k = 64u * j + lane;
+                    const uint32_t o = (uint32_t)q[(q_head + k) % QCAP];
+                    voff[j] = k < m ? (int)((base_px + o) * 4u) : (int)bytes; // past the end: loads return (0,0,0,0) = transparent, stores are dropped
+                    acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
+                }
+                lb = q_start; le = q_r;
+                q_head += m;
+                st_rounds += 1u; st_rpx += m; st_rlay += le - lb;
+            } else {
+                const uint32_t o0 = nat_next * UPX + lane;
+#pragma unroll
+                for (int j = 0; j < PX; ++j) voff[j] = (int)((base_px + o0 + 64u * j) * 4u);
+                if (nat_split) {                      // early pixels come back from the destination (the others' values do not matter)
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {
+                        const pfx_v4f v = pfx_buffer_load_format_v4f32(rs_acc, voff[j], 0, 0);
+                        acc[j][0] = v.x; acc[j][1] = v.y; acc[j][2] = v.z; acc[j][3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; // :573
+                }
+                lb = nat_start; le = n_layers;
+                st_nlay += le - lb;
+                nat_next += 1u;
             }
         }
-
-        int voff[PX];
-        float acc[PX][4];
-        uint32_t lb, le;
-        int push_n = -1, push_o = -1;
-        bool load_acc, opaque_class = false;
-        if (qi >= 0) {
-            const uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)qh, qi);
-            const uint32_t m = min((uint32_t)__builtin_amdgcn_readlane((int)qt, qi) - head, UPX);
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const uint32_t k = 64u * j + lane;
-                const uint32_t o = (uint32_t)q[qi][(head + k) % QCAP];
-                voff[j] = k < m ? (int)((base_px + o) * 4u) : (int)bytes; // past the end: loads return (0,0,0,0) = transparent, stores are dropped
-            }
-            qh = lane_write(qh, head + m, (uint32_t)qi);
-            if (qi == 0) { lb = q_start; le = q_r; load_acc = false; }
-            else {
-                lb = qi <= 2 ? s1 : s2;
-                le = qi == 1 ? s2 : n_layers;
-                load_acc = true;
-                opaque_class = qi == 2 || qi == 4;
-                if (qi == 1 && s2 < n_layers) { push_n = 3; push_o = 4; }
-                st_urounds += 1u;
-            }
-            st_rounds += 1u; st_rpx += m; st_rlay += le - lb;
-        } else {
-            const uint32_t o0 = nat_next * UPX + lane;
-#pragma unroll
-            for (int j = 0; j < PX; ++j) voff[j] = (int)((base_px + o0 + 64u * j) * 4u);
-            lb = nat_start; le = s1;
-            load_acc = nat_split;                     // early pixels come back from the destination; a unit without any starts from (0,0,0,0), :573
-            if (s1 < n_layers) { push_n = 1; push_o = 2; }
-            st_nlay += le - lb;
-            nat_next += 1u;
-        }
-        if (load_acc) {
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const pfx_v4f v = pfx_buffer_load_format_v4f32(rs_acc, voff[j], 0, 0);
-                acc[j][0] = v.x; acc[j][1] = v.y; acc[j][2] = v.z; acc[j][3] = opaque_class ? 1.0f : v.w;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < PX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
-        }
-        dle_layers<PX, NB, 0>(acc, layers, lb, le, bytes, voff, (C.stats & 2u) != 0u);
+        srt_layers<PX>(acc, layers, lb, le, bytes, voff, s1, P.seg, s_x, s_v, st_moves, (C.stats & 2u) != 0u);
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             pfx_v4f v; v.x = acc[j][0]; v.y = acc[j][1]; v.z = acc[j][2]; v.w = acc[j][3];
-            pfx_buffer_store_format_v4f32(v, rs_acc, voff[j], 0, 0);   // parks the accumulator, or is the result
+            pfx_buffer_store_format_v4f32(v, rs_acc, voff[j], 0, 0);   // parks an early pixel's accumulator, or is the result
         }
-        if (push_n >= 0) {
-            uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)qt, push_n), to = (uint32_t)__builtin_amdgcn_readlane((int)qt, push_o);
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const bool valid = (uint32_t)voff[j] < bytes;
-                const bool is_o = valid && acc[j][3] == 1.0f, is_n = valid && !is_o;
-                const uint64_t mo = __ballot(is_o), mn = __ballot(is_n);
-                const uint32_t pre_o = __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u));
-                const uint32_t pre_n = __builtin_amdgcn_mbcnt_hi((uint32_t)(mn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mn, 0u));
-                const uint16_t off = (uint16_t)((uint32_t)voff[j] / 4u - base_px);
-                if (is_o) q[push_o][(to + pre_o) % QCAP] = off;
-                if (is_n) q[push_n][(tn + pre_n) % QCAP] = off;
-                to += (uint32_t)__popcll(mo); tn += (uint32_t)__popcll(mn);
-            }
-            qt = lane_write(qt, tn, (uint32_t)push_n);
-            qt = lane_write(qt, to, (uint32_t)push_o);
-        }
-        wave_lds_sync();
     }
 }
 
@@ -871,8 +949,8 @@ __global__ __launch_bounds__(256) void unorm_store_check_kernel(uint8_t* __restr
 // per-document behaviour; atomics because batch workers and device groups run one context per thread.
 std::atomic<int> g_dle_stats_on{0}, g_dle_cfg{0}, g_dle_sched{1}, g_dle_fracA{75}, g_dle_fracB{20};
 std::atomic<int> g_dle_units{0}; // units per wave (0 = default)
-std::atomic<int> g_dle_kernel{0}; // 0 = class queues (flatten_cls_kernel), 1 = round 3's flatten_dle_kernel
-std::atomic<int> g_dle_s1{-1}, g_dle_s2{-1}, g_dle_split_units{8}; // class-queue plan: layers above the topmost candidate of the two split points (-1: automatic; 0: none)
+std::atomic<int> g_dle_kernel{0}; // 0 = class sorting inside a unit (flatten_srt_kernel), 1 = round 3's flatten_dle_kernel
+std::atomic<int> g_dle_s1{-1}, g_dle_s2{-1}; // re-deal plan: first attempt this many layers above the topmost candidate (-1: 1; 0: never), then every g_dle_s2 layers (-1: 3)
 std::atomic<int> g_flatten_variant{0}; // tuning knob (pfxk_flatten_set_variant): 0 = shipped (2 px x 2 sets, grid stride up to 16 layers), 1-5 = PX / register-set variants, 6 = 3 px x 3 sets (the round-2 shape), +10 = grid-stride launch, 8 = no elimination kernel, 9 = the general kernel
 
 // per 64 x 64 chunk of a layer: bit 0 = every alpha is 255, bit 1 = no alpha is 0 (computed when a layer enters the layer store)
@@ -1058,12 +1136,11 @@ extern "C" void pfxk_flatten_set_dle_sched(int sched, int fracA, int fracB)
     if (fracA >= 0 && fracA <= 100) g_dle_fracA = fracA;
     if (fracB >= 0 && fracB <= 100 - g_dle_fracA) g_dle_fracB = fracB;
 }
-extern "C" void pfxk_flatten_set_dle_plan(int kernel, int s1, int s2, int split_units)
+extern "C" void pfxk_flatten_set_dle_plan(int kernel, int s1, int s2)
 {
     if (kernel >= 0) g_dle_kernel = kernel;
     if (s1 >= -1) g_dle_s1 = s1;
     if (s2 >= -1) g_dle_s2 = s2;
-    if (split_units >= 1) g_dle_split_units = split_units;
 }
 extern "C" hipError_t pfxk_unorm_store_check(hipStream_t s, uint8_t* d_scratch1k, unsigned long long* d_out)
 {
@@ -1145,7 +1222,7 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
         if (cands && cands->n > 0 && flatten_variant != 8) {
             // dle_cfg: 0 = 3 pixels per lane, 2 register sets (6 waves per SIMD; measured best), 1 = 2 pixels per lane, 2 = 3 pixels per lane, 3 sets (old kernel only);
             // dle_sched 0 = equal streams of dle_units
-            const bool cls_kernel = g_dle_kernel == 0 && dst_parking_ok;
+            const bool srt_kernel = g_dle_kernel == 0 && dst_parking_ok;
             const uint32_t px = dle_cfg == 1 ? 2u : 3u;
             const uint32_t upx = 64u * px;
             const uint32_t units = (uint32_t)((n_px + upx - 1) / upx);
@@ -1167,25 +1244,17 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
             const uint32_t waves = SC.wavesA + SC.wavesB + (rest + SC.UC - 1) / SC.UC;
             pfxk_dle_cands C = *cands;
             C.stats = (uint32_t)g_dle_stats_on;
-            if (cls_kernel) {
-                // class-queue plan: s1 = the layer above the topmost candidate (everything below it is the natural pass), s2 = s1 + about a third of
-                // what is left — by then most pixels that will ever be opaque are (S2: the non-opaque share falls 0.69 -> 0.29 over six layers)
+            if (srt_kernel) {
+                // re-deal attempts start right above the topmost candidate (below it the early pixels' rounds and the reset layer itself run) and
+                // repeat every `seg` layers
                 dle_plan P{};
-                const uint32_t top = C.layer[C.n - 1u];
-                const uint32_t above = n_layers - (top + 1u);
                 const int o1 = g_dle_s1, o2 = g_dle_s2;
-                if (o1 > 0 || (o1 < 0 && above >= 6u)) {           // automatic: only where enough layers follow to repay the two transitions
-                    P.s1 = top + (o1 > 0 ? (uint32_t)o1 : 1u);
-                    if (P.s1 >= n_layers) P.s1 = 0u;
-                }
-                if (P.s1 != 0u && (o2 > 0 || (o2 < 0 && n_layers - P.s1 >= 10u))) {
-                    P.s2 = P.s1 + (o2 > 0 ? (uint32_t)o2 : (n_layers - P.s1) / 3u);
-                    if (P.s2 >= n_layers) P.s2 = 0u;
-                }
-                P.min_units = (uint32_t)g_dle_split_units;
+                P.s1 = C.layer[C.n - 1u] + (o1 > 0 ? (uint32_t)o1 : 1u);
+                P.seg = o2 < 0 ? 3u : (o2 == 0 ? 1000u : (uint32_t)o2);   // 0: a single attempt
+                if (o1 == 0) P.seg = 0u;                                   // no attempts at all: round 3's natural pass + parking in the destination
 #define PFX_ARGS <<<waves, 64, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, SC, P)
-                if (dle_cfg == 1) flatten_cls_kernel<2, 2> PFX_ARGS;
-                else flatten_cls_kernel<3, 2> PFX_ARGS;
+                if (dle_cfg == 1) flatten_srt_kernel<2, 2> PFX_ARGS;
+                else flatten_srt_kernel<3, 2> PFX_ARGS;
 #undef PFX_ARGS
                 return hipGetLastError();
             }

@@ -327,7 +327,7 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
         }
         if (ctx->chunk_state != 3) d_chunk_start = (const uint8_t*)ctx->d_chunk_start.p; // pending or useful: the table of THIS stack is in the buffer
     }
-    // The class-queue compositor parks accumulators in the destination between its passes (k_flatten.hip: flatten_cls_kernel): the destination
+    // The class-sorting compositor parks accumulators in the destination between its passes (k_flatten.hip: flatten_srt_kernel): the destination
     // must not overlap a layer it still has to read, and the device's float -> UNORM8 store conversion must round-trip RN(k / 255) (checked once
     // per context on the device itself).  Otherwise the round-3 kernel, which keeps them in LDS, runs.
     int parking_ok = 0;
@@ -1253,10 +1253,9 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "dle_frac_a") == 0) { pfxk_flatten_set_dle_sched(-1, value, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_frac_b") == 0) { pfxk_flatten_set_dle_sched(-1, -1, value); return PFX_OK; }
     if (std::strcmp(key, "dle_cfg") == 0) { pfxk_flatten_set_dle_dev(-1, value); return PFX_OK; }
-    if (std::strcmp(key, "dle_kernel") == 0) { pfxk_flatten_set_dle_plan(value, -2, -2, 0); return PFX_OK; }   // 0 = class queues, 1 = round-3 kernel
-    if (std::strcmp(key, "dle_s1") == 0) { pfxk_flatten_set_dle_plan(-1, value, -2, 0); return PFX_OK; }       // split points of the class queues (-1 auto, 0 none)
-    if (std::strcmp(key, "dle_s2") == 0) { pfxk_flatten_set_dle_plan(-1, -2, value, 0); return PFX_OK; }
-    if (std::strcmp(key, "dle_split_units") == 0) { pfxk_flatten_set_dle_plan(-1, -2, -2, value); return PFX_OK; }
+    if (std::strcmp(key, "dle_kernel") == 0) { pfxk_flatten_set_dle_plan(value, -2, -2); return PFX_OK; }   // 0 = class sorting, 1 = round-3 kernel
+    if (std::strcmp(key, "dle_s1") == 0) { pfxk_flatten_set_dle_plan(-1, value, -2); return PFX_OK; }       // re-deal attempts: first one this many layers above the topmost candidate (-1: 1, 0: never)
+    if (std::strcmp(key, "dle_s2") == 0) { pfxk_flatten_set_dle_plan(-1, -2, value); return PFX_OK; }       // ... then every this many layers (-1: 3, 0: only the first)
     if (std::strcmp(key, "median_search1") == 0) { pfxk_median_set_search1(value); return PFX_OK; }
     if (std::strcmp(key, "outline_bits") == 0) { ctx->outline_bits = value != 0; return PFX_OK; }
     if (std::strcmp(key, "median_bits_min") == 0) { ctx->median_bits_min = value; return PFX_OK; } // smallest radius on the bit-plane kernel (8: never)

@@ -55,8 +55,8 @@ hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uin
                         uint32_t h, uint8_t* d_dst, const pfxk_preview* preview /* may be NULL */,
                         const pfxk_region* region /* may be NULL */, const pfxk_dle_cands* cands /* may be NULL: no elimination */,
                         const uint8_t* d_chunk_start /* may be NULL: per-chunk first layer that can show (pfxk_chunk_start) */,
-                        int dst_parking_ok /* d_dst overlaps no layer and the device's UNORM8 store conversion is verified: the class-queue kernel
-                                              may park accumulators in it (k_flatten.hip: flatten_cls_kernel) */);
+                        int dst_parking_ok /* d_dst overlaps no layer and the device's UNORM8 store conversion is verified: the class-sorting
+                                              kernel may park accumulators in it (k_flatten.hip: flatten_srt_kernel) */);
 // per-chunk alpha summary of a stored layer (bit 0: all 255, bit 1: none 0) over the chunk rectangle [cx0, cx0+ncx) x [cy0, cy0+ncy), and the
 // per-chunk start table of a stack (want[k]: 1 = Normal at opacity >= 1 needs bit 0, 2 = Overwrite needs bit 1, 0 = layer k never resets)
 hipError_t pfxk_chunk_alpha_flags(hipStream_t s, const uint8_t* d_px, uint32_t w, uint32_t h, uint32_t cx0, uint32_t cy0, uint32_t ncx, uint32_t ncy,
@@ -67,7 +67,8 @@ void       pfxk_flatten_set_dle(int units_per_wave /* 0 = default, < 0 = keep */
 hipError_t pfxk_flatten_dle_stats(unsigned long long* out8 /* may be NULL */, int reset); // synchronises the device
 void       pfxk_flatten_set_dle_dev(int stats_on /* < 0 keep */, int cfg /* < 0 keep */);
 void       pfxk_flatten_set_dle_sched(int sched /* 0 equal streams, 1 shrinking */, int fracA, int fracB); // < 0 keeps
-void       pfxk_flatten_set_dle_plan(int kernel /* 0 class queues, 1 round-3 kernel; < 0 keeps */, int s1 /* -1 auto, 0 none; < -1 keeps */, int s2, int split_units /* < 1 keeps */);
+void       pfxk_flatten_set_dle_plan(int kernel /* 0 class sorting, 1 round-3 kernel; < 0 keeps */, int s1 /* first re-deal attempt, layers above the topmost candidate: -1 = 1, 0 = never; < -1 keeps */,
+                                     int s2 /* layers between attempts: -1 = 3, 0 = one attempt only; < -1 keeps */);
 // out[0] += byte values for which a typed UNORM8 store of RN(k / 255) does not write k or the typed load does not return RN(k / 255)
 hipError_t pfxk_unorm_store_check(hipStream_t s, uint8_t* d_scratch1k, unsigned long long* d_out);
 void       pfxk_flatten_set_variant(int v); // tuning knob: 0 = shipped kernel, 1.. = experimental pixels-per-lane / occupancy variants

@@ -27,7 +27,7 @@ def gpu():
     g.r.tune("dle_units", 0)
     g.r.tune("dle_cfg", 0)
     g.r.tune("flatten_variant", 0)
-    set_config(g, (0, 0, 1, 8, -1, -1))
+    set_config(g, (0, 0, 1, -1, -1))
 
 
 def check(gpu, stack, modes, opac, what):
@@ -51,29 +51,29 @@ def blocky_alpha(rng, h, w, cell, p_zero, p_opaque):
     return np.kron(coarse, np.ones((cell, cell), np.uint8))[:h, :w]
 
 
-# (dle_kernel, dle_cfg, dle_sched, dle_split_units, dle_s1, dle_s2): kernel 0 = class queues (flatten_cls_kernel: accumulators parked in the destination,
-# pixels routed by "accumulator opaque?" above the topmost reset layer), 1 = round 3's kernel (accumulators parked in an LDS ring).  dle_s1 / dle_s2: layers
-# between the topmost candidate and the first split / between the splits (-1 automatic, 0 none); dle_split_units 1 = even one-unit streams split.
+# (dle_kernel, dle_cfg, dle_sched, dle_s1, dle_s2): kernel 0 = class sorting (flatten_srt_kernel: early pixels' accumulators parked in the destination,
+# a unit's pixels re-dealt to the lanes by "accumulator opaque?" between segments of its natural pass), 1 = round 3's kernel (accumulators parked in an
+# LDS ring, lane order throughout).  dle_s1: the first re-deal attempt, in layers above the topmost candidate (-1 = 1, 0 = never); dle_s2: layers between
+# attempts (-1 = 3, 0 = only the first).
 CONFIGS = {
-    "cls-px3-split-auto": (0, 0, 1, 1, -1, -1),
-    "cls-px3-split-1-1": (0, 0, 1, 1, 1, 1),
-    "cls-px3-split-2-3-equal": (0, 0, 0, 1, 2, 3),
-    "cls-px3-single-level": (0, 0, 1, 1, 1, 0),
-    "cls-px3-default-thresholds": (0, 0, 1, 8, -1, -1),
-    "cls-px2-split-1-2": (0, 1, 1, 1, 1, 2),
-    "cls-px2-equal-nosplit": (0, 1, 0, 1, 0, 0),
-    "r3-px3x2sets-shrinking": (1, 0, 1, 8, -1, -1),
-    "r3-px2-shrinking": (1, 1, 1, 8, -1, -1),
-    "r3-px3x3sets-equal": (1, 2, 0, 8, -1, -1),
+    "srt-px3-default": (0, 0, 1, -1, -1),
+    "srt-px3-every-layer": (0, 0, 1, 1, 1),
+    "srt-px3-from-3-every-3-equal": (0, 0, 0, 3, 3),
+    "srt-px3-one-attempt": (0, 0, 1, 2, 0),
+    "srt-px3-never": (0, 0, 1, 0, -1),
+    "srt-px2-every-layer": (0, 1, 1, 1, 1),
+    "srt-px2-equal-default": (0, 1, 0, -1, -1),
+    "r3-px3x2sets-shrinking": (1, 0, 1, -1, -1),
+    "r3-px2-shrinking": (1, 1, 1, -1, -1),
+    "r3-px3x3sets-equal": (1, 2, 0, -1, -1),
 }
 
 
 def set_config(gpu, cfg):
-    kernel, dcfg, sched, split_units, s1, s2 = cfg
+    kernel, dcfg, sched, s1, s2 = cfg
     gpu.r.tune("dle_kernel", kernel)
     gpu.r.tune("dle_cfg", dcfg)
     gpu.r.tune("dle_sched", sched)
-    gpu.r.tune("dle_split_units", split_units)
     gpu.r.tune("dle_s1", s1)
     gpu.r.tune("dle_s2", s2)
 
@@ -81,10 +81,10 @@ def set_config(gpu, cfg):
 @pytest.fixture(params=list(CONFIGS.values()), ids=list(CONFIGS.keys()), autouse=True)
 def every_kernel_configuration(request, gpu):
     """every test of this file runs on both elimination kernels, their instantiations (pfx_tune "dle_cfg": pixels per lane, register sets), both stream
-    schedules ("dle_sched": equal streams, or streams that shrink towards the end of the launch) and several class-queue plans"""
+    schedules ("dle_sched": equal streams, or streams that shrink towards the end of the launch) and several re-deal plans of the class-sorting kernel"""
     set_config(gpu, request.param)
     yield request.param
-    set_config(gpu, (0, 0, 1, 8, -1, -1))
+    set_config(gpu, (0, 0, 1, -1, -1))
 
 
 @pytest.mark.parametrize("units", [0, 1, 2, 5, 340])
@@ -304,8 +304,8 @@ def class_stack(rng, w, h, n, reset_at, p_opaque_top, modes_above):
 
 @pytest.mark.parametrize("p_opaque_top", [0.0, 0.02, 0.25, 0.6, 1.0])
 def test_accumulator_classes_at_every_mixture(gpu, p_opaque_top):
-    """above the reset layer the accumulators turn opaque at a rate set by p_opaque_top: never (the opaque queues stay empty), rarely (they are only
-    ever flushed partly filled), S2's rate, mostly, and at once (the general queues stay empty)"""
+    """above the reset layer the accumulators turn opaque at a rate set by p_opaque_top: never (no re-deal ever pays), rarely (one group completes late),
+    S2's rate, mostly, and at once (every group is opaque after the first layer)"""
     rng = np.random.default_rng(int(p_opaque_top * 100) + 900)
     w, h, n = 451, 233, 20
     stack, modes, opac = class_stack(rng, w, h, n, 6, p_opaque_top, {})
@@ -316,7 +316,7 @@ def test_accumulator_classes_at_every_mixture(gpu, p_opaque_top):
 @pytest.mark.parametrize("pos", [8, 10, 14, 19])
 def test_xor_or_overwrite_above_the_split_resets_the_classes(gpu, breaker, pos):
     """an Xor layer (canvas_state.rs:1283: lowers alpha, to zero where both are opaque) or a translucent Overwrite layer above the split points makes opaque
-    accumulators non-opaque again INSIDE the opaque queues' layer range: the class is only a hint, the per-layer test must notice"""
+    accumulators non-opaque again in groups that were dealt as opaque: the grouping is only a hint, the per-layer test must notice"""
     rng = np.random.default_rng(breaker * 100 + pos)
     w, h, n = 333, 197, 20
     stack, modes, opac = class_stack(rng, w, h, n, 5, 0.4, {pos: breaker})
@@ -340,7 +340,7 @@ def test_opaque_bottom_without_early_pixels_and_all_early_pixels(gpu):
 
 
 def test_destination_that_aliases_a_layer_takes_the_ring_kernel(gpu):
-    """the class-queue kernel parks accumulators in the destination; a destination that IS one of the layers must not be used that way (the library
+    """the class-sorting kernel parks accumulators in the destination; a destination that IS one of the layers must not be used that way (the library
     falls back to the kernel that parks in LDS): compositing in place over layer 9 still equals the oracle"""
     rng = np.random.default_rng(5)
     w, h, n = 384, 96, 18
