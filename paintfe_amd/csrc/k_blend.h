@@ -460,11 +460,38 @@ PFX_DEV void blend_nx_dispatch_lead(uint32_t mode, float (&acc)[PX][4], const fl
 }
 // `lead` = leading groups known to be opaque wave-wide (k_flatten.hip: srt_layers keeps the count up to date: an opaque accumulator stays opaque under
 // every mode but Xor and Overwrite, so the count is only re-taken behind those, at re-deal attempts and at the start of a pass; a stale-low count is
-// merely conservative)
+// merely conservative).  ONE switch over (class variant, mode): with a dispatch per variant the variants' results met in different registers and the
+// copies that reconcile them were 7 % of the executed VALU instructions (profiles/r04_tuning.md).
+#if !defined(PFX_ONE_SWITCH)
+#define PFX_ONE_SWITCH 1
+#endif
 template <int PX>
 PFX_DEV void blend_layer_nx_groups(uint32_t mode, float (&acc)[PX][4], const float (&top)[PX][4], float opc, uint32_t lead)
 {
     static_assert(PX == 2 || PX == 3, "two or three groups");
+#if PFX_ONE_SWITCH
+    uint32_t v = lead;                                   // 0 .. PX - 1: that many leading opaque groups
+    if (lead == (uint32_t)PX) {
+        const float tmin = alpha_min<PX>(top);
+        v = (opc >= 1.0f && __all(tmin == 1.0f)) ? 4u : 3u; // 3: every group opaque, 4: and an opaque layer at 100 %
+    }
+    const uint32_t m = mode > 24u ? 0u : mode;           // BlendMode::from_u8 fallback, layers.rs:183
+    switch (v * 32u + m) {
+#define PFX_CASE(M) case 0u * 32u + M: blendN_nx<M, PX, 0>(acc, top, opc, opc); break; \
+                    case 1u * 32u + M: blendN_nx_lead<M, PX, 1>(acc, top, opc, opc); break; \
+                    case 2u * 32u + M: blendN_nx_lead<M, PX, (PX == 3 ? 2 : 1)>(acc, top, opc, opc); break; \
+                    case 3u * 32u + M: blendN_nx<M, PX, 1>(acc, top, opc, opc); break; \
+                    case 4u * 32u + M: blendN_nx<M, PX, 2>(acc, top, opc, opc); break;
+        PFX_CASE(M_NORMAL) PFX_CASE(M_MULTIPLY) PFX_CASE(M_SCREEN) PFX_CASE(M_ADDITIVE) PFX_CASE(M_REFLECT)
+        PFX_CASE(M_GLOW) PFX_CASE(M_COLOR_BURN) PFX_CASE(M_COLOR_DODGE) PFX_CASE(M_OVERLAY) PFX_CASE(M_DIFFERENCE)
+        PFX_CASE(M_NEGATION) PFX_CASE(M_LIGHTEN) PFX_CASE(M_DARKEN) PFX_CASE(M_XOR) PFX_CASE(M_OVERWRITE)
+        PFX_CASE(M_HARD_LIGHT) PFX_CASE(M_SOFT_LIGHT) PFX_CASE(M_EXCLUSION) PFX_CASE(M_SUBTRACT) PFX_CASE(M_DIVIDE)
+        PFX_CASE(M_LINEAR_BURN) PFX_CASE(M_VIVID_LIGHT) PFX_CASE(M_LINEAR_LIGHT) PFX_CASE(M_PIN_LIGHT)
+        PFX_CASE(M_HARD_MIX)
+#undef PFX_CASE
+    default: break;
+    }
+#else
     if (lead == 0u) blend_nx_dispatch<PX, 0>(mode, acc, top, opc, opc);
     else if (lead == (uint32_t)PX) {
         const float tmin = alpha_min<PX>(top);
@@ -472,6 +499,7 @@ PFX_DEV void blend_layer_nx_groups(uint32_t mode, float (&acc)[PX][4], const flo
         else blend_nx_dispatch<PX, 1>(mode, acc, top, opc, opc);
     } else if (PX == 3 && lead == 2u) blend_nx_dispatch_lead<PX, (PX == 3 ? 2 : 1)>(mode, acc, top, opc, opc);
     else blend_nx_dispatch_lead<PX, 1>(mode, acc, top, opc, opc);
+#endif
 }
 // number of leading groups whose accumulators are all opaque (three compares and scalar counting)
 template <int PX>
