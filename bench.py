@@ -87,6 +87,61 @@ def pmc_profile(w: int, h: int, n: int):
         return None
 
 
+def clock_power_sample(torch, step_fn, dev_index, seconds=0.4):
+    """Sustained core clock and socket power WHILE the timed workload runs: the compositor runs at the board's power limit, so the
+    clock it sustains is part of the bound statement.  `step_fn` is repeated back to back for `seconds` after the timed region while a thread
+    reads amdsmi's gpu_metrics (current_gfxclk, current_socket_power; tools/lab/clock_probe.py shows the raw series); the first 40 % of the window
+    (clock still settling) is dropped.  Returns None where amdsmi is not importable or reports nothing."""
+    try:
+        import threading
+        import amdsmi
+        amdsmi.amdsmi_init()
+        hs = amdsmi.amdsmi_get_processor_handles()
+        h0 = hs[dev_index] if dev_index < len(hs) else hs[0]
+        cap = None
+        try:
+            cap = amdsmi.amdsmi_get_power_cap_info(h0).get("power_cap")
+            cap = round(cap / 1e6, 1) if isinstance(cap, (int, float)) and cap > 1e5 else cap
+        except Exception:
+            pass
+        try:
+            clk_max = amdsmi.amdsmi_get_clock_info(h0, amdsmi.AmdSmiClkType.GFX).get("max_clk")
+        except Exception:
+            clk_max = None
+        samples, stop = [], [False]
+
+        def sampler():
+            while not stop[0]:
+                try:
+                    m = amdsmi.amdsmi_get_gpu_metrics_info(h0)
+                    samples.append((time.perf_counter(), m.get("current_gfxclk"), m.get("current_socket_power")))
+                except Exception:
+                    pass
+                time.sleep(0.002)
+
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        t0 = time.perf_counter()
+        n_steps = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                step_fn()
+            torch.cuda.synchronize()
+            n_steps += 20
+        t1 = time.perf_counter()
+        stop[0] = True
+        th.join()
+        use = [(c, p) for (t, c, p) in samples if t0 + 0.4 * (t1 - t0) <= t <= t1 and isinstance(c, (int, float)) and isinstance(p, (int, float))]
+        if not use:
+            return None
+        return {"clock_ghz_sustained": round(sum(c for c, _ in use) / len(use) / 1e3, 3), "clock_ghz_min": round(min(c for c, _ in use) / 1e3, 3),
+                "clock_ghz_max_spec": round(clk_max / 1e3, 3) if isinstance(clk_max, (int, float)) else None,
+                "socket_power_w": round(sum(p for _, p in use) / len(use), 1), "power_cap_w": cap, "samples": len(use),
+                "how": f"amdsmi gpu_metrics every 2 ms over {n_steps} back-to-back steps after the timed region ({(t1 - t0) / n_steps * 1e3:.4f} ms/step there)"}
+    except Exception:
+        return None
+
+
 def usable_cores() -> int:
     """threads the CPU baseline may really use: scheduler affinity, capped by the cgroup CPU quota if there is one"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -501,6 +556,8 @@ def main() -> int:
 
         elapsed, kern = timed(step)
         flat_view = flat
+        if world == 1:
+            state["clock_power"] = clock_power_sample(torch, step, dev_index)
 
     px_per_step = w * h
     docs = 1 if (band_mode or world == 1) else world         # band mode: the whole job is one document per step
@@ -532,7 +589,8 @@ def main() -> int:
                 # per-class issue costs (FMA / MUL / ADD 2 cycles, transcendental 8, compare / select / min / max / trunc / convert 4: tools/lab/
                 # valu_tput.hip) applied to the profiled instruction mix, against THIS run's kernel duration at the profiled clock
                 lo, hi = fl["valu_issue_cycles_weighted"]
-                roofline["valu_frac_weighted_by_issue_cost"] = [round(lo / (1024 * clk * 1e9 * d_ms * 1e-3), 3), round(hi / (1024 * clk * 1e9 * d_ms * 1e-3), 3)]
+                # A MODEL, not a counter: two experiments of round 3 contradicted its price for selects (profiles/r03_tuning.md, r04_tuning.md)
+                roofline["valu_issue_model_frac"] = [round(lo / (1024 * clk * 1e9 * d_ms * 1e-3), 3), round(hi / (1024 * clk * 1e9 * d_ms * 1e-3), 3)]
             # against what the chip's VALU sustains: a pure v_fma_f32 loop (tools/ubench_valu, profiles/rNN_valu_peak.json); a quarter-rate
             # (transcendental) instruction takes four plain instructions' worth of the pipe
             try:
@@ -546,9 +604,12 @@ def main() -> int:
         roofline["per_kernel_bound"] = pmc.get("bounds")
         # traffic / valu_* / per_kernel_bound come from a committed counter pass, not from this run (PMC collection needs rocprofv3 around
         # the process): say so, and which build the pass profiled
-        roofline["static"] = {"fields": ["traffic", "valu_frac", "valu_frac_weighted_by_issue_cost", "valu_insts_per_layer_px", "valu_frac_of_sustained_fma_rate", "per_kernel_bound"],
+        roofline["static"] = {"fields": ["traffic", "valu_frac", "valu_issue_model_frac", "valu_insts_per_layer_px", "valu_frac_of_sustained_fma_rate", "per_kernel_bound"],
                               "profile": pmc.get("_file"), "profiled_commit": pmc.get("commit"), "static": True}
 
+    if state.get("clock_power"):
+        roofline.update({k: state["clock_power"][k] for k in ("clock_ghz_sustained", "socket_power_w", "power_cap_w")})
+        roofline["clock_power"] = state["clock_power"]
     out = {"metric": "Mpixels/sec: 8K 32-layer flatten + Gaussian sigma=16; HBM GB/s vs peak", "value": round(value, 1),
            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,

@@ -366,8 +366,8 @@ int pfx_chunk_populated(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h
  * f32 path, so an in-place call can differ from an out-of-place one by the +-1 LSB of the default (MFMA) mode unless the context is
  * in exact mode.  Every other call that reads a neighbourhood or gathers (median, pixelate, warps, the effect bank) returns
  * PFX_ERR_INVALID when the two images overlap; partially overlapping buffers are always refused. */
-/* pfx_flatten_dev: `dst_dev` may be one of the layers (the result replaces it) but must not partially overlap any; a destination that is distinct
- * from every layer lets deep stacks use it as the parking space of their accumulators (faster: k_flatten.hip, flatten_srt_kernel). */
+/* pfx_flatten_dev: `dst_dev` may be one of the layers (the result replaces it: every pixel is written after its last read) but must not partially
+ * overlap any. */
 int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev /* may be NULL */,
                     const pfx_layer_info* layers, uint32_t n_layers, uint32_t w, uint32_t h, void* dst_dev);
 int pfx_flatten_preview_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void* const* mask_ptrs_dev, const pfx_layer_info* layers,
@@ -464,8 +464,8 @@ int pfx_selftest_division(pfx_ctx* ctx, uint64_t seed, uint32_t n_millions, uint
 int pfx_selftest_round_pack(pfx_ctx* ctx, uint64_t* mismatches, uint64_t* signalling_nan_mismatches);
 
 /* device self-test: the texture path's conversions the compositor relies on — a typed UNORM8 buffer store of RN(k / 255) writes the byte k and a
- * typed load of the byte k returns RN(k / 255), for all 256 k on every channel; *mismatches must come back 0 (the class-sorting compositor, which parks
- * accumulators in the destination image that way, is only used on a device where it does: checked once per context). */
+ * typed load of the byte k returns RN(k / 255), for all 256 k on every channel; *mismatches must come back 0 (the class-sorting compositor, which writes its
+ * result that way, is only used on a device where it does: checked once per context). */
 int pfx_selftest_unorm_store(pfx_ctx* ctx, uint64_t* mismatches);
 
 /* development tuning knobs (kernel tile configurations); unknown keys return PFX_ERR_INVALID.  Results never change.  The knobs that select among

@@ -736,26 +736,23 @@ PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
     }
 }
 
-// ---- class sorting inside a unit: accumulators parked in the destination image, a unit's pixels grouped by accumulator class (round 4) ----
-// The blend of a layer pixel over an OPAQUE accumulator costs about 60 % of the general one (out_a == 1: no division, no base-alpha
-// products, no alpha re-quantisation, no select for a transparent layer pixel: k_blend.h, OB = 1), but the specialisation only runs when all the
-// accumulators a wave holds are opaque.  On per-pixel-random alpha (BASELINE's S2) that never happens above the reset layer although 30 .. 90 % of
-// the pixels are opaque there.  This kernel is flatten_dle_kernel with two changes:
-//   * in front of some layers of a unit's natural pass (srt_layers) the unit's pixels are re-dealt to the lanes so that opaque accumulators
-//     fill whole 64-pixel groups first (a stable partition: ballot + mbcnt ranks; accumulators and pixel offsets move through a 3.75 KB LDS tile as
-//     16-byte and 4-byte items, no arithmetic), and blend_layer_nx_groups' per-group class test then finds wave-uniform opaque groups.  Lane l, group j
-//     afterwards holds SOME pixel of the same 64 PX-pixel unit: the wave's loads touch the same cache lines in another lane order, which the texture
-//     path serves at 98 % of the lane-order rate (tools/lab/perm_load.hip: 4.62 against 4.72 TB/s; gathering across 4 units instead: 2.55 — what
-//     made a FIFO-per-class version of this kernel, with twice the HBM traffic, slower than round 3's).  A re-deal only happens when it completes
-//     another group (the attempt costs three compares and scalar counting); opaque accumulators stay opaque, so at most PX re-deals per unit.
-//     Xor / Overwrite above only make the per-group test fail again: the grouping is a performance hint, never a correctness condition;
-//   * an accumulator that leaves the registers (an early pixel between its compacted round and its unit's natural pass) is parked IN THE
-//     DESTINATION IMAGE at its own pixel — RGBA8 is the reference's accumulator type (canvas_state.rs:573) — with a typed buffer store (float ->
-//     UNORM8 in the texture path) and comes back with a typed load: no pack / unpack arithmetic, no LDS ring, and the result is written the same
-//     way.  Store -> load of one address by one wave is ordered by the memory pipeline like any spill.  A pixel whose accumulator does not matter
-//     (its reset layer is still ahead) loads whatever the destination holds: UNORM8 loads are finite values in [0, 1], the reset layer replaces them.
-// Requires: dst overlaps no layer (the launcher checks; otherwise flatten_dle_kernel runs), and the device's float -> UNORM8 store conversion
-// returns k for RN(k / 255) (pfxk_unorm_store_check, verified once per context).
+// ---- class sorting inside a unit (round 4) -------------------------------------------------------------------------------------------------------
+// Two per-pixel properties decide how much a layer costs a pixel: whether the layer is dead for it (below its topmost reset layer: dead-layer
+// elimination, above) and whether its accumulator is opaque (out_a == 1: no division, no base-alpha products, no alpha re-quantisation, no select for
+// a transparent layer pixel — about 60 % of the general blend: k_blend.h, OB = 1).  Both only pay when a whole 64-lane group agrees, and on per-pixel-random
+// alpha (BASELINE's S2) no group of consecutive pixels ever does.  This kernel re-deals the pixels of ONE unit (64 PX consecutive pixels) to the lanes so
+// that groups agree — a stable partition by ballot + mbcnt ranks; accumulators and pixel offsets move through a 3.75 KB LDS tile as 16-byte and 4-byte
+// items, no arithmetic.  Lane l, group j then holds SOME pixel of the unit: the wave's loads touch the same cache lines in another lane order, which
+// the texture path serves at 98 % of the lane-order rate (tools/lab/perm_load.hip: 4.62 against 4.72 TB/s), whereas gathering across four units — what
+// round 3's FIFO of early pixels does, and what a FIFO-per-class version of this kernel did with twice the HBM traffic — runs at 2.55 TB/s.
+//   * early pixels first: a unit whose pixels disagree about their reset layer is dealt with the EARLY pixels (reset below the split layer r) in the
+//     leading group(s); layers [start, r) then run on those groups alone (one group at a time through the one-pixel-per-lane layer loop), the other
+//     groups' pixels start at r from (0,0,0,0) as before.  No queue across units, no parked accumulators, no partially filled rounds;
+//   * opaque accumulators first: in front of layers s1, s1 + seg, ... of the natural pass (srt_layers) the unit is re-dealt when that completes
+//     another wave-uniform opaque group; opaque accumulators stay opaque under every mode but Xor and Overwrite, so at most PX re-deals per unit.
+// Every decision is a performance hint: a pixel runs each of its layers exactly once, in order, with arithmetic chosen by a per-group test of the
+// actual accumulators.  The result leaves through a typed buffer store (float -> UNORM8 in the texture path, verified once per context by
+// pfxk_unorm_store_check): no pack arithmetic.
 struct dle_plan { uint32_t s1, seg; }; // re-deal attempts in front of layers s1, s1 + seg, s1 + 2 seg, ... (seg == 0: none)
 
 template <int PX, int NB = 2>
@@ -763,10 +760,8 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
                                                                          uint8_t* __restrict__ dst, const pfxk_dle_cands C, const dle_sched SC,
                                                                          const dle_plan P)
 {
-    constexpr uint32_t UPX = 64u * PX, QCAP = PX == 2 ? 256u : 512u, NREC = 16u;
-    __shared__ uint16_t s_q[QCAP];          // FIFO of early pixels (offset from the wave's first pixel)
-    __shared__ uint32_t s_rec[NREC][2];     // per unit in flight: {first layer of its natural pass, queue tail after its append (0: no early pixels)}
-    __shared__ float4 s_x[UPX];             // re-deal tile: accumulators ...
+    constexpr uint32_t UPX = 64u * PX;
+    __shared__ float4 s_x[UPX];             // re-deal tile: accumulators (or the layer in flight) ...
     __shared__ uint32_t s_v[UPX];           // ... and pixel byte offsets, at their new slots
     soft_d_fill(threadIdx.x, 64u);
     __syncthreads();
@@ -782,147 +777,111 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
     const uint32_t base_px = u0 * UPX;
     const uint32_t bytes = n_px * 4u;
     const pfx_v4i rs_acc = make_rsrc(dst, bytes, PFX_RSRC_UNORM8X4);
-    uint16_t* const q = s_q;
-    uint32_t (*const rec)[2] = s_rec;
-
-    uint32_t cls_next = 0, nat_next = 0;          // units classified / finished so far (relative to u0)
-    uint32_t q_head = 0, q_tail = 0;              // monotone counters; entry k lives at q[k % QCAP]
-    uint32_t q_r = 0, q_start = 0;                // layers [q_start, q_r) are what the queued pixels still need
-    uint32_t st_rounds = 0, st_rpx = 0, st_rlay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_moves = 0;
-    uint32_t probe_fail = 0, skip_left = 0;
     const uint32_t s1 = P.seg != 0u ? P.s1 : 0xFFFFFFFFu;
-    for (;;) {
+    uint32_t st_egroups = 0, st_elay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_moves = 0;
+    uint32_t probe_fail = 0, skip_left = 0;      // classification back-off (flatten_dle_kernel)
+    for (uint32_t u = 0; u < nu; ++u) {
         int voff[PX];
         float acc[PX][4];
-        uint32_t lb, le;
-        bool run_queue = false;
-        {
-            const uint32_t q_cnt = q_tail - q_head;
-            bool run_nat = false, nat_split = false;
-            uint32_t nat_start = 0;
-            run_queue = q_cnt >= UPX;
-            if (!run_queue && nat_next < cls_next) {
-                const uint32_t slot = nat_next % NREC;
-                const uint32_t need = __builtin_amdgcn_readfirstlane(rec[slot][1]);
-                if (need <= q_head) { run_nat = true; nat_split = need != 0u; nat_start = __builtin_amdgcn_readfirstlane(rec[slot][0]); }
-            }
-            if (!run_queue && !run_nat) {
-                if (cls_next < nu && cls_next - nat_next < NREC) {
-                    // ---- classify unit cls_next (flatten_dle_kernel's rules) ----
-                    const uint32_t u = cls_next;
-                    const uint32_t o0 = u * UPX + lane;
-                    uint32_t cls[PX];
 #pragma unroll
-                    for (int j = 0; j < PX; ++j) cls[j] = 0u;
-                    const bool probe = skip_left == 0u;
-                    if (!probe) skip_left -= 1u;
-                    bool done = !probe;
+        for (int j = 0; j < PX; ++j) {
+            voff[j] = (int)((base_px + u * UPX + 64u * j + lane) * 4u);
+            acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;    // :573
+        }
+        // ---- classify: each pixel's topmost reset candidate (flatten_dle_kernel's rules) ----
+        uint32_t cls[PX];
 #pragma unroll
-                    for (int i = 3; i >= 0; --i) {
-                        if ((uint32_t)i < C.n && !done) {
-                            const pfx_v4i ra = make_rsrc(layers[C.layer[i]].pixels, bytes, PFX_RSRC_ALPHA8);
-                            bool all_found = true;
+        for (int j = 0; j < PX; ++j) cls[j] = 0u;
+        const bool probe = skip_left == 0u;
+        if (!probe) skip_left -= 1u;
+        bool done = !probe;
 #pragma unroll
-                            for (int j = 0; j < PX; ++j) {
-                                const float a = pfx_buffer_load_format_f32(ra, (int)((base_px + o0 + 64u * j) * 4u), 0, 0);
-                                const bool hit = C.kind[i] ? (a == 1.0f) : (a != 0.0f);
-                                cls[j] = (cls[j] == 0u && hit) ? (uint32_t)(i + 1) : cls[j];
-                                all_found = all_found && cls[j] != 0u;
-                            }
-                            done = __all(all_found);
-                            st_reads += 1u;
-                        }
-                    }
-                    uint32_t cn[5] = {UPX, 0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (int i = 1; i <= 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < PX; ++j) cn[i] += (uint32_t)__popcll(__ballot(cls[j] >= (uint32_t)i));
-                    uint32_t cmin = 0;
-#pragma unroll
-                    for (int i = 1; i <= 4; ++i) if (cn[i] == UPX) cmin = (uint32_t)i;
-                    const uint32_t lay[5] = {0u, C.layer[0], C.layer[1], C.layer[2], C.layer[3]};
-                    uint32_t s_u = 0;
-#pragma unroll
-                    for (int i = 1; i <= 4; ++i) if (cmin == (uint32_t)i) s_u = lay[i];
-                    uint32_t best = 0, best_sav = 0, r = s_u;
-#pragma unroll
-                    for (int i = 1; i <= 4; ++i) {
-                        if ((uint32_t)i > cmin && (uint32_t)i <= C.n && cn[i] * 10u >= UPX * 3u) {
-                            const uint32_t sav = cn[i] * (lay[i] - s_u);
-                            if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; }
-                        }
-                    }
-                    if (best != 0u && q_cnt != 0u && q_r != r) { best = 0u; r = s_u; } // one split layer in the queue at a time
-                    if (probe) {
-                        if (best != 0u || s_u != 0u) probe_fail = 0u;
-                        else if (++probe_fail >= 2u) { probe_fail = 0u; skip_left = 14u; }
-                    }
-                    if (best != 0u) {
-                        st_cunits += 1u;
-                        if (q_cnt == 0u) q_start = s_u; else q_start = min(q_start, s_u);
-                        q_r = r;
-#pragma unroll
-                        for (int j = 0; j < PX; ++j) {
-                            const bool early = cls[j] < best;
-                            const uint64_t m = __ballot(early);
-                            const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (early) q[(q_tail + pre) % QCAP] = (uint16_t)(o0 + 64u * j);
-                            q_tail += (uint32_t)__popcll(m);
-                        }
-                    }
-                    if (lane == 0) { rec[u % NREC][0] = r; rec[u % NREC][1] = best != 0u ? q_tail : 0u; }
-                    wave_lds_sync();
-                    cls_next = u + 1u;
-                    continue;
-                }
-                if (q_cnt == 0u) {                    // everything classified, run and stored
-                    if (lane == 0 && (C.stats & 1u)) {
-                        atomicAdd(&g_dle_stats[0], st_rounds); atomicAdd(&g_dle_stats[1], st_rpx); atomicAdd(&g_dle_stats[2], st_rlay);
-                        atomicAdd(&g_dle_stats[3], nat_next); atomicAdd(&g_dle_stats[4], st_nlay); atomicAdd(&g_dle_stats[5], st_reads);
-                        atomicAdd(&g_dle_stats[6], st_cunits); atomicAdd(&g_dle_stats[7], st_moves);
-                    }
-                    break;
-                }
-                run_queue = true;                     // flush a partial round: the window is full or the stream has ended
-            }
-            if (run_queue) {
-                const uint32_t m = min(q_cnt, UPX);
+        for (int i = 3; i >= 0; --i) {
+            if ((uint32_t)i < C.n && !done) {
+                const pfx_v4i ra = make_rsrc(layers[C.layer[i]].pixels, bytes, PFX_RSRC_ALPHA8);
+                bool all_found = true;
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
-                    const uint32_t k = 64u * j + lane;
-                    const uint32_t o = (uint32_t)q[(q_head + k) % QCAP];
-                    voff[j] = k < m ? (int)((base_px + o) * 4u) : (int)bytes; // past the end: loads return (0,0,0,0) = transparent, stores are dropped
-                    acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
+                    const float a = pfx_buffer_load_format_f32(ra, voff[j], 0, 0);
+                    const bool hit = C.kind[i] ? (a == 1.0f) : (a != 0.0f);
+                    cls[j] = (cls[j] == 0u && hit) ? (uint32_t)(i + 1) : cls[j];
+                    all_found = all_found && cls[j] != 0u;
                 }
-                lb = q_start; le = q_r;
-                q_head += m;
-                st_rounds += 1u; st_rpx += m; st_rlay += le - lb;
-            } else {
-                const uint32_t o0 = nat_next * UPX + lane;
-#pragma unroll
-                for (int j = 0; j < PX; ++j) voff[j] = (int)((base_px + o0 + 64u * j) * 4u);
-                if (nat_split) {                      // early pixels come back from the destination (the others' values do not matter)
-#pragma unroll
-                    for (int j = 0; j < PX; ++j) {
-                        const pfx_v4f v = pfx_buffer_load_format_v4f32(rs_acc, voff[j], 0, 0);
-                        acc[j][0] = v.x; acc[j][1] = v.y; acc[j][2] = v.z; acc[j][3] = v.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < PX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; // :573
-                }
-                lb = nat_start; le = n_layers;
-                st_nlay += le - lb;
-                nat_next += 1u;
+                done = __all(all_found);
+                st_reads += 1u;
             }
         }
-        srt_layers<PX>(acc, layers, lb, le, bytes, voff, s1, P.seg, s_x, s_v, st_moves, (C.stats & 2u) != 0u);
+        uint32_t cn[5] = {UPX, 0u, 0u, 0u, 0u};  // cn[i] = pixels of the unit whose reset class is >= i
+#pragma unroll
+        for (int i = 1; i <= 4; ++i)
+#pragma unroll
+            for (int j = 0; j < PX; ++j) cn[i] += (uint32_t)__popcll(__ballot(cls[j] >= (uint32_t)i));
+        uint32_t cmin = 0;
+#pragma unroll
+        for (int i = 1; i <= 4; ++i) if (cn[i] == UPX) cmin = (uint32_t)i;
+        const uint32_t lay[5] = {0u, C.layer[0], C.layer[1], C.layer[2], C.layer[3]};
+        uint32_t s_u = 0;
+#pragma unroll
+        for (int i = 1; i <= 4; ++i) if (cmin == (uint32_t)i) s_u = lay[i];
+        // split class: the candidate whose early pixels (class below it) fit the fewest groups for the most layers
+        uint32_t best = 0, best_sav = 0, r = s_u, eg = 0;
+#pragma unroll
+        for (int i = 1; i <= 4; ++i) {
+            if ((uint32_t)i > cmin && (uint32_t)i <= C.n) {
+                const uint32_t g = (UPX - cn[i] + 63u) / 64u;          // groups the early pixels of this split need
+                const uint32_t sav = ((uint32_t)PX - g) * (lay[i] - s_u);
+                if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; eg = g; }
+            }
+        }
+        if (probe) {
+            if (best != 0u || s_u != 0u) probe_fail = 0u;
+            else if (++probe_fail >= 2u) { probe_fail = 0u; skip_left = 14u; }
+        }
+        if (best != 0u) {
+            // ---- early pixels to the leading groups (the accumulators are all (0,0,0,0): only the offsets move), then their layers [s_u, r) ----
+            st_cunits += 1u;
+            uint32_t pre_e = 0u, pre_l = UPX - cn[best];
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const bool early = cls[j] < best;
+                const uint64_t m = __ballot(early);
+                const uint32_t rank_e = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t c = (uint32_t)__popcll(m);
+                s_v[early ? pre_e + rank_e : pre_l + (lane - rank_e)] = (uint32_t)voff[j];
+                pre_e += c; pre_l += 64u - c;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < PX; ++j) voff[j] = (int)s_v[64u * j + lane];
+            wave_lds_sync();
+            for (uint32_t g = 0; g < eg; ++g) {       // eg < PX: one group at a time through the one-pixel-per-lane loop (one call site)
+                int v1[1];
+                float a1[1][4] = {{0.0f, 0.0f, 0.0f, 0.0f}};
+                v1[0] = voff[0];
+#pragma unroll
+                for (int j = 1; j < PX; ++j) v1[0] = g == (uint32_t)j ? voff[j] : v1[0];
+                dle_layers<1, 2, 0>(a1, layers, s_u, r, bytes, v1, (C.stats & 2u) != 0u);
+#pragma unroll
+                for (int j = 0; j < PX; ++j)
+                    if (g == (uint32_t)j) { acc[j][0] = a1[0][0]; acc[j][1] = a1[0][1]; acc[j][2] = a1[0][2]; acc[j][3] = a1[0][3]; }
+            }
+            st_egroups += eg; st_elay += eg * (r - s_u);
+        }
+        // ---- natural pass: every group from r on, re-dealt by accumulator class on the way ----
+        st_nlay += n_layers - r;
+        srt_layers<PX>(acc, layers, r, n_layers, bytes, voff, s1, P.seg, s_x, s_v, st_moves, (C.stats & 2u) != 0u);
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             pfx_v4f v; v.x = acc[j][0]; v.y = acc[j][1]; v.z = acc[j][2]; v.w = acc[j][3];
-            pfx_buffer_store_format_v4f32(v, rs_acc, voff[j], 0, 0);   // parks an early pixel's accumulator, or is the result
+            pfx_buffer_store_format_v4f32(v, rs_acc, voff[j], 0, 0);
         }
+    }
+    if (lane == 0 && (C.stats & 1u)) {
+        // [0] early groups run, [1] pixels in them (64 each), [2] layers x early groups, [3] units, [4] layers x units of the natural passes,
+        // [5] candidate alpha reads (units), [6] units that split, [7] re-deals by accumulator class
+        atomicAdd(&g_dle_stats[0], st_egroups); atomicAdd(&g_dle_stats[1], st_egroups * 64u); atomicAdd(&g_dle_stats[2], st_elay);
+        atomicAdd(&g_dle_stats[3], nu); atomicAdd(&g_dle_stats[4], st_nlay); atomicAdd(&g_dle_stats[5], st_reads);
+        atomicAdd(&g_dle_stats[6], st_cunits); atomicAdd(&g_dle_stats[7], st_moves);
     }
 }
 
@@ -1189,7 +1148,7 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                                    const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
                                    int chunk_active_ready, uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region,
-                                   const pfxk_dle_cands* cands, const uint8_t* d_chunk_start, int dst_parking_ok)
+                                   const pfxk_dle_cands* cands, const uint8_t* d_chunk_start, int typed_store_ok)
 {
     size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
@@ -1222,7 +1181,7 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
         if (cands && cands->n > 0 && flatten_variant != 8) {
             // dle_cfg: 0 = 3 pixels per lane, 2 register sets (6 waves per SIMD; measured best), 1 = 2 pixels per lane, 2 = 3 pixels per lane, 3 sets (old kernel only);
             // dle_sched 0 = equal streams of dle_units
-            const bool srt_kernel = g_dle_kernel == 0 && dst_parking_ok;
+            const bool srt_kernel = g_dle_kernel == 0 && typed_store_ok;
             const uint32_t px = dle_cfg == 1 ? 2u : 3u;
             const uint32_t upx = 64u * px;
             const uint32_t units = (uint32_t)((n_px + upx - 1) / upx);

@@ -327,16 +327,11 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
         }
         if (ctx->chunk_state != 3) d_chunk_start = (const uint8_t*)ctx->d_chunk_start.p; // pending or useful: the table of THIS stack is in the buffer
     }
-    // The class-sorting compositor parks accumulators in the destination between its passes (k_flatten.hip: flatten_srt_kernel): the destination
-    // must not overlap a layer it still has to read, and the device's float -> UNORM8 store conversion must round-trip RN(k / 255) (checked once
-    // per context on the device itself).  Otherwise the round-3 kernel, which keeps them in LDS, runs.
+    // The class-sorting compositor (k_flatten.hip: flatten_srt_kernel) writes its result with typed UNORM8 buffer stores: the device's float -> UNORM8
+    // conversion must return k for RN(k / 255), which is checked once per context on the device itself.  Otherwise round 3's kernel runs.
     int parking_ok = 0;
     if (cands.n > 0 && !general && fast_div && !region && !PV.pixels) {
-        parking_ok = 1;
-        const pfxk_layer_desc* hd = (const pfxk_layer_desc*)ctx->desc_cache.data();
-        for (uint32_t k = 0; k < n_desc && parking_ok; ++k)
-            if (hd[k].pixels && ranges_overlap(hd[k].pixels, dst_dev, img_bytes(w, h))) parking_ok = 0;
-        if (parking_ok && ctx->unorm_store_ok < 0) {
+        if (ctx->unorm_store_ok < 0) {
             PFX_TRY(pfx_reserve(ctx, ctx->d_misc, 2048));
             PFX_HIP(ctx, hipMemsetAsync(ctx->d_misc.p, 0, 2048, ctx->stream));
             PFX_HIP(ctx, pfxk_unorm_store_check(ctx->stream, (uint8_t*)ctx->d_misc.p, (unsigned long long*)((uint8_t*)ctx->d_misc.p + 1024)));
@@ -345,7 +340,7 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
             PFX_TRY(pfx_sync(ctx)); // once per context
             ctx->unorm_store_ok = bad == 0 ? 1 : 0;
         }
-        if (parking_ok && ctx->unorm_store_ok != 1) parking_ok = 0;
+        parking_ok = ctx->unorm_store_ok == 1;
     }
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,

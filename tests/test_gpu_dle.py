@@ -51,9 +51,9 @@ def blocky_alpha(rng, h, w, cell, p_zero, p_opaque):
     return np.kron(coarse, np.ones((cell, cell), np.uint8))[:h, :w]
 
 
-# (dle_kernel, dle_cfg, dle_sched, dle_s1, dle_s2): kernel 0 = class sorting (flatten_srt_kernel: early pixels' accumulators parked in the destination,
-# a unit's pixels re-dealt to the lanes by "accumulator opaque?" between segments of its natural pass), 1 = round 3's kernel (accumulators parked in an
-# LDS ring, lane order throughout).  dle_s1: the first re-deal attempt, in layers above the topmost candidate (-1 = 1, 0 = never); dle_s2: layers between
+# (dle_kernel, dle_cfg, dle_sched, dle_s1, dle_s2): kernel 0 = class sorting (flatten_srt_kernel: a unit's pixels re-dealt to the lanes — early pixels first
+# for the layers below the split, then by "accumulator opaque?" along its natural pass), 1 = round 3's kernel (early pixels queued across units, accumulators
+# parked in an LDS ring, lane order throughout).  dle_s1: the first re-deal attempt, in layers above the topmost candidate (-1 = 1, 0 = never); dle_s2: layers between
 # attempts (-1 = 3, 0 = only the first).
 CONFIGS = {
     "srt-px3-default": (0, 0, 1, -1, -1),
@@ -339,9 +339,9 @@ def test_opaque_bottom_without_early_pixels_and_all_early_pixels(gpu):
     check(gpu, stack, modes, opac, "reset layer covering the left half")
 
 
-def test_destination_that_aliases_a_layer_takes_the_ring_kernel(gpu):
-    """the class-sorting kernel parks accumulators in the destination; a destination that IS one of the layers must not be used that way (the library
-    falls back to the kernel that parks in LDS): compositing in place over layer 9 still equals the oracle"""
+def test_destination_that_aliases_a_layer(gpu):
+    """pfx_flatten_dev allows the destination to BE one of the layers (include/pfx.h): every pixel is written after its last read, whichever kernel
+    runs; compositing in place over layer 9 equals the oracle"""
     rng = np.random.default_rng(5)
     w, h, n = 384, 96, 18
     stack, modes, opac = class_stack(rng, w, h, n, 6, 0.3, {})

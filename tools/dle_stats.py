@@ -26,8 +26,9 @@ for _ in range(50): r.flatten_dev(ptrs, info, w, h, flat.data_ptr())
 torch.cuda.synchronize(); r.timing_enable(False)
 ms = r.timing_read("flatten")[0] / 50
 units = (w * h + 191) // 192
-st["layer_units_run"] = st["round_layers"] + st["nat_layers"]
+kernel0 = not any(a == "dle_kernel=1" for a in sys.argv[1:])   # class-sorting kernel: "rounds" are early GROUPS (a third of a unit each)
+st["layer_units_run"] = (st["round_layers"] / 3 if kernel0 else st["round_layers"]) + st["nat_layers"]
 st["layer_units_full"] = units * n
 st["work_fraction"] = round(st["layer_units_run"] / st["layer_units_full"], 4)
-st["round_fill"] = round(st["round_px"] / max(st["rounds"] * 192, 1), 4)
+st["round_fill"] = round(st["round_px"] / max(st["rounds"] * (64 if kernel0 else 192), 1), 4)
 print(json.dumps({"args": sys.argv[1:], "flatten_ms": round(ms, 4), **st}))
