@@ -239,6 +239,18 @@ PFX_DEV pfx_v4i make_rsrc(const void* base, uint32_t bytes, uint32_t word3)
     return r;
 }
 
+// the same for a pointer that is known to be a canonical device address (bits 48 .. 63 clear: word 1's stride / swizzle fields stay zero without the mask)
+PFX_DEV pfx_v4i make_rsrc_canonical(const void* base, uint32_t bytes, uint32_t word3)
+{
+    const uint64_t a = (uint64_t)base;
+    pfx_v4i r;
+    r.x = (int)(uint32_t)a;
+    r.y = (int)(uint32_t)(a >> 32);
+    r.z = (int)bytes;
+    r.w = (int)word3;
+    return r;
+}
+
 template <int PX>
 PFX_DEV void stream_fetch(float (&t)[PX][4], const uint8_t* pixels, uint32_t bytes, int voff)
 {
@@ -641,37 +653,41 @@ PFX_DEV void stream_layer_groups(float (&acc)[PX][4], const float (&t)[PX][4], u
 // dle_layers for the class-sorting kernel (two register sets): blends layers [lb, le) and, in front of layers s1, s1 + seg, ..., re-deals the unit's
 // pixels to the lanes when that completes another wave-uniform opaque group.  A re-deal moves the accumulators, the pixel offsets and the one layer
 // that is already in flight (requested with the old offsets) through the LDS tile; the next request uses the new offsets.
-template <int PX>
+// Scalar work per layer is kept short — the CU's one scalar unit serves all 24 waves, and round 4's counters show it more than half busy: the descriptor
+// pointer advances instead of being indexed, nothing clamps it (the host appends two copies of the last descriptor: pfx_api.cpp:build_stack; what is
+// fetched through them or beyond `le` is never blended), the whole 32-byte descriptor comes with one scalar load, the resource needs no mask.
+// NOBLEND (diagnostic, pfx_tune "dle_stats" = 2): the load stream without the arithmetic — results are garbage.
+template <int PX, bool NOBLEND = false>
 PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__ layers, uint32_t lb, uint32_t le, uint32_t bytes, int (&voff)[PX],
-                        uint32_t s1, uint32_t seg, float4* s_x, uint32_t* s_v, uint32_t& st_moves, bool noblend)
+                        uint32_t s1, uint32_t seg, float4* s_x, uint32_t* s_v, uint32_t& st_moves)
 {
     float t[2][PX][4];
     uint32_t m[2], o[2];
-    const uint32_t last = le - 1u;
-    const uint8_t* npx = layers[lb].pixels;
-    uint32_t nmode = layers[lb].mode;
-    uint32_t nop = layers[lb].adj_off; // raster layers: bits of the clamped opacity (pfx_kernels.h)
+    const pfxk_layer_desc* nptr = layers + lb;
+    pfxk_layer_desc nd = *nptr;    // raster layers: adj_off = bits of the clamped opacity (pfx_kernels.h)
     uint32_t next_attempt = lb < s1 ? s1 : lb + 1u;
     uint32_t lead = 0u;            // leading groups known to be opaque wave-wide
     bool recount = true;           // ... to be re-taken in front of the next blend (start of the pass; behind Xor / Overwrite, which can lower alpha)
-    auto fetch = [&](auto SET, uint32_t K) {
+    auto fetch = [&](auto SET) {
         constexpr int S = decltype(SET)::value;
-        m[S] = nmode; o[S] = nop;
-        const pfx_v4i rs = make_rsrc(npx, bytes, PFX_RSRC_UNORM8X4);
+        m[S] = nd.mode; o[S] = nd.adj_off;
+        const pfx_v4i rs = make_rsrc_canonical(nd.pixels, bytes, PFX_RSRC_UNORM8X4);
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             const pfx_v4f v = pfx_buffer_load_format_v4f32(rs, voff[j], 0, 0);
             t[S][j][0] = v.x; t[S][j][1] = v.y; t[S][j][2] = v.z; t[S][j][3] = v.w;
         }
-        const uint32_t kn = (K + 1u < last) ? K + 1u : last;
-        npx = layers[kn].pixels; nmode = layers[kn].mode; nop = layers[kn].adj_off;
+        nptr += 1;
+        nd = *nptr;
     };
     auto blend = [&](auto SET, uint32_t K) {
         constexpr int S = decltype(SET)::value;
         if (K < le) {
-            if (noblend) { // diagnostic (pfx_tune "dle_stats" = 2): the load stream without the arithmetic — results are garbage
+            if constexpr (NOBLEND) {
 #pragma unroll
                 for (int j = 0; j < PX; ++j) { acc[j][0] += t[S][j][0]; acc[j][1] += t[S][j][1]; acc[j][2] += t[S][j][2]; acc[j][3] = t[S][j][3]; }
+            } else if constexpr (PX == 1) {
+                stream_layer<1>(acc, t[S], m[S], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(o[S])));
             } else {
                 if (recount) { lead = count_lead<PX>(acc); recount = false; }
                 stream_layer_groups<PX>(acc, t[S], m[S], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(o[S])), lead);
@@ -684,6 +700,7 @@ PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
 #if !PFX_SRT_REDEAL
         return;
 #endif
+        if constexpr (PX == 1 || NOBLEND) return;
         if (K != next_attempt || K >= le) return;
         next_attempt = K + seg;
         uint64_t mo[PX];
@@ -729,10 +746,10 @@ PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
         wave_lds_sync();
         st_moves += 1u;
     };
-    fetch(std::integral_constant<int, 0>{}, lb);
+    fetch(std::integral_constant<int, 0>{});
     for (uint32_t li = lb; li < le; li += 2) {
-        fetch(std::integral_constant<int, 1>{}, li + 1); blend(std::integral_constant<int, 0>{}, li); redeal(std::integral_constant<int, 1>{}, li + 1);
-        fetch(std::integral_constant<int, 0>{}, li + 2); blend(std::integral_constant<int, 1>{}, li + 1); redeal(std::integral_constant<int, 0>{}, li + 2);
+        fetch(std::integral_constant<int, 1>{}); blend(std::integral_constant<int, 0>{}, li); redeal(std::integral_constant<int, 1>{}, li + 1);
+        fetch(std::integral_constant<int, 0>{}); blend(std::integral_constant<int, 1>{}, li + 1); redeal(std::integral_constant<int, 0>{}, li + 2);
     }
 }
 
@@ -755,7 +772,7 @@ PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
 // pfxk_unorm_store_check): no pack arithmetic.
 struct dle_plan { uint32_t s1, seg; }; // re-deal attempts in front of layers s1, s1 + seg, s1 + 2 seg, ... (seg == 0: none)
 
-template <int PX, int NB = 2>
+template <int PX, bool NOBLEND = false>
 __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers, uint32_t n_px,
                                                                          uint8_t* __restrict__ dst, const pfxk_dle_cands C, const dle_sched SC,
                                                                          const dle_plan P)
@@ -860,7 +877,8 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
                 v1[0] = voff[0];
 #pragma unroll
                 for (int j = 1; j < PX; ++j) v1[0] = g == (uint32_t)j ? voff[j] : v1[0];
-                dle_layers<1, 2, 0>(a1, layers, s_u, r, bytes, v1, (C.stats & 2u) != 0u);
+                uint32_t none = 0u;
+                srt_layers<1, NOBLEND>(a1, layers, s_u, r, bytes, v1, 0xFFFFFFFFu, 0u, s_x, s_v, none);
 #pragma unroll
                 for (int j = 0; j < PX; ++j)
                     if (g == (uint32_t)j) { acc[j][0] = a1[0][0]; acc[j][1] = a1[0][1]; acc[j][2] = a1[0][2]; acc[j][3] = a1[0][3]; }
@@ -869,7 +887,7 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
         }
         // ---- natural pass: every group from r on, re-dealt by accumulator class on the way ----
         st_nlay += n_layers - r;
-        srt_layers<PX>(acc, layers, r, n_layers, bytes, voff, s1, P.seg, s_x, s_v, st_moves, (C.stats & 2u) != 0u);
+        srt_layers<PX, NOBLEND>(acc, layers, r, n_layers, bytes, voff, s1, P.seg, s_x, s_v, st_moves);
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             pfx_v4f v; v.x = acc[j][0]; v.y = acc[j][1]; v.z = acc[j][2]; v.w = acc[j][3];
@@ -1212,8 +1230,9 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
                 P.seg = o2 < 0 ? 3u : (o2 == 0 ? 1000u : (uint32_t)o2);   // 0: a single attempt
                 if (o1 == 0) P.seg = 0u;                                   // no attempts at all: round 3's natural pass + parking in the destination
 #define PFX_ARGS <<<waves, 64, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, SC, P)
-                if (dle_cfg == 1) flatten_srt_kernel<2, 2> PFX_ARGS;
-                else flatten_srt_kernel<3, 2> PFX_ARGS;
+                if (C.stats & 2u) flatten_srt_kernel<3, true> PFX_ARGS;      // diagnostic: the load stream without the arithmetic
+                else if (dle_cfg == 1) flatten_srt_kernel<2> PFX_ARGS;
+                else flatten_srt_kernel<3> PFX_ARGS;
 #undef PFX_ARGS
                 return hipGetLastError();
             }

@@ -237,6 +237,9 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
             cands->n++;
         }
     }
+    // two copies of the last descriptor behind the stack: the class-sorting compositor requests a layer's descriptor two stages ahead without clamping
+    // the index (k_flatten.hip: srt_layers; what it fetches through them is never blended)
+    if (!desc.empty()) { desc.push_back(desc.back()); desc.push_back(desc.back()); }
     // the tables only travel when they differ from what the device already holds (a render loop re-composites the same stack: the
     // small pageable-memory copy in front of every launch was a ~10 us bubble on the stream)
     const size_t desc_bytes = desc.size() * sizeof(pfxk_layer_desc), adj_bytes = adj.size() * sizeof(float);
