@@ -45,11 +45,22 @@ bool ranges_overlap(const void* a, const void* b, size_t bytes)
     const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
     return x < y + bytes && y < x + bytes;
 }
+bool ranges_overlap2(const void* a, size_t a_bytes, const void* b, size_t b_bytes)
+{
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return x < y + b_bytes && y < x + a_bytes;
+}
 int check_disjoint(pfx_ctx* ctx, const void* src, const void* dst, uint32_t w, uint32_t h, const char* who, bool same_ok = false)
 {
     if (src == dst) return same_ok ? PFX_OK : pfx_fail(ctx, PFX_ERR_INVALID, "%s: src and dst must be different buffers", who);
     if (ranges_overlap(src, dst, (size_t)w * h * 4))
         return pfx_fail(ctx, PFX_ERR_INVALID, "%s: src and dst overlap", who);
+    return PFX_OK;
+}
+// the same for a source whose extent differs from the destination's (the warps sample an sw x sh image into a w x h one)
+int check_disjoint2(pfx_ctx* ctx, const void* src, uint32_t sw, uint32_t sh, const void* dst, uint32_t w, uint32_t h, const char* who)
+{
+    if (ranges_overlap2(src, (size_t)sw * sh * 4, dst, (size_t)w * h * 4)) return pfx_fail(ctx, PFX_ERR_INVALID, "%s: src and dst overlap", who);
     return PFX_OK;
 }
 
@@ -528,6 +539,7 @@ int pfx_adjust_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w,
                    uint32_t n_params, const uint8_t* lut_host, const void* mask_dev, int sparse_mode)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_adjust_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_adjust_dev", true)); // in place is fine (pointwise); a partial overlap races
     PFX_REQUIRE(ctx, sparse_mode >= PFX_DENSE && sparse_mode <= PFX_IN_PLACE, "unknown sparse mode");
     pfxk_params P;
     bool needs_lut = false;
@@ -582,8 +594,8 @@ int pfx_warp_displacement_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, ui
                               uint32_t h, void* dst_dev)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_warp_displacement_dev"));
-    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_warp_displacement_dev"));
     PFX_REQUIRE(ctx, disp_dev && sw && sh, "pfx_warp_displacement_dev: bad arguments");
+    PFX_TRY(check_disjoint2(ctx, src_dev, sw, sh, dst_dev, w, h, "pfx_warp_displacement_dev")); // the SOURCE's extent: it may be larger than the output
     pfx_timer t(ctx, "warp_displacement");
     PFX_HIP(ctx, pfxk_warp_displacement(ctx->stream, (const uint8_t*)src_dev, sw, sh, (const float*)disp_dev, w, h, (uint8_t*)dst_dev));
     return PFX_OK;
@@ -808,6 +820,7 @@ int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h,
 int pfx_tiled_roundtrip_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_tiled_roundtrip_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_tiled_roundtrip_dev", true));
     pfx_timer t(ctx, "tiled_roundtrip");
     PFX_HIP(ctx, pfxk_tiled_roundtrip(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, w, h));
     return PFX_OK;

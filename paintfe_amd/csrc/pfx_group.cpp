@@ -25,18 +25,37 @@
 //          an all-gather".  librccl is loaded at run time (dlopen) the first time this transport is selected: libpfx.so itself does
 //          not link it, and a process that already carries an RCCL (PyTorch) keeps using that copy.
 #include <dlfcn.h>
-#include <rccl/rccl.h> // types and prototypes only; the functions are resolved with dlsym
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "pfx_internal.h"
+
+// The handful of RCCL declarations this file needs, restated locally (NCCL's stable C API: nccl.h 2.x — ncclResult_t 0 = success, ncclUint8 = 1 in
+// ncclDataType_t): libpfx.so neither links librccl nor needs its development headers to build; the functions are resolved with dlsym at run time.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;   // enum in nccl.h; passed and returned as int by the C ABI
+typedef int ncclDataType_t;
+}
+enum : int { ncclSuccess = 0, ncclUint8 = 1 };
+typedef ncclResult_t (*pfx_ncclCommInitAll_t)(ncclComm_t* comms, int ndev, const int* devlist);
+typedef ncclResult_t (*pfx_ncclCommDestroy_t)(ncclComm_t comm);
+typedef ncclResult_t (*pfx_ncclGroupStart_t)(void);
+typedef ncclResult_t (*pfx_ncclGroupEnd_t)(void);
+typedef ncclResult_t (*pfx_ncclSend_t)(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+typedef ncclResult_t (*pfx_ncclRecv_t)(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+typedef ncclResult_t (*pfx_ncclBroadcast_t)(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream);
+typedef const char* (*pfx_ncclGetErrorString_t)(ncclResult_t result);
+typedef ncclResult_t (*pfx_ncclCommGetAsyncError_t)(ncclComm_t comm, ncclResult_t* asyncError);
+typedef ncclResult_t (*pfx_ncclCommAbort_t)(ncclComm_t comm);
 
 struct pfx_group_member {
     pfx_ctx* ctx = nullptr;
@@ -104,33 +123,44 @@ hipStream_t stream_of(const pfx_group_member& mem) { return (hipStream_t)pfx_ctx
 // ---- RCCL, resolved at run time ----
 struct rccl_api {
     void* lib = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclBroadcast) Broadcast = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    pfx_ncclCommInitAll_t CommInitAll = nullptr;
+    pfx_ncclCommDestroy_t CommDestroy = nullptr;
+    pfx_ncclGroupStart_t GroupStart = nullptr;
+    pfx_ncclGroupEnd_t GroupEnd = nullptr;
+    pfx_ncclSend_t Send = nullptr;
+    pfx_ncclRecv_t Recv = nullptr;
+    pfx_ncclBroadcast_t Broadcast = nullptr;
+    pfx_ncclGetErrorString_t GetErrorString = nullptr;
+    pfx_ncclCommAbort_t CommAbort = nullptr;     // optional: only the watchdog uses it
     bool ok = false;
+    std::string why;                             // why loading failed (dlerror() text, taken where the failure happened)
 };
 rccl_api& rccl()
 {
     static rccl_api R;
-    static bool tried = false;
-    if (tried) return R;
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        R.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (R.lib) break;
-    }
-    if (!R.lib) return R;
-#define PFX_SYM(field, sym) R.field = (decltype(R.field))dlsym(R.lib, #sym)
-    PFX_SYM(CommInitAll, ncclCommInitAll); PFX_SYM(CommDestroy, ncclCommDestroy); PFX_SYM(GroupStart, ncclGroupStart);
-    PFX_SYM(GroupEnd, ncclGroupEnd); PFX_SYM(Send, ncclSend); PFX_SYM(Recv, ncclRecv); PFX_SYM(Broadcast, ncclBroadcast);
-    PFX_SYM(GetErrorString, ncclGetErrorString);
-#undef PFX_SYM
-    R.ok = R.CommInitAll && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv && R.Broadcast && R.GetErrorString;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            R.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (R.lib) break;
+            const char* e = dlerror();               // read once: the call clears the message
+            if (e) R.why = e;
+        }
+        if (!R.lib) { if (R.why.empty()) R.why = "librccl.so not found"; return; }
+        R.why.clear();
+        auto sym = [](const char* name) -> void* {
+            (void)dlerror();
+            void* p = dlsym(R.lib, name);
+            if (!p) { const char* e = dlerror(); R.why += (R.why.empty() ? "missing symbol " : ", ") + std::string(e ? e : name); }
+            return p;
+        };
+        R.CommInitAll = (pfx_ncclCommInitAll_t)sym("ncclCommInitAll"); R.CommDestroy = (pfx_ncclCommDestroy_t)sym("ncclCommDestroy");
+        R.GroupStart = (pfx_ncclGroupStart_t)sym("ncclGroupStart"); R.GroupEnd = (pfx_ncclGroupEnd_t)sym("ncclGroupEnd");
+        R.Send = (pfx_ncclSend_t)sym("ncclSend"); R.Recv = (pfx_ncclRecv_t)sym("ncclRecv"); R.Broadcast = (pfx_ncclBroadcast_t)sym("ncclBroadcast");
+        R.GetErrorString = (pfx_ncclGetErrorString_t)sym("ncclGetErrorString");
+        R.ok = R.CommInitAll && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv && R.Broadcast && R.GetErrorString;
+        R.CommAbort = (pfx_ncclCommAbort_t)dlsym(R.lib, "ncclCommAbort");
+    });
     return R;
 }
 #define PFXG_NCCL(g, call)                                                                                              \
@@ -356,7 +386,7 @@ int pfx_group_set_transport(pfx_group* g, int transport)
         return gfail(g, PFX_ERR_INVALID, "unknown transport %d", transport);
     quiesce(g); // a transport change must not overtake copies of the old one
     if (transport == PFX_GROUP_RCCL && !g->rccl_ready) {
-        if (!rccl().ok) return gfail(g, PFX_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+        if (!rccl().ok) return gfail(g, PFX_ERR_UNSUPPORTED, "librccl could not be loaded: %s", rccl().why.c_str());
         const size_t n = g->m.size();
         for (size_t a = 0; a < n; ++a)
             for (size_t b2 = a + 1; b2 < n; ++b2)
@@ -394,6 +424,11 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
     for (uint32_t l = 0; l < n_layers; ++l)
         if (layers[l].kind == PFX_LAYER_RASTER && layers[l].layer_idx >= g->n_layers)
             return gfail(g, PFX_ERR_INVALID, "layer_idx %u outside the document", layers[l].layer_idx);
+    // parameters the filter itself would refuse are refused HERE, before any buffer is (re)allocated or a member has flattened anything — and a NaN
+    // never reaches the float -> integer conversions below
+    if (filter != PFX_BAND_NONE && !std::isfinite(param)) return gfail(g, PFX_ERR_INVALID, "band filter parameter is not finite");
+    if (filter == PFX_BAND_BOX && ceilf(param) >= 2040.0f) return gfail(g, PFX_ERR_UNSUPPORTED, "box blur radius %g beyond the device limit", (double)param);
+    if (filter == PFX_BAND_MEDIAN && param > (float)PFX_MEDIAN_MAX_RADIUS) return gfail(g, PFX_ERR_UNSUPPORTED, "median radius %g beyond PFX_MEDIAN_MAX_RADIUS", (double)param);
     uint32_t halo = 0;
     if (band_filter_halo(filter, param, &halo) != PFX_OK) return gfail(g, PFX_ERR_INVALID, "unknown band filter %d", filter);
     const bool blur = halo >= 1;

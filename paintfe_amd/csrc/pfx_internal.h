@@ -91,6 +91,13 @@ int pfx_fail(pfx_ctx* ctx, int status, const char* fmt, ...);
         if (!(cond)) return pfx_fail((ctx), PFX_ERR_INVALID, "%s", (msg)); \
     } while (0)
 
+// do [a, a + a_bytes) and [b, b + b_bytes) share a byte?  (aliasing rule of the `_dev` entry points, include/pfx.h)
+inline bool pfx_ranges_overlap(const void* a, size_t a_bytes, const void* b, size_t b_bytes)
+{
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return x < y + b_bytes && y < x + a_bytes;
+}
+
 // ---- helpers (pfx_ctx.cpp) ----
 int pfx_use(pfx_ctx* ctx);                                     // hipSetDevice
 int pfx_reserve(pfx_ctx* ctx, pfx_devbuf& b, size_t bytes);    // grow-on-demand

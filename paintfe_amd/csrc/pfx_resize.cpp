@@ -85,6 +85,7 @@ int pfx_resize_image_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t
     PFX_REQUIRE(ctx, src_dev && dst_dev && src_dev != dst_dev, "pfx_resize_image_dev: bad image pointers");
     PFX_REQUIRE(ctx, w && h && new_w && new_h && (uint64_t)w * h <= 256000000ull && (uint64_t)new_w * new_h <= 256000000ull, "pfx_resize_image_dev: bad size");
     PFX_REQUIRE(ctx, filter >= PFX_RESIZE_NEAREST && filter <= PFX_RESIZE_LANCZOS3, "pfx_resize_image_dev: unknown filter");
+    PFX_REQUIRE(ctx, !pfx_ranges_overlap(src_dev, (size_t)w * h * 4, dst_dev, (size_t)new_w * new_h * 4), "pfx_resize_image_dev: src and dst overlap");
     PFX_TRY(pfx_use(ctx));
     if (new_w == w && new_h == h) { // the crate copies instead of resampling
         PFX_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, (size_t)w * h * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -133,6 +134,7 @@ int pfx_affine_transform_dev(pfx_ctx* ctx, const void* src_dev, uint32_t src_w, 
     PFX_REQUIRE(ctx, canvas_w && canvas_h && (uint64_t)canvas_w * canvas_h <= 256000000ull && (uint64_t)src_w * src_h <= 256000000ull,
                 "pfx_affine_transform_dev: bad size");
     PFX_REQUIRE(ctx, interpolation == PFX_RESIZE_NEAREST || interpolation == PFX_RESIZE_BILINEAR, "pfx_affine_transform_dev: nearest or bilinear only");
+    PFX_REQUIRE(ctx, !pfx_ranges_overlap(src_dev, (size_t)src_w * src_h * 4, dst_dev, (size_t)canvas_w * canvas_h * 4), "pfx_affine_transform_dev: src and dst overlap");
     PFX_TRY(pfx_use(ctx));
     pfxk_affine_params P{};
     P.cx = (float)canvas_w * 0.5f;
@@ -183,6 +185,7 @@ int pfx_flip_rotate_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t 
     if (!ctx) return PFX_ERR_INVALID;
     PFX_REQUIRE(ctx, src_dev && dst_dev && src_dev != dst_dev && w && h && (uint64_t)w * h <= 256000000ull, "pfx_flip_rotate_dev: bad arguments");
     PFX_REQUIRE(ctx, op >= PFX_CANVAS_FLIP_HORIZONTAL && op <= PFX_CANVAS_ROTATE_180, "pfx_flip_rotate_dev: unknown operation");
+    PFX_REQUIRE(ctx, !pfx_ranges_overlap(src_dev, (size_t)w * h * 4, dst_dev, (size_t)w * h * 4), "pfx_flip_rotate_dev: src and dst overlap");
     PFX_TRY(pfx_use(ctx));
     static const int mode_of[5] = {0, 1, 3, 4, 2}; // FLIP_H, FLIP_V, ROTATE_90CW, ROTATE_90CCW, ROTATE_180 -> k_script.hip permutation modes
     pfx_timer t(ctx, "permute");
@@ -211,6 +214,7 @@ int pfx_resize_canvas_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_
     if (!ctx) return PFX_ERR_INVALID;
     PFX_REQUIRE(ctx, src_dev && dst_dev && src_dev != dst_dev && w && h && new_w && new_h && (uint64_t)new_w * new_h <= 256000000ull,
                 "pfx_resize_canvas_dev: bad arguments");
+    PFX_REQUIRE(ctx, !pfx_ranges_overlap(src_dev, (size_t)w * h * 4, dst_dev, (size_t)new_w * new_h * 4), "pfx_resize_canvas_dev: src and dst overlap");
     PFX_TRY(pfx_use(ctx));
     const int32_t off_x = anchor_x == 0 ? 0 : (anchor_x == 1 ? ((int32_t)new_w - (int32_t)w) / 2 : (int32_t)new_w - (int32_t)w);
     const int32_t off_y = anchor_y == 0 ? 0 : (anchor_y == 1 ? ((int32_t)new_h - (int32_t)h) / 2 : (int32_t)new_h - (int32_t)h);

@@ -86,3 +86,32 @@ def test_neighbourhood_ops_refuse_overlapping_buffers(env):
     except PfxError:
         pass
     torch.cuda.synchronize()
+
+
+def test_pointwise_and_resampling_ops_refuse_partial_overlaps(env):
+    """pfx_adjust_dev accepts src == dst (pointwise) but a PARTIAL overlap races silently; the displacement warp must test the SOURCE's extent
+    (an sw x sh image, possibly larger than the w x h output); the resize family only compared the two pointers"""
+    from paintfe_amd._lib import PfxError, ERR_INVALID
+    torch, r, dev = env
+    w, h = 128, 64
+    buf = torch.zeros((4 * h, w, 4), dtype=torch.uint8, device=dev)
+    base = buf.data_ptr()
+    before = buf.clone()
+    r.adjust_dev(base, base, w, h, "invert")                          # in place: allowed
+    torch.cuda.synchronize()
+    buf.copy_(before)
+    for s_, d_ in ((base, base + w * 4 * 7), (base + 16, base)):
+        with pytest.raises(PfxError) as e:
+            r.adjust_dev(s_, d_, w, h, "invert")
+        assert e.value.status == ERR_INVALID
+    # warp: a 128 x 192 source whose TAIL overlaps the 128 x 64 output buffer (the head does not)
+    disp = torch.zeros((h, w, 2), dtype=torch.float32, device=dev)
+    with pytest.raises(PfxError) as e:
+        r.warp_displacement_dev(base, w, 3 * h, disp.data_ptr(), w, h, base + w * 4 * (2 * h))
+    assert e.value.status == ERR_INVALID
+    r.warp_displacement_dev(base, w, 3 * h, disp.data_ptr(), w, h, base + w * 4 * (3 * h))   # disjoint: fine
+    with pytest.raises(PfxError) as e:
+        r.resize_image_dev(base, w, h, base + w * 4 * (h // 2), w // 2, h // 2)
+    assert e.value.status == ERR_INVALID
+    torch.cuda.synchronize()
+    assert torch.equal(buf[:3 * h], before[:3 * h]), "a refused call must not touch its buffers"
