@@ -404,6 +404,14 @@ int pfx_mesh_displacement_dev(pfx_ctx* ctx, const float* orig_pts_xy, const floa
 int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float* orig_pts_xy,
                                   const float* deformed_pts_xy, uint32_t cols, uint32_t rows, uint32_t w, uint32_t h,
                                   void* dst_dev);
+/* Band forms of the two warps for a document sharded by rows ("replicate the source, warp bands of the output"; the CPU path's
+ * `par_chunks_mut(w * 4)` rows, ref: src/ops/transform.rs:1288-1345, 1687-1761): `dst_band_dev` / `disp_band_dev` hold rows [first_row, first_row +
+ * band_rows) of the output / the field, the source is whole.  Bit-identical to the same rows of the whole-image call. */
+int pfx_warp_displacement_band_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, uint32_t sh, const void* disp_band_dev, uint32_t w,
+                                   uint32_t band_rows, void* dst_band_dev, uint32_t first_row);
+int pfx_warp_mesh_catmull_rom_band_dev(pfx_ctx* ctx, const void* src_dev, const float* orig_pts_xy, const float* deformed_pts_xy,
+                                       uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, void* dst_band_dev, uint32_t first_row,
+                                       uint32_t band_rows);
 int pfx_brush_stamps_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush,
                          const float* points_xy, uint32_t n_points, const void* selection_dev);
 int pfx_brush_stamps_ex_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t h, const pfx_brush* brush, const pfx_brush_dynamics* dyn,
@@ -657,6 +665,19 @@ enum { PFX_GROUP_PEER = 0, PFX_GROUP_RCCL = 1, PFX_GROUP_STAGED = 2 };
 int         pfx_group_set_transport(pfx_group* g, int transport);
 int         pfx_group_transport(const pfx_group* g);
 int         pfx_group_synchronize(pfx_group* g);
+/* Watchdog: the next `calls` pipeline calls (0xFFFFFFFF: all) end with a host-side wait of at most `timeout_ms` for every member's streams; a member
+ * that does not finish turns a hang (a mis-paired RCCL group, a peer that never sends) into PFX_ERR_HIP whose message names the busy members and the
+ * halo transfers (consumer <- producer, rows) they take part in.  An RCCL transport that times out has its communicators aborted and is replaced by
+ * PEER.  timeout_ms == 0 switches it off.  Selecting PFX_GROUP_RCCL arms it for the first two calls (20 s) unless it was configured before. */
+int         pfx_group_set_watchdog(pfx_group* g, uint32_t timeout_ms, uint32_t calls);
+int         pfx_group_synchronize_timeout(pfx_group* g, uint32_t timeout_ms); /* pfx_group_synchronize with the same bounded wait and report */
+/* Warps of the sharded document ("replicate the source, warp bands of the output"; ref: src/ops/transform.rs:1288-1345, 1687-1761): the
+ * flattened bands are all-gathered so that every member holds the whole source, then every member warps its band of the output with
+ * pfx_warp_displacement_band_dev (`disp_host` = w*h xy pairs, scattered to the members by rows; blocking until the field has been copied) or
+ * pfx_warp_mesh_catmull_rom_band_dev.  The result stays sharded (pfx_group_result_band_dev / pfx_group_download); bit-identical to the single-GPU calls. */
+int         pfx_group_flatten_warp_displacement(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, const float* disp_host);
+int         pfx_group_flatten_warp_mesh(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, const float* orig_pts_xy /* may be NULL */,
+                                        const float* deformed_pts_xy, uint32_t cols, uint32_t rows);
 void*       pfx_group_result_band_dev(pfx_group* g, uint32_t rank);  /* rows [y0, y1) of the last result on member `rank` */
 void*       pfx_group_gathered_dev(pfx_group* g, uint32_t rank);     /* w*h*4 on member `rank` after an all_gather call */
 int         pfx_group_download(pfx_group* g, uint8_t* dst_host);     /* concatenated bands -> host w*h*4; blocking */

@@ -72,9 +72,11 @@ constexpr uint32_t WARP_YR = 4; // rows per lane: the field entries of all of th
 // One lane per output column, WARP_YR rows: a pixel needs two dependent memory round trips (its field entry, then the four taps the
 // entry points at), so with one pixel per lane the kernel is bound by latency x occupancy (Little's law: 0.60 ms at 16K for 2.1 GB
 // = 3.5 TB/s); four pixels' worth of requests in flight per lane move it towards the HBM rate.
+// `y_off`: index of the buffers' row 0 in the whole output when `disp` / `dst` are a band of it (a document sharded by rows, SURVEY 8e: the source is
+// replicated, every member warps its band of the output); 0 for a whole image.
 __global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restrict__ src, int32_t sw, int32_t sh,
                                                         const float2* __restrict__ disp, uint32_t w, uint32_t h,
-                                                        uint32_t* __restrict__ dst)
+                                                        uint32_t* __restrict__ dst, uint32_t y_off)
 {
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y0 = (blockIdx.y * 4u + (threadIdx.x >> 6)) * WARP_YR;
     if (x >= w || y0 >= h) return;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restri
     for (uint32_t k = 0; k < WARP_YR; ++k) d[k] = disp[(size_t)min(y0 + k, h - 1u) * w + x]; // rows past the end re-read the last one (unused)
     bilinear_taps taps[WARP_YR];
 #pragma unroll
-    for (uint32_t k = 0; k < WARP_YR; ++k) taps[k] = bilinear_fetch(src, sw, sh, (float)x, (float)min(y0 + k, h - 1u), d[k].x, d[k].y);
+    for (uint32_t k = 0; k < WARP_YR; ++k) taps[k] = bilinear_fetch(src, sw, sh, (float)x, (float)(min(y0 + k, h - 1u) + y_off), d[k].x, d[k].y);
 #pragma unroll
     for (uint32_t k = 0; k < WARP_YR; ++k)
         if (y0 + k < h) dst[(size_t)(y0 + k) * w + x] = bilinear_finish(taps[k]);
@@ -182,8 +184,9 @@ template <int MODE, bool IN_LDS>
 __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ g_orig,
                                                    const float2* __restrict__ g_def, uint32_t cols, uint32_t rows,
                                                    uint32_t w, uint32_t h, float2* __restrict__ disp,
-                                                   uint32_t* __restrict__ dst)
+                                                   uint32_t* __restrict__ dst, uint32_t y_off, uint32_t h_full)
 {
+    // h = rows of `disp` / `dst`; they are rows [y_off, y_off + h) of an h_full-row image (y_off = 0, h_full = h: the whole image); `src` is always whole
     __shared__ float2 s_orig[IN_LDS ? MESH_LDS_PTS : 1];
     __shared__ float2 s_def[IN_LDS ? MESH_LDS_PTS : 1];
     if constexpr (IN_LDS) {
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ 
         if (y_first >= h) break;           // whole wave
         // a wave shares its rows: lane k (< MESH_YR) evaluates row k's v-dependent half once, everyone reads it back through
         // v_readlane (scalar operands from then on) instead of recomputing ~30 operations per pixel
-        cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_first + (lane & (MESH_YR - 1u))) + 0.5f, (float)h) * (float)rows);
+        cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_first + y_off + (lane & (MESH_YR - 1u))) + 0.5f, (float)h_full) * (float)rows);
         const uint32_t y_end = min(y_first + MESH_YR, h);
         bilinear_taps taps[MESH_YR]; // MODE 1: every row's four taps are requested before any is consumed (latency-bound otherwise)
 #pragma unroll
@@ -226,11 +229,11 @@ __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ 
             if (g_orig) {
                 if constexpr (IN_LDS) o = cr_column_eval(co, s_orig, cols, rows, R);
                 else o = cr_column_eval(co, g_orig, cols, rows, R);
-            } else o = make_float2((float)x + 0.5f, (float)y + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
+            } else o = make_float2((float)x + 0.5f, (float)(y + y_off) + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
             const float ddx = d.x - o.x, ddy = d.y - o.y;
             const size_t i = (size_t)y * w + x;
             if constexpr (MODE == 0) { if (x_valid) disp[i] = make_float2(ddx, ddy); }
-            else taps[k] = bilinear_fetch(src, (int32_t)w, (int32_t)h, (float)x, (float)y, ddx, ddy);
+            else taps[k] = bilinear_fetch(src, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), ddx, ddy);
         }
         if constexpr (MODE == 1) {
 #pragma unroll
@@ -245,12 +248,12 @@ __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ 
 } // namespace
 
 extern "C" hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh,
-                                             const float* d_disp, uint32_t w, uint32_t h, uint8_t* d_dst)
+                                             const float* d_disp, uint32_t w, uint32_t h, uint8_t* d_dst, uint32_t first_row)
 {
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 4 * WARP_YR - 1) / (4 * WARP_YR));
     warp_disp_kernel<<<g, 256, 0, s>>>((const uint32_t*)d_src, (int32_t)sw, (int32_t)sh, (const float2*)d_disp, w, h,
-                                       (uint32_t*)d_dst);
+                                       (uint32_t*)d_dst, first_row);
     return hipGetLastError();
 }
 
@@ -328,20 +331,21 @@ extern "C" hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig,
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 4 * MESH_YR * MESH_YB - 1) / (4 * MESH_YR * MESH_YB));
     if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
-        mesh_kernel<0, true><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr);
+        mesh_kernel<0, true><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr, 0u, h);
     else
-        mesh_kernel<0, false><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr);
+        mesh_kernel<0, false><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr, 0u, h);
     return hipGetLastError();
 }
 
+// band form: d_dst holds rows [first_row, first_row + h) of an h_full-row result; d_src is the whole w x h_full source
 extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const float* d_orig, const float* d_def,
-                                     uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst)
+                                     uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst, uint32_t first_row, uint32_t h_full)
 {
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 4 * MESH_YR * MESH_YB - 1) / (4 * MESH_YR * MESH_YB));
     if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
-        mesh_kernel<1, true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst);
+        mesh_kernel<1, true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst, first_row, h_full);
     else
-        mesh_kernel<1, false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst);
+        mesh_kernel<1, false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst, first_row, h_full);
     return hipGetLastError();
 }

@@ -590,15 +590,22 @@ int pfx_rhai_adjust_dev(pfx_ctx* ctx, void* pixels_dev, uint32_t w, uint32_t h, 
     return PFX_OK;
 }
 
+int pfx_warp_displacement_band_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, uint32_t sh, const void* disp_band_dev, uint32_t w,
+                                   uint32_t band_rows, void* dst_band_dev, uint32_t first_row)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_band_dev, w, band_rows, "pfx_warp_displacement_dev"));
+    PFX_REQUIRE(ctx, disp_band_dev && sw && sh, "pfx_warp_displacement_dev: bad arguments");
+    PFX_REQUIRE(ctx, (uint64_t)first_row + band_rows <= 0x7fffffffull, "pfx_warp_displacement_dev: band outside any image");
+    PFX_TRY(check_disjoint2(ctx, src_dev, sw, sh, dst_band_dev, w, band_rows, "pfx_warp_displacement_dev")); // the SOURCE's extent: it may be larger than the output
+    pfx_timer t(ctx, "warp_displacement");
+    PFX_HIP(ctx, pfxk_warp_displacement(ctx->stream, (const uint8_t*)src_dev, sw, sh, (const float*)disp_band_dev, w, band_rows, (uint8_t*)dst_band_dev, first_row));
+    return PFX_OK;
+}
+
 int pfx_warp_displacement_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, uint32_t sh, const void* disp_dev, uint32_t w,
                               uint32_t h, void* dst_dev)
 {
-    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_warp_displacement_dev"));
-    PFX_REQUIRE(ctx, disp_dev && sw && sh, "pfx_warp_displacement_dev: bad arguments");
-    PFX_TRY(check_disjoint2(ctx, src_dev, sw, sh, dst_dev, w, h, "pfx_warp_displacement_dev")); // the SOURCE's extent: it may be larger than the output
-    pfx_timer t(ctx, "warp_displacement");
-    PFX_HIP(ctx, pfxk_warp_displacement(ctx->stream, (const uint8_t*)src_dev, sw, sh, (const float*)disp_dev, w, h, (uint8_t*)dst_dev));
-    return PFX_OK;
+    return pfx_warp_displacement_band_dev(ctx, src_dev, sw, sh, disp_dev, w, h, dst_dev, 0);
 }
 
 // DisplacementField::apply_* on a device-resident field: per-dab prologue (radius clamp, sigma, loop bounds) on the host exactly as
@@ -666,16 +673,23 @@ int pfx_mesh_displacement_dev(pfx_ctx* ctx, const float* orig_pts_xy, const floa
     return PFX_OK;
 }
 
-int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float* orig_pts_xy, const float* deformed_pts_xy,
-                                  uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, void* dst_dev)
+int pfx_warp_mesh_catmull_rom_band_dev(pfx_ctx* ctx, const void* src_dev, const float* orig_pts_xy, const float* deformed_pts_xy,
+                                       uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, void* dst_band_dev, uint32_t first_row, uint32_t band_rows)
 {
-    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_warp_mesh_catmull_rom_dev"));
-    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_warp_mesh_catmull_rom_dev"));
+    PFX_TRY(check_img(ctx, src_dev, dst_band_dev, w, h, "pfx_warp_mesh_catmull_rom_dev"));
+    PFX_REQUIRE(ctx, band_rows >= 1 && (uint64_t)first_row + band_rows <= h, "pfx_warp_mesh_catmull_rom_dev: band outside the image");
+    PFX_REQUIRE(ctx, !pfx_ranges_overlap(src_dev, (size_t)w * h * 4, dst_band_dev, (size_t)w * band_rows * 4), "pfx_warp_mesh_catmull_rom_dev: src and dst overlap");
     const float *d_orig, *d_def;
     PFX_TRY(upload_points(ctx, orig_pts_xy, deformed_pts_xy, cols, rows, &d_orig, &d_def));
     pfx_timer t(ctx, "warp_mesh");
-    PFX_HIP(ctx, pfxk_warp_mesh(ctx->stream, (const uint8_t*)src_dev, d_orig, d_def, cols, rows, w, h, (uint8_t*)dst_dev));
+    PFX_HIP(ctx, pfxk_warp_mesh(ctx->stream, (const uint8_t*)src_dev, d_orig, d_def, cols, rows, w, band_rows, (uint8_t*)dst_band_dev, first_row, h));
     return PFX_OK;
+}
+
+int pfx_warp_mesh_catmull_rom_dev(pfx_ctx* ctx, const void* src_dev, const float* orig_pts_xy, const float* deformed_pts_xy,
+                                  uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, void* dst_dev)
+{
+    return pfx_warp_mesh_catmull_rom_band_dev(ctx, src_dev, orig_pts_xy, deformed_pts_xy, cols, rows, w, h, dst_dev, 0, h);
 }
 
 // Per-stamp host prologue of draw_circle_no_dirty / draw_image_tip_no_dirty (brush_render.rs:148-256, 552-632): the reference

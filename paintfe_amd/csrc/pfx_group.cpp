@@ -30,8 +30,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
+#include <chrono>
 #include <cstdio>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -66,6 +68,8 @@ struct pfx_group_member {
     void* padded = nullptr;             // [top halo | flattened band | bottom halo], (rows + 2 * halo_cap) * w * 4
     void* blurred = nullptr;            // same shape: blur of `padded`
     void* gathered = nullptr;           // full w * h * 4 image (all-gather target), allocated on first use
+    void* disp = nullptr;               // band of a displacement field (pfx_group_flatten_warp_displacement), (y1 - y0) * w * 8 bytes
+    size_t disp_cap = 0;
     size_t padded_cap = 0;
     hipEvent_t ev_flat = nullptr, ev_done = nullptr; // flatten finished / result band final (halo pulls and blur done), on the compute stream
     hipStream_t s_copy = nullptr;       // the all-gather's pushes run here, behind ev_done, so that the next call's flatten overlaps them
@@ -89,6 +93,11 @@ struct pfx_group {
     int transport = PFX_GROUP_PEER;
     std::vector<uint8_t> peer_ok;       // [a * n + b]: device of member a may access member b's memory directly (or they share a device)
     bool rccl_ready = false;
+    // watchdog (pfx_group_set_watchdog): the next `watch_calls` pipeline calls end with a bounded host-side wait for every member's work; a member
+    // that does not finish in time turns a hang (a deadlocked RCCL group, a peer that never sends) into PFX_ERR_HIP naming the pairs involved
+    uint32_t watch_ms = 0, watch_calls = 0;
+    struct halo_piece { uint32_t i, j, s0, s1; };
+    std::vector<halo_piece> last_pieces; // halo transfers of the last call (consumer i <- producer j, image rows [s0, s1)): the watchdog's report
     std::string err;
 };
 
@@ -190,6 +199,8 @@ void free_member_buffers(pfx_group_member& mem)
     if (mem.padded) (void)hipFree(mem.padded);
     if (mem.blurred) (void)hipFree(mem.blurred);
     if (mem.gathered) (void)hipFree(mem.gathered);
+    if (mem.disp) (void)hipFree(mem.disp);
+    mem.disp = nullptr; mem.disp_cap = 0;
     mem.padded = mem.blurred = mem.gathered = nullptr;
     mem.padded_cap = 0;
     if (mem.h_halo) (void)hipHostFree(mem.h_halo);
@@ -398,12 +409,152 @@ int pfx_group_set_transport(pfx_group* g, int transport)
         PFXG_NCCL(g, rccl().CommInitAll(comms.data(), (int)n, devs.data()));
         for (size_t k = 0; k < n; ++k) g->m[k].comm = comms[k];
         g->rccl_ready = true;
+        // the first exchanges over fresh communicators are where a mis-paired group would hang: watch them unless the caller configured otherwise
+        if (g->watch_ms == 0) { g->watch_ms = 20000; g->watch_calls = 2; }
     }
     g->transport = transport;
     return PFX_OK;
 }
 
 int pfx_group_transport(const pfx_group* g) { return g ? g->transport : -1; }
+
+// ---- watchdog ----
+// Bounded wait for everything the members have enqueued (compute and copy streams).  On expiry the report names the members that are still busy
+// and, from the last call's halo plan, the (consumer <- producer) pairs they take part in; an RCCL group that never completes is aborted (its
+// communicators would block every later call) and the transport falls back to PEER.
+static void stall_host_fn(void* ms) { std::this_thread::sleep_for(std::chrono::milliseconds((intptr_t)ms)); }
+static int wait_bounded(pfx_group* g, uint32_t timeout_ms, const char* what)
+{
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    std::vector<uint8_t> busy(g->m.size(), 1);
+    for (;;) {
+        bool any = false;
+        for (size_t k = 0; k < g->m.size(); ++k) {
+            if (!busy[k]) continue;
+            auto& mem = g->m[k];
+            (void)hipSetDevice(mem.device);
+            const hipError_t a = hipStreamQuery(stream_of(mem)), b = mem.s_copy ? hipStreamQuery(mem.s_copy) : hipSuccess;
+            if (a == hipSuccess && b == hipSuccess) busy[k] = 0;
+            else if ((a != hipSuccess && a != hipErrorNotReady) || (b != hipSuccess && b != hipErrorNotReady))
+                return gfail(g, PFX_ERR_HIP, "%s: member %zu (device %d): %s", what, k, mem.device, hipGetErrorString(a != hipSuccess && a != hipErrorNotReady ? a : b));
+            else any = true;
+        }
+        if (!any) return PFX_OK;
+        if (std::chrono::steady_clock::now() >= deadline) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    std::string who, pairs;
+    for (size_t k = 0; k < g->m.size(); ++k)
+        if (busy[k]) who += (who.empty() ? "" : ", ") + std::to_string(k) + " (device " + std::to_string(g->m[k].device) + ")";
+    for (const auto& p : g->last_pieces)
+        if (busy[p.i] || busy[p.j]) {
+            if (pairs.size() > 200) { pairs += " ..."; break; }
+            pairs += (pairs.empty() ? "" : ", ") + std::to_string(p.i) + " <- " + std::to_string(p.j) + " rows [" + std::to_string(p.s0) + ", " + std::to_string(p.s1) + ")";
+        }
+    static const char* const tname[] = {"PEER", "RCCL", "STAGED"};
+    const int t = g->transport;
+    if (t == PFX_GROUP_RCCL && g->rccl_ready) {
+        if (rccl().CommAbort) for (auto& mem : g->m) if (mem.comm) { (void)rccl().CommAbort(mem.comm); mem.comm = nullptr; }
+        g->rccl_ready = false;
+        g->transport = PFX_GROUP_PEER;
+    }
+    g->have_result = false;
+    return gfail(g, PFX_ERR_HIP, "%s: member(s) %s did not finish within %u ms (transport %s%s); halo transfers involving them: %s", what, who.c_str(), timeout_ms,
+                 t >= 0 && t <= 2 ? tname[t] : "?", t == PFX_GROUP_RCCL ? ": communicators aborted, transport reset to PEER" : "", pairs.empty() ? "none" : pairs.c_str());
+}
+static int watchdog_after_call(pfx_group* g, const char* what)
+{
+    if (g->watch_calls == 0 || g->watch_ms == 0) return PFX_OK;
+    if (g->watch_calls != 0xFFFFFFFFu) g->watch_calls -= 1u;
+    return wait_bounded(g, g->watch_ms, what);
+}
+
+// all-gather: every member's result band lands in every member's full image.  The transfers run on the members' copy streams behind ev_done:
+// the next call's flatten (compute stream) overlaps them, its filter waits for them.
+static int gather_result(pfx_group* g, bool blur)
+{
+    const uint32_t world = (uint32_t)g->m.size(), w = g->w, h = g->h;
+    const size_t row_bytes = (size_t)w * 4;
+    const bool use_rccl = g->transport == PFX_GROUP_RCCL;
+    for (auto& mem : g->m)
+        if (!mem.gathered) {
+            PFXG_HIP(g, hipSetDevice(mem.device));
+            PFXG_HIP(g, hipMalloc(&mem.gathered, std::max<size_t>((size_t)h * row_bytes, 256)));
+        }
+    auto band_of = [&](const pfx_group_member& mem) { return (const uint8_t*)(blur ? mem.blurred : mem.padded) + (size_t)mem.top * row_bytes; };
+    if (use_rccl) {
+        for (auto& mem : g->m) {
+            PFXG_HIP(g, hipSetDevice(mem.device));
+            PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
+        }
+        // one broadcast per band (bands are ragged by a chunk row, so ncclAllGather's equal counts do not fit), all in one group
+        PFXG_NCCL(g, rccl().GroupStart());
+        for (uint32_t k = 0; k < world; ++k) {
+            const uint32_t rows = g->m[k].y1 - g->m[k].y0;
+            if (!rows) continue;
+            for (auto& mem : g->m) {
+                uint8_t* d = (uint8_t*)mem.gathered + (size_t)g->m[k].y0 * row_bytes;
+                const ncclResult_t r = rccl().Broadcast(&mem == &g->m[k] ? (const void*)band_of(mem) : (const void*)d, d, (size_t)rows * row_bytes, ncclUint8,
+                                                        (int)k, mem.comm, mem.s_copy);
+                if (r != ncclSuccess) { (void)rccl().GroupEnd(); return gfail(g, PFX_ERR_HIP, "ncclBroadcast failed: %s", rccl().GetErrorString(r)); }
+            }
+        }
+        PFXG_NCCL(g, rccl().GroupEnd());
+        for (auto& mem : g->m) {
+            PFXG_HIP(g, hipSetDevice(mem.device));
+            PFXG_HIP(g, hipEventRecord(mem.ev_gather, mem.s_copy));
+            mem.gather_pending = true;
+        }
+    } else {
+        for (uint32_t k = 0; k < world; ++k) {
+            auto& mem = g->m[k];
+            const uint32_t rows = mem.y1 - mem.y0;
+            if (!rows) continue;
+            const size_t bytes = (size_t)rows * row_bytes;
+            bool any_staged = false;
+            for (uint32_t d = 0; d < world; ++d) any_staged = any_staged || !direct(g, d, k);
+            PFXG_HIP(g, hipSetDevice(mem.device));
+            PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
+            if (any_staged) {
+                if (mem.h_band_cap < bytes) {
+                    quiesce(g);
+                    if (mem.h_band) (void)hipHostFree(mem.h_band);
+                    mem.h_band = nullptr; mem.h_band_cap = 0;
+                    PFXG_HIP(g, hipHostMalloc((void**)&mem.h_band, bytes, hipHostMallocPortable));
+                    mem.h_band_cap = bytes;
+                    PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
+                }
+                // the previous gather's H2Ds out of this bounce buffer run on the destinations' copy streams
+                for (auto& dst : g->m)
+                    if (dst.gin_pending) PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, dst.ev_gin, 0));
+                PFXG_HIP(g, hipMemcpyAsync(mem.h_band, band_of(mem), bytes, hipMemcpyDeviceToHost, mem.s_copy));
+                PFXG_HIP(g, hipEventRecord(mem.ev_staged_band, mem.s_copy));
+            }
+            for (uint32_t d = 0; d < world; ++d) {
+                auto& dst = g->m[d];
+                uint8_t* out = (uint8_t*)dst.gathered + (size_t)mem.y0 * row_bytes;
+                if (direct(g, d, k)) {
+                    // enqueued on the PRODUCER's copy stream; hipMemcpyPeerAsync accepts any stream
+                    if (dst.device == mem.device) PFXG_HIP(g, hipMemcpyAsync(out, band_of(mem), bytes, hipMemcpyDeviceToDevice, mem.s_copy));
+                    else PFXG_HIP(g, hipMemcpyPeerAsync(out, dst.device, band_of(mem), mem.device, bytes, mem.s_copy));
+                } else {
+                    PFXG_HIP(g, hipSetDevice(dst.device));
+                    PFXG_HIP(g, hipStreamWaitEvent(dst.s_copy, mem.ev_staged_band, 0));
+                    PFXG_HIP(g, hipMemcpyAsync(out, mem.h_band, bytes, hipMemcpyHostToDevice, dst.s_copy));
+                    PFXG_HIP(g, hipSetDevice(mem.device));
+                }
+            }
+            PFXG_HIP(g, hipEventRecord(mem.ev_gather, mem.s_copy));
+            mem.gather_pending = true;
+        }
+        for (auto& dst : g->m) { // staged arrivals into `dst` are complete when its copy stream reaches this point
+            PFXG_HIP(g, hipSetDevice(dst.device));
+            PFXG_HIP(g, hipEventRecord(dst.ev_gin, dst.s_copy));
+            dst.gin_pending = true;
+        }
+    }
+    return PFX_OK;
+}
 
 // halo rows of a band filter: what pfx_*_band_dev needs around a band ("halo rows of the Gaussian / box / median vertical pass")
 static int band_filter_halo(int filter, float param, uint32_t* halo)
@@ -467,13 +618,19 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
             PFXG_CTX(g, mem, pfx_flatten_dev(mem.ctx, ptrs.data(), nullptr, li.data(), n_layers, w, rows,
                                              (uint8_t*)mem.padded + (size_t)mem.top * row_bytes));
         }
+        if (&mem == &g->m.back()) {
+            // test hook: a peer that is late (PFX_GROUP_TEST_STALL_MS): its stream sleeps in a host function in front of the event its neighbours wait for
+            const char* stall = std::getenv("PFX_GROUP_TEST_STALL_MS");
+            if (stall && std::atoi(stall) > 0) PFXG_HIP(g, hipLaunchHostFunc(stream_of(mem), stall_host_fn, (void*)(intptr_t)std::atoi(stall)));
+        }
         PFXG_HIP(g, hipEventRecord(mem.ev_flat, stream_of(mem)));
     }
     if (blur) {
         // 2. halo rows: member i needs rows [y0 - top, y0) and [y1, y1 + bottom) from whichever members own them.
         // Every (consumer i, producer j, image rows [s0, s1)) piece is listed once and then moved by the transport in use.
-        struct piece { uint32_t i, j, s0, s1; };
-        std::vector<piece> pieces;
+        using piece = pfx_group::halo_piece;
+        std::vector<piece>& pieces = g->last_pieces;
+        pieces.clear();
         for (uint32_t i = 0; i < world; ++i) {
             const auto& mem = g->m[i];
             if (mem.y1 == mem.y0) continue;
@@ -563,86 +720,10 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
         PFXG_HIP(g, hipSetDevice(mem.device));
         PFXG_HIP(g, hipEventRecord(mem.ev_done, stream_of(mem)));
     }
-    // 4. all-gather: every member's result band lands in every member's full image.  The transfers run on the members' copy streams
-    // behind ev_done: the next call's flatten (compute stream) overlaps them, its filter waits for them.
+    // 4. all-gather (gather_result above)
     if (all_gather) {
-        for (auto& mem : g->m)
-            if (!mem.gathered) {
-                PFXG_HIP(g, hipSetDevice(mem.device));
-                PFXG_HIP(g, hipMalloc(&mem.gathered, std::max<size_t>((size_t)h * row_bytes, 256)));
-            }
-        auto band_of = [&](const pfx_group_member& mem) { return (const uint8_t*)(blur ? mem.blurred : mem.padded) + (size_t)mem.top * row_bytes; };
-        if (use_rccl) {
-            for (auto& mem : g->m) {
-                PFXG_HIP(g, hipSetDevice(mem.device));
-                PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
-            }
-            // one broadcast per band (bands are ragged by a chunk row, so ncclAllGather's equal counts do not fit), all in one group
-            PFXG_NCCL(g, rccl().GroupStart());
-            for (uint32_t k = 0; k < world; ++k) {
-                const uint32_t rows = g->m[k].y1 - g->m[k].y0;
-                if (!rows) continue;
-                for (auto& mem : g->m) {
-                    uint8_t* d = (uint8_t*)mem.gathered + (size_t)g->m[k].y0 * row_bytes;
-                    const ncclResult_t r = rccl().Broadcast(&mem == &g->m[k] ? (const void*)band_of(mem) : (const void*)d, d, (size_t)rows * row_bytes, ncclUint8,
-                                                            (int)k, mem.comm, mem.s_copy);
-                    if (r != ncclSuccess) { (void)rccl().GroupEnd(); return gfail(g, PFX_ERR_HIP, "ncclBroadcast failed: %s", rccl().GetErrorString(r)); }
-                }
-            }
-            PFXG_NCCL(g, rccl().GroupEnd());
-            for (auto& mem : g->m) {
-                PFXG_HIP(g, hipSetDevice(mem.device));
-                PFXG_HIP(g, hipEventRecord(mem.ev_gather, mem.s_copy));
-                mem.gather_pending = true;
-            }
-        } else {
-            for (uint32_t k = 0; k < world; ++k) {
-                auto& mem = g->m[k];
-                const uint32_t rows = mem.y1 - mem.y0;
-                if (!rows) continue;
-                const size_t bytes = (size_t)rows * row_bytes;
-                bool any_staged = false;
-                for (uint32_t d = 0; d < world; ++d) any_staged = any_staged || !direct(g, d, k);
-                PFXG_HIP(g, hipSetDevice(mem.device));
-                PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
-                if (any_staged) {
-                    if (mem.h_band_cap < bytes) {
-                        quiesce(g);
-                        if (mem.h_band) (void)hipHostFree(mem.h_band);
-                        mem.h_band = nullptr; mem.h_band_cap = 0;
-                        PFXG_HIP(g, hipHostMalloc((void**)&mem.h_band, bytes, hipHostMallocPortable));
-                        mem.h_band_cap = bytes;
-                        PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, mem.ev_done, 0));
-                    }
-                    // the previous gather's H2Ds out of this bounce buffer run on the destinations' copy streams
-                    for (auto& dst : g->m)
-                        if (dst.gin_pending) PFXG_HIP(g, hipStreamWaitEvent(mem.s_copy, dst.ev_gin, 0));
-                    PFXG_HIP(g, hipMemcpyAsync(mem.h_band, band_of(mem), bytes, hipMemcpyDeviceToHost, mem.s_copy));
-                    PFXG_HIP(g, hipEventRecord(mem.ev_staged_band, mem.s_copy));
-                }
-                for (uint32_t d = 0; d < world; ++d) {
-                    auto& dst = g->m[d];
-                    uint8_t* out = (uint8_t*)dst.gathered + (size_t)mem.y0 * row_bytes;
-                    if (direct(g, d, k)) {
-                        // enqueued on the PRODUCER's copy stream; hipMemcpyPeerAsync accepts any stream
-                        if (dst.device == mem.device) PFXG_HIP(g, hipMemcpyAsync(out, band_of(mem), bytes, hipMemcpyDeviceToDevice, mem.s_copy));
-                        else PFXG_HIP(g, hipMemcpyPeerAsync(out, dst.device, band_of(mem), mem.device, bytes, mem.s_copy));
-                    } else {
-                        PFXG_HIP(g, hipSetDevice(dst.device));
-                        PFXG_HIP(g, hipStreamWaitEvent(dst.s_copy, mem.ev_staged_band, 0));
-                        PFXG_HIP(g, hipMemcpyAsync(out, mem.h_band, bytes, hipMemcpyHostToDevice, dst.s_copy));
-                        PFXG_HIP(g, hipSetDevice(mem.device));
-                    }
-                }
-                PFXG_HIP(g, hipEventRecord(mem.ev_gather, mem.s_copy));
-                mem.gather_pending = true;
-            }
-            for (auto& dst : g->m) { // staged arrivals into `dst` are complete when its copy stream reaches this point
-                PFXG_HIP(g, hipSetDevice(dst.device));
-                PFXG_HIP(g, hipEventRecord(dst.ev_gin, dst.s_copy));
-                dst.gin_pending = true;
-            }
-        }
+        const int gs = gather_result(g, blur);
+        if (gs != PFX_OK) return gs;
     }
     g->have_result = true;
     return PFX_OK;
@@ -651,7 +732,10 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
 // the C ABI must not let a C++ exception (std::vector growth) escape
 int pfx_group_flatten_filter(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, int filter, float param, int all_gather)
 {
-    try { return flatten_filter_impl(g, layers, n_layers, filter, param, all_gather); }
+    try {
+        const int s = flatten_filter_impl(g, layers, n_layers, filter, param, all_gather);
+        return s != PFX_OK ? s : watchdog_after_call(g, "pfx_group_flatten_filter");
+    }
     catch (const std::bad_alloc&) { return g ? gfail(g, PFX_ERR_OOM, "out of host memory") : PFX_ERR_OOM; }
     catch (...) { return g ? gfail(g, PFX_ERR_HIP, "unexpected exception") : PFX_ERR_HIP; }
 }
@@ -659,6 +743,91 @@ int pfx_group_flatten_filter(pfx_group* g, const pfx_layer_info* layers, uint32_
 int pfx_group_flatten_blur(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, float sigma, int all_gather)
 {
     return pfx_group_flatten_filter(g, layers, n_layers, pfx_host_gaussian_radius(sigma) >= 1 ? PFX_BAND_GAUSSIAN : PFX_BAND_NONE, sigma, all_gather);
+}
+
+int pfx_group_set_watchdog(pfx_group* g, uint32_t timeout_ms, uint32_t calls)
+{
+    if (!g) return PFX_ERR_INVALID;
+    g->watch_ms = timeout_ms;
+    g->watch_calls = timeout_ms ? calls : 0u;
+    return PFX_OK;
+}
+
+int pfx_group_synchronize_timeout(pfx_group* g, uint32_t timeout_ms)
+{
+    if (!g) return PFX_ERR_INVALID;
+    return wait_bounded(g, timeout_ms, "pfx_group_synchronize_timeout");
+}
+
+// ---- warps of a sharded document (replicate the source, bands of the output; ref: src/ops/transform.rs:1288-1345, 1687-1761) ----
+// flatten (bands) -> all-gather of the flattened bands, so that every member holds the whole source -> every member warps its band of the output.
+// kind 0: displacement field (disp_host = w * h xy pairs), kind 1: fused Catmull-Rom mesh warp.
+static int flatten_warp_impl(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, int kind, const float* disp_host, const float* orig_pts,
+                             const float* def_pts, uint32_t cols, uint32_t rows_grid)
+{
+    if (!g || !layers || n_layers == 0) return PFX_ERR_INVALID;
+    if (kind == 0 && !disp_host) return gfail(g, PFX_ERR_INVALID, "null displacement field");
+    if (kind == 1 && (!def_pts || cols == 0 || rows_grid == 0)) return gfail(g, PFX_ERR_INVALID, "bad mesh");
+    {
+        const int s = flatten_filter_impl(g, layers, n_layers, PFX_BAND_NONE, 0.0f, 1);
+        if (s != PFX_OK) return s;
+    }
+    const uint32_t w = g->w, h = g->h;
+    const size_t row_bytes = (size_t)w * 4;
+    for (auto& mem : g->m) {
+        const uint32_t rows = mem.y1 - mem.y0;
+        PFXG_HIP(g, hipSetDevice(mem.device));
+        // the whole source has arrived when every producer's pushes (their copy streams) and the staged arrivals into this member are done
+        for (auto& prod : g->m) PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), prod.ev_gather, 0));
+        if (mem.gin_pending) PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), mem.ev_gin, 0));
+        mem.gather_pending = false;
+        if (!rows) continue;
+        uint8_t* out = (uint8_t*)mem.blurred + (size_t)mem.top * row_bytes;
+        if (kind == 0) {
+            const size_t need = (size_t)rows * w * 8;
+            if (mem.disp_cap < need) {
+                PFXG_CTX(g, mem, pfx_ctx_synchronize(mem.ctx)); // the previous warp may still read the old buffer
+                if (mem.disp) (void)hipFree(mem.disp);
+                mem.disp = nullptr; mem.disp_cap = 0;
+                PFXG_HIP(g, hipMalloc(&mem.disp, need));
+                mem.disp_cap = need;
+            }
+            PFXG_HIP(g, hipMemcpyAsync(mem.disp, disp_host + (size_t)mem.y0 * w * 2, need, hipMemcpyHostToDevice, stream_of(mem)));
+            PFXG_CTX(g, mem, pfx_warp_displacement_band_dev(mem.ctx, mem.gathered, w, h, mem.disp, w, rows, out, mem.y0));
+        } else {
+            PFXG_CTX(g, mem, pfx_warp_mesh_catmull_rom_band_dev(mem.ctx, mem.gathered, orig_pts, def_pts, cols, rows_grid, w, h, out, mem.y0, rows));
+        }
+    }
+    for (auto& mem : g->m) {
+        PFXG_HIP(g, hipSetDevice(mem.device));
+        PFXG_HIP(g, hipEventRecord(mem.ev_done, stream_of(mem)));
+    }
+    g->result_blurred = true; // the result bands live in `blurred`
+    g->have_result = true;
+    if (kind == 0) // the field is pageable host memory of the caller: its copies must have left it when this returns
+        for (auto& mem : g->m) PFXG_CTX(g, mem, pfx_ctx_synchronize(mem.ctx));
+    return PFX_OK;
+}
+
+int pfx_group_flatten_warp_displacement(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, const float* disp_host)
+{
+    try {
+        const int s = flatten_warp_impl(g, layers, n_layers, 0, disp_host, nullptr, nullptr, 0, 0);
+        return s != PFX_OK ? s : watchdog_after_call(g, "pfx_group_flatten_warp_displacement");
+    }
+    catch (const std::bad_alloc&) { return g ? gfail(g, PFX_ERR_OOM, "out of host memory") : PFX_ERR_OOM; }
+    catch (...) { return g ? gfail(g, PFX_ERR_HIP, "unexpected exception") : PFX_ERR_HIP; }
+}
+
+int pfx_group_flatten_warp_mesh(pfx_group* g, const pfx_layer_info* layers, uint32_t n_layers, const float* orig_pts_xy, const float* deformed_pts_xy,
+                                uint32_t cols, uint32_t rows)
+{
+    try {
+        const int s = flatten_warp_impl(g, layers, n_layers, 1, nullptr, orig_pts_xy, deformed_pts_xy, cols, rows);
+        return s != PFX_OK ? s : watchdog_after_call(g, "pfx_group_flatten_warp_mesh");
+    }
+    catch (const std::bad_alloc&) { return g ? gfail(g, PFX_ERR_OOM, "out of host memory") : PFX_ERR_OOM; }
+    catch (...) { return g ? gfail(g, PFX_ERR_HIP, "unexpected exception") : PFX_ERR_HIP; }
 }
 
 int pfx_group_synchronize(pfx_group* g)

@@ -191,13 +191,15 @@ hipError_t pfxk_affine(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_
                        const pfxk_affine_params* P);
 
 // ---- k_warp.hip ----
+// first_row: index of d_disp's / d_dst's row 0 in the whole output when they are a band of it (0: whole image)
 hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t sw, uint32_t sh, const float* d_disp,
-                                  uint32_t w, uint32_t h, uint8_t* d_dst);
+                                  uint32_t w, uint32_t h, uint8_t* d_dst, uint32_t first_row);
 // d_pts: orig points (may be NULL => "fast" identity original) then deformed points, (cols+1)*(rows+1) xy pairs each
 hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig, const float* d_def, uint32_t cols, uint32_t rows,
                                   uint32_t w, uint32_t h, float* d_disp);
+// d_dst = rows [first_row, first_row + h) of the h_full-row result; d_src = the whole w x h_full source (first_row = 0, h_full = h: whole image)
 hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const float* d_orig, const float* d_def, uint32_t cols,
-                          uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst);
+                          uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst, uint32_t first_row, uint32_t h_full);
 
 // DisplacementField dabs (k_warp.hip): bounds and Gaussian constants are prepared on the host like the reference's prologue
 typedef struct pfxk_disp_dab { int32_t mode, x0, y0, x1, y1; float cx, cy, delta_x, delta_y, r, sigma_sq_2, strength; } pfxk_disp_dab;

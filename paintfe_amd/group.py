@@ -81,6 +81,31 @@ class GpuGroup:
             arr[k].layer_idx, arr[k].opacity, arr[k].visible, arr[k].blend_mode, arr[k].kind = idx, op, 1 if vis else 0, mode, 0
         self._check(self.lib.pfx_group_flatten_filter(self.g, arr, C.c_uint32(len(infos)), C.c_int(filt), C.c_float(param), C.c_int(1 if all_gather else 0)))
 
+    def _infos(self, infos):
+        arr = (L.LayerInfo * len(infos))()
+        for k, (idx, op, vis, mode) in enumerate(infos):
+            arr[k].layer_idx, arr[k].opacity, arr[k].visible, arr[k].blend_mode, arr[k].kind = idx, op, 1 if vis else 0, mode, 0
+        return arr
+
+    def flatten_warp_displacement(self, infos, disp: np.ndarray):
+        """pfx_group_flatten_warp_displacement: flatten, replicate the flattened image, every member warps its band; disp = (h, w, 2) float32"""
+        d = np.ascontiguousarray(disp, dtype=np.float32)
+        assert d.shape == (self.h, self.w, 2)
+        self._check(self.lib.pfx_group_flatten_warp_displacement(self.g, self._infos(infos), C.c_uint32(len(infos)), d.ctypes.data_as(C.c_void_p)))
+
+    def flatten_warp_mesh(self, infos, orig_pts, deformed_pts, cols: int, rows: int):
+        """pfx_group_flatten_warp_mesh: orig_pts may be None (uniform original grid); points are (rows + 1, cols + 1, 2) float32"""
+        dp = np.ascontiguousarray(deformed_pts, dtype=np.float32)
+        op = None if orig_pts is None else np.ascontiguousarray(orig_pts, dtype=np.float32)
+        self._check(self.lib.pfx_group_flatten_warp_mesh(self.g, self._infos(infos), C.c_uint32(len(infos)), None if op is None else op.ctypes.data_as(C.c_void_p),
+                                                         dp.ctypes.data_as(C.c_void_p), C.c_uint32(cols), C.c_uint32(rows)))
+
+    def set_watchdog(self, timeout_ms: int, calls: int = 0xFFFFFFFF):
+        self._check(self.lib.pfx_group_set_watchdog(self.g, C.c_uint32(timeout_ms), C.c_uint32(calls)))
+
+    def synchronize_timeout(self, timeout_ms: int):
+        self._check(self.lib.pfx_group_synchronize_timeout(self.g, C.c_uint32(timeout_ms)))
+
     def set_transport(self, transport: int):
         self._check(self.lib.pfx_group_set_transport(self.g, C.c_int(transport)))
 

@@ -628,6 +628,17 @@ class GpuRenderer:
         self._check(self._lib.pfx_warp_displacement_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(sw), C.c_uint32(sh),
                                                         C.c_void_p(disp_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr)))
 
+    def warp_displacement_band_dev(self, src_ptr, sw, sh, disp_band_ptr, w, band_rows, dst_band_ptr, first_row):
+        """rows [first_row, first_row + band_rows) of the warp: the field and the output are bands, the source is whole (pfx_warp_displacement_band_dev)"""
+        self._check(self._lib.pfx_warp_displacement_band_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(sw), C.c_uint32(sh), C.c_void_p(disp_band_ptr),
+                                                             C.c_uint32(w), C.c_uint32(band_rows), C.c_void_p(dst_band_ptr), C.c_uint32(first_row)))
+
+    def warp_mesh_catmull_rom_band_dev(self, src_ptr, orig, deformed, cols, rows, w, h, dst_band_ptr, first_row, band_rows):
+        o = None if orig is None else np.ascontiguousarray(orig, np.float32)
+        d = np.ascontiguousarray(deformed, np.float32)
+        self._check(self._lib.pfx_warp_mesh_catmull_rom_band_dev(self._h, C.c_void_p(src_ptr), _p(o), _p(d), C.c_uint32(cols), C.c_uint32(rows), C.c_uint32(w),
+                                                                 C.c_uint32(h), C.c_void_p(dst_band_ptr), C.c_uint32(first_row), C.c_uint32(band_rows)))
+
     def selftest_round_pack(self):
         """(mismatches, signalling-NaN mismatches) of the device's round-and-pack against the step-by-step formula over all 2^32 floats"""
         bad, snan = C.c_uint64(0), C.c_uint64(0)

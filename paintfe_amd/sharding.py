@@ -106,6 +106,32 @@ def gather_bands(band, height: int, group=None):
     return torch.cat([o[:b1 - b0] for o, (b0, b1) in zip(outs, bands)], dim=0)
 
 
+def warp_sharded(renderer, flat_band, height: int, kind: str, disp_band=None, mesh=None, group=None):
+    """Warp of a document sharded by rows, one process per GPU ("replicate the source, warp bands of the output"; ref:
+    src/ops/transform.rs:1288-1345, 1687-1761): `flat_band` = this rank's flattened band (rows, w, 4) on the device.  The bands are all-gathered so
+    that every rank holds the whole source, then the rank warps ITS band of the output with the band entry points of the C ABI — no halo, because a
+    displacement may reach anywhere.  kind "displacement": disp_band = (rows, w, 2) float32 device tensor; kind "mesh": mesh = (orig or None, deformed,
+    cols, rows).  Returns the rank's band of the result; gather_bands() assembles the whole image where one consumer wants it."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    y0, y1 = band_rows(height, world, rank)
+    w = flat_band.shape[1]
+    source = gather_bands(flat_band, height, group=group).contiguous()
+    out = torch.empty_like(flat_band)
+    if y1 > y0:
+        if kind == "displacement":
+            renderer.warp_displacement_band_dev(source.data_ptr(), w, height, disp_band.data_ptr(), w, y1 - y0, out.data_ptr(), y0)
+        elif kind == "mesh":
+            orig, deformed, cols, rows = mesh
+            renderer.warp_mesh_catmull_rom_band_dev(source.data_ptr(), orig, deformed, cols, rows, w, height, out.data_ptr(), y0, y1 - y0)
+        else:
+            raise ValueError(kind)
+    return out
+
+
 class BandPipeline:
     """flatten -> halo exchange -> Gaussian (or box blur / median) -> all-gather of ONE document on this rank's band, buffers allocated once.
 

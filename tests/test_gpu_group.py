@@ -171,3 +171,111 @@ def test_group_back_to_back_calls_with_overlapping_gathers():
             assert np.array_equal(g.download_gathered(k), ref), f"after {upto} calls: gathered image on member {k}"
         assert np.array_equal(g.download(), ref)
     g.close()
+
+
+@pytest.mark.parametrize("transport", ["peer", "staged"])
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_group_warps_of_a_sharded_document(world, transport):
+    """the flattened bands are all-gathered (every member holds the whole source) and every member warps its band of the output —
+    displacement field and fused Catmull-Rom mesh warp, ragged bands, back to back; equal to flatten + warp on one GPU (and to the oracle)"""
+    from paintfe_amd import GpuRenderer
+    from paintfe_amd.group import GpuGroup
+    from tests import oracle_lib as O
+    w, h, n = 208, 333, 4
+    stack, modes, opac = I.layer_stack(w, h, n, seed=200 + world)
+    infos = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+    rng = np.random.default_rng(world)
+    disp = (rng.standard_normal((h, w, 2)) * 9.0).astype(np.float32)
+    orig, deformed = I.jittered_mesh(6, 6, w, h, seed=world)
+    r = GpuRenderer(0)
+    for k in range(n):
+        r.ensure_layer_texture(k, stack[k], generation=1)
+    flat = r.composite(w, h, infos)
+    ref_d = r.warp_displacement(flat, disp)
+    ref_m = r.warp_mesh_catmull_rom(flat, orig, deformed, 6, 6)
+    assert np.array_equal(ref_d, O.warp_displacement(flat, disp))
+    g = GpuGroup(_devices(world))
+    g.set_transport({"peer": g.PEER, "staged": g.STAGED}[transport])
+    g.set_document(w, h, n)
+    for k in range(n):
+        g.upload_layer(k, stack[k])
+    for _ in range(2):
+        g.flatten_warp_displacement(infos, disp)
+        assert np.array_equal(g.download(), ref_d), "displacement warp"
+        g.flatten_warp_mesh(infos, orig, deformed, 6, 6)
+        assert np.array_equal(g.download(), ref_m), "mesh warp"
+    g.flatten_warp_mesh(infos, None, deformed, 6, 6)          # uniform original grid (the `_fast` form, transform.rs:1735-1736)
+    fast = r.warp_displacement(flat, r.generate_displacement(deformed, 6, 6, w, h))
+    assert np.array_equal(g.download(), fast), "mesh warp, uniform original grid"
+    g.flatten_blur(infos, 2.0, all_gather=True)               # the filter pipeline still works behind a warp (buffers, events)
+    assert np.array_equal(g.download(), r.blur_rgba(flat, 2.0))
+    g.close()
+
+
+def test_group_watchdog_names_the_late_member(monkeypatch):
+    """a peer that never sends must become an error, not a hang.  The last member's stream sleeps in a host function in front of the
+    event its neighbours wait for (PFX_GROUP_TEST_STALL_MS); with a 60 ms watchdog the call returns PFX_ERR_HIP naming the busy members and the halo
+    transfers they take part in; once the sleep is over the group works again"""
+    from paintfe_amd import GpuRenderer
+    from paintfe_amd._lib import PfxError, ERR_HIP
+    from paintfe_amd.group import GpuGroup
+    w, h, n, world = 128, 400, 3, 3
+    stack, modes, opac = I.layer_stack(w, h, n, seed=77)
+    infos = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+    g = GpuGroup(_devices(world))
+    g.set_document(w, h, n)
+    for k in range(n):
+        g.upload_layer(k, stack[k])
+    g.flatten_blur(infos, 3.0)                                 # warm: allocations, first launches
+    g.synchronize()
+    g.set_watchdog(60, 1)
+    monkeypatch.setenv("PFX_GROUP_TEST_STALL_MS", "700")
+    with pytest.raises(PfxError) as e:
+        g.flatten_blur(infos, 3.0)
+    monkeypatch.delenv("PFX_GROUP_TEST_STALL_MS")
+    assert e.value.status == ERR_HIP
+    msg = str(e.value)
+    assert "did not finish within 60 ms" in msg and "member(s)" in msg and "<-" in msg and "2 (device" in msg, msg
+    with pytest.raises(PfxError):
+        g.synchronize_timeout(5)                              # still sleeping
+    g.synchronize()                                           # ... and over
+    r = GpuRenderer(0)
+    for k in range(n):
+        r.ensure_layer_texture(k, stack[k], generation=1)
+    g.flatten_blur(infos, 3.0)                                 # the watchdog's budget of calls is spent; the group is intact
+    assert np.array_equal(g.download(), r.blur_rgba(r.composite(w, h, infos), 3.0))
+    g.synchronize_timeout(2000)
+    g.close()
+
+
+def test_warp_band_entry_points_equal_the_rows_of_the_whole_image_call():
+    """pfx_warp_displacement_band_dev / pfx_warp_mesh_catmull_rom_band_dev: ragged bands of the output, the source whole — bit-identical to the same
+    rows of the whole-image calls (what paintfe_amd.sharding.warp_sharded and pfx_group_flatten_warp_* rest on)"""
+    import torch
+    from paintfe_amd import GpuRenderer
+    from paintfe_amd.group import band_rows
+    w, h = 300, 333
+    r = GpuRenderer(0)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    img = I.random_rgba(w, h, 3)
+    rng = np.random.default_rng(4)
+    disp = (rng.standard_normal((h, w, 2)) * 11.0).astype(np.float32)
+    orig, deformed = I.jittered_mesh(6, 6, w, h, seed=8)
+    ref_d = r.warp_displacement(img, disp)
+    ref_m = r.warp_mesh_catmull_rom(img, orig, deformed, 6, 6)
+    src = torch.from_numpy(img).to(dev)
+    for world in (1, 3, 6):
+        for k in range(world):
+            y0, y1 = band_rows(h, world, k)
+            if y1 == y0:
+                continue
+            dband = torch.from_numpy(np.ascontiguousarray(disp[y0:y1])).to(dev)
+            out = torch.zeros((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
+            r.warp_displacement_band_dev(src.data_ptr(), w, h, dband.data_ptr(), w, y1 - y0, out.data_ptr(), y0)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), ref_d[y0:y1]), f"displacement band {k} of {world}"
+            r.warp_mesh_catmull_rom_band_dev(src.data_ptr(), orig, deformed, 6, 6, w, h, out.data_ptr(), y0, y1 - y0)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), ref_m[y0:y1]), f"mesh band {k} of {world}"
+    r.close()

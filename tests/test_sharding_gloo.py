@@ -72,6 +72,90 @@ def test_band_sharded_pipeline_matches_single_process(tmp_path, world, filt):
         assert np.array_equal(got, ref), f"rank {r}: {(got != ref).any(-1).sum()} px differ"
 
 
+class _CpuWarpRenderer:
+    """CPU stand-in for the two band entry points S.warp_sharded calls (tests only): the oracle's whole-image warp, cut to the band"""
+
+    @staticmethod
+    def _np(ptr_owner):
+        return ptr_owner
+
+    def __init__(self, tensors):
+        self.t = tensors  # data_ptr -> tensor (the stand-in cannot dereference raw pointers)
+
+    def warp_displacement_band_dev(self, src_ptr, sw, sh, disp_ptr, w, band_rows, dst_ptr, first_row):
+        src, disp, dst = self.t[src_ptr].numpy(), self.t[disp_ptr].numpy(), self.t[dst_ptr]
+        full = np.zeros((sh, w, 2), np.float32)
+        full[first_row:first_row + band_rows] = disp
+        dst.copy_(torch.from_numpy(O.warp_displacement(src, full, threads=1)[first_row:first_row + band_rows].copy()))
+
+    def warp_mesh_catmull_rom_band_dev(self, src_ptr, orig, deformed, cols, rows, w, h, dst_ptr, first_row, band_rows):
+        src, dst = self.t[src_ptr].numpy(), self.t[dst_ptr]
+        dst.copy_(torch.from_numpy(O.warp_mesh_catmull_rom(src, orig, deformed, cols, rows, threads=1)[first_row:first_row + band_rows].copy()))
+
+
+class _Registry(dict):
+    """tensors by data_ptr, filled lazily: warp_sharded allocates `source` and `out` itself, so the stand-in looks them up through torch's allocator"""
+
+    def __missing__(self, ptr):
+        raise KeyError(ptr)
+
+
+def _warp_worker(rank, world, port, out_dir, kind):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        stack, modes, opac = I.layer_stack(W, H, NL, seed=12)
+        y0, y1 = S.band_rows(H, world, rank)
+        flat_band = torch.from_numpy(O.flatten_stack(np.ascontiguousarray(stack[:, y0:y1]), modes, opac, threads=1) if y1 > y0 else np.zeros((0, W, 4), np.uint8))
+        rng = np.random.default_rng(5)
+        disp = (rng.standard_normal((H, W, 2)) * 6.0).astype(np.float32)
+        orig, deformed = I.jittered_mesh(4, 5, W, H, seed=9)
+        reg = _Registry()
+        real_empty_like, real_gather = torch.empty_like, S.gather_bands
+
+        def tracking_empty_like(t, *a, **k):
+            o = real_empty_like(t, *a, **k); reg[o.data_ptr()] = o; return o
+
+        def tracking_gather(*a, **k):
+            o = real_gather(*a, **k).contiguous(); reg[o.data_ptr()] = o; return o
+
+        torch.empty_like, S.gather_bands = tracking_empty_like, tracking_gather
+        try:
+            disp_band = torch.from_numpy(np.ascontiguousarray(disp[y0:y1]))
+            reg[disp_band.data_ptr()] = disp_band
+            r = _CpuWarpRenderer(reg)
+            if kind == "displacement":
+                band = S.warp_sharded(r, flat_band, H, "displacement", disp_band=disp_band)
+            else:
+                band = S.warp_sharded(r, flat_band, H, "mesh", mesh=(orig, deformed, 4, 5))
+        finally:
+            torch.empty_like, S.gather_bands = real_empty_like, real_gather
+        full = S.gather_bands(band, H).numpy()
+        np.save(os.path.join(out_dir, f"w{rank}.npy"), full)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "displacement"), (3, "displacement"), (2, "mesh"), (3, "mesh")])
+def test_warp_of_a_sharded_document_matches_single_process(tmp_path, world, kind):
+    """replicate the flattened source (all-gather of the bands), every rank warps its band of the output, the bands concatenate to
+    the single-process warp — displacement field and Catmull-Rom mesh, ragged bands (300 rows over 2 and 3 ranks)"""
+    port = _free_port()
+    mp.spawn(_warp_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
+    stack, modes, opac = I.layer_stack(W, H, NL, seed=12)
+    flat = O.flatten_stack(stack, modes, opac, threads=2)
+    if kind == "displacement":
+        rng = np.random.default_rng(5)
+        ref = O.warp_displacement(flat, (rng.standard_normal((H, W, 2)) * 6.0).astype(np.float32))
+    else:
+        orig, deformed = I.jittered_mesh(4, 5, W, H, seed=9)
+        ref = O.warp_mesh_catmull_rom(flat, orig, deformed, 4, 5)
+    for r in range(world):
+        got = np.load(tmp_path / f"w{r}.npy")
+        assert np.array_equal(got, ref), f"rank {r}: {(got != ref).any(-1).sum()} px differ"
+
+
 def test_band_partition_properties():
     for h in (1, 63, 64, 65, 300, 4320, 8640):
         for world in (1, 2, 3, 4, 8, 100):
