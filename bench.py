@@ -142,6 +142,17 @@ def clock_power_sample(torch, step_fn, dev_index, seconds=0.4):
         return None
 
 
+def nan_to_none(x):
+    """a run whose band pipeline failed carries NaN times: the line must stay valid JSON"""
+    if isinstance(x, float) and x != x:
+        return None
+    if isinstance(x, dict):
+        return {k: nan_to_none(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [nan_to_none(v) for v in x]
+    return x
+
+
 def usable_cores() -> int:
     """threads the CPU baseline may really use: scheduler affinity, capped by the cgroup CPU quota if there is one"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -424,10 +435,13 @@ def main() -> int:
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # a collective that never completes must become an error well inside the driver's patience (the default watchdog waits 10 minutes)
+        tmo = datetime.timedelta(seconds=int(os.environ.get("PFX_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=tmo)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=tmo)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if args.gpus != world:
@@ -511,21 +525,30 @@ def main() -> int:
         ptrs = [stack[k].data_ptr() for k in range(n)]
 
         def step():
+            if os.environ.get("PFX_BENCH_TEST_FAIL_BAND"):  # test hook: what an RCCL error in the band pipeline looks like to this script
+                raise RuntimeError("injected band pipeline failure (PFX_BENCH_TEST_FAIL_BAND)")
             state["result"] = pipe.step(ptrs, info)
 
-        elapsed, kern = timed(step)
-        flat_view = pipe.flat_band()
+        # The band pipeline is the only part of this run with collectives in its timed region.  If it fails (an RCCL error, a watchdog timeout) the
+        # line must still carry what needs none — `doc_mode` below — so that a partial scaling curve survives (VERDICT r03 #5b): the headline value
+        # is then null and the error is on the line.
         band_sharded = None
-        if not args.no_gather:
-            # the same band pipeline with the result left sharded (every rank keeps its band of the blurred image: halo exchange only) —
-            # SURVEY 8(e) names skipping the all-gather as the way past it when a consumer can take bands; reported beside the headline
-            pipe.finish()
-            pipe.gather = False
-            b_el, _ = timed(step)
-            pipe.gather = True
-            band_sharded = {"value": round(w * h * args.steps / b_el / 1e6, 1), "unit": "Mpixels/s", "scaling": "strong",
-                            "ms_per_step": round(b_el / args.steps * 1e3, 4),
-                            "sharding": "ONE document in chunk-row bands, halo exchange only: the blurred result stays sharded (no all-gather)"}
+        try:
+            elapsed, kern = timed(step)
+            flat_view = pipe.flat_band()
+            if not args.no_gather:
+                # the same band pipeline with the result left sharded (every rank keeps its band of the blurred image: halo exchange only) —
+                # SURVEY 8(e) names skipping the all-gather as the way past it when a consumer can take bands; reported beside the headline
+                pipe.finish()
+                pipe.gather = False
+                b_el, _ = timed(step)
+                pipe.gather = True
+                band_sharded = {"value": round(w * h * args.steps / b_el / 1e6, 1), "unit": "Mpixels/s", "scaling": "strong",
+                                "ms_per_step": round(b_el / args.steps * 1e3, 4),
+                                "sharding": "ONE document in chunk-row bands, halo exchange only: the blurred result stays sharded (no all-gather)"}
+        except Exception as e:  # noqa: BLE001 — reported on the line, the process still exits non-zero
+            state["band_error"] = f"{type(e).__name__}: {e}"[:500]
+            elapsed, kern, flat_view = float("nan"), {}, None
         # the collective-free mode in the same run (one independent 8K document per rank), reported beside the headline
         del stack
         torch.cuda.empty_cache()
@@ -631,6 +654,10 @@ def main() -> int:
     if band_mode and band_sharded:
         out["band_sharded_result"] = band_sharded
     failed = []
+    if state.get("band_error"):
+        out["value"] = None
+        out["band_pipeline_error"] = state["band_error"]
+        failed.append("band_pipeline")
 
     if rank == 0:
         # correctness of the TIMED result against the oracle: a crop of the flatten (per-pixel, so a crop of the full-size flatten
@@ -647,7 +674,7 @@ def main() -> int:
             if not ok:
                 out["check"]["mismatching_px"] = int((ref != got).any(-1).sum())
                 failed.append("flatten_crop_bitexact")
-        if band_mode and hh > 0:
+        if band_mode and hh > 0 and not state.get("band_error"):
             # rank 0 rebuilds a window around its band from the shared seeds and runs the single-process oracle pipeline on it
             lo, hi = max(y0 - 2 * radius, 0), min(y1 + 2 * radius, h)
             if (hi - lo) * w <= (1 << 25):
@@ -711,7 +738,7 @@ def main() -> int:
         if failed:  # a wrong-but-fast kernel must not be scored
             out["value"] = None
             out["failed_checks"] = failed
-        print(json.dumps(out), flush=True)
+        print(json.dumps(nan_to_none(out)), flush=True)
 
     if world > 1:
         dist.barrier()

@@ -48,6 +48,21 @@ def test_band_mode_is_the_default_and_matches_single_process(nproc):
     assert d["check"]["band_blur_max_diff_vs_oracle"] <= 1  # matrix-core Gaussian: the stated +-1 LSB
 
 
+def test_failed_band_pipeline_still_reports_the_collective_free_mode():
+    """VERDICT r03 #5b: when the band pipeline (the only timed region with collectives) fails, the line still carries `doc_mode` — a partial scaling
+    curve survives — with a null headline value, the error on the line and a non-zero exit code"""
+    env = dict(os.environ, PFX_BENCH_BACKEND="gloo", PFX_BENCH_TEST_FAIL_BAND="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29661",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "640", "--height", "400", "--layers", "6", "--sigma", "3.0",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode != 0 and len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and "band_pipeline" in d["failed_checks"] and "injected" in d["band_pipeline_error"]
+    assert d["doc_mode"]["value"] > 0 and d["doc_mode"]["scaling"] == "weak"
+
+
 def test_gpus_flag_without_that_many_ranks_fails_loudly():
     """`--gpus 2` started as a single process must refuse to print a number (the driver launches N ranks; a job that silently ran on
     fewer would report a wrong N-GPU value)"""
