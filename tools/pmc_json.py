@@ -31,7 +31,8 @@ def name(kernel):
 
 
 px = W * H
-fl, gs = ("flatten_dle_kernel" if "flatten_dle_kernel" in txt else "flatten_stream_kernel"), "gauss_strip_kernel"
+fl = next((k for k in ("flatten_srt_kernel", "flatten_dle_kernel", "flatten_stream_kernel") if k in txt), "flatten_stream_kernel")
+gs = "gauss_strip_kernel"
 cyc_f, cyc_g = val(fl, "GRBM_GUI_ACTIVE") / 8, val(gs, "GRBM_GUI_ACTIVE") / 8
 d = {
     "source": "tools/prof.sh -> tools/prof_summary.py -> tools/pmc_json.py (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group; "
@@ -44,6 +45,11 @@ d = {
         "clock_ghz": round(cyc_f / avg_ns(fl), 3),
         "valu_issue_frac_profiled": round(val(fl, "SQ_INSTS_VALU") * 2 / (1024 * cyc_f), 3),  # 2 issue cycles per wave64 VALU, 1024 SIMDs
         "valu_insts_per_layer_px": round(val(fl, "SQ_INSTS_VALU") * 64 / (px * N), 2),
+        # one scalar unit per CU, one instruction per cycle, shared by the CU's 24 waves
+        "salu_unit_frac_profiled": round(val(fl, "SQ_INSTS_SALU") / (256 * cyc_f), 3),
+        "vmem_rd_wave_insts": val(fl, "SQ_INSTS_VMEM_RD"),
+        # a typed (UNORM8 x 4) wave-load occupies the CU's texture path for ~29 cycles (load-only kernel: tools/lab/perm_load.hip, 4.72 TB/s)
+        "texture_path_frac_profiled": (round(val(fl, "SQ_INSTS_VMEM_RD") * 29 / (256 * cyc_f), 3) if val(fl, "SQ_INSTS_VMEM_RD") else None),
     },
     "commit": (sys.argv[3] if len(sys.argv) > 3 else None),
     "gauss_strip": {
@@ -73,9 +79,12 @@ if all(v is not None for v in mix.values()):
     f["valu_issue_cycles_weighted"] = [lo, hi]
     f["valu_issue_frac_weighted"] = [round(lo / (1024 * cyc_f), 3), round(hi / (1024 * cyc_f), 3)]
 d["bounds"] = {
-    "flatten": f"VALU issue: {f['valu_issue_frac_profiled'] * 100:.0f} % of the issue slots if every instruction took 2 cycles, "
-               + (f"{f['valu_issue_frac_weighted'][0] * 100:.0f}-{f['valu_issue_frac_weighted'][1] * 100:.0f} % with the measured per-class issue costs " if "valu_issue_frac_weighted" in f else "")
-               + f"at the profiled {f['clock_ghz']:.2f} GHz; HBM traffic {f['hbm_bytes'] / f['algorithmic_bytes']:.3f}x algorithmic",
+    "flatten": f"three units of the CU near their limits at once, at a clock the 1400 W board limit sets ({f['clock_ghz']:.2f} GHz profiled): VALU issue "
+               f"{f['valu_issue_frac_profiled'] * 100:.0f} % of the slots at 2 cycles per instruction"
+               + (f" ({f['valu_issue_frac_weighted'][0] * 100:.0f}-{f['valu_issue_frac_weighted'][1] * 100:.0f} % by the per-class cost MODEL)" if "valu_issue_frac_weighted" in f else "")
+               + f", the CU's one scalar unit {f['salu_unit_frac_profiled'] * 100:.0f} % busy"
+               + (f", the texture path ~{f['texture_path_frac_profiled'] * 100:.0f} % (typed loads: 4.7 TB/s is their ceiling with no arithmetic at all)" if f.get("texture_path_frac_profiled") else "")
+               + f"; HBM traffic {f['hbm_bytes'] / f['algorithmic_bytes']:.3f}x algorithmic",
     "gauss_strip": f"barrier-to-barrier dependency chain of the producer / consumer wave roles (MFMA pipe {g['mfma_pipe_frac_profiled'] * 100:.0f} % busy, LDS "
                    f"{g['lds_busy_frac_profiled'] * 100:.0f} %; HBM traffic {g['hbm_bytes'] / g['algorithmic_bytes']:.2f}x algorithmic: the 4x x-halo overlap of neighbouring strips "
                    "is served by one XCD's L2 since the strip order is XCD-aware)",
