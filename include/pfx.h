@@ -476,7 +476,14 @@ int pfx_selftest_round_pack(pfx_ctx* ctx, uint64_t* mismatches, uint64_t* signal
  * result that way, is only used on a device where it does: checked once per context). */
 int pfx_selftest_unorm_store(pfx_ctx* ctx, uint64_t* mismatches);
 
-/* development tuning knobs (kernel tile configurations); unknown keys return PFX_ERR_INVALID.  Results never change.  The knobs that select among
+/* host-side: the f16 tap tables of the matrix-core Gaussian for `sigma` (radius 1 .. 80), as the library uploads them: three parts of 256 entries,
+ * tap t at index 48 + t — [0] and [1] the two-piece split w * 256 = w1 + w2, [2] the single-piece table the default mode multiplies with (every weight
+ * one f16, the table's sum nudged to the exact weights' sum).  *bias_split / *bias_single = 1024 * the tables' sums (the sample encoding's offset).
+ * Returns the number of taps, or a negative PFX_ERR_* (diagnostics for tests/: the kernel's +-1 LSB bound rests on these tables). */
+int pfx_gaussian_f16_tables(float sigma, uint16_t out_768[768], float* bias_split, float* bias_single);
+
+/* development tuning knobs (kernel tile configurations); unknown keys return PFX_ERR_INVALID.  Results never change — except under "gauss_parts", which
+ * selects among +-1 LSB class variants of the default-mode Gaussian (f16 pieces per weight / per horizontal result: 12 shipped, 22, 11).  The knobs that select among
  * kernel shapes of the compositor ("flatten_variant", "dle_*") are process-wide (one setting for every context), the rest per context. */
 int pfx_tune(pfx_ctx* ctx, const char* key, int value);
 /* work counters of the compositor's dead-layer elimination since the last reset (diagnostics for profiles/ and the tests; the call

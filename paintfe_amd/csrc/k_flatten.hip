@@ -639,6 +639,9 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
 #ifndef PFX_SRT_REDEAL
 #define PFX_SRT_REDEAL 1   // development A/B: 0 = no re-deal code in the layer loop
 #endif
+#ifndef PFX_SRT_NATSTORE
+#define PFX_SRT_NATSTORE 1 // development A/B: 0 = a dealt unit is stored in dealt order (three partial writes per 64-byte piece)
+#endif
 template <int PX>
 PFX_DEV void stream_layer_groups(float (&acc)[PX][4], const float (&t)[PX][4], uint32_t mode, float opacity, uint32_t lead)
 {
@@ -887,7 +890,24 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
         }
         // ---- natural pass: every group from r on, re-dealt by accumulator class on the way ----
         st_nlay += n_layers - r;
+        const uint32_t moves_before = st_moves;
         srt_layers<PX, NOBLEND>(acc, layers, r, n_layers, bytes, voff, s1, P.seg, s_x, s_v, st_moves);
+        // A dealt unit goes back to lane order before it is stored: a store instruction whose lanes cover a third of every 64-byte piece of the
+        // unit is written through as partial pieces — three stores per piece, 2.7x the result's bytes on the way to HBM (profiles/r04_pmc.json:
+        // WRITE_SIZE 354 MB for a 133 MB frame).  Three 16-byte LDS writes and reads per unit buy whole-line stores.
+        if (PFX_SRT_NATSTORE && (best != 0u || st_moves != moves_before)) {
+            const uint32_t ub = (base_px + u * UPX) * 4u;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) s_x[((uint32_t)voff[j] - ub) >> 2] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const float4 a = s_x[64u * j + lane];
+                acc[j][0] = a.x; acc[j][1] = a.y; acc[j][2] = a.z; acc[j][3] = a.w;
+                voff[j] = (int)(ub + (64u * j + lane) * 4u);
+            }
+            wave_lds_sync();
+        }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             pfx_v4f v; v.x = acc[j][0]; v.y = acc[j][1]; v.z = acc[j][2]; v.w = acc[j][3];

@@ -182,6 +182,12 @@ hipError_t launch_v_cfg(hipStream_t stream, const float4* tmp, uint8_t* d_dst, c
 unsigned long long* g_dbg_buf = nullptr; // development: phase timestamps of gauss_strip_kernel (pfxk_gauss_set_dbg_buf)
 int g_v_cfg = 0; // tuning knob (pfxk_gauss_set_v_config); 0 is the shipped configuration
 int g_mfma_seg = 0; // tuning knob (pfxk_gauss_set_mfma_segments): row segments per strip of the matrix-core kernel, 0 = automatic
+// f16 pieces per weight / per horizontal result in the matrix-core kernel (pfxk_gauss_set_mfma_parts).  Shipped: ONE piece per weight, two per
+// horizontal result (round 4, tools/gauss_parts.py at 8K against the bit-exact mode): sigma 16 0.177 -> 0.138 ms, sigma 4 0.119 -> 0.090, sigma 24
+// 0.243 -> 0.190; channels that differ (all by 1): uniform noise 4.9e-5 -> 3.6e-4, photograph-like ramps + noise 5.0e-5 -> 4.8e-5, smooth ramps
+// 1e-7 -> 8e-9.  One piece for both (pfx_tune "gauss_parts" = 11) runs sigma 16 in 0.114 ms but rounds the horizontal result to 11 bits — 0.125 LSB
+// steps at the bright end: 2 % of a smooth ramp's channels come out one off; kept as a measured variant, not shipped.
+int g_mfma_wp = 1, g_mfma_hp = 2;
 
 template <bool EXACT>
 hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const float* wts, int radius, uint32_t w, uint32_t h)
@@ -212,6 +218,10 @@ hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const
 //     65504) is split S*h = h1 + h2 the same way.  H pass: p*w1 + p*w2.  V pass: h1*w1 + h1*w2 + h2*w1; the dropped h2*w2 is < 2^-22
 //     of the sum.  The result differs from the CPU path's f32 mul/add chain by rounding noise only (+-1 LSB class, tests and
 //     bench.py assert it; at 8K ~1e-4 of the channels differ).
+//     WP = 1 (shipped since round 4): the weight is ONE f16, w * S rounded to 11 bits and the table nudged so that its sum is that of the exact
+//     weights (pfx_host_gaussian_split_f16): H pass p*w1', V pass h1*w1' + h2*w1' — 3 MFMAs per K block and output tile instead of 5.  The filter
+//     applied is a Gaussian whose taps are off by <= 2^-12 relative with zero sum: a flat image blurs to itself, an adversarial one moves by
+//     at most sum|delta| * 255 / S < 0.1 LSB per pass, so the +-1 LSB bound holds by construction (rates: the g_mfma_wp comment above).
 //   * u8 -> f16 without arithmetic: the half with bit pattern 0x6400 | b is exactly 1024 + b, so one v_perm_b32 per two samples
 //     builds a fragment; the constant 1024 * sum(T[.][n]) it adds to every output is the H accumulator's start value.
 //   * the 16 NKB samples of a window are dealt to the MFMA's K slots as runs of 8: slot (lane half hh, K block kb) holds samples
@@ -258,15 +268,15 @@ constexpr int GM_WLEN = 256;            // entries per weight part
 constexpr int GS_DEPTH = 3;             // register sets of source pixels in flight per producer lane
 constexpr int gs_xrow(int nkb) { return 16 * (nkb > 8 ? nkb : 8) + 16; } // bytes per (channel, row) line of the de-interleave patch: 16 NKB samples + 16 (bank spread)
 
-inline size_t gauss_strip_lds_bytes(int nkb)
+inline size_t gauss_strip_lds_bytes(int nkb, int hp)
 {
     const int ring = 16 * nkb + 32;
-    return (size_t)8 * (GM_COLS * (ring + 8) + 32) * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * gs_xrow(nkb);
+    return (size_t)4 * hp * (GM_COLS * (ring + 8) + 32) * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * gs_xrow(nkb);
 }
 
 // DBG: the development instantiation (switchable parts, s_memtime stamps); the shipped one has none of those branches — a dozen
 // skipped-over stamps per iteration were 10 % of the kernel
-template <bool FAST, int NKB, bool DBG>
+template <bool FAST, int NKB, bool DBG, int WP = 2, int HP = 2>
 __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8, float inv_scale2,
                                                              float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg, int dbg_arg,
@@ -276,8 +286,8 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
     constexpr int RING = 16 * NKB + 32, YP = RING + 8, PLANE = GM_COLS * YP + 32, HALF = NKB / 2, PPL = 2 * NKB; // PPL: pixels per producer lane
     extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
     _Float16* HR = reinterpret_cast<_Float16*>(gm_lds);                            // [part][c][x][YP], rows = ring slots
-    uint32_t* OUT = reinterpret_cast<uint32_t*>(gm_lds + (size_t)8 * PLANE * 2);    // [2][32][GM_OUT_PITCH]
-    uint8_t* XP = gm_lds + (size_t)8 * PLANE * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4; // [producer wave][c][row][GS_XROW]
+    uint32_t* OUT = reinterpret_cast<uint32_t*>(gm_lds + (size_t)4 * HP * PLANE * 2); // [2][32][GM_OUT_PITCH]
+    uint8_t* XP = gm_lds + (size_t)4 * HP * PLANE * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4; // [producer wave][c][row][GS_XROW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
@@ -285,8 +295,9 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 
     pfx_f16x8 B1[NKB], B2[NKB]; // Toeplitz fragments, resident for the whole kernel
     {
-        const _Float16* w1 = reinterpret_cast<const _Float16*>(wsplit) + GM_WOFF;
-        const _Float16* w2 = w1 + GM_WLEN;
+        // WP == 1: the third table, every weight ONE f16 (pfx_host_gaussian_split_f16); B2 is then never used
+        const _Float16* w1 = reinterpret_cast<const _Float16*>(wsplit) + GM_WOFF + (WP == 1 ? 2 * GM_WLEN : 0);
+        const _Float16* w2 = reinterpret_cast<const _Float16*>(wsplit) + GM_WOFF + GM_WLEN;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const int t0 = 16 * kb + 8 * hh - i - (R8 - r); // in [-46, 16 NKB - 8]
@@ -395,13 +406,16 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                         pfx_f16x4 h1, h2;
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) {
-                            const float va = acc[4 * g + e] + acc2[4 * g + e], vb = acc[4 * g + e + 1] + acc2[4 * g + e + 1];
-                            const pfx_f16x2 hi = pkrtz(va, vb);
-                            const pfx_f16x2 lo = pkrtz(va - (float)hi[0], vb - (float)hi[1]);
-                            h1[e] = hi[0]; h1[e + 1] = hi[1]; h2[e] = lo[0]; h2[e + 1] = lo[1];
+                            const float va = WP == 2 ? acc[4 * g + e] + acc2[4 * g + e] : acc[4 * g + e];
+                            const float vb = WP == 2 ? acc[4 * g + e + 1] + acc2[4 * g + e + 1] : acc[4 * g + e + 1];
+                            if constexpr (HP == 2) {
+                                const pfx_f16x2 hi = pkrtz(va, vb);
+                                const pfx_f16x2 lo = pkrtz(va - (float)hi[0], vb - (float)hi[1]);
+                                h1[e] = hi[0]; h1[e + 1] = hi[1]; h2[e] = lo[0]; h2[e + 1] = lo[1];
+                            } else { h1[e] = (_Float16)va; h1[e + 1] = (_Float16)vb; }   // one piece: round to nearest (no bias)
                         }
                         *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(0 * 4 + g) * PLANE + i * YP + ro) = h1;
-                        *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * PLANE + i * YP + ro) = h2;
+                        if constexpr (HP == 2) *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * PLANE + i * YP + ro) = h2;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B1[kb], kb ? acc : neg_bias, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], kb ? acc2 : pfx_f32x16{}, 0, 0, 0);
+                        if constexpr (WP == 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], kb ? acc2 : pfx_f32x16{}, 0, 0, 0);
                     }
                 }
                 stamp(it, 4);
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
         constexpr int EARLY = NKB - 2;
         const int xb = wave - 4, xl = i >> 2, c = i & 3;
         const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
-        const _Float16* a2p = HR + (size_t)(1 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
+        const _Float16* a2p = HR + (size_t)((HP - 1) * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
         const int st_t = tid - 256, st_rr = st_t >> 3, st_cg = 4 * (st_t & 7);
         pfx_f16x8 a1[NKB], a2[NKB];
         auto request = [&](int rbase, auto k0c, auto k1c) { // K blocks [K0, K1) of the block whose window starts at ring row rbase
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 int ro = rbase + 16 * kb;
                 ro = ro >= RING ? ro - RING : ro;
                 a1[kb] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
-                a2[kb] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
+                if constexpr (HP == 2) a2[kb] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
             }
         };
         int rbase = 0; // (32 v) mod RING for v = -HALF - 1 (RING = 32 (HALF + 1))
@@ -520,9 +534,9 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
             if (active) {
 #pragma unroll
                 for (int kb = 0; kb < EARLY; ++kb) {
-                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], kb ? accX : pfx_f32x16{}, 0, 0, 0);
+                    if constexpr (WP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], kb ? accX : pfx_f32x16{}, 0, 0, 0);
                     accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B1[kb], kb ? accA : pfx_f32x16{}, 0, 0, 0);
-                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], accX, 0, 0, 0);
+                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], (kb || WP == 2) ? accX : pfx_f32x16{}, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -541,9 +555,9 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
             if (active) {
 #pragma unroll
                 for (int kb = EARLY; kb < NKB; ++kb) {
-                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], accX, 0, 0, 0);
+                    if constexpr (WP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], accX, 0, 0, 0);
                     accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B1[kb], accA, 0, 0, 0);
-                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], accX, 0, 0, 0);
+                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], accX, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                     // the f32 summation order already costs) and saturates to [0, 255]
                     uint32_t px = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) px = __builtin_amdgcn_cvt_pk_u8_f32((accA[4 * g + e] + accX[4 * g + e]) * inv_scale2, e, px);
+                    for (int e = 0; e < 4; ++e) px = __builtin_amdgcn_cvt_pk_u8_f32(((WP == 2 || HP == 2) ? accA[4 * g + e] + accX[4 * g + e] : accA[4 * g + e]) * inv_scale2, e, px);
                     orow[2 * g] = px;
                 }
             }
@@ -581,6 +595,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 extern "C" int pfxk_gauss_max_radius(void) { return 850; }
 extern "C" void pfxk_gauss_set_v_config(int cfg) { g_v_cfg = cfg; }
 extern "C" void pfxk_gauss_set_mfma_segments(int n) { g_mfma_seg = n > 0 && n < 256 ? n : 0; }
+extern "C" void pfxk_gauss_set_mfma_parts(int wp, int hp) { g_mfma_wp = wp == 1 ? 1 : 2; g_mfma_hp = (hp == 1 && wp == 1) ? 1 : 2; }
 extern "C" void pfxk_gauss_set_dbg_buf(unsigned long long* p) { g_dbg_buf = p; }
 extern "C" int pfxk_gauss_weight_pad(void) { return W_PAD; }
 
@@ -607,10 +622,12 @@ extern "C" int pfxk_gauss_mfma_max_radius(void) { return GM_MAXR; }
 extern "C" int pfxk_gauss_mfma_wlen(void) { return GM_WLEN; }
 extern "C" int pfxk_gauss_mfma_woff(void) { return GM_WOFF; }
 extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit,
-                                      int radius, float inv_scale2, float bias_c, uint32_t w, uint32_t h, uint32_t first_row, int n_cus)
+                                      int radius, float inv_scale2, float bias_c, float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus)
 {
     if (w == 0 || h == 0) return hipSuccess;
     if (radius < 1 || radius > GM_MAXR) return hipErrorInvalidValue;
+    const int wp = g_mfma_wp, hp = g_mfma_hp;
+    if (wp == 1) bias_c = bias_single;
     const int R8 = (radius + 15) & ~15;                    // window start x0 - R8: pieces of 4 pixels stay 16-byte aligned
     const int nkb = ((GM_COLS + R8 + radius + 15) / 16 + 1) & ~1; // 4, 6, 8, 10 or 12
     const int tiles_x = ((int)w + GM_COLS - 1) / GM_COLS;
@@ -622,7 +639,7 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     hipError_t errs = hipSuccess;
     auto launch_s = [&](auto nkb_c) {
         constexpr int NK = decltype(nkb_c)::value;
-        const size_t lds = gauss_strip_lds_bytes(NK);
+        const size_t lds = gauss_strip_lds_bytes(NK, hp);
         // cut every strip into n_seg row segments so that the launch is ONE round of resident workgroups (LDS-bound: two per CU with 4 K blocks,
         // one from 6 up): every workgroup starts at once and none waits for a second round, and a segment pays NK/2 - 1 run-in steps.  Measured
         // (tools/lab/gauss_seg.py, sigma 16): 8K 1 / 2 / 3 segments = 0.166 / 0.175 / 0.184 ms, 4K 0.080 / 0.053 / 0.070, 1080p 4 segments 0.023
@@ -642,6 +659,8 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
             kern<<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, dbg, g_dbg_buf);
         };
         if (fast && dbg) go(gauss_strip_kernel<true, NK, true>); // development (tools/gauss_dbg.py, tools/gauss_timeline.py)
+        else if (fast && wp == 1 && hp == 2) go(gauss_strip_kernel<true, NK, false, 1, 2>);
+        else if (fast && wp == 1 && hp == 1) go(gauss_strip_kernel<true, NK, false, 1, 1>);
         else if (fast) go(gauss_strip_kernel<true, NK, false>);
         else go(gauss_strip_kernel<false, NK, false>);
     };

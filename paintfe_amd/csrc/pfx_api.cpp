@@ -433,7 +433,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
             std::vector<float> k;
             pfx_host_gaussian_kernel(sigma, k);
             std::vector<uint16_t> ws;
-            ctx->wsplit_inv_scale = pfx_host_gaussian_split_f16(k, pfxk_gauss_mfma_wlen(), pfxk_gauss_mfma_woff(), ws, &ctx->wsplit_bias);
+            ctx->wsplit_inv_scale = pfx_host_gaussian_split_f16(k, pfxk_gauss_mfma_wlen(), pfxk_gauss_mfma_woff(), ws, &ctx->wsplit_bias, &ctx->wsplit_bias_single);
             PFX_TRY(pfx_reserve(ctx, ctx->d_wsplit, ws.size() * sizeof(uint16_t)));
             PFX_TRY(pfx_h2d(ctx, ctx->d_wsplit.p, ws.data(), ws.size() * sizeof(uint16_t)));
             ctx->wsplit_sigma_bits = sigma_bits;
@@ -441,7 +441,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
         }
         pfx_timer t(ctx, "gauss_mfma");
         PFX_HIP(ctx, pfxk_gauss_mfma(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint16_t*)ctx->d_wsplit.p,
-                                     radius, ctx->wsplit_inv_scale, ctx->wsplit_bias, w, h, first_row, ctx->n_cus > 0 ? ctx->n_cus : 256));
+                                     radius, ctx->wsplit_inv_scale, ctx->wsplit_bias, ctx->wsplit_bias_single, w, h, first_row, ctx->n_cus > 0 ? ctx->n_cus : 256));
         return PFX_OK;
     }
     const int pad = pfxk_gauss_weight_pad(); // zero taps on both sides: the kernels' register blocking reads past the ends
@@ -1268,6 +1268,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (!ctx || !key) return PFX_ERR_INVALID;
     if (std::strcmp(key, "gauss_v_cfg") == 0) { pfxk_gauss_set_v_config(value); return PFX_OK; }
     if (std::strcmp(key, "gauss_mfma_segments") == 0) { pfxk_gauss_set_mfma_segments(value); return PFX_OK; }
+    if (std::strcmp(key, "gauss_parts") == 0) { pfxk_gauss_set_mfma_parts(value / 10, value % 10); return PFX_OK; } // f16 pieces per weight, per horizontal result: 22, 12, 11
     if (std::strcmp(key, "flatten_variant") == 0) { pfxk_flatten_set_variant(value); return PFX_OK; }
     if (std::strcmp(key, "dle_units") == 0) { pfxk_flatten_set_dle(value, -1); return PFX_OK; }
     if (std::strcmp(key, "dle_ring") == 0) { pfxk_flatten_set_dle(-1, value); return PFX_OK; }

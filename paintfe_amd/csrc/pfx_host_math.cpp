@@ -81,10 +81,14 @@ float f16_to_f32(uint16_t hv)
 // weights are < 1, so w * S is in range too) and split w * S = w1 + w2, two f16: 22 significant bits, or an absolute 2^-25 where
 // w2 is subnormal.  Returns 1 / S^2 (the two passes' scales, applied once at the end); *bias = 1024 * sum(w1 + w2), the constant
 // the kernel's 0x6400 | byte sample encoding adds to every horizontal sum.
-float pfx_host_gaussian_split_f16(const std::vector<float>& k, int wlen, int woff, std::vector<uint16_t>& out, float* bias)
+// Third table (out[2 * wlen ...]): every weight as ONE f16, w1' = RN(w * S) nudged by single ulps (symmetric pairs, the taps whose rounding
+// error asks for it most first) until the table's sum is within one smallest ulp of sum(w * S) — a flat image then blurs to itself as with the
+// split weights; what remains is a relative 2^-12 per tap with zero sum: at most 0.1 LSB per pass on an adversarial image (sum |delta| * 255 / S),
+// ~1e-3 LSB on noise.  *bias_single = 1024 * sum(w1').
+float pfx_host_gaussian_split_f16(const std::vector<float>& k, int wlen, int woff, std::vector<uint16_t>& out, float* bias, float* bias_single)
 {
     const int s = 8;
-    out.assign((size_t)2 * wlen, 0);
+    out.assign((size_t)3 * wlen, 0);
     double sum = 0.0;
     for (size_t t = 0; t < k.size() && (int)t + woff < wlen; ++t) {
         const float ws = std::ldexp(k[t], s);
@@ -95,6 +99,38 @@ float pfx_host_gaussian_split_f16(const std::vector<float>& k, int wlen, int wof
         sum += (double)f16_to_f32(h1) + (double)f16_to_f32(h2);
     }
     if (bias) *bias = (float)(1024.0 * sum);
+    {
+        const size_t n = std::min(k.size(), (size_t)std::max(wlen - woff, 0));
+        std::vector<uint16_t> q(n);
+        std::vector<double> want(n);
+        double target = 0.0, have = 0.0;
+        for (size_t t = 0; t < n; ++t) { want[t] = (double)std::ldexp(k[t], s); q[t] = f32_to_f16_rn((float)want[t]); target += want[t]; have += (double)f16_to_f32(q[t]); }
+        auto ulp_up = [&](uint16_t hv) { return (double)f16_to_f32((uint16_t)(hv + 1)) - (double)f16_to_f32(hv); };
+        auto ulp_dn = [&](uint16_t hv) { return hv ? (double)f16_to_f32(hv) - (double)f16_to_f32((uint16_t)(hv - 1)) : 0.0; };
+        std::vector<char> moved(n, 0);
+        for (int guard = 0; guard < 4096; ++guard) {
+            const double e = target - have; // > 0: the table is short
+            // candidate = a symmetric pair (t, n-1-t) (or the centre tap) not moved yet whose step brings the sum closer; the largest such step first,
+            // among equal steps the tap whose own rounding error points the same way most strongly.  No tap ends more than one f16 step from w * S.
+            double best_gain = 0.0, best_step = 0.0; size_t best = n;
+            for (size_t t = 0; t * 2 < n + 1 && t < n; ++t) {
+                const size_t u = n - 1 - t;
+                const int mult = (u == t) ? 1 : 2;
+                const double step = e > 0 ? ulp_up(q[t]) : -ulp_dn(q[t]);
+                if (moved[t] || step == 0.0 || q[t] != q[u] || std::fabs(mult * step) >= 2.0 * std::fabs(e)) continue; // would not reduce |e|
+                const double own = want[t] - (double)f16_to_f32(q[t]);
+                const double gain = own * (e > 0 ? 1.0 : -1.0) / std::fabs(step);
+                if (best == n || std::fabs(step) > std::fabs(best_step) || (std::fabs(step) == std::fabs(best_step) && gain > best_gain)) { best_gain = gain; best = t; best_step = step; }
+            }
+            if (best == n) break;
+            const size_t u = n - 1 - best;
+            q[best] = (uint16_t)(q[best] + (e > 0 ? 1 : -1)); have += best_step; moved[best] = 1;
+            if (u != best) { q[u] = q[best]; have += best_step; moved[u] = 1; }
+        }
+        double sum1 = 0.0;
+        for (size_t t = 0; t < n; ++t) { out[(size_t)2 * wlen + woff + t] = q[t]; sum1 += (double)f16_to_f32(q[t]); }
+        if (bias_single) *bias_single = (float)(1024.0 * sum1);
+    }
     return std::ldexp(1.0f, -2 * s);
 }
 
@@ -125,6 +161,22 @@ float pfx_host_bc_factor(float contrast) { return (259.0f * (contrast + 255.0f))
 float pfx_host_exposure_gain(float ev) { return powf(2.0f, ev); }
 
 extern "C" {
+
+int pfx_gaussian_f16_tables(float sigma, uint16_t out_768[768], float* bias_split, float* bias_single)
+{
+    if (!out_768 || !(sigma > 0.0f)) return PFX_ERR_INVALID;
+    const int radius = pfx_host_gaussian_radius(sigma);
+    if (radius < 1 || radius > 80) return PFX_ERR_UNSUPPORTED;
+    std::vector<float> k;
+    pfx_host_gaussian_kernel(sigma, k);
+    std::vector<uint16_t> ws;
+    float b2 = 0.0f, b1 = 0.0f;
+    pfx_host_gaussian_split_f16(k, 256, 48, ws, &b2, &b1);
+    std::copy(ws.begin(), ws.end(), out_768);
+    if (bias_split) *bias_split = b2;
+    if (bias_single) *bias_single = b1;
+    return (int)k.size();
+}
 
 // ref: build_levels_lut, src/ops/adjustments.rs:465-488
 void pfx_build_levels_lut(float in_black, float in_white, float gamma, float out_black, float out_white, uint8_t lut[256])

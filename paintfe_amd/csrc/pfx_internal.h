@@ -65,7 +65,7 @@ struct pfx_ctx {
     int unorm_store_ok = -1;  // -1 not checked yet, 1 = typed UNORM8 stores round-trip RN(k / 255) exactly on this device (pfxk_unorm_store_check), 0 = they do not
     int dle_min_layers = 16;  // stacks at least this deep may take the compositor's dead-layer elimination kernel (pfx_api.cpp:build_stack)
     bool wts_valid = false, wsplit_valid = false; // explicit flags: every 32-bit pattern is some sigma (0xffffffff is a NaN)
-    float wsplit_inv_scale = 1.0f, wsplit_bias = 0.0f;
+    float wsplit_inv_scale = 1.0f, wsplit_bias = 0.0f, wsplit_bias_single = 0.0f;
     pfx_devbuf d_wsplit;
     // GpuLiquifyPipeline's cached source texture (ref: src/gpu/compute/liquify.rs:166-176); 0 x 0 = none / invalidated
     pfx_devbuf warp_src;
@@ -134,6 +134,6 @@ int pfx_int_project_run_script(pfx_ctx* ctx, pfx_project* p, const char* source,
 int  pfx_host_gaussian_radius(float sigma);                            // ceil(3 sigma) as the reference casts it
 int  pfx_host_gaussian_kernel(float sigma, std::vector<float>& out);  // ref: src/ops/filters.rs:214-234
 // w * 2^s = w1 + w2 as two f16 arrays (pfxk_gauss_mfma layout); returns 2^-2s, *bias = 1024 * sum(w1 + w2)
-float pfx_host_gaussian_split_f16(const std::vector<float>& k, int wlen, int woff, std::vector<uint16_t>& out, float* bias);
+float pfx_host_gaussian_split_f16(const std::vector<float>& k, int wlen, int woff, std::vector<uint16_t>& out, float* bias, float* bias_single);
 float pfx_host_bc_factor(float contrast);                             // ref: src/ops/adjustments.rs:273
 float pfx_host_exposure_gain(float ev);                               // ref: src/ops/adjustments.rs:353

@@ -87,7 +87,8 @@ int        pfxk_gauss_mfma_max_radius(void);
 int        pfxk_gauss_mfma_wlen(void);
 int        pfxk_gauss_mfma_woff(void);
 hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit,
-                           int radius, float inv_scale2, float bias_c, uint32_t w, uint32_t h, uint32_t first_row, int n_cus);
+                           int radius, float inv_scale2, float bias_c, float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus);
+void       pfxk_gauss_set_mfma_parts(int weight_parts, int h_parts); // f16 pieces per weight (2 or 1) / per horizontal result (2, or 1 with single weights)
 hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8_t* d_dst, const float* d_wts_tap0, int radius,
                         uint32_t w, uint32_t h, int exact);
 

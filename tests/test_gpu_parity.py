@@ -258,6 +258,30 @@ def test_gaussian_fma_mismatch_rate_is_float_noise(gpu):
     assert (d > 0).mean() < 1e-3, f"{(d > 0).mean():.2e} of channels differ"
 
 
+@pytest.mark.parametrize("parts", [12, 22, 11])
+@pytest.mark.parametrize("sigma", [0.8, 4.0, 16.0, 24.0])
+def test_gaussian_matrix_core_piece_counts(gpu, parts, sigma):
+    """k_gauss.hip WP / HP: one f16 per weight (shipped, "gauss_parts" = 12), the two-piece split of rounds 2-3 (22) and one piece for the horizontal
+    result as well (11, measured and not shipped) all stay within 1 LSB of the CPU path — on noise, on flat fields at every level that matters
+    (0, 1, 127, 128, 254, 255: a flat image must blur to ITSELF, the table's sum is the exact taps' sum), on a hard edge and on a 1-pixel checkerboard."""
+    w, h = 320, 160
+    rng = np.random.default_rng(int(sigma * 10) + parts)
+    noise = I.random_rgba(w, h, 77 + parts)
+    edge = np.zeros((h, w, 4), np.uint8); edge[:, w // 2:, :] = 255; edge[h // 2:, :, 1] = 255 - edge[h // 2:, :, 1]
+    yy, xx = np.mgrid[0:h, 0:w]
+    checker = (((xx + yy) & 1) * 255).astype(np.uint8)[..., None].repeat(4, axis=2)
+    gpu.r.tune("gauss_parts", parts)
+    try:
+        for name, img in (("noise", noise), ("edge", edge), ("checker", checker)):
+            assert_same(gpu.gaussian_blur(img, sigma), O.gaussian_blur(img, sigma), 1, f"parts={parts} sigma={sigma} {name}")
+        for level in (0, 1, 127, 128, 254, 255):
+            flat = np.full((h, w, 4), level, np.uint8)
+            assert_same(gpu.gaussian_blur(flat, sigma), flat, 0, f"parts={parts} sigma={sigma} flat {level}")
+    finally:
+        gpu.r.tune("gauss_parts", 12)
+    _ = rng
+
+
 def test_gaussian_identity_and_selection(gpu, oracle):
     img = I.random_rgba(200, 120, 9)
     assert_same(gpu.gaussian_blur(img, 0.0), img, 0, "sigma=0 identity (visual_filters.rs:291)")

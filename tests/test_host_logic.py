@@ -165,3 +165,39 @@ def test_shared_column_median_networks_are_what_the_generator_emits_and_select_t
         for j in range(4):
             want = np.sort(px[:, j:j + 5].reshape(25, -1), axis=0)[12]
             assert np.array_equal(v[outs[j]], want), f"window {j}, {levels} levels"
+
+
+def test_gaussian_single_piece_f16_table_keeps_the_sum_and_the_one_lsb_bound(lib):
+    """pfx_host_math.cpp:pfx_host_gaussian_split_f16 — the default-mode matrix-core Gaussian multiplies with ONE f16 per tap (k_gauss.hip, WP = 1).
+    Its +-1 LSB bound is a property of the table: every tap at most one f16 step from RN(w * 256), the table symmetric, its sum equal to the exact taps'
+    sum to within the smallest step (a flat image blurs to itself), and sum |delta| * 255 / 256 — what an adversarial image can move one pass by —
+    well below half an LSB for both passes together.  The two-piece split must reproduce w * 256 to 2^-20 relative."""
+    lib.pfx_gaussian_f16_tables.restype = C.c_int
+    for sigma in (0.5, 1.0, 2.0, 4.0, 7.3, 10.0, 16.0, 24.0, 26.6):
+        tab = (C.c_uint16 * 768)()
+        b2, b1 = C.c_float(), C.c_float()
+        n = lib.pfx_gaussian_f16_tables(C.c_float(sigma), tab, C.byref(b2), C.byref(b1))
+        assert n == 2 * int(np.ceil(np.float32(sigma) * np.float32(3.0))) + 1
+        t = np.frombuffer(tab, dtype=np.uint16).copy()
+        w1, w2, ws = (t[p * 256:(p + 1) * 256].view(np.float16).astype(np.float64) for p in range(3))
+        want = O.gaussian_kernel(sigma).astype(np.float64) * 256.0 if hasattr(O, "gaussian_kernel") else None
+        if want is None:  # the reference's kernel builder restated (filters.rs:214-234), f32 like the library's
+            r = (n - 1) // 2
+            x = np.arange(n, dtype=np.float32) - np.float32(r)
+            v = np.exp(-x * x / (np.float32(2.0) * np.float32(sigma) * np.float32(sigma))).astype(np.float32)
+            s = np.float32(0.0)
+            for e in v: s = np.float32(s + e)
+            want = (v * (np.float32(1.0) / s)).astype(np.float64) * 256.0
+        sl = slice(48, 48 + n)
+        outside = np.ones(256, bool); outside[sl] = False
+        assert not w1[outside].any() and not w2[outside].any() and not ws[outside].any()
+        assert np.abs(w1[sl] + w2[sl] - want).max() <= want.max() * 2.0 ** -20
+        ulp = np.spacing(ws[sl].astype(np.float16)).astype(np.float64)
+        delta = ws[sl] - want
+        assert (np.abs(delta) <= 1.5 * ulp).all(), "a tap is more than one f16 step away from its rounded value"
+        assert np.array_equal(ws[sl], ws[sl][::-1]) or np.abs(ws[sl] - ws[sl][::-1]).max() <= ulp.max()
+        # what is left of the sum error is below the coarsest step the nudging could still take: a flat image moves by < 0.02 LSB (and rounds to itself)
+        assert abs(delta.sum()) <= max(2.0 * ulp.min(), 2.0 ** -6), f"sigma {sigma}: table sum off by {delta.sum()}"
+        if sigma >= 4.0: assert abs(delta.sum()) <= 2.0 ** -11, f"sigma {sigma}: table sum off by {delta.sum()}"
+        assert np.abs(delta).sum() * 255.0 / 256.0 < 0.12, "one pass could move an adversarial image by more than 0.12 LSB"
+        assert abs(b1.value - 1024.0 * ws.sum()) <= 1e-3 * 1024 and abs(b2.value - 1024.0 * (w1 + w2).sum()) <= 1e-3 * 1024
