@@ -658,7 +658,8 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
             if (errs) return;
             kern<<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, dbg, g_dbg_buf);
         };
-        if (fast && dbg) go(gauss_strip_kernel<true, NK, true>); // development (tools/gauss_dbg.py, tools/gauss_timeline.py)
+        if (fast && dbg && wp == 1 && hp == 2) go(gauss_strip_kernel<true, NK, true, 1, 2>); // development (tools/gauss_dbg.py, tools/gauss_timeline.py)
+        else if (fast && dbg) go(gauss_strip_kernel<true, NK, true>);
         else if (fast && wp == 1 && hp == 2) go(gauss_strip_kernel<true, NK, false, 1, 2>);
         else if (fast && wp == 1 && hp == 1) go(gauss_strip_kernel<true, NK, false, 1, 1>);
         else if (fast) go(gauss_strip_kernel<true, NK, false>);

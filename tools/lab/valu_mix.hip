@@ -1,5 +1,5 @@
 // tools/lab/valu_mix.hip — VERDICT r03 "next round" #3: what a VALU instruction costs INSIDE a multiply / fused-multiply-add stream at the compositor's occupancy
-// (6 waves per SIMD, one-wave workgroups), instead of as an isolated chain (tools/lab/valu_tput.hip, profiles/r03_valu_rates.txt).  Two experiments
+// (6 waves per SIMD: six 4-wave workgroups per CU, one round), instead of as an isolated chain (tools/lab/valu_tput.hip, profiles/r03_valu_rates.txt).  Two experiments
 // contradicted the isolated prices in round 3 (v_bitop3 selects, the larger if-conversion budget: profiles/r03_tuning.md), so the question is the MARGINAL
 // cost: a base block of 16 v_fma_f32 / v_mul_f32 on 8 chains, against the same block with 8 test instructions interleaved (one behind every second
 // base instruction).  Cycles come from s_memtime inside the waves (shader clock: power-capped clock changes do not move them), averaged over the waves:
@@ -33,10 +33,10 @@
 #define T_MOV(n) "v_mov_b32 %" #n ", %17\n"
 
 #define KERNEL(NAME, T, TAIL)                                                                                                              \
-    __global__ __launch_bounds__(64) void NAME(uint32_t* out, unsigned long long* cyc, uint32_t seed)                                       \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, unsigned long long* cyc, uint32_t seed)                                       \
     {                                                                                                                                       \
         __shared__ float tab[256];                                                                                                          \
-        for (uint32_t i = threadIdx.x; i < 256u; i += 64u) tab[i] = (float)i;                                                               \
+        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) tab[i] = (float)i;                                                               \
         __syncthreads();                                                                                                                    \
         float x[16];                                                                                                                        \
         for (int j = 0; j < 16; ++j) x[j] = (float)((threadIdx.x * 2654435761u + j + seed) & 1023u) * 0.001f;                               \
@@ -55,8 +55,8 @@
         const unsigned long long t1 = __builtin_readcyclecounter();                                                                         \
         float s = 0;                                                                                                                        \
         for (int j = 0; j < 16; ++j) s += x[j];                                                                                             \
-        out[blockIdx.x * 64 + threadIdx.x] = __builtin_bit_cast(uint32_t, s);                                                               \
-        if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                                                                    \
+        out[blockIdx.x * 256 + threadIdx.x] = __builtin_bit_cast(uint32_t, s);                                                               \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                                                                    \
     }
 KERNEL(k_base, T_NONE, "")
 KERNEL(k_fma, T_FMA, "")
@@ -78,7 +78,7 @@ KERNEL(k_dsread, T_DSREAD, "s_waitcnt lgkmcnt(0)\n")
 KERNEL(k_dsread_rnd, T_DSREAD_RND, "s_waitcnt lgkmcnt(0)\n")
 // round-mode switches around a group of adds (requant through an LDS table would add 2^23 under round-toward-zero): 8 adds + 2 s_setreg per block
 #define T_ADD(n) "v_add_f32 %" #n ", %" #n ", %17\n"
-__global__ __launch_bounds__(64) void k_setreg(uint32_t* out, unsigned long long* cyc, uint32_t seed)
+__global__ __launch_bounds__(256) void k_setreg(uint32_t* out, unsigned long long* cyc, uint32_t seed)
 {
     float x[16];
     for (int j = 0; j < 16; ++j) x[j] = (float)((threadIdx.x * 2654435761u + j + seed) & 1023u) * 0.001f;
@@ -94,10 +94,10 @@ __global__ __launch_bounds__(64) void k_setreg(uint32_t* out, unsigned long long
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0;
     for (int j = 0; j < 16; ++j) s += x[j];
-    out[blockIdx.x * 64 + threadIdx.x] = __builtin_bit_cast(uint32_t, s);
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    out[blockIdx.x * 256 + threadIdx.x] = __builtin_bit_cast(uint32_t, s);
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
-__global__ __launch_bounds__(64) void k_add8(uint32_t* out, unsigned long long* cyc, uint32_t seed)
+__global__ __launch_bounds__(256) void k_add8(uint32_t* out, unsigned long long* cyc, uint32_t seed)
 {
     float x[16];
     for (int j = 0; j < 16; ++j) x[j] = (float)((threadIdx.x * 2654435761u + j + seed) & 1023u) * 0.001f;
@@ -112,35 +112,36 @@ __global__ __launch_bounds__(64) void k_add8(uint32_t* out, unsigned long long* 
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0;
     for (int j = 0; j < 16; ++j) s += x[j];
-    out[blockIdx.x * 64 + threadIdx.x] = __builtin_bit_cast(uint32_t, s);
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    out[blockIdx.x * 256 + threadIdx.x] = __builtin_bit_cast(uint32_t, s);
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
 template <class K> static double run(K k, uint32_t* out, unsigned long long* cyc, int wgs, float* ms_out)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    k<<<wgs, 64>>>(out, cyc, 3u); hipDeviceSynchronize();
+    k<<<wgs, 256>>>(out, cyc, 3u); hipDeviceSynchronize();
     hipEventRecord(a);
-    k<<<wgs, 64>>>(out, cyc, 3u);
+    k<<<wgs, 256>>>(out, cyc, 3u);
     hipEventRecord(b); hipEventSynchronize(b);
     hipEventElapsedTime(ms_out, a, b);
-    std::vector<unsigned long long> h(wgs);
-    hipMemcpy(h.data(), cyc, wgs * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> h(wgs * 4);
+    hipMemcpy(h.data(), cyc, wgs * 4 * 8, hipMemcpyDeviceToHost);
     double s = 0; for (auto v : h) s += (double)v;
-    return s / wgs;
+    return s / (wgs * 4);
 }
 
 int main(int argc, char** argv)
 {
     const int wps = argc > 1 ? atoi(argv[1]) : 6;             // waves per SIMD
-    const int wgs = 256 * 4 * wps;
-    uint32_t* out; hipMalloc(&out, (size_t)wgs * 64 * 4);
-    unsigned long long* cyc; hipMalloc(&cyc, (size_t)wgs * 8);
+    const int wgs = 256 * wps;                               // 4-wave workgroups, one wave per SIMD: wps workgroups per CU, one round
+    uint32_t* out; hipMalloc(&out, (size_t)wgs * 256 * 4);
+    unsigned long long* cyc; hipMalloc(&cyc, (size_t)wgs * 4 * 8);
     float ms;
     const double base = run(k_base, out, cyc, wgs, &ms);
     // s_memtime counts at a fixed 100 MHz on this part or at the shader clock?  report both views: cycles per base instruction should be 2 if it is the shader clock
-    printf("{\"waves_per_simd\": %d, \"base_counter_per_wave\": %.0f, \"base_ms\": %.4f, \"counter_per_base_inst_per_simd_share\": %.3f}\n", wps, base, ms, base / wps / (16.0 * ITERS));
-    const double unit = base / wps / (16.0 * ITERS) / 2.0;    // counter ticks per shader cycle, taking the base instructions at 2 cycles
+    // s_memtime ticks are shader cycles (guides/MI355X_MICROARCH.md); one round of resident waves <=> kernel time ~ a wave's cycles / clock
+    printf("{\"waves_per_simd\": %d, \"base_cycles_per_wave\": %.0f, \"base_ms\": %.4f, \"implied_clock_ghz_if_one_round\": %.2f, \"cycles_per_base_inst\": %.3f}\n", wps, base, ms, base / (ms * 1e6), base / wps / (16.0 * ITERS));
+    const double unit = 1.0;
 #define REPORT(NAME, K, NTEST) { const double c = run(K, out, cyc, wgs, &ms); \
     printf("{\"test\": \"%s\", \"marginal_cycles_per_inst\": %.2f, \"ms\": %.4f}\n", NAME, (c - base) / wps / ((NTEST) * (double)ITERS) / unit, ms); fflush(stdout); }
     REPORT("v_fma_f32 (control)", k_fma, 8) REPORT("v_mov_b32", k_mov, 8) REPORT("v_trunc_f32", k_trunc, 8) REPORT("v_max_f32", k_max, 8)

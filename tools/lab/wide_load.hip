@@ -61,7 +61,7 @@ template <int MODE> DEV void convert(float (&t)[4], uint32_t raw, const float* t
 }
 
 // WPB waves per workgroup share the table; every wave walks its own units
-template <int MODE, int F, int DEPTH, int WPB>
+template <int MODE, int F, int DEPTH, int WPB, bool IL = false>
 __global__ __launch_bounds__(64 * WPB) void k(Layers L, int n_layers, uint32_t n_px, uint32_t units_per_wave, uint8_t* dst)
 {
     __shared__ float tab[MODE == 3 ? 256 * 32 : 256];
@@ -72,7 +72,11 @@ __global__ __launch_bounds__(64 * WPB) void k(Layers L, int n_layers, uint32_t n
     const uint32_t lane_base = (lane & 31u) * 4u;
     const uint32_t bytes = n_px * 4u, n_units = n_px / 192u;
     const v4i rd = rsrc(dst, bytes, RAW32);
-    for (uint32_t u = wave * units_per_wave; u < min((wave + 1u) * units_per_wave, n_units); ++u) {
+    // IL: the WPB waves of a workgroup walk ADJACENT units side by side (a layer is read in pieces of WPB x 768 bytes instead of 768)
+    const uint32_t wib = threadIdx.x >> 6;
+    for (uint32_t it = 0; it < units_per_wave; ++it) {
+        const uint32_t u = IL ? (blockIdx.x * units_per_wave + it) * WPB + wib : wave * units_per_wave + it;
+        if (u >= n_units) break;
         int voff[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) voff[j] = (int)((u * 192u + 64u * j + lane) * 4u);
@@ -127,7 +131,7 @@ __global__ void fill(uint32_t* p, size_t n, uint32_t seed)
     }
 }
 
-template <int MODE, int F, int DEPTH, int WPB>
+template <int MODE, int F, int DEPTH, int WPB, bool IL = false>
 static void run(const Layers& L, uint32_t n_px, uint8_t* dst, std::vector<uint32_t>* ref, uint32_t upw)
 {
     const int n_layers = 32;
@@ -136,7 +140,7 @@ static void run(const Layers& L, uint32_t n_px, uint8_t* dst, std::vector<uint32
     std::vector<float> ms;
     for (int it = 0; it < 14; ++it) {
         hipEventRecord(e0);
-        k<MODE, F, DEPTH, WPB><<<blocks, 64 * WPB>>>(L, n_layers, n_px, upw, dst);
+        k<MODE, F, DEPTH, WPB, IL><<<blocks, 64 * WPB>>>(L, n_layers, n_px, upw, dst);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float t; hipEventElapsedTime(&t, e0, e1);
         if (it >= 4) ms.push_back(t);
@@ -146,9 +150,9 @@ static void run(const Layers& L, uint32_t n_px, uint8_t* dst, std::vector<uint32
     hipMemcpy(out.data(), dst, out.size() * 4, hipMemcpyDeviceToHost);
     int same = -1;
     if (F == 0) { if (MODE == 0) *ref = out; else same = (out == *ref); }
-    hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)k<MODE, F, DEPTH, WPB>);
-    printf("{\"mode\": %d, \"fma_per_px\": %d, \"depth\": %d, \"waves_per_wg\": %d, \"units_per_wave\": %u, \"vgprs\": %d, \"ms_min\": %.4f, \"ms_med\": %.4f, \"TBs\": %.3f, \"same_as_typed\": %d}\n",
-           MODE, F, MODE == 0 ? 2 : DEPTH, WPB, upw, fa.numRegs, ms.front(), ms[ms.size() / 2], (double)n_px * 4 * 33 / ms.front() * 1e-9, same);
+    hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)k<MODE, F, DEPTH, WPB, IL>);
+    printf("{\"interleaved\": %d, \"mode\": %d, \"fma_per_px\": %d, \"depth\": %d, \"waves_per_wg\": %d, \"units_per_wave\": %u, \"vgprs\": %d, \"ms_min\": %.4f, \"ms_med\": %.4f, \"TBs\": %.3f, \"same_as_typed\": %d}\n",
+           (int)IL, MODE, F, MODE == 0 ? 2 : DEPTH, WPB, upw, fa.numRegs, ms.front(), ms[ms.size() / 2], (double)n_px * 4 * 33 / ms.front() * 1e-9, same);
     fflush(stdout);
 }
 
@@ -164,6 +168,13 @@ int main(int argc, char** argv)
     std::vector<uint32_t> ref;
 #define ROW(F) run<0, F, 2, 1>(L, n_px, dst, &ref, upw); run<1, F, 4, 1>(L, n_px, dst, &ref, upw); run<2, F, 4, 1>(L, n_px, dst, &ref, upw); \
                run<2, F, 8, 1>(L, n_px, dst, &ref, upw); run<3, F, 4, 8>(L, n_px, dst, &ref, upw); run<3, F, 8, 8>(L, n_px, dst, &ref, upw);
+    if (argc > 2) {   // chunk-size study: load stream alone and F = 40, waves of a workgroup side by side
+#define IROW(F) run<0, F, 2, 4, true>(L, n_px, dst, &ref, upw); run<0, F, 2, 8, true>(L, n_px, dst, &ref, upw); run<0, F, 2, 4, false>(L, n_px, dst, &ref, upw); \
+                run<2, F, 4, 4, true>(L, n_px, dst, &ref, upw); run<2, F, 4, 8, true>(L, n_px, dst, &ref, upw); run<2, F, 8, 4, true>(L, n_px, dst, &ref, upw); run<2, F, 4, 4, false>(L, n_px, dst, &ref, upw);
+        run<0, 0, 2, 1>(L, n_px, dst, &ref, upw);
+        IROW(0) IROW(40) IROW(64)
+        return 0;
+    }
     ROW(0) ROW(40) ROW(80) ROW(120)
     return 0;
 }

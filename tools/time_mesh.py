@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paintfe_amd import GpuRenderer
 from tests import inputs as I
 r = GpuRenderer(0); r.set_stream(torch.cuda.current_stream().cuda_stream)
+for kv in sys.argv[1:]:
+    k, v = kv.split("="); r.tune(k, int(v))
 w, h = 15360, 8640
 src = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
 orig, deformed = I.jittered_mesh(6, 6, w, h)
