@@ -608,12 +608,11 @@ def main() -> int:
             clk = fl.get("clock_ghz", 2.0)
             roofline["valu_frac"] = round(fl["valu_wave_insts"] * 2 / (1024 * clk * 1e9 * d_ms * 1e-3), 3)
             roofline["valu_insts_per_layer_px"] = round(fl["valu_wave_insts"] * 64 / (n * px_per_launch), 1)
-            if fl.get("valu_issue_cycles_weighted"):
-                # per-class issue costs (FMA / MUL / ADD 2 cycles, transcendental 8, compare / select / min / max / trunc / convert 4: tools/lab/
-                # valu_tput.hip) applied to the profiled instruction mix, against THIS run's kernel duration at the profiled clock
-                lo, hi = fl["valu_issue_cycles_weighted"]
-                # A MODEL, not a counter: two experiments of round 3 contradicted its price for selects (profiles/r03_tuning.md, r04_tuning.md)
-                roofline["valu_issue_model_frac"] = [round(lo / (1024 * clk * 1e9 * d_ms * 1e-3), 3), round(hi / (1024 * clk * 1e9 * d_ms * 1e-3), 3)]
+            if fl.get("valu_issue_cycles_inmix"):
+                # the profiled instruction mix at its IN-MIX issue costs (every plain VALU instruction 2 SIMD cycles with >= 2 waves resident, v_rcp / v_sqrt
+                # 7.85: tools/lab/valu_mix.hip, profiles/r04_valu_rates.txt) against THIS run's kernel duration at the profiled clock.  Measured costs applied
+                # to counted instructions — still arithmetic on counters, not a busy counter; round 3's 2 / 4 / 8 class prices (isolated chains) over-priced it.
+                roofline["valu_issue_frac_inmix_costs"] = round(fl["valu_issue_cycles_inmix"] / (1024 * clk * 1e9 * d_ms * 1e-3), 3)
             # against what the chip's VALU sustains: a pure v_fma_f32 loop (tools/ubench_valu, profiles/rNN_valu_peak.json); a quarter-rate
             # (transcendental) instruction takes four plain instructions' worth of the pipe
             try:
@@ -627,7 +626,7 @@ def main() -> int:
         roofline["per_kernel_bound"] = pmc.get("bounds")
         # traffic / valu_* / per_kernel_bound come from a committed counter pass, not from this run (PMC collection needs rocprofv3 around
         # the process): say so, and which build the pass profiled
-        roofline["static"] = {"fields": ["traffic", "valu_frac", "valu_issue_model_frac", "valu_insts_per_layer_px", "valu_frac_of_sustained_fma_rate", "per_kernel_bound"],
+        roofline["static"] = {"fields": ["traffic", "valu_frac", "valu_issue_frac_inmix_costs", "valu_insts_per_layer_px", "valu_frac_of_sustained_fma_rate", "per_kernel_bound"],
                               "profile": pmc.get("_file"), "profiled_commit": pmc.get("commit"), "static": True}
 
     if state.get("clock_power"):

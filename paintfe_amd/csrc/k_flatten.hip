@@ -639,8 +639,12 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
 #ifndef PFX_SRT_REDEAL
 #define PFX_SRT_REDEAL 1   // development A/B: 0 = no re-deal code in the layer loop
 #endif
+#ifndef PFX_SRT_TYPED_STORE
+#define PFX_SRT_TYPED_STORE 0 // development A/B: 1 = the result leaves through buffer_store_format_xyzw (float -> UNORM8 in the texture path, no pack arithmetic):
+                              // 1.120-1.124 ms against 1.106-1.112 for four v_cvt_pk_u8_f32 and a dword store, two alternations on one box (tools/r4_s10.sh)
+#endif
 #ifndef PFX_SRT_NATSTORE
-#define PFX_SRT_NATSTORE 1 // development A/B: 0 = a dealt unit is stored in dealt order (three partial writes per 64-byte piece)
+#define PFX_SRT_NATSTORE 1 // development A/B: 0 = a dealt unit is stored in dealt order
 #endif
 template <int PX>
 PFX_DEV void stream_layer_groups(float (&acc)[PX][4], const float (&t)[PX][4], uint32_t mode, float opacity, uint32_t lead)
@@ -796,7 +800,11 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
     const uint32_t nu = min(U, units_total - u0);
     const uint32_t base_px = u0 * UPX;
     const uint32_t bytes = n_px * 4u;
+#if PFX_SRT_TYPED_STORE
     const pfx_v4i rs_acc = make_rsrc(dst, bytes, PFX_RSRC_UNORM8X4);
+#else
+    const pfx_v4i rs_dst = make_rsrc(dst, bytes, PFX_RSRC_RAW32);
+#endif
     const uint32_t s1 = P.seg != 0u ? P.s1 : 0xFFFFFFFFu;
     uint32_t st_egroups = 0, st_elay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_moves = 0;
     uint32_t probe_fail = 0, skip_left = 0;      // classification back-off (flatten_dle_kernel)
@@ -844,13 +852,13 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
 #pragma unroll
         for (int i = 1; i <= 4; ++i) if (cmin == (uint32_t)i) s_u = lay[i];
         // split class: the candidate whose early pixels (class below it) fit the fewest groups for the most layers
-        uint32_t best = 0, best_sav = 0, r = s_u, eg = 0;
-#pragma unroll
+        uint32_t best = 0, best_sav = 0, r = s_u, eg = 0, cn_best = 0; // cn_best = cn[best], carried along: indexing cn[] with `best` put the array in
+#pragma unroll                                                   // scratch, and its 32 bytes per lane and unit were written through to HBM (WRITE_SIZE 354 MB for a 133 MB frame)
         for (int i = 1; i <= 4; ++i) {
             if ((uint32_t)i > cmin && (uint32_t)i <= C.n) {
                 const uint32_t g = (UPX - cn[i] + 63u) / 64u;          // groups the early pixels of this split need
                 const uint32_t sav = ((uint32_t)PX - g) * (lay[i] - s_u);
-                if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; eg = g; }
+                if (sav > best_sav) { best_sav = sav; best = (uint32_t)i; r = lay[i]; eg = g; cn_best = cn[i]; }
             }
         }
         if (probe) {
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
         if (best != 0u) {
             // ---- early pixels to the leading groups (the accumulators are all (0,0,0,0): only the offsets move), then their layers [s_u, r) ----
             st_cunits += 1u;
-            uint32_t pre_e = 0u, pre_l = UPX - cn[best];
+            uint32_t pre_e = 0u, pre_l = UPX - cn_best;
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
                 const bool early = cls[j] < best;
@@ -892,9 +900,8 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
         st_nlay += n_layers - r;
         const uint32_t moves_before = st_moves;
         srt_layers<PX, NOBLEND>(acc, layers, r, n_layers, bytes, voff, s1, P.seg, s_x, s_v, st_moves);
-        // A dealt unit goes back to lane order before it is stored: a store instruction whose lanes cover a third of every 64-byte piece of the
-        // unit is written through as partial pieces — three stores per piece, 2.7x the result's bytes on the way to HBM (profiles/r04_pmc.json:
-        // WRITE_SIZE 354 MB for a 133 MB frame).  Three 16-byte LDS writes and reads per unit buy whole-line stores.
+        // A dealt unit goes back to lane order before it is stored (three 16-byte LDS writes and reads per unit): whole-line stores instead of three
+        // stores that each cover a third of every 64-byte piece.  Worth ~1 % of the step on one box (tools/r4_s6.sh), nothing in WRITE_SIZE.
         if (PFX_SRT_NATSTORE && (best != 0u || st_moves != moves_before)) {
             const uint32_t ub = (base_px + u * UPX) * 4u;
 #pragma unroll
@@ -910,8 +917,16 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
         }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
+#if PFX_SRT_TYPED_STORE
             pfx_v4f v; v.x = acc[j][0]; v.y = acc[j][1]; v.z = acc[j][2]; v.w = acc[j][3];
             pfx_buffer_store_format_v4f32(v, rs_acc, voff[j], 0, 0);
+#else
+            // bn = RN(k / 255)  =>  bn * 255 = k (1 + e), |e| < 2^-23: v_cvt_pk_u8_f32 (round to nearest, saturating) recovers k
+            uint32_t px = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) px = __builtin_amdgcn_cvt_pk_u8_f32(acc[j][c] * 255.0f, c, px);
+            pfx_buffer_store_i32((int)px, rs_dst, voff[j], 0, 0);
+#endif
         }
     }
     if (lane == 0 && (C.stats & 1u)) {

@@ -64,27 +64,27 @@ d = {
     },
 }
 f, g = d["flatten"], d["gauss_strip"]
-# weighted issue cycles: FMA / MUL / ADD f32 at 2 cycles per wave64 instruction, transcendentals at 8, every other class at 4
-# (measured: tools/lab/valu_tput.hip, profiles/r03_valu_rates.txt; integer add / logic / moves are also 2-cycle, so this is an upper bound
-# for the INT32 class and the result is quoted as a range)
+# issue cycles by the IN-MIX costs (tools/lab/valu_mix.hip, profiles/r04_valu_rates.txt): every plain VALU instruction 2 cycles of the SIMD with >= 2 waves
+# resident, v_rcp / v_sqrt 7.85.  (Round 3 priced compare / select / min / max / trunc / convert at 4 from isolated chains: a second pipe that only saturates
+# when nothing else is issued.  That over-priced the compositor by a quarter; kept below as valu_issue_frac_r03_model for comparison.)
 mix = {k: val(fl, "SQ_INSTS_VALU_" + k) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "CVT", "INT32")}
 if all(v is not None for v in mix.values()):
     total = val(fl, "SQ_INSTS_VALU")
     fast = mix["ADD_F32"] + mix["MUL_F32"] + mix["FMA_F32"]
     rest = total - fast - mix["TRANS_F32"] - mix["INT32"]
-    lo = 2 * (fast + mix["INT32"]) + 8 * mix["TRANS_F32"] + 4 * rest
-    hi = lo + 2 * mix["INT32"]
     f["valu_class_mix"] = {k.lower(): v for k, v in mix.items()}
-    f["valu_class_mix"]["other_half_rate (compare, select, min/max, trunc, moves)"] = rest
-    f["valu_issue_cycles_weighted"] = [lo, hi]
-    f["valu_issue_frac_weighted"] = [round(lo / (1024 * cyc_f), 3), round(hi / (1024 * cyc_f), 3)]
+    f["valu_class_mix"]["other (compare, select, min/max, trunc, moves)"] = rest
+    inmix = 2 * (total - mix["TRANS_F32"]) + 7.85 * mix["TRANS_F32"]
+    f["valu_issue_cycles_inmix"] = inmix
+    f["valu_issue_frac_inmix"] = round(inmix / (1024 * cyc_f), 3)
+    lo = 2 * (fast + mix["INT32"]) + 8 * mix["TRANS_F32"] + 4 * rest
+    f["valu_issue_frac_r03_model"] = [round(lo / (1024 * cyc_f), 3), round((lo + 2 * mix["INT32"]) / (1024 * cyc_f), 3)]
 d["bounds"] = {
-    "flatten": f"three units of the CU near their limits at once, at a clock the 1400 W board limit sets ({f['clock_ghz']:.2f} GHz profiled): VALU issue "
-               f"{f['valu_issue_frac_profiled'] * 100:.0f} % of the slots at 2 cycles per instruction"
-               + (f" ({f['valu_issue_frac_weighted'][0] * 100:.0f}-{f['valu_issue_frac_weighted'][1] * 100:.0f} % by the per-class cost MODEL)" if "valu_issue_frac_weighted" in f else "")
-               + f", the CU's one scalar unit {f['salu_unit_frac_profiled'] * 100:.0f} % busy"
-               + (f", the texture path ~{f['texture_path_frac_profiled'] * 100:.0f} % (typed loads: 4.7 TB/s is their ceiling with no arithmetic at all)" if f.get("texture_path_frac_profiled") else "")
-               + f"; HBM traffic {f['hbm_bytes'] / f['algorithmic_bytes']:.3f}x algorithmic",
+    "flatten": f"no unit saturated: the typed-load stream (0.97-1.0 ms alone, 4.5 TB/s) and the blend arithmetic (0.75-0.8 ms alone) meet at a clock the 1400 W board "
+               f"limit sets ({f['clock_ghz']:.2f} GHz profiled) - VALU issue {f.get('valu_issue_frac_inmix', f['valu_issue_frac_profiled']) * 100:.0f} % of the SIMDs' cycles by the in-mix instruction costs "
+               f"(profiles/r04_valu_rates.txt), the CU's one scalar unit {f['salu_unit_frac_profiled'] * 100:.0f} %"
+               + (f", the texture path ~{f['texture_path_frac_profiled'] * 100:.0f} %" if f.get("texture_path_frac_profiled") else "")
+               + f"; a loop of nothing but the same loads and 40 FMAs per layer-pixel takes the same 1.06-1.13 ms (profiles/r04_wide_load.jsonl); HBM traffic {f['hbm_bytes'] / f['algorithmic_bytes']:.3f}x algorithmic",
     "gauss_strip": f"barrier-to-barrier dependency chain of the producer / consumer wave roles (MFMA pipe {g['mfma_pipe_frac_profiled'] * 100:.0f} % busy, LDS "
                    f"{g['lds_busy_frac_profiled'] * 100:.0f} %; HBM traffic {g['hbm_bytes'] / g['algorithmic_bytes']:.2f}x algorithmic: the 4x x-halo overlap of neighbouring strips "
                    "is served by one XCD's L2 since the strip order is XCD-aware)",
