@@ -201,3 +201,10 @@ def test_gaussian_single_piece_f16_table_keeps_the_sum_and_the_one_lsb_bound(lib
         if sigma >= 4.0: assert abs(delta.sum()) <= 2.0 ** -11, f"sigma {sigma}: table sum off by {delta.sum()}"
         assert np.abs(delta).sum() * 255.0 / 256.0 < 0.12, "one pass could move an adversarial image by more than 0.12 LSB"
         assert abs(b1.value - 1024.0 * ws.sum()) <= 1e-3 * 1024 and abs(b2.value - 1024.0 * (w1 + w2).sum()) <= 1e-3 * 1024
+
+
+def test_design_md_measured_blocks_are_generated_from_the_committed_profiles():
+    """DESIGN.md's measured figures are produced by tools/design_tables.py from profiles/rNN_{ops.txt,bench_n1.json,pmc.json}: a block edited by hand, or
+    a newer profile without a regenerated DESIGN.md, fails here."""
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
