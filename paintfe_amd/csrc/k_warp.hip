@@ -34,7 +34,9 @@ PFX_DEV int32_t cvt_i32_sat(float v)
 // up at the join and put s_waitcnt vmcnt(0) in front of every later pixel's address arithmetic — the eight rows of a batch became eight dependent
 // round trips.  Now every tap is loaded from a clamped (always valid) address and the texels that lie outside are zeroed afterwards from a 4-bit
 // mask; the wave-uniform interior test only skips the clamps and the mask (no load behind a branch, the waits are counted exactly).
-struct bilinear_taps { uint32_t tl, tr, bl, br; float fx, fy; uint32_t m; }; // m: bit 0 tl, 1 tr, 2 bl, 3 br inside the source (0: output transparent)
+struct bilinear_taps { uint32_t tl, tr, bl, br; float fx, fy; uint32_t m; }; // m: bit 0 tl, 1 tr, 2 bl, 3 br inside the source (0: output transparent); bits 4 / 5: pair loads at the left / right border
+// PAIR (compile-time, chosen by the launcher: src_w >= 2): a run-time test here would put the loads behind a branch again
+template <bool PAIR>
 PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t src_w, int32_t src_h, float x, float y, float ddx, float ddy)
 {
     bilinear_taps T;
@@ -56,16 +58,14 @@ PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t s
     }
     const uint32_t* ra = src + (size_t)(uint32_t)ya * (uint32_t)src_w;
     const uint32_t* rb = src + (size_t)(uint32_t)yb * (uint32_t)src_w;
-    if (src_w >= 2) {
+    if constexpr (PAIR) {
         // the two texels of a row as ONE 8-byte load (the address unit is what bounds these kernels: half the instructions): the pair starts at
         // clamp(x0, 0, w - 2); at the left / right border the texel that exists sits in the other half of the pair (the one that does not is masked)
         const int32_t xp = min(max(x0, 0), src_w - 2);
         const uint2 pa = *reinterpret_cast<const uint2*>(ra + (uint32_t)xp), pb = *reinterpret_cast<const uint2*>(rb + (uint32_t)xp);
         T.tl = pa.x; T.tr = pa.y; T.bl = pb.x; T.br = pb.y;
-        if (!__all(interior)) {
-            if (x0 < xp) { T.tr = pa.x; T.br = pb.x; }        // x0 == -1: tr is texel 0
-            else if (x0 > xp) { T.tl = pa.y; T.bl = pb.y; }   // x0 == w - 1: tl is the last texel
-        }
+        // which half holds the texel that exists is settled in bilinear_finish (bits 4 / 5 of m): nothing here waits for the loads
+        if (!__all(interior)) T.m |= (x0 < xp ? 16u : 0u) | (x0 > xp ? 32u : 0u);
     } else { T.tl = ra[(uint32_t)xa]; T.tr = ra[(uint32_t)xb]; T.bl = rb[(uint32_t)xa]; T.br = rb[(uint32_t)xb]; }
     return T;
 }
@@ -73,13 +73,17 @@ PFX_DEV uint32_t bilinear_finish(const bilinear_taps& T)
 {
     uint32_t tl = T.tl, tr = T.tr, bl = T.bl, br = T.br;
     if (!__all(T.m == 15u)) { // texels outside the source are 0 (:1318-1331)
+        if (T.m & 16u) { tr = tl; br = bl; }        // x0 == -1: the pair started at texel 0, which is tr / br
+        else if (T.m & 32u) { tl = tr; bl = br; }   // x0 == w - 1: the pair ended at the last texel, which is tl / bl
         tl = (T.m & 1u) ? tl : 0u; tr = (T.m & 2u) ? tr : 0u; bl = (T.m & 4u) ? bl : 0u; br = (T.m & 8u) ? br : 0u;
     }
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float ftl = (float)((tl >> (8 * c)) & 0xffu), ftr = (float)((tr >> (8 * c)) & 0xffu);
-        const float fbl = (float)((bl >> (8 * c)) & 0xffu), fbr = (float)((br >> (8 * c)) & 0xffu);
+        // pinned as floats: left alone, hipcc turns `(float)b - (float)a` into an SDWA byte subtract + v_cvt_f32_i32 — exact, but an SDWA form costs the SIMD
+        // 4.75 cycles in the mix against 2 for v_cvt_f32_ubyteN and 2 for v_sub_f32 (profiles/r04_valu_rates.txt)
+        const float ftl = pin((float)((tl >> (8 * c)) & 0xffu)), ftr = pin((float)((tr >> (8 * c)) & 0xffu));
+        const float fbl = pin((float)((bl >> (8 * c)) & 0xffu)), fbr = pin((float)((br >> (8 * c)) & 0xffu));
         const float top = ftl + (ftr - ftl) * T.fx; // :1337-1339
         const float bot = fbl + (fbr - fbl) * T.fx;
         o[c] = top + (bot - top) * T.fy;
@@ -94,6 +98,7 @@ constexpr uint32_t WARP_YR = 4; // rows per lane: the field entries of all of th
 // = 3.5 TB/s); four pixels' worth of requests in flight per lane move it towards the HBM rate.
 // `y_off`: index of the buffers' row 0 in the whole output when `disp` / `dst` are a band of it (a document sharded by rows, SURVEY 8e: the source is
 // replicated, every member warps its band of the output); 0 for a whole image.
+template <bool PAIR>
 __global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restrict__ src, int32_t sw, int32_t sh,
                                                         const float2* __restrict__ disp, uint32_t w, uint32_t h,
                                                         uint32_t* __restrict__ dst, uint32_t y_off)
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restri
     for (uint32_t k = 0; k < WARP_YR; ++k) d[k] = disp[(size_t)min(y0 + k, h - 1u) * w + x]; // rows past the end re-read the last one (unused)
     bilinear_taps taps[WARP_YR];
 #pragma unroll
-    for (uint32_t k = 0; k < WARP_YR; ++k) taps[k] = bilinear_fetch(src, sw, sh, (float)x, (float)(min(y0 + k, h - 1u) + y_off), d[k].x, d[k].y);
+    for (uint32_t k = 0; k < WARP_YR; ++k) taps[k] = bilinear_fetch<PAIR>(src, sw, sh, (float)x, (float)(min(y0 + k, h - 1u) + y_off), d[k].x, d[k].y);
 #pragma unroll
     for (uint32_t k = 0; k < WARP_YR; ++k)
         if (y0 + k < h) dst[(size_t)(y0 + k) * w + x] = bilinear_finish(taps[k]);
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256) void mesh_kernel(const float2* __restrict__ g_
 #endif
 // Rolling form of the fused warp (round 4): D rows' taps in flight all the time — row k + D is requested as soon as row k has been interpolated —
 // instead of batches of eight requested together and then consumed together; 7 D registers of taps instead of 56, so more waves fit.
-template <bool IN_LDS, int D>
+template <bool IN_LDS, int D, bool PAIR>
 __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ g_orig, const float2* __restrict__ g_def,
                                                         uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint32_t* __restrict__ dst, uint32_t y_off,
                                                         uint32_t h_full)
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
         float2 o;
         if (g_orig) o = cr_column_eval(co, p_orig, cols, rows, R);
         else o = make_float2((float)x + 0.5f, (float)(y + y_off) + 0.5f);
-        return bilinear_fetch(src, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), d.x - o.x, d.y - o.y);
+        return bilinear_fetch<PAIR>(src, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), d.x - o.x, d.y - o.y);
     };
     bilinear_taps taps[D];
 #pragma unroll
@@ -328,8 +333,8 @@ extern "C" hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src
 {
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 4 * WARP_YR - 1) / (4 * WARP_YR));
-    warp_disp_kernel<<<g, 256, 0, s>>>((const uint32_t*)d_src, (int32_t)sw, (int32_t)sh, (const float2*)d_disp, w, h,
-                                       (uint32_t*)d_dst, first_row);
+    if (sw >= 2u) warp_disp_kernel<true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (int32_t)sw, (int32_t)sh, (const float2*)d_disp, w, h, (uint32_t*)d_dst, first_row);
+    else warp_disp_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (int32_t)sw, (int32_t)sh, (const float2*)d_disp, w, h, (uint32_t*)d_dst, first_row);
     return hipGetLastError();
 }
 
@@ -422,9 +427,10 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
     // rows in flight per lane: 2 measured best at 16K (tools/r4_s9.sh: 0.565 ms against 0.573-0.59 for 3 / 4, 0.63 for 6 and for round 3's batches of 8)
     constexpr int ROLL = PFX_MESH_ROLL;
     const size_t lds = (size_t)(cols + 1u) * (rows + 1u) * 16u;
-    if ((cols + 1u) * (rows + 1u) <= MESH_LDS_PTS)
-        mesh_roll_kernel<true, ROLL><<<g, 256, lds, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full);
-    else
-        mesh_roll_kernel<false, ROLL><<<g, 256, 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full);
+    const bool in_lds = (cols + 1u) * (rows + 1u) <= MESH_LDS_PTS;
+#define PFX_ROLL(L, P) mesh_roll_kernel<L, ROLL, P><<<g, 256, (L) ? lds : 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full)
+    if (in_lds) { if (w >= 2u) PFX_ROLL(true, true); else PFX_ROLL(true, false); }
+    else { if (w >= 2u) PFX_ROLL(false, true); else PFX_ROLL(false, false); }
+#undef PFX_ROLL
     return hipGetLastError();
 }
