@@ -541,6 +541,36 @@ def test_warp_displacement_random_field(gpu, oracle):
     assert_same(gpu.warp_displacement(img, zero), img, 0, "identity field (transform_ops.rs:125)")
 
 
+@pytest.mark.parametrize("size", [(1, 1), (1, 9), (2, 2), (2, 70), (3, 5), (5, 4), (64, 3), (67, 66), (130, 2)])
+def test_warp_samples_on_and_around_every_border(gpu, oracle, size):
+    """k_warp.hip:bilinear_fetch — a row's two texels are one 8-byte load from clamp(x0, 0, w - 2) (w >= 2; four dword loads for a one-pixel-wide source),
+    texels outside the source are masked to 0 afterwards and the border picks the half of the pair that exists.  Every output pixel is sent to a source
+    coordinate on, just inside, just outside and far outside each border (x0 / y0 = -2, -1, 0, w - 2, w - 1, w and fractional neighbours), in waves
+    that mix interior and border lanes and in waves that are all border (transform.rs:1288-1345)."""
+    w, h = size
+    img = I.random_rgba(w, h, 900 + 7 * w + h)
+    img[..., 3] = np.maximum(img[..., 3], 1)
+    rng = np.random.default_rng(w * 131 + h)
+    xs = np.array([-2.5, -2.0, -1.5, -1.0, -0.75, -0.5, 0.0, 0.25, w - 2.0, w - 1.5, w - 1.0, w - 0.5, w - 0.001, w, w + 0.5, w + 7.0], np.float32)
+    ys = np.array([-2.5, -2.0, -1.5, -1.0, -0.75, -0.5, 0.0, 0.25, h - 2.0, h - 1.5, h - 1.0, h - 0.5, h - 0.001, h, h + 0.5, h + 7.0], np.float32)
+    gx, gy = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    for trial in range(3):
+        tx = xs[rng.integers(0, len(xs), size=(h, w))]
+        ty = ys[rng.integers(0, len(ys), size=(h, w))]
+        if trial == 1: ty = gy + np.float32(0.25)          # only x crosses borders
+        if trial == 2: tx = gx + np.float32(0.5)           # only y crosses borders
+        disp = np.stack([gx - tx, gy - ty], axis=-1).astype(np.float32)   # sample coordinate = x - dx = tx
+        assert_same(gpu.warp_displacement(img, disp), oracle.warp_displacement(img, disp), 0, f"{size} trial {trial}")
+    # a wider field than the source (transform.rs takes the source's size for the bounds, the field's for the output)
+    fw, fh = w + 3, h + 2
+    disp = (rng.random((fh, fw, 2)).astype(np.float32) - np.float32(0.5)) * np.float32(2 * max(w, h) + 4)
+    assert_same(gpu.warp_displacement(img, disp), oracle.warp_displacement(img, disp), 0, f"{size} wide random field")
+    if w >= 2 and h >= 2:
+        orig, deformed = I.jittered_mesh(2, 2, w, h, seed=w + h)
+        deformed = deformed + np.float32(1.25) * np.array([w, h], np.float32) * (rng.random(deformed.shape).astype(np.float32) - np.float32(0.5))  # interior AND border points move: samples leave the image
+        assert_same(gpu.warp_mesh(img, orig, deformed.astype(np.float32), 2, 2), oracle.warp_mesh(img, orig, deformed.astype(np.float32), 2, 2), 0, f"{size} mesh")
+
+
 def test_warp_source_size_differs_from_field(gpu, oracle):
     img = I.random_rgba(90, 60, 4)
     disp = (np.random.default_rng(7).random((80, 120, 2)).astype(np.float32) - np.float32(0.5)) * np.float32(30.0)
