@@ -472,8 +472,8 @@ int pfx_selftest_division(pfx_ctx* ctx, uint64_t seed, uint32_t n_millions, uint
 int pfx_selftest_round_pack(pfx_ctx* ctx, uint64_t* mismatches, uint64_t* signalling_nan_mismatches);
 
 /* device self-test: the texture path's conversions the compositor relies on — a typed UNORM8 buffer store of RN(k / 255) writes the byte k and a
- * typed load of the byte k returns RN(k / 255), for all 256 k on every channel; *mismatches must come back 0 (the class-sorting compositor, which writes its
- * result that way, is only used on a device where it does: checked once per context). */
+ * typed load of the byte k returns RN(k / 255), for all 256 k on every channel; *mismatches must come back 0 (the class-sorting compositor, which reads every
+ * layer through these conversions, is only used on a device where they hold: checked once per context). */
 int pfx_selftest_unorm_store(pfx_ctx* ctx, uint64_t* mismatches);
 
 /* host-side: the f16 tap tables of the matrix-core Gaussian for `sigma` (radius 1 .. 80), as the library uploads them: three parts of 256 entries,

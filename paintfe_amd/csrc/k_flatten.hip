@@ -775,8 +775,9 @@ PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
 //   * opaque accumulators first: in front of layers s1, s1 + seg, ... of the natural pass (srt_layers) the unit is re-dealt when that completes
 //     another wave-uniform opaque group; opaque accumulators stay opaque under every mode but Xor and Overwrite, so at most PX re-deals per unit.
 // Every decision is a performance hint: a pixel runs each of its layers exactly once, in order, with arithmetic chosen by a per-group test of the
-// actual accumulators.  The result leaves through a typed buffer store (float -> UNORM8 in the texture path, verified once per context by
-// pfxk_unorm_store_check): no pack arithmetic.
+// actual accumulators.  The unit goes back to lane order and leaves as four v_cvt_pk_u8_f32 and a dword store per pixel (the typed format
+// store, float -> UNORM8 in the texture path, measured 1 % slower: PFX_SRT_TYPED_STORE; the context's one-time check of the texture path's conversions,
+// pfxk_unorm_store_check, still gates this kernel — it reads every layer through the same conversions).
 struct dle_plan { uint32_t s1, seg; }; // re-deal attempts in front of layers s1, s1 + seg, s1 + 2 seg, ... (seg == 0: none)
 
 template <int PX, bool NOBLEND = false>
