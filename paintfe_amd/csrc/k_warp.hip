@@ -44,7 +44,9 @@ PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t s
     const int32_t x0 = cvt_i32_sat(__builtin_floorf(sx)), y0 = cvt_i32_sat(__builtin_floorf(sy));
     T.fx = sx - (float)x0;
     T.fy = sy - (float)y0;
-    const bool interior = x0 >= 0 && y0 >= 0 && x0 < src_w - 1 && y0 < src_h - 1;
+    // a NaN coordinate converts to texel 0 with NaN weights: such a lane must not count as interior (its wave would skip the test that makes it transparent)
+    const float wsum = T.fx + T.fy;
+    const bool interior = x0 >= 0 && y0 >= 0 && x0 < src_w - 1 && y0 < src_h - 1 && wsum == wsum;
     int32_t xa = x0, xb = x0 + 1, ya = y0, yb = y0 + 1;
     T.m = 15u;
     if (!__all(interior)) {

@@ -571,6 +571,20 @@ def test_warp_samples_on_and_around_every_border(gpu, oracle, size):
         assert_same(gpu.warp_mesh(img, orig, deformed.astype(np.float32), 2, 2), oracle.warp_mesh(img, orig, deformed.astype(np.float32), 2, 2), 0, f"{size} mesh")
 
 
+def test_warp_nan_and_infinite_coordinates_inside_interior_waves(gpu, oracle):
+    """A NaN / infinite field entry among lanes that all sample strictly inside the source (the wave-uniform fast path of bilinear_fetch): `NaN as i32` is
+    texel 0 with NaN weights, every channel `NaN as u8` = 0 (transform.rs:1300-1345); infinities saturate and land outside."""
+    w, h = 256, 24
+    img = I.random_rgba(w, h, 77)
+    img[..., 3] = 255
+    disp = np.full((h, w, 2), 0.25, np.float32)           # every sample 0.25 px up-left: interior everywhere but row 0 / column 0
+    disp[:, 0, 0] = -0.5; disp[0, :, 1] = -0.5             # ... which sample inside as well
+    for (y, x, v) in ((10, 100, (np.nan, 0.25)), (11, 101, (0.25, np.nan)), (12, 130, (np.nan, np.nan)), (13, 64, (np.inf, 0.25)), (14, 191, (0.25, -np.inf)),
+                      (5, 5, (3.0e9, 0.25)), (6, 70, (-3.0e9, -3.0e9))):
+        disp[y, x] = v
+    assert_same(gpu.warp_displacement(img, disp), oracle.warp_displacement(img, disp), 0, "NaN / inf entries in interior waves")
+
+
 def test_warp_source_size_differs_from_field(gpu, oracle):
     img = I.random_rgba(90, 60, 4)
     disp = (np.random.default_rng(7).random((80, 120, 2)).astype(np.float32) - np.float32(0.5)) * np.float32(30.0)
