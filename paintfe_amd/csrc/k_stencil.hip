@@ -307,11 +307,18 @@ __global__ __launch_bounds__(256) void median3_kernel(const uint32_t* __restrict
     for (int j = 0; j < 3; ++j) {
         const uint32_t* row = src + (size_t)min(max(y + j - 1, 0), h - 1) * w;
         if constexpr (VEC) {
+            // No load behind a per-lane condition (round 4: with the wave's two edge pixels fetched under `if (lane == 0)` / `if (lane == 63)` hipcc waited
+            // vmcnt(0) between the rows — three dependent round trips per output row).  Every lane issues ONE more dword load instead: even lanes the pixel
+            // left of the wave's span, odd lanes the pixel right of it (two distinct addresses per wave); lane 0 (even) and lane 63 (odd) then hold
+            // their own edge, everyone else takes the neighbour's register.  A lane at the image's edge clamps to its own v.x / v.w (w % 4 == 0).
+            const int wx0 = x0 - 4 * lane;
             const uint4 v = *reinterpret_cast<const uint4*>(row + x0);
+            const uint32_t edge = row[(lane & 1) ? min(wx0 + 256, w - 1) : max(wx0 - 1, 0)];
             p[j][1] = v.x; p[j][2] = v.y; p[j][3] = v.z; p[j][4] = v.w;
             uint32_t left = __shfl_up(v.w, 1), right = __shfl_down(v.x, 1);
-            if (lane == 0) left = row[max(x0 - 1, 0)];
-            if (lane == 63 || x0 + 4 >= w) right = row[min(x0 + 4, w - 1)];
+            left = lane == 0 ? edge : left;
+            right = lane == 63 ? edge : right;
+            right = (x0 + 4 >= w) ? v.w : right;   // last lane of the row: column x0 + 4 clamps to w - 1 = x0 + 3
             p[j][0] = left; p[j][5] = right;
         } else {
 #pragma unroll
