@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""tools/soak.py [--seconds S] [--seed N] — randomized parity soak on the GPU against the oracle (test infrastructure, like tests/): random layer stacks
+(sizes, depths, modes, opacities, alpha structure: noise, opaque / transparent runs and blocks, reset layers at random depths) through pfx_composite — which
+picks the class-sorting, streaming or general compositor by itself —, random-sigma Gaussians in the default (<= 1 LSB) and exact (bit-exact) modes, random
+displacement and mesh warps (bit-exact).  Prints one JSON line; exits 1 on the first mismatch with the case's seed."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from paintfe_amd import GpuRenderer
+from tests import inputs as I
+from tests import oracle_lib as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+r = GpuRenderer(0)
+t_end = time.time() + a.seconds
+counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0}
+case = a.seed * 1000003
+
+
+def alpha_plane(rng, w, h):
+    kind = rng.integers(0, 6)
+    if kind == 0: return rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    if kind == 1: return np.full((h, w), 255, np.uint8)
+    if kind == 2:  # S2-like mixture
+        sel = rng.integers(0, 4, size=(h, w)); v = rng.integers(1, 255, size=(h, w), dtype=np.uint8)
+        return np.where(sel == 0, 0, np.where(sel == 1, 255, v)).astype(np.uint8)
+    if kind == 3:  # opaque with transparent blocks
+        p = np.full((h, w), 255, np.uint8)
+        for _ in range(int(rng.integers(1, 6))):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w)); p[y:y + int(rng.integers(1, h + 1)), x:x + int(rng.integers(1, w + 1))] = int(rng.integers(0, 2)) * int(rng.integers(0, 256))
+        return p
+    if kind == 4:  # runs along rows (units of the compositor are 192 consecutive pixels)
+        flat = np.repeat(rng.choice(np.array([0, 255, 128], np.uint8), size=(w * h) // 37 + 2), 37)[: w * h]
+        return flat.reshape(h, w)
+    return (rng.random((h, w)) < rng.random()).astype(np.uint8) * 255
+
+
+while time.time() < t_end:
+    case += 1
+    rng = np.random.default_rng(case)
+    what = rng.integers(0, 10)
+    try:
+        if what < 6:
+            w, h = int(rng.integers(1, 700)), int(rng.integers(1, 120))
+            if rng.random() < 0.3: w, h = int(rng.integers(180, 400)) * int(rng.integers(1, 4)), int(rng.integers(1, 40))
+            n = int(rng.choice([1, 2, 5, 9, 15, 16, 17, 24, 32, 40]))
+            stack = rng.integers(0, 256, size=(n, h, w, 4), dtype=np.uint8)
+            modes = rng.integers(0, 25, size=n).astype(np.uint8)
+            opac = np.where(rng.random(n) < 0.5, 1.0, rng.random(n) * 0.98 + 0.01).astype(np.float32)
+            for k in range(n):
+                stack[k, ..., 3] = alpha_plane(rng, w, h)
+                if rng.random() < 0.25: modes[k] = 14 if rng.random() < 0.5 else 0      # reset candidates: Overwrite / Normal
+                if rng.random() < 0.15: modes[k] = 13                                    # Xor lowers alpha
+            for k in range(n): r.ensure_layer_texture(k, stack[k], generation=case)
+            got = r.composite(w, h, [(k, float(opac[k]), True, int(modes[k])) for k in range(n)])
+            ref = O.flatten_stack(stack, modes, opac)
+            if not np.array_equal(got, ref): raise AssertionError(f"flatten {w}x{h}x{n}: {(got != ref).any(axis=-1).sum()} pixels differ")
+            counts["stacks"] += 1
+        elif what < 8:
+            w, h = int(rng.integers(1, 500)), int(rng.integers(1, 300))
+            sigma = float(rng.choice([0.3, 0.7, 1.5, 3.0, 5.3, 8.0, 12.0, 16.0, 21.0, 26.6, 31.0])) * float(0.9 + 0.2 * rng.random())
+            img = I.random_rgba(w, h, case) if rng.random() < 0.6 else I.create_test_gradient(w, h)
+            ref = O.gaussian_blur(img, sigma)
+            d = np.abs(r.blur_rgba(img, sigma).astype(np.int16) - ref.astype(np.int16)).max()
+            if d > 1: raise AssertionError(f"gaussian {w}x{h} sigma {sigma}: max diff {d}")
+            r.set_exact(True)
+            try:
+                if not np.array_equal(r.blur_rgba(img, sigma), ref): raise AssertionError(f"exact gaussian {w}x{h} sigma {sigma}")
+            finally:
+                r.set_exact(False)
+            counts["gauss"] += 1
+        elif what == 8:
+            w, h = int(rng.integers(1, 600)), int(rng.integers(1, 200))
+            sw, sh = (w, h) if rng.random() < 0.6 else (int(rng.integers(1, 600)), int(rng.integers(1, 200)))
+            img = I.random_rgba(sw, sh, case)
+            amp = float(rng.choice([0.5, 3.0, 20.0, 400.0]))
+            disp = ((rng.random((h, w, 2)) - 0.5) * amp).astype(np.float32)
+            if not np.array_equal(r.warp_displacement(img, disp), O.warp_displacement(img, disp)): raise AssertionError(f"warp {sw}x{sh} -> {w}x{h} amp {amp}")
+            counts["warps"] += 1
+        else:
+            w, h = int(rng.integers(2, 500)), int(rng.integers(2, 200))
+            cols, rows = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+            img = I.random_rgba(w, h, case)
+            orig, deformed = I.jittered_mesh(cols, rows, w, h, seed=case)
+            if rng.random() < 0.3: deformed = (deformed + (rng.random(deformed.shape) - 0.5) * np.array([w, h]) * 0.8).astype(np.float32)
+            if not np.array_equal(r.warp_mesh_catmull_rom(img, orig, deformed, cols, rows), O.warp_mesh_catmull_rom(img, orig, deformed, cols, rows)):
+                raise AssertionError(f"mesh {w}x{h} grid {cols}x{rows}")
+            counts["mesh"] += 1
+    except AssertionError as e:
+        print(json.dumps({"ok": False, "case_seed": case, "error": str(e), **counts})); sys.exit(1)
+print(json.dumps({"ok": True, "seconds": a.seconds, "first_case": a.seed * 1000003 + 1, "last_case": case, **counts}))
