@@ -507,26 +507,34 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
         const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
         const _Float16* a2p = HR + (size_t)((HP - 1) * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
         const int st_t = tid - 256, st_rr = st_t >> 3, st_cg = 4 * (st_t & 7);
-        pfx_f16x8 a1[NKB], a2[NKB];
-        auto request = [&](int rbase, auto k0c, auto k1c) { // K blocks [K0, K1) of the block whose window starts at ring row rbase
+        // Round 4: the window's fragments STAY in registers.  Block v + 1's window is block v's moved down by 32 rows: K blocks 2 .. NKB - 1 of v are K blocks
+        // 0 .. NKB - 3 of v + 1, the same rows of the same columns — the same fragment.  So a fragment lives in slot g mod NKB (g = 2 v + kb, its K block's
+        // index down the strip), an iteration loads only the two K blocks whose rows the producers finished before the last barrier, and K block kb of
+        // block v multiplies slot (2 v + kb) mod NKB with B[kb]: the loop is unrolled over v mod NKB / 2 so that every slot index is static.  (Rounds 2-3
+        // re-read all NKB fragments of a block from the ring: 16 of the consumers' 20 LDS reads per iteration, and the reason the ring had to hold the
+        // whole window.)
+        pfx_f16x8 f1[NKB], f2[NKB];
 #pragma unroll
-            for (int kb = decltype(k0c)::value; kb < decltype(k1c)::value; ++kb) {
-                int ro = rbase + 16 * kb;
-                ro = ro >= RING ? ro - RING : ro;
-                a1[kb] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
-                if constexpr (HP == 2) a2[kb] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
-            }
-        };
+        for (int kb = 0; kb < NKB; ++kb) { f1[kb] = pfx_f16x8{}; f2[kb] = pfx_f16x8{}; }
         int rbase = 0; // (32 v) mod RING for v = -HALF - 1 (RING = 32 (HALF + 1))
-        request(rbase, std::integral_constant<int, 0>{}, std::integral_constant<int, EARLY>{});
-        for (int it = 0; it < n_iter; ++it) {
+        auto consume = [&](auto phasec, int it) {
+            constexpr int PH = decltype(phasec)::value;   // v mod HALF
             stamp(it, 0);
             const int v = it - HALF - 1, vp = v - 1;
             const bool active = v >= 0 && v < nst && !(dbg & 4);
             const int st_y = 32 * (t_first + vp) - y_phase + st_rr;
             const bool do_store = vp >= 0 && vp < nst && !(dbg & 1) && st_y >= 0 && st_y < h && (!FAST || x0 + st_cg < w);
             const uint4 ov = *reinterpret_cast<const uint4*>(OUT + (vp & 1) * 32 * GM_OUT_PITCH + st_rr * GM_OUT_PITCH + st_cg);
-            request(rbase, std::integral_constant<int, EARLY>{}, std::integral_constant<int, NKB>{});
+            // the two K blocks finished before the barrier (every LDS address is valid in every iteration: the ring offset just keeps turning)
+#pragma unroll
+            for (int kb = EARLY; kb < NKB; ++kb) {
+                constexpr int dummy = 0; (void)dummy;
+                int ro = rbase + 16 * kb;
+                ro = ro >= RING ? ro - RING : ro;
+                const int slot = (2 * PH + kb) % NKB;
+                f1[slot] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
+                if constexpr (HP == 2) f2[slot] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
+            }
             __builtin_amdgcn_sched_barrier(0);
             stamp(it, 1);
             // chain A = h1 * w1; chain X = h1 * w2 + h2 * w1 (the two small terms share an accumulator, A's MFMA sits between them)
@@ -534,9 +542,10 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
             if (active) {
 #pragma unroll
                 for (int kb = 0; kb < EARLY; ++kb) {
-                    if constexpr (WP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], kb ? accX : pfx_f32x16{}, 0, 0, 0);
-                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B1[kb], kb ? accA : pfx_f32x16{}, 0, 0, 0);
-                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], (kb || WP == 2) ? accX : pfx_f32x16{}, 0, 0, 0);
+                    const int slot = (2 * PH + kb) % NKB;
+                    if constexpr (WP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B2[kb], kb ? accX : pfx_f32x16{}, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B1[kb], kb ? accA : pfx_f32x16{}, 0, 0, 0);
+                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[slot], B1[kb], (kb || WP == 2) ? accX : pfx_f32x16{}, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -555,16 +564,15 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
             if (active) {
 #pragma unroll
                 for (int kb = EARLY; kb < NKB; ++kb) {
-                    if constexpr (WP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B2[kb], accX, 0, 0, 0);
-                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kb], B1[kb], accA, 0, 0, 0);
-                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kb], B1[kb], accX, 0, 0, 0);
+                    const int slot = (2 * PH + kb) % NKB;
+                    if constexpr (WP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B2[kb], accX, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B1[kb], accA, 0, 0, 0);
+                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[slot], B1[kb], accX, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             stamp(it, 3);
             rbase = rbase + 32 >= RING ? rbase + 32 - RING : rbase + 32;
-            request(rbase, std::integral_constant<int, 0>{}, std::integral_constant<int, EARLY>{}); // block v + 1: rows complete since the last barrier
-            __builtin_amdgcn_sched_barrier(0);
             stamp(it, 4);
             if (active) {
                 // D[m][n]: n = output row i of the block; reg q -> m = (q & 3) + 8 (q >> 2) + 4 hh = xl' * 4 + c' with c' = q & 3,
@@ -585,6 +593,19 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
             __syncthreads();
             stamp(it, 7);
             flush_stamps(it);
+        };
+        // iteration `it` runs block v = it - HALF - 1, whose phase v mod HALF is (it + HALF - 1) mod HALF: static in a loop unrolled HALF times
+        auto phase_call = [&](auto qc, int it) {
+            constexpr int Q = decltype(qc)::value;
+            if (it < n_iter) consume(std::integral_constant<int, (Q + HALF - 1) % HALF>{}, it);
+        };
+        for (int it = 0; it < n_iter; it += HALF) {
+            phase_call(std::integral_constant<int, 0>{}, it);
+            phase_call(std::integral_constant<int, 1>{}, it + 1);
+            if constexpr (HALF > 2) phase_call(std::integral_constant<int, 2 % HALF>{}, it + 2);
+            if constexpr (HALF > 3) phase_call(std::integral_constant<int, 3 % HALF>{}, it + 3);
+            if constexpr (HALF > 4) phase_call(std::integral_constant<int, 4 % HALF>{}, it + 4);
+            if constexpr (HALF > 5) phase_call(std::integral_constant<int, 5 % HALF>{}, it + 5);
         }
     }
 }
