@@ -231,14 +231,15 @@ hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const
 //     nothing but the documented C/D map (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
 //
 // Column-strip walk: a workgroup owns a 32-column strip and walks down it in steps of 32 rows with the horizontal results in an
-// LDS RING of 16 NKB + 32 rows (f16 pairs, transposed so that a column's rows are contiguous).  Waves 0-3 ("producers") compute the
-// 32 new rows of a step (8 rows x 4 channels each, 2 NKB MFMAs); waves 4-7 ("consumers") run the vertical pass of a 32-row output
-// block on the 16 NKB rows in the ring (8 columns x 4 channels each, 3 NKB MFMAs) — disjoint ring slots, one barrier per iteration,
-// each SIMD hosts one wave of either role.  No row is computed twice, the f32 intermediate never touches HBM: 8 algorithmic
+// LDS ring of two 32-row steps (f16 pairs, transposed so that a column's rows are contiguous; rounds 2-3 kept the whole 16 NKB-row window there).  Waves 0-3 ("producers") compute the
+// 32 new rows of a step (8 rows x 4 channels each, NKB MFMAs with one-piece weights); waves 4-7 ("consumers") run the vertical pass of a
+// 32-row output block on its 16 NKB-row window (8 columns x 4 channels each, 2 NKB MFMAs) — the window's fragments stay in the consumers'
+// registers from block to block, only the 32 newest rows come from the ring; disjoint ring halves, one barrier per iteration, each SIMD hosts
+// one wave of either role per workgroup, and up to 8 K blocks two workgroups share a CU.  No row is computed twice, the f32 intermediate never touches HBM: 8 algorithmic
 // bytes per pixel are the kernel's only HBM traffic (+ the x-halo re-reads, served by L2).
 //   * the two waves of a SIMD share its matrix pipe (32 cycles per MFMA, 40 MFMAs per iteration) and a wave issues a VALU
 //     instruction only every ~6 cycles, so an iteration is arranged in ANTI-PHASE (s_memtime timeline: tools/gauss_timeline.py):
-//     first the consumers multiply — the fragments of all but the last two K blocks were requested one iteration ahead, the
+//     first the consumers multiply — the fragments of all but the last two K blocks are in registers already, the
 //     last two (the rows finished before the barrier) arrive under those MFMAs — while the producers split and store the rows
 //     whose MFMAs they issued BEFORE the barrier, de-interleave the next step and build its fragments; then the producers issue
 //     their MFMAs (and go to the barrier without waiting for them) while the consumers round and pack.  Step s is multiplied in
@@ -265,25 +266,33 @@ constexpr int GM_MAXR = 80;             // largest radius (sigma <= 26.6: 12 K b
 constexpr int GM_OUT_PITCH = 36;        // dwords per staged output row (16-byte aligned rows: the block leaves as ds_read_b128)
 constexpr int GM_WOFF = 48;             // wsplit[GM_WOFF + t] = tap t; zeros elsewhere
 constexpr int GM_WLEN = 256;            // entries per weight part
-constexpr int GS_DEPTH = 3;             // register sets of source pixels in flight per producer lane
+#ifndef PFX_GAUSS_TWO_WG8
+#define PFX_GAUSS_TWO_WG8 1   // development A/B: 0 = the 8-K-block build keeps B1 in registers and 3 source steps in flight (148 registers: one workgroup per CU)
+#endif
+constexpr int GS_DEPTH = 3;             // register sets of source pixels in flight per producer lane (2 in the 8-K-block build, whose register budget is 128: see gauss_strip_kernel)
 constexpr int gs_xrow(int nkb) { return 16 * (nkb > 8 ? nkb : 8) + 16; } // bytes per (channel, row) line of the de-interleave patch: 16 NKB samples + 16 (bank spread)
 
 inline size_t gauss_strip_lds_bytes(int nkb, int hp)
 {
-    const int ring = 16 * nkb + 32;
-    return (size_t)4 * hp * (GM_COLS * (ring + 8) + 32) * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * gs_xrow(nkb);
+    const int ring = 64; // two 32-row steps (the vertical window itself lives in the consumers' registers)
+    return (size_t)4 * hp * (GM_COLS * (ring + 8) + 32) * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * gs_xrow(nkb) + (size_t)nkb * 64 * 16; // the last term (B1 fragments) is used by the 8-K-block one-piece build only
 }
 
 // DBG: the development instantiation (switchable parts, s_memtime stamps); the shipped one has none of those branches — a dozen
 // skipped-over stamps per iteration were 10 % of the kernel
 template <bool FAST, int NKB, bool DBG, int WP = 2, int HP = 2>
-__global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(512, ((NKB <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && WP == 1) ? 4 : 2)) void gauss_strip_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8, float inv_scale2,
                                                              float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg, int dbg_arg,
                                                              unsigned long long* __restrict__ dbg_buf)
 {
     constexpr int GS_XROW = gs_xrow(NKB);
-    constexpr int RING = 16 * NKB + 32, YP = RING + 8, PLANE = GM_COLS * YP + 32, HALF = NKB / 2, PPL = 2 * NKB; // PPL: pixels per producer lane
+    // ring = two steps of 32 rows: the one the consumers load this iteration (finished before the last barrier) and the one the producers are storing
+    constexpr int RING = 64, YP = RING + 8, PLANE = GM_COLS * YP + 32, HALF = NKB / 2, PPL = 2 * NKB; // PPL: pixels per producer lane
+    // The 8-K-block build (sigma 10.7 .. 16) is the one that needs help to fit two workgroups per CU (128 registers per wave): its B1 fragments live in LDS and
+    // it keeps 2 source steps in flight instead of 3.  4 and 6 K blocks fit as they are; 10 and 12 (96+ registers of window fragments) stay at one workgroup.
+    constexpr bool B_LDS = PFX_GAUSS_TWO_WG8 && NKB == 8 && WP == 1;
+    constexpr int GSD = B_LDS ? 2 : GS_DEPTH;
     extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
     _Float16* HR = reinterpret_cast<_Float16*>(gm_lds);                            // [part][c][x][YP], rows = ring slots
     uint32_t* OUT = reinterpret_cast<uint32_t*>(gm_lds + (size_t)4 * HP * PLANE * 2); // [2][32][GM_OUT_PITCH]
@@ -293,7 +302,11 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
     const int i = lane & 31, hh = lane >> 5;
     const bool producer = wave < 4;
 
-    pfx_f16x8 B1[NKB], B2[NKB]; // Toeplitz fragments, resident for the whole kernel
+    // Toeplitz fragments.  B1 (the one-piece weights, or the high piece) lives in LDS — 1 KB per K block, the same for every wave (a lane's fragment depends on
+    // its position in the wave alone) — and is read in front of the MFMA that multiplies with it: 4 NKB registers per wave freed, which with the two-step ring
+    // is what lets two workgroups share a CU.  B2 (two-piece weights only: pfx_tune "gauss_parts" = 22) stays in registers.
+    pfx_f16x8* const BL = reinterpret_cast<pfx_f16x8*>(gm_lds + (size_t)4 * HP * PLANE * 2 + (size_t)2 * 32 * GM_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * GS_XROW);
+    pfx_f16x8 B1r[B_LDS ? 1 : NKB], B2[NKB];
     {
         // WP == 1: the third table, every weight ONE f16 (pfx_host_gaussian_split_f16); B2 is then never used
         const _Float16* w1 = reinterpret_cast<const _Float16*>(wsplit) + GM_WOFF + (WP == 1 ? 2 * GM_WLEN : 0);
@@ -301,14 +314,19 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const int t0 = 16 * kb + 8 * hh - i - (R8 - r); // in [-46, 16 NKB - 8]
+            pfx_f16x8 b1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { B1[kb][j] = w1[t0 + j]; B2[kb][j] = w2[t0 + j]; }
+            for (int j = 0; j < 8; ++j) { b1[j] = w1[t0 + j]; B2[kb][j] = w2[t0 + j]; }
+            if constexpr (B_LDS) { if (wave == 0) BL[kb * 64 + lane] = b1; }
+            else B1r[kb] = b1;
         }
         // settle the fragments here: otherwise the waitcnt bookkeeping treats them as "possibly still loading" at their first use in
         // every loop iteration and drains the wave's prefetches / stores there (vmcnt(3) .. vmcnt(0) in front of the MFMAs)
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) { asm volatile("" : "+v"(B1[kb])); asm volatile("" : "+v"(B2[kb])); }
+        for (int kb = 0; kb < NKB; ++kb) { asm volatile("" : "+v"(B2[kb])); if constexpr (!B_LDS) asm volatile("" : "+v"(B1r[kb])); }
+        if constexpr (B_LDS) __syncthreads();
     }
+    auto B1 = [&](int kb) -> pfx_f16x8 { if constexpr (B_LDS) return BL[kb * 64 + lane]; else return B1r[kb]; };
     // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the swizzle hands every XCD a run of NEIGHBOURING strips, whose
     // source windows overlap by 3/4 (a 32-column strip reads 16 NKB columns), so the overlap is fetched into one L2 instead of up to 8
     const int bid = (int)xcd_swizzle(blockIdx.x, gridDim.x);
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
     const int n_hsteps = nst + HALF - 1;        // producer steps 0 .. n_hsteps - 1; consumer step v needs producer steps v .. v + HALF - 1
     // a step's MFMAs are issued in iteration `step`, its rows reach the ring in step + 1; block v runs in iteration v + HALF + 1 and leaves in
     // v + HALF + 2
-    const int last = nst + HALF + 1, n_iter = ((last + GS_DEPTH) / GS_DEPTH) * GS_DEPTH; // iterations 0 .. n_iter - 1 (surplus ones only synchronise)
+    const int last = nst + HALF + 1, n_iter = ((last + GSD) / GSD) * GSD; // iterations 0 .. n_iter - 1 (surplus ones only synchronise)
 
     // development: s_memtime at phase boundaries of iterations 10..13, one interior block, waves 0 and 4.  The reads are not waited for
     // where they are issued (that would drain the wave's LDS queue and distort the phase); flush_stamps() waits once per iteration.
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
             // fetch role of a lane: row fr = lane >> 3 of the wave's 8 rows, pixels [fs * PPL, (fs + 1) * PPL) of the 16 NKB window
             const int frow = lane >> 3, fs = lane & 7;
             const int fx = x0 - R8 + fs * PPL;
-            uint32_t raw[GS_DEPTH][PPL];
+            uint32_t raw[GSD][PPL];
             auto fetch = [&](auto bufc, int hs_req) {
                 constexpr int BUF = decltype(bufc)::value;
                 const int hs = min(hs_req, n_hsteps - 1);                                   // past the end: re-read the last step (unused)
@@ -454,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 }
                 stamp(it, 2);
                 __builtin_amdgcn_sched_barrier(0); // keep the refill HERE: the scheduler would sink it next to its use, steps later
-                if (!(dbg & 8)) fetch(std::integral_constant<int, BUF>{}, it + GS_DEPTH);
+                if (!(dbg & 8)) fetch(std::integral_constant<int, BUF>{}, it + GSD);
                 __builtin_amdgcn_sched_barrier(0);
                 // (2) A fragments: row m = i = channel * 8 + row, K slot (hh, kb) holds samples [16 kb + 8 hh, +8); 0x6400 | byte = 1024 + byte
                 pfx_f16x8 fr[NKB];
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 if (it < n_hsteps && !(dbg & 2)) { // horizontal pass of 32 new rows
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B1[kb], kb ? acc : neg_bias, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B1(kb), kb ? acc : neg_bias, 0, 0, 0);
                         if constexpr (WP == 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], B2[kb], kb ? acc2 : pfx_f32x16{}, 0, 0, 0);
                     }
                 }
@@ -484,24 +502,22 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 flush_stamps(it);
             };
             fetch(std::integral_constant<int, 0>{}, 0);
-            if constexpr (GS_DEPTH > 1) fetch(std::integral_constant<int, 1>{}, 1);
-            if constexpr (GS_DEPTH > 2) fetch(std::integral_constant<int, 2>{}, 2);
-            for (int it = 0; it < n_iter; it += GS_DEPTH) {
+            if constexpr (GSD > 1) fetch(std::integral_constant<int, 1>{}, 1);
+            if constexpr (GSD > 2) fetch(std::integral_constant<int, 2>{}, 2);
+            for (int it = 0; it < n_iter; it += GSD) {
                 produce(std::integral_constant<int, 0>{}, it);
-                if constexpr (GS_DEPTH > 1) produce(std::integral_constant<int, 1>{}, it + 1);
-                if constexpr (GS_DEPTH > 2) produce(std::integral_constant<int, 2>{}, it + 2);
+                if constexpr (GSD > 1) produce(std::integral_constant<int, 1>{}, it + 1);
+                if constexpr (GSD > 2) produce(std::integral_constant<int, 2>{}, it + 2);
             }
         };
         const bool interior = __builtin_amdgcn_readfirstlane((x0 - R8 >= 0 && x0 - R8 + 16 * NKB <= w) ? 1 : 0) != 0;
         if (interior) walk(std::false_type{}); else walk(std::true_type{});
     } else {
-        // Consumer iteration `it` runs block v = it - HALF - 1 on ring rows [32 v, 32 v + 16 NKB) (mod RING).  K slot (hh, kb) holds window rows
-        // [16 kb + 8 hh, +8), so only the last two K blocks touch the 32 rows the producers finished in the previous iteration: the
-        // fragments of K blocks 0 .. NKB - 3 are requested one iteration ahead (straight after the MFMAs that free their registers)
-        // and the matrix pipe starts at the top of the iteration.  (1) request the previous block's packed pixels (one 16-byte LDS
-        // read per lane) and the two late K blocks; (2) MFMAs of the early K blocks; (3) the previous block goes to memory as 128-byte
-        // row segments (256 lanes x 16 bytes); (4) late MFMAs; (5) request block v + 1's early fragments; (6) round, pack, stage
-        // block v.  Every LDS address is valid in every iteration (the ring offset just keeps turning), so no load sits behind a branch.
+        // Consumer iteration `it` runs block v = it - HALF - 1 on window rows [32 v, 32 v + 16 NKB) of the strip.  K slot (hh, kb) holds window rows
+        // [16 kb + 8 hh, +8), so only the last two K blocks touch the 32 rows the producers finished in the previous iteration.  (1) request the
+        // previous block's packed pixels (one 16-byte LDS read per lane) and those two K blocks; (2) MFMAs of the other K blocks, whose fragments are
+        // in registers from earlier iterations; (3) the previous block goes to memory as 128-byte row segments (256 lanes x 16 bytes); (4) the last
+        // two K blocks' MFMAs; (5) round, pack, stage block v.  Every LDS address is valid in every iteration, so no load sits behind a branch.
         constexpr int EARLY = NKB - 2;
         const int xb = wave - 4, xl = i >> 2, c = i & 3;
         const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
@@ -516,7 +532,6 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
         pfx_f16x8 f1[NKB], f2[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) { f1[kb] = pfx_f16x8{}; f2[kb] = pfx_f16x8{}; }
-        int rbase = 0; // (32 v) mod RING for v = -HALF - 1 (RING = 32 (HALF + 1))
         auto consume = [&](auto phasec, int it) {
             constexpr int PH = decltype(phasec)::value;   // v mod HALF
             stamp(it, 0);
@@ -529,8 +544,7 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
 #pragma unroll
             for (int kb = EARLY; kb < NKB; ++kb) {
                 constexpr int dummy = 0; (void)dummy;
-                int ro = rbase + 16 * kb;
-                ro = ro >= RING ? ro - RING : ro;
+                const int ro = 32 * (it & 1) + 16 * (kb - EARLY);   // step it - 2 (stored during iteration it - 1) sits in ring half (it & 1)
                 const int slot = (2 * PH + kb) % NKB;
                 f1[slot] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
                 if constexpr (HP == 2) f2[slot] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
@@ -544,8 +558,8 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 for (int kb = 0; kb < EARLY; ++kb) {
                     const int slot = (2 * PH + kb) % NKB;
                     if constexpr (WP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B2[kb], kb ? accX : pfx_f32x16{}, 0, 0, 0);
-                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B1[kb], kb ? accA : pfx_f32x16{}, 0, 0, 0);
-                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[slot], B1[kb], (kb || WP == 2) ? accX : pfx_f32x16{}, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B1(kb), kb ? accA : pfx_f32x16{}, 0, 0, 0);
+                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[slot], B1(kb), (kb || WP == 2) ? accX : pfx_f32x16{}, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -566,13 +580,12 @@ __global__ __launch_bounds__(512, 1) void gauss_strip_kernel(const uint8_t* __re
                 for (int kb = EARLY; kb < NKB; ++kb) {
                     const int slot = (2 * PH + kb) % NKB;
                     if constexpr (WP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B2[kb], accX, 0, 0, 0);
-                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B1[kb], accA, 0, 0, 0);
-                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[slot], B1[kb], accX, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], B1(kb), accA, 0, 0, 0);
+                    if constexpr (HP == 2) accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[slot], B1(kb), accX, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             stamp(it, 3);
-            rbase = rbase + 32 >= RING ? rbase + 32 - RING : rbase + 32;
             stamp(it, 4);
             if (active) {
                 // D[m][n]: n = output row i of the block; reg q -> m = (q & 3) + 8 (q >> 2) + 4 hh = xl' * 4 + c' with c' = q & 3,
@@ -660,12 +673,14 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     hipError_t errs = hipSuccess;
     auto launch_s = [&](auto nkb_c) {
         constexpr int NK = decltype(nkb_c)::value;
-        const size_t lds = gauss_strip_lds_bytes(NK, hp);
+        const int hp_k = (fast && wp == 1 && hp == 1) ? 1 : 2;   // the instantiation chosen below: only the aligned one-piece build has the HP = 1 variant
+        const size_t lds = gauss_strip_lds_bytes(NK, hp_k);
         // cut every strip into n_seg row segments so that the launch is ONE round of resident workgroups (LDS-bound: two per CU with 4 K blocks,
         // one from 6 up): every workgroup starts at once and none waits for a second round, and a segment pays NK/2 - 1 run-in steps.  Measured
         // (tools/lab/gauss_seg.py, sigma 16): 8K 1 / 2 / 3 segments = 0.166 / 0.175 / 0.184 ms, 4K 0.080 / 0.053 / 0.070, 1080p 4 segments 0.023
         // against 0.033 for the 7 the previous rule ("just under two workgroups per CU") chose
-        const int resident = n_cus * (int)std::max<size_t>(1, (size_t)160 * 1024 / lds);
+        // workgroups per CU: LDS (one ring + patches: two fit) and registers (the kernel is built for 4 waves per SIMD up to 8 K blocks, 2 beyond)
+        const int resident = n_cus * (int)std::min<size_t>((NK <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && wp == 1) ? 2 : 1, std::max<size_t>(1, (size_t)160 * 1024 / lds));
         int n_seg = resident / tiles_x;
         if (g_mfma_seg > 0) n_seg = g_mfma_seg; // tuning override (its own key: "gauss_v_cfg" only configures the VALU vertical pass)
         if (n_seg < 1) n_seg = 1;
@@ -684,6 +699,7 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
         else if (fast && wp == 1 && hp == 2) go(gauss_strip_kernel<true, NK, false, 1, 2>);
         else if (fast && wp == 1 && hp == 1) go(gauss_strip_kernel<true, NK, false, 1, 1>);
         else if (fast) go(gauss_strip_kernel<true, NK, false>);
+        else if (wp == 1) go(gauss_strip_kernel<false, NK, false, 1, 2>); // unaligned buffers / widths: the same tables and bias as the fast instantiation
         else go(gauss_strip_kernel<false, NK, false>);
     };
     switch (nkb) {

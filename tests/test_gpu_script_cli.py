@@ -127,7 +127,7 @@ def test_cli_batch(tmp_path):
         got = _read_png(out_dir / f"{name}.png")
         ref = O.tiled_roundtrip(O.gaussian_blur(O.tiled_roundtrip(src), 4.0))
         d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
-        assert d.max() <= 1 and (d > 0).mean() < 1e-3       # Gaussian FMA class
+        assert d.max() <= 1 and (d > 0).mean() < 4e-3       # default-mode Gaussian: 1 LSB; on white noise at sigma 4 up to 2e-3 of the channels (one f16 per tap)
     # format conversion only (no script), explicit output, palette/greyscale decode paths are exercised in the unit below
     p = subprocess.run([exe, "-i", str(tmp_path / "a.png"), "-o", str(tmp_path / "copy.png")], capture_output=True, text=True)
     assert p.returncode == 0 and np.array_equal(_read_png(tmp_path / "copy.png"), a)
