@@ -14,7 +14,27 @@
 
 using namespace pfxk;
 
+// LLVM buffer intrinsic hipcc has no __builtin for (declared outside the anonymous namespace: an external symbol)
+typedef int pfx_w_v4i __attribute__((ext_vector_type(4)));
+typedef int pfx_w_v2i __attribute__((ext_vector_type(2)));
+__device__ pfx_w_v2i pfx_w_buffer_load_v2i32(pfx_w_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
+
 namespace {
+
+// Source images below 4 GiB are sampled through a raw buffer resource and 32-bit byte offsets: the two 64-bit address computations of a pixel's row
+// pairs (v_mad_u64_u32, v_lshl_add_u64 x 2, ...) become one 24-bit multiply-add and a shift each — the fused mesh warp is bound by VALU issue.
+struct warp_src { const uint32_t* p; pfx_w_v4i rs; };
+PFX_DEV warp_src make_warp_src(const uint32_t* src, int32_t src_w, int32_t src_h)
+{
+    const uint64_t a = (uint64_t)src;
+    warp_src S;
+    S.p = src;
+    S.rs.x = (int)(uint32_t)a;
+    S.rs.y = (int)((uint32_t)(a >> 32) & 0xffffu);
+    S.rs.z = (int)((uint32_t)src_w * (uint32_t)src_h * 4u);
+    S.rs.w = (int)(0xFACu | (7u << 12) | (4u << 15));   // untyped dword access, stride 0: offsets and num_records are bytes
+    return S;
+}
 
 // warp_displacement_full's sampler (:1288-1345: bilinear, lerp form a + (b - a) * t, texels outside the source are 0, output
 // transparent when floor(sx) < -1 || floor(sy) < -1 || >= size), split at the memory boundary so that a lane can have the taps of
@@ -36,9 +56,10 @@ PFX_DEV int32_t cvt_i32_sat(float v)
 // mask; the wave-uniform interior test only skips the clamps and the mask (no load behind a branch, the waits are counted exactly).
 struct bilinear_taps { uint32_t tl, tr, bl, br; float fx, fy; uint32_t m; }; // m: bit 0 tl, 1 tr, 2 bl, 3 br inside the source (0: output transparent); bits 4 / 5: pair loads at the left / right border
 // PAIR (compile-time, chosen by the launcher: src_w >= 2): a run-time test here would put the loads behind a branch again
-template <bool PAIR>
-PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t src_w, int32_t src_h, float x, float y, float ddx, float ddy)
+template <bool PAIR, bool BUF32 = false>
+PFX_DEV bilinear_taps bilinear_fetch(const warp_src& S, int32_t src_w, int32_t src_h, float x, float y, float ddx, float ddy)
 {
+    const uint32_t* __restrict__ src = S.p;
     bilinear_taps T;
     const float sx = x - ddx, sy = y - ddy;
     const int32_t x0 = cvt_i32_sat(__builtin_floorf(sx)), y0 = cvt_i32_sat(__builtin_floorf(sy));
@@ -64,7 +85,12 @@ PFX_DEV bilinear_taps bilinear_fetch(const uint32_t* __restrict__ src, int32_t s
         // the two texels of a row as ONE 8-byte load (the address unit is what bounds these kernels: half the instructions): the pair starts at
         // clamp(x0, 0, w - 2); at the left / right border the texel that exists sits in the other half of the pair (the one that does not is masked)
         const int32_t xp = min(max(x0, 0), src_w - 2);
-        const uint2 pa = *reinterpret_cast<const uint2*>(ra + (uint32_t)xp), pb = *reinterpret_cast<const uint2*>(rb + (uint32_t)xp);
+        uint2 pa, pb;
+        if constexpr (BUF32) {   // rows and columns of an image are below 2^24: v_mad_u32_u24 is exact and full rate
+            const pfx_w_v2i va = pfx_w_buffer_load_v2i32(S.rs, (int)((__umul24((uint32_t)ya, (uint32_t)src_w) + (uint32_t)xp) << 2), 0, 0);
+            const pfx_w_v2i vb = pfx_w_buffer_load_v2i32(S.rs, (int)((__umul24((uint32_t)yb, (uint32_t)src_w) + (uint32_t)xp) << 2), 0, 0);
+            pa = make_uint2((uint32_t)va.x, (uint32_t)va.y); pb = make_uint2((uint32_t)vb.x, (uint32_t)vb.y);
+        } else { pa = *reinterpret_cast<const uint2*>(ra + (uint32_t)xp); pb = *reinterpret_cast<const uint2*>(rb + (uint32_t)xp); }
         T.tl = pa.x; T.tr = pa.y; T.bl = pb.x; T.br = pb.y;
         // which half holds the texel that exists is settled in bilinear_finish (bits 4 / 5 of m): nothing here waits for the loads
         if (!__all(interior)) T.m |= (x0 < xp ? 16u : 0u) | (x0 > xp ? 32u : 0u);
@@ -100,7 +126,7 @@ constexpr uint32_t WARP_YR = 4; // rows per lane: the field entries of all of th
 // = 3.5 TB/s); four pixels' worth of requests in flight per lane move it towards the HBM rate.
 // `y_off`: index of the buffers' row 0 in the whole output when `disp` / `dst` are a band of it (a document sharded by rows, SURVEY 8e: the source is
 // replicated, every member warps its band of the output); 0 for a whole image.
-template <bool PAIR>
+template <bool PAIR, bool BUF32>
 __global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restrict__ src, int32_t sw, int32_t sh,
                                                         const float2* __restrict__ disp, uint32_t w, uint32_t h,
                                                         uint32_t* __restrict__ dst, uint32_t y_off)
@@ -110,9 +136,10 @@ __global__ __launch_bounds__(256) void warp_disp_kernel(const uint32_t* __restri
     float2 d[WARP_YR];
 #pragma unroll
     for (uint32_t k = 0; k < WARP_YR; ++k) d[k] = disp[(size_t)min(y0 + k, h - 1u) * w + x]; // rows past the end re-read the last one (unused)
+    const warp_src S = make_warp_src(src, sw, sh);
     bilinear_taps taps[WARP_YR];
 #pragma unroll
-    for (uint32_t k = 0; k < WARP_YR; ++k) taps[k] = bilinear_fetch<PAIR>(src, sw, sh, (float)x, (float)(min(y0 + k, h - 1u) + y_off), d[k].x, d[k].y);
+    for (uint32_t k = 0; k < WARP_YR; ++k) taps[k] = bilinear_fetch<PAIR, BUF32>(S, sw, sh, (float)x, (float)(min(y0 + k, h - 1u) + y_off), d[k].x, d[k].y);
 #pragma unroll
     for (uint32_t k = 0; k < WARP_YR; ++k)
         if (y0 + k < h) dst[(size_t)(y0 + k) * w + x] = bilinear_finish(taps[k]);
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(256) void mesh_kernel(const float2* __restrict__ g_
 #endif
 // Rolling form of the fused warp (round 4): D rows' taps in flight all the time — row k + D is requested as soon as row k has been interpolated —
 // instead of batches of eight requested together and then consumed together; 7 D registers of taps instead of 56, so more waves fit.
-template <bool IN_LDS, int D, bool PAIR>
+template <bool IN_LDS, int D, bool PAIR, bool BUF32>
 __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ g_orig, const float2* __restrict__ g_def,
                                                         uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint32_t* __restrict__ dst, uint32_t y_off,
                                                         uint32_t h_full)
@@ -302,6 +329,7 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
     const uint32_t n_rows = min(WALK, h - y_walk);
     // lane k (< 32) evaluates row k's v-dependent half once (mesh_kernel)
     const cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_walk + y_off + (lane & 31u)) + 0.5f, (float)h_full) * (float)rows);
+    const warp_src S = make_warp_src(src, (int32_t)w, (int32_t)h_full);
     auto fetch = [&](uint32_t k) {         // rows past the end repeat the last one (never stored): no branch around the loads
         const uint32_t kk = min(k, n_rows - 1u), y = y_walk + kk;
         cr_row R;
@@ -312,7 +340,7 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
         float2 o;
         if (g_orig) o = cr_column_eval(co, p_orig, cols, rows, R);
         else o = make_float2((float)x + 0.5f, (float)(y + y_off) + 0.5f);
-        return bilinear_fetch<PAIR>(src, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), d.x - o.x, d.y - o.y);
+        return bilinear_fetch<PAIR, BUF32>(S, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), d.x - o.x, d.y - o.y);
     };
     bilinear_taps taps[D];
 #pragma unroll
@@ -335,8 +363,10 @@ extern "C" hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src
 {
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 63) / 64, (h + 4 * WARP_YR - 1) / (4 * WARP_YR));
-    if (sw >= 2u) warp_disp_kernel<true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (int32_t)sw, (int32_t)sh, (const float2*)d_disp, w, h, (uint32_t*)d_dst, first_row);
-    else warp_disp_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (int32_t)sw, (int32_t)sh, (const float2*)d_disp, w, h, (uint32_t*)d_dst, first_row);
+    const bool buf32 = sw >= 2u && sw < (1u << 24) && sh < (1u << 24) && (uint64_t)sw * sh * 4u < (1ull << 32);   // 32-bit byte offsets through a buffer resource
+#define PFX_WD(P, B) warp_disp_kernel<P, B><<<g, 256, 0, s>>>((const uint32_t*)d_src, (int32_t)sw, (int32_t)sh, (const float2*)d_disp, w, h, (uint32_t*)d_dst, first_row)
+    if (buf32) PFX_WD(true, true); else if (sw >= 2u) PFX_WD(true, false); else PFX_WD(false, false);
+#undef PFX_WD
     return hipGetLastError();
 }
 
@@ -430,9 +460,10 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
     constexpr int ROLL = PFX_MESH_ROLL;
     const size_t lds = (size_t)(cols + 1u) * (rows + 1u) * 16u;
     const bool in_lds = (cols + 1u) * (rows + 1u) <= MESH_LDS_PTS;
-#define PFX_ROLL(L, P) mesh_roll_kernel<L, ROLL, P><<<g, 256, (L) ? lds : 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full)
-    if (in_lds) { if (w >= 2u) PFX_ROLL(true, true); else PFX_ROLL(true, false); }
-    else { if (w >= 2u) PFX_ROLL(false, true); else PFX_ROLL(false, false); }
+    const bool buf32 = w >= 2u && w < (1u << 24) && h_full < (1u << 24) && (uint64_t)w * h_full * 4u < (1ull << 32);
+#define PFX_ROLL(L, P, B) mesh_roll_kernel<L, ROLL, P, B><<<g, 256, (L) ? lds : 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full)
+    if (in_lds) { if (buf32) PFX_ROLL(true, true, true); else if (w >= 2u) PFX_ROLL(true, true, false); else PFX_ROLL(true, false, false); }
+    else { if (buf32) PFX_ROLL(false, true, true); else if (w >= 2u) PFX_ROLL(false, true, false); else PFX_ROLL(false, false, false); }
 #undef PFX_ROLL
     return hipGetLastError();
 }
