@@ -618,7 +618,8 @@ def main() -> int:
             try:
                 import glob
                 vp = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_peak.json")))[-1]))
-                slots = fl["valu_wave_insts"] + 3 * vp["flatten"]["transcendental_wave_insts"]
+                trans = (fl.get("valu_class_mix") or {}).get("trans_f32", vp["flatten"]["transcendental_wave_insts"])   # this profile's own count
+                slots = fl["valu_wave_insts"] + 3 * trans
                 roofline["valu_frac_of_sustained_fma_rate"] = round(slots * 64 / (d_ms * 1e-3) / (vp["fma_sustained_T_lane_ops_s"] * 1e12), 3)
                 roofline["fma_sustained_T_lane_ops_s"] = vp["fma_sustained_T_lane_ops_s"]
             except Exception:
