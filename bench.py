@@ -240,7 +240,7 @@ def other_configs(args, torch, r, device, O, flat, blurred):
     hsl_ok = bool(np.array_equal(O.adjust(got_blur, "hsl", hp), got_hsl))
     ms2 = k.get("gauss_mfma", 0.0) + k.get("adjust", 0.0)
     out["config2_gaussian16_hsl_8k"] = entry(ms2, 16 * px, kernel_ms={n: round(v, 4) for n, v in k.items()},
-                                             gaussian_mode="f16-split MFMA, f32 accumulate (+-1 LSB class)",
+                                             gaussian_mode="matrix cores: one f16 per tap, horizontal result as two f16, f32 accumulate (+-1 LSB class)",
                                              check={"gaussian_window_max_diff_vs_oracle": dmax, "hsl_window_bitexact_on_the_gpu_blur": hsl_ok})
     if dmax > 1: failed.append("config2_gaussian")
     if not hsl_ok: failed.append("config2_hsl")
@@ -640,7 +640,7 @@ def main() -> int:
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{w}x{h} RGBA8 x {n} layers (25 blend modes cycling, S2) flatten -> Gaussian sigma={args.sigma:g}",
                       "width": w, "height": h, "layers": n, "sigma": args.sigma,
-                      "gaussian_mode": "exact (f32, no FMA)" if args.exact else "f16-split MFMA, f32 accumulate (+-1 LSB class)",
+                      "gaussian_mode": "exact (f32, no FMA)" if args.exact else "matrix cores: one f16 per tap, horizontal result as two f16, f32 accumulate (+-1 LSB class)",
                       "sharding": ("ONE document in chunk-row bands: RCCL send/recv of %d halo rows before the blur%s" %
                                    (radius, "" if args.no_gather else ", all-gather of the result bands (asynchronous: it overlaps the next step's flatten)")) if band_mode else
                                   ("one independent document per GPU, no collective" if world > 1 else "single GPU")},
