@@ -161,13 +161,23 @@ int main(int argc, char** argv)
     const uint32_t w = 7680, h = 4320, n_px = w * h;
     const uint32_t upw = argc > 1 ? (uint32_t)atoi(argv[1]) : 8u;
     Layers L;
-    for (int l = 0; l < 32; ++l) { hipMalloc((void**)&L.p[l], (size_t)n_px * 4); fill<<<4096, 256>>>((uint32_t*)L.p[l], n_px, 0x1234567u * (l + 1)); }
+    // argv[3] = skew in bytes: layer l starts l * skew bytes further than a 2 MiB-aligned slot (do 33 streams that advance in lock step at the same offset of
+    // identically aligned buffers meet in the same HBM channels / banks?)
+    const size_t skew = argc > 3 ? (size_t)atol(argv[3]) : 0;
+    const size_t slot = (((size_t)n_px * 4 + (2u << 20) - 1) / (2u << 20)) * (2u << 20) + (skew ? (4u << 20) : 0);
+    uint8_t* big; hipMalloc((void**)&big, slot * 32 + (8u << 20));
+    for (int l = 0; l < 32; ++l) { L.p[l] = big + slot * l + skew * l; fill<<<4096, 256>>>((uint32_t*)L.p[l], n_px, 0x1234567u * (l + 1)); }
     L.p[32] = L.p[33] = L.p[31];
     uint8_t* dst; hipMalloc(&dst, (size_t)n_px * 4);
     hipDeviceSynchronize();
     std::vector<uint32_t> ref;
 #define ROW(F) run<0, F, 2, 1>(L, n_px, dst, &ref, upw); run<1, F, 4, 1>(L, n_px, dst, &ref, upw); run<2, F, 4, 1>(L, n_px, dst, &ref, upw); \
                run<2, F, 8, 1>(L, n_px, dst, &ref, upw); run<3, F, 4, 8>(L, n_px, dst, &ref, upw); run<3, F, 8, 8>(L, n_px, dst, &ref, upw);
+    if (argc > 3) {   // skew study: the load stream alone and F = 40, typed and raw
+        printf("{\"skew_bytes\": %zu}\n", skew);
+        run<0, 0, 2, 1>(L, n_px, dst, &ref, upw); run<2, 0, 4, 1>(L, n_px, dst, &ref, upw); run<0, 40, 2, 1>(L, n_px, dst, &ref, upw); run<2, 40, 4, 1>(L, n_px, dst, &ref, upw);
+        return 0;
+    }
     if (argc > 2) {   // chunk-size study: load stream alone and F = 40, waves of a workgroup side by side
 #define IROW(F) run<0, F, 2, 4, true>(L, n_px, dst, &ref, upw); run<0, F, 2, 8, true>(L, n_px, dst, &ref, upw); run<0, F, 2, 4, false>(L, n_px, dst, &ref, upw); \
                 run<2, F, 4, 4, true>(L, n_px, dst, &ref, upw); run<2, F, 4, 8, true>(L, n_px, dst, &ref, upw); run<2, F, 8, 4, true>(L, n_px, dst, &ref, upw); run<2, F, 4, 4, false>(L, n_px, dst, &ref, upw);
