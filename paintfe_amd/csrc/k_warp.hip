@@ -10,6 +10,7 @@
 // source is read roughly once from HBM).  The fused mesh warp evaluates the two bicubic surfaces in registers from
 // control points staged in LDS and never materialises the 8 B/px displacement field.
 #include "k_common.h"
+#include <type_traits>
 #include "pfx_kernels.h"
 
 using namespace pfxk;
@@ -54,7 +55,8 @@ PFX_DEV int32_t cvt_i32_sat(float v)
 // up at the join and put s_waitcnt vmcnt(0) in front of every later pixel's address arithmetic — the eight rows of a batch became eight dependent
 // round trips.  Now every tap is loaded from a clamped (always valid) address and the texels that lie outside are zeroed afterwards from a 4-bit
 // mask; the wave-uniform interior test only skips the clamps and the mask (no load behind a branch, the waits are counted exactly).
-struct bilinear_taps { uint32_t tl, tr, bl, br; float fx, fy; uint32_t m; }; // m: bit 0 tl, 1 tr, 2 bl, 3 br inside the source (0: output transparent); bits 4 / 5: pair loads at the left / right border
+struct bilinear_taps { uint32_t tl, tr, bl, br; float fx, fy; uint32_t m; bool all_in; }; // m: bit 0 tl, 1 tr, 2 bl, 3 br inside the source (0: output transparent); bits 4 / 5: pair loads at the left / right border
+// all_in: every lane of the wave samples strictly inside the source (wave-uniform, lives in a scalar register): m is then not even materialised
 // PAIR (compile-time, chosen by the launcher: src_w >= 2): a run-time test here would put the loads behind a branch again
 template <bool PAIR, bool BUF32 = false>
 PFX_DEV bilinear_taps bilinear_fetch(const warp_src& S, int32_t src_w, int32_t src_h, float x, float y, float ddx, float ddy)
@@ -65,12 +67,16 @@ PFX_DEV bilinear_taps bilinear_fetch(const warp_src& S, int32_t src_w, int32_t s
     const int32_t x0 = cvt_i32_sat(__builtin_floorf(sx)), y0 = cvt_i32_sat(__builtin_floorf(sy));
     T.fx = sx - (float)x0;
     T.fy = sy - (float)y0;
-    // a NaN coordinate converts to texel 0 with NaN weights: such a lane must not count as interior (its wave would skip the test that makes it transparent)
-    const float wsum = T.fx + T.fy;
-    const bool interior = x0 >= 0 && y0 >= 0 && x0 < src_w - 1 && y0 < src_h - 1 && wsum == wsum;
+    // strictly inside: 0 <= x0 < w - 1 as ONE unsigned compare per axis; a NaN coordinate converts to texel 0 with NaN weights, so such a lane must not
+    // count as interior (its wave would skip the test that makes it transparent): one unordered compare covers both coordinates (an infinite one
+    // saturates x0 / y0 and fails the range test)
+    // as lane masks straight from the compares (hip's __all() and the ballot builtin first materialise the predicate in a VGPR): 36 = unsigned <, 7 = ordered
+    const uint64_t interior = __builtin_amdgcn_uicmp((uint32_t)x0, (uint32_t)(src_w - 1), 36) & __builtin_amdgcn_uicmp((uint32_t)y0, (uint32_t)(src_h - 1), 36) &
+                              __builtin_amdgcn_fcmpf(sx, sy, 7);
+    T.all_in = interior == __builtin_amdgcn_ballot_w64(true);
     int32_t xa = x0, xb = x0 + 1, ya = y0, yb = y0 + 1;
-    T.m = 15u;
-    if (!__all(interior)) {
+    int32_t xp = x0;                         // PAIR: first texel of the 8-byte pair
+    if (!T.all_in) {
         // :1310; a NaN coordinate converts to texel 0 with NaN weights: every channel would be `NaN as u8` = 0, the same as "outside"
         const bool ok = !(x0 < -1 || y0 < -1 || x0 >= src_w || y0 >= src_h) && T.fx == T.fx && T.fy == T.fy;
         const uint32_t mx = (x0 >= 0 ? 5u : 0u) | (x0 + 1 < src_w ? 10u : 0u), my = (y0 >= 0 ? 3u : 0u) | (y0 + 1 < src_h ? 12u : 0u);
@@ -78,29 +84,44 @@ PFX_DEV bilinear_taps bilinear_fetch(const warp_src& S, int32_t src_w, int32_t s
         if (!ok) { T.fx = 0.0f; T.fy = 0.0f; }   // all four texels read as 0: the lerp of zeros with finite weights is the transparent pixel
         xa = min(max(xa, 0), src_w - 1); xb = min(max(xb, 0), src_w - 1);
         ya = min(max(ya, 0), src_h - 1); yb = min(max(yb, 0), src_h - 1);
+        if constexpr (PAIR) {
+            // the pair starts at clamp(x0, 0, w - 2); at the left / right border the texel that exists sits in the other half of the pair (the one
+            // that does not is masked); which half is settled in bilinear_finish (bits 4 / 5 of m): nothing here waits for the loads
+            xp = min(max(x0, 0), src_w - 2);
+            T.m |= (x0 < xp ? 16u : 0u) | (x0 > xp ? 32u : 0u);
+        }
     }
-    const uint32_t* ra = src + (size_t)(uint32_t)ya * (uint32_t)src_w;
-    const uint32_t* rb = src + (size_t)(uint32_t)yb * (uint32_t)src_w;
     if constexpr (PAIR) {
-        // the two texels of a row as ONE 8-byte load (the address unit is what bounds these kernels: half the instructions): the pair starts at
-        // clamp(x0, 0, w - 2); at the left / right border the texel that exists sits in the other half of the pair (the one that does not is masked)
-        const int32_t xp = min(max(x0, 0), src_w - 2);
+        // the two texels of a row as ONE 8-byte load (the address unit is what bounds these kernels: half the instructions)
         uint2 pa, pb;
         if constexpr (BUF32) {   // rows and columns of an image are below 2^24: v_mad_u32_u24 is exact and full rate
-            const pfx_w_v2i va = pfx_w_buffer_load_v2i32(S.rs, (int)((__umul24((uint32_t)ya, (uint32_t)src_w) + (uint32_t)xp) << 2), 0, 0);
-            const pfx_w_v2i vb = pfx_w_buffer_load_v2i32(S.rs, (int)((__umul24((uint32_t)yb, (uint32_t)src_w) + (uint32_t)xp) << 2), 0, 0);
+            // interior waves: the lower row is the upper one's offset plus the pitch, which rides in the load's scalar offset (no second address)
+            const uint32_t oa = (__umul24((uint32_t)ya, (uint32_t)src_w) + (uint32_t)xp) << 2;
+            uint32_t ob = oa, sb = (uint32_t)src_w << 2;
+            if (!T.all_in) {
+                ob = (__umul24((uint32_t)yb, (uint32_t)src_w) + (uint32_t)xp) << 2; sb = 0u;
+                asm volatile("" : "+v"(ob));   // stays on the border path (if-conversion would compute it for every wave and select)
+            }
+            const pfx_w_v2i va = pfx_w_buffer_load_v2i32(S.rs, (int)oa, 0, 0);
+            const pfx_w_v2i vb = pfx_w_buffer_load_v2i32(S.rs, (int)ob, (int)sb, 0);
             pa = make_uint2((uint32_t)va.x, (uint32_t)va.y); pb = make_uint2((uint32_t)vb.x, (uint32_t)vb.y);
-        } else { pa = *reinterpret_cast<const uint2*>(ra + (uint32_t)xp); pb = *reinterpret_cast<const uint2*>(rb + (uint32_t)xp); }
+        } else {
+            const uint32_t* ra = src + (size_t)(uint32_t)ya * (uint32_t)src_w;
+            const uint32_t* rb = src + (size_t)(uint32_t)yb * (uint32_t)src_w;
+            pa = *reinterpret_cast<const uint2*>(ra + (uint32_t)xp); pb = *reinterpret_cast<const uint2*>(rb + (uint32_t)xp);
+        }
         T.tl = pa.x; T.tr = pa.y; T.bl = pb.x; T.br = pb.y;
-        // which half holds the texel that exists is settled in bilinear_finish (bits 4 / 5 of m): nothing here waits for the loads
-        if (!__all(interior)) T.m |= (x0 < xp ? 16u : 0u) | (x0 > xp ? 32u : 0u);
-    } else { T.tl = ra[(uint32_t)xa]; T.tr = ra[(uint32_t)xb]; T.bl = rb[(uint32_t)xa]; T.br = rb[(uint32_t)xb]; }
+    } else {
+        const uint32_t* ra = src + (size_t)(uint32_t)ya * (uint32_t)src_w;
+        const uint32_t* rb = src + (size_t)(uint32_t)yb * (uint32_t)src_w;
+        T.tl = ra[(uint32_t)xa]; T.tr = ra[(uint32_t)xb]; T.bl = rb[(uint32_t)xa]; T.br = rb[(uint32_t)xb];
+    }
     return T;
 }
 PFX_DEV uint32_t bilinear_finish(const bilinear_taps& T)
 {
     uint32_t tl = T.tl, tr = T.tr, bl = T.bl, br = T.br;
-    if (!__all(T.m == 15u)) { // texels outside the source are 0 (:1318-1331)
+    if (!T.all_in) { // texels outside the source are 0 (:1318-1331)
         if (T.m & 16u) { tr = tl; br = bl; }        // x0 == -1: the pair started at texel 0, which is tr / br
         else if (T.m & 32u) { tl = tr; bl = br; }   // x0 == w - 1: the pair ended at the last texel, which is tl / bl
         tl = (T.m & 1u) ? tl : 0u; tr = (T.m & 2u) ? tr : 0u; bl = (T.m & 4u) ? bl : 0u; br = (T.m & 8u) ? br : 0u;
@@ -207,22 +228,27 @@ PFX_DEV cr_row cr_row_of(uint32_t rows, float v_global)
     cr_weights(row_f - (float)R.ri, R.wv);
     return R;
 }
-PFX_DEV float2 cr_column_eval(cr_column& C, const float2* __restrict__ pts, uint32_t cols, uint32_t rows, const cr_row& R)
+// the per-control-row partial sums of cell row `ri` (the u-dependent half)
+PFX_DEV void cr_column_fill(cr_column& C, const float2* __restrict__ pts, uint32_t cols, uint32_t rows, uint32_t ri)
 {
     const uint32_t ppr = cols + 1u, num_rows = rows + 1u;
-    const uint32_t ri = R.ri;
-    const float (&wv)[4] = R.wv;
-    if (ri != C.ri_cached) { // uniform across the wave
-        C.ri_cached = ri;
-        const uint32_t rv[4] = {ri == 0u ? 0u : ri - 1u, ri, min(ri + 1u, num_rows - 1u), min(ri + 2u, num_rows - 1u)};
+    C.ri_cached = ri;
+    const uint32_t rv[4] = {ri == 0u ? 0u : ri - 1u, ri, min(ri + 1u, num_rows - 1u), min(ri + 2u, num_rows - 1u)};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float2* base = pts + rv[j] * ppr;
-            const float2 p0 = base[C.cu[0]], p1 = base[C.cu[1]], p2 = base[C.cu[2]], p3 = base[C.cu[3]];
-            C.rx[j] = C.wu[0] * p0.x + C.wu[1] * p1.x + C.wu[2] * p2.x + C.wu[3] * p3.x;
-            C.ry[j] = C.wu[0] * p0.y + C.wu[1] * p1.y + C.wu[2] * p2.y + C.wu[3] * p3.y;
-        }
+    for (int j = 0; j < 4; ++j) {
+        const float2* base = pts + rv[j] * ppr;
+        const float2 p0 = base[C.cu[0]], p1 = base[C.cu[1]], p2 = base[C.cu[2]], p3 = base[C.cu[3]];
+        C.rx[j] = C.wu[0] * p0.x + C.wu[1] * p1.x + C.wu[2] * p2.x + C.wu[3] * p3.x;
+        C.ry[j] = C.wu[0] * p0.y + C.wu[1] * p1.y + C.wu[2] * p2.y + C.wu[3] * p3.y;
     }
+}
+// FILLED: the caller has filled the sums for this row's cell row (no test)
+template <bool FILLED = false>
+PFX_DEV float2 cr_column_eval(cr_column& C, const float2* __restrict__ pts, uint32_t cols, uint32_t rows, const cr_row& R)
+{
+    const float (&wv)[4] = R.wv;
+    if constexpr (!FILLED)
+        if (R.ri != C.ri_cached) cr_column_fill(C, pts, cols, rows, R.ri); // uniform across the wave
     return make_float2(wv[0] * C.rx[0] + wv[1] * C.rx[1] + wv[2] * C.rx[2] + wv[3] * C.rx[3],
                        wv[0] * C.ry[0] + wv[1] * C.ry[1] + wv[2] * C.ry[2] + wv[3] * C.ry[3]);
 }
@@ -318,7 +344,9 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
     }
     const float2* p_def = IN_LDS ? s_def : g_def;
     const float2* p_orig = IN_LDS ? s_orig : g_orig;
-    const uint32_t lane = threadIdx.x & 63u, x_lane = blockIdx.x * 64u + lane, y_walk = (blockIdx.y * 4u + (threadIdx.x >> 6)) * WALK;
+    // the wave's first row as a scalar: row counters, the rows' v_readlane indices and the end-of-image tests then stay on the scalar unit
+    const uint32_t lane = threadIdx.x & 63u, x_lane = blockIdx.x * 64u + lane;
+    const uint32_t y_walk = (blockIdx.y * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * WALK;
     if (y_walk >= h) return;               // whole wave
     const bool x_valid = x_lane < w;
     const uint32_t x = x_valid ? x_lane : w - 1u;
@@ -330,30 +358,41 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
     // lane k (< 32) evaluates row k's v-dependent half once (mesh_kernel)
     const cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_walk + y_off + (lane & 31u)) + 0.5f, (float)h_full) * (float)rows);
     const warp_src S = make_warp_src(src, (int32_t)w, (int32_t)h_full);
-    auto fetch = [&](uint32_t k) {         // rows past the end repeat the last one (never stored): no branch around the loads
-        const uint32_t kk = min(k, n_rows - 1u), y = y_walk + kk;
-        cr_row R;
-        R.ri = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, (int)kk);
+    // ONE_CELL_ROW: all rows of the walk lie in one row of mesh cells (all but one walk in rows-of-cells / 32): the per-control-row sums are loop
+    // invariants — no cache test per row, and none of the register copies the compiler puts at that test's join
+    auto walk = [&](auto one_cell_row) {
+        constexpr bool ONE = decltype(one_cell_row)::value;
+        auto fetch = [&](uint32_t k) {         // rows past the end repeat the last one (never stored): no branch around the loads
+            const uint32_t kk = min(k, n_rows - 1u), y = y_walk + kk;
+            cr_row R;
+            R.ri = ONE ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, (int)kk);   // unused under ONE
 #pragma unroll
-        for (int j = 0; j < 4; ++j) R.wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.wv[j]), (int)kk));
-        const float2 d = cr_column_eval(cd, p_def, cols, rows, R);
-        float2 o;
-        if (g_orig) o = cr_column_eval(co, p_orig, cols, rows, R);
-        else o = make_float2((float)x + 0.5f, (float)(y + y_off) + 0.5f);
-        return bilinear_fetch<PAIR, BUF32>(S, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), d.x - o.x, d.y - o.y);
-    };
-    bilinear_taps taps[D];
+            for (int j = 0; j < 4; ++j) R.wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.wv[j]), (int)kk));
+            const float2 d = cr_column_eval<ONE>(cd, p_def, cols, rows, R);
+            float2 o;
+            if (g_orig) o = cr_column_eval<ONE>(co, p_orig, cols, rows, R);
+            else o = make_float2((float)x + 0.5f, (float)(y + y_off) + 0.5f);
+            return bilinear_fetch<PAIR, BUF32>(S, (int32_t)w, (int32_t)h_full, (float)x, (float)(y + y_off), d.x - o.x, d.y - o.y);
+        };
+        bilinear_taps taps[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) taps[j] = fetch((uint32_t)j);
-    for (uint32_t k0 = 0; k0 < n_rows; k0 += D) {
+        for (int j = 0; j < D; ++j) taps[j] = fetch((uint32_t)j);
+        for (uint32_t k0 = 0; k0 < n_rows; k0 += D) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const uint32_t k = k0 + j;
-            const uint32_t px = bilinear_finish(taps[j]);
-            if (x_valid && k < n_rows) dst[(size_t)(y_walk + k) * w + x] = px;
-            taps[j] = fetch(k + D);
+            for (int j = 0; j < D; ++j) {
+                const uint32_t k = k0 + j;
+                const uint32_t px = bilinear_finish(taps[j]);
+                if (x_valid && k < n_rows) dst[(size_t)(y_walk + k) * w + x] = px;
+                taps[j] = fetch(k + D);
+            }
         }
-    }
+    };
+    const uint32_t ri_first = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, 0), ri_last = (uint32_t)__builtin_amdgcn_readlane((int)mine.ri, (int)(n_rows - 1u));
+    if (ri_first == ri_last) {
+        cr_column_fill(cd, p_def, cols, rows, ri_first);
+        if (g_orig) cr_column_fill(co, p_orig, cols, rows, ri_first);
+        walk(std::true_type{});
+    } else walk(std::false_type{});
 }
 
 } // namespace
