@@ -323,6 +323,17 @@ __global__ __launch_bounds__(256) void mesh_kernel(const float2* __restrict__ g_
 #ifndef PFX_MESH_ROLL
 #define PFX_MESH_ROLL 2
 #endif
+#ifndef PFX_MESH_WALK
+#define PFX_MESH_WALK 48
+#endif
+#ifndef PFX_MESH_WX
+#define PFX_MESH_WX 4
+#endif
+// rows walked by a lane (<= 64: lane k evaluates row k's v-dependent half) and waves of a workgroup side by side in x.  16K, three alternations on one box
+// (profiles/r04_tuning.md): 32 x 1 0.447 ms, 16 x 1 0.48, 8 x 1 0.52, 32 x 4 0.434, 48 x 4 0.422, 64 x 4 0.427 — a workgroup writes 1 KB runs of a row, and the
+// u-dependent half of the surface is set up once per 48 rows
+constexpr uint32_t MESH_WALK = PFX_MESH_WALK, MESH_WX = PFX_MESH_WX;
+static_assert(MESH_WALK <= 64 && (MESH_WX == 1 || MESH_WX == 2 || MESH_WX == 4), "mesh_roll_kernel: lane k evaluates row k; 4 waves per workgroup");
 // Rolling form of the fused warp (round 4): D rows' taps in flight all the time — row k + D is requested as soon as row k has been interpolated —
 // instead of batches of eight requested together and then consumed together; 7 D registers of taps instead of 56, so more waves fit.
 template <bool IN_LDS, int D, bool PAIR, bool BUF32>
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
                                                         uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint32_t* __restrict__ dst, uint32_t y_off,
                                                         uint32_t h_full)
 {
-    constexpr uint32_t WALK = 32u; // rows per lane; a workgroup covers 64 x 128 pixels
+    constexpr uint32_t WALK = MESH_WALK, WX = MESH_WX; // rows per lane; a workgroup covers (64 WX) x (WALK 4 / WX) pixels
     extern __shared__ __attribute__((aligned(16))) uint8_t mesh_lds[];
     float2* const s_orig = reinterpret_cast<float2*>(mesh_lds);
     float2* const s_def = s_orig + (IN_LDS ? (cols + 1u) * (rows + 1u) : 0u);
@@ -345,8 +356,9 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
     const float2* p_def = IN_LDS ? s_def : g_def;
     const float2* p_orig = IN_LDS ? s_orig : g_orig;
     // the wave's first row as a scalar: row counters, the rows' v_readlane indices and the end-of-image tests then stay on the scalar unit
-    const uint32_t lane = threadIdx.x & 63u, x_lane = blockIdx.x * 64u + lane;
-    const uint32_t y_walk = (blockIdx.y * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * WALK;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u, x_lane = (blockIdx.x * WX + wave % WX) * 64u + lane;
+    const uint32_t y_walk = (blockIdx.y * (4u / WX) + wave / WX) * WALK;
     if (y_walk >= h) return;               // whole wave
     const bool x_valid = x_lane < w;
     const uint32_t x = x_valid ? x_lane : w - 1u;
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
     if (g_orig) cr_column_init(co, cols, u);
     const uint32_t n_rows = min(WALK, h - y_walk);
     // lane k (< 32) evaluates row k's v-dependent half once (mesh_kernel)
-    const cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_walk + y_off + (lane & 31u)) + 0.5f, (float)h_full) * (float)rows);
+    const cr_row mine = cr_row_of(rows, fdiv_fast((float)(y_walk + y_off + (lane & (WALK <= 32u ? 31u : 63u))) + 0.5f, (float)h_full) * (float)rows);
     const warp_src S = make_warp_src(src, (int32_t)w, (int32_t)h_full);
     // ONE_CELL_ROW: all rows of the walk lie in one row of mesh cells (all but one walk in rows-of-cells / 32): the per-control-row sums are loop
     // invariants — no cache test per row, and none of the register copies the compiler puts at that test's join
@@ -494,7 +506,7 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
                                      uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst, uint32_t first_row, uint32_t h_full)
 {
     if (w == 0 || h == 0) return hipSuccess;
-    dim3 g((w + 63) / 64, (h + 4 * MESH_YR * MESH_YB - 1) / (4 * MESH_YR * MESH_YB));
+    dim3 g((w + 64 * MESH_WX - 1) / (64 * MESH_WX), (h + MESH_WALK * (4 / MESH_WX) - 1) / (MESH_WALK * (4 / MESH_WX)));
     // rows in flight per lane: 2 measured best at 16K (tools/r4_s9.sh: 0.565 ms against 0.573-0.59 for 3 / 4, 0.63 for 6 and for round 3's batches of 8)
     constexpr int ROLL = PFX_MESH_ROLL;
     const size_t lds = (size_t)(cols + 1u) * (rows + 1u) * 16u;

@@ -15,8 +15,8 @@ for d in "abcd":
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv"%d, recursive=True):
         acc=collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
-            k=row["Kernel_Name"]
-            if "mesh_kernel" in k or "warp_disp" in k:
+            k=row["Kernel_Name"].replace("(anonymous namespace)::","")
+            if "mesh_" in k or "warp_disp" in k:
                 acc[(k.split("(")[0][-40:],row["Counter_Name"])].append(float(row["Counter_Value"]))
         for k,v in sorted(acc.items()): print(d,k[0],k[1],"%.6g"%(sum(v)/len(v)),len(v))
 PY
