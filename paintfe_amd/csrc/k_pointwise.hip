@@ -13,11 +13,7 @@
 // workgroup-wide OR of alpha with no extra pass over memory.  256-entry LUTs are staged in LDS.
 #include "k_common.h"
 #include "pfx_kernels.h"
-#include <type_traits>
 
-#ifndef PFX_PW_GROUP
-#define PFX_PW_GROUP 4
-#endif
 using namespace pfxk;
 
 namespace {
@@ -42,11 +38,8 @@ PFX_DEV hsl3 rgb_to_hsl(float r, float g, float b)
     const float s = fdiv_fast(d, (l > 0.5f) ? (2.0f - mx - mn) : (mx + mn)); // selecting the operand == selecting the quotient
     const rdiv kd = rdiv_prepare(d), k6 = rdiv_prepare(6.0f);
     const bool is_r = mx == r, is_g = mx == g;
-    // all three differences are computed and then selected: a pinned value inside a conditional becomes an exec-mask branch per pixel (the asm cannot be
-    // speculated), and a branch between two pixels also keeps the scheduler from interleaving their chains
-    const float n_gb = pin(g - b), n_br = pin(b - r), n_rg = pin(r - g);
-    const float n_rb = is_g ? n_br : n_rg;
-    const float sector = rdiv_apply(kd, is_r ? n_gb : n_rb);
+    const float n_rb = pin(is_g ? (b - r) : (r - g));
+    const float sector = rdiv_apply(kd, is_r ? pin(g - b) : n_rb);
     // red sector: `if h < 0 { h += 6 }` (adding +0.0 otherwise leaves the value as it is); green: + 2; blue: + 4
     const float offset = is_r ? ((sector < 0.0f) ? 6.0f : 0.0f) : (is_g ? 2.0f : 4.0f);
     const float h = rdiv_apply(k6, sector + offset);
@@ -216,9 +209,7 @@ PFX_DEV void rhai_px(const pfxk_params& P, const uint8_t* __restrict__ lut, uint
     } else { o[0] = r; o[1] = g; o[2] = b; }
 }
 
-// FINITE (HSL / vibrance only): the host found every parameter finite (P.p[11]); decided once per lane batch by the caller, not per pixel — a wave-uniform
-// branch between two pixels is still a basic-block boundary
-template <int OP, bool RHAI, bool FINITE = false>
+template <int OP, bool RHAI>
 PFX_DEV uint32_t apply_px(const pfxk_params& P, const uint8_t* __restrict__ lut, uint32_t px)
 {
     float o[4];
@@ -228,7 +219,7 @@ PFX_DEV uint32_t apply_px(const pfxk_params& P, const uint8_t* __restrict__ lut,
     } else {
         adjust_px<OP>(P, lut, ubyte0(px), ubyte1(px), ubyte2(px), ubyte3(px), o);
         if constexpr (OP == PFXK_OP_INVERT_ALPHA || OP == PFXK_OP_LUT_RGBA) return pack_round_rgba(o[0], o[1], o[2], o[3]);
-        else if ((OP == PFXK_OP_HSL || OP == PFXK_OP_VIBRANCE) && (FINITE || P.p[11] != 0.0f)) { // wave-uniform: the host found every parameter finite
+        else if ((OP == PFXK_OP_HSL || OP == PFXK_OP_VIBRANCE) && P.p[11] != 0.0f) { // wave-uniform: the host found every parameter finite
             // hsl_to_rgb returns finite values for finite h, s, l (sums and products of numbers in [0, 2]; the grey lanes' 0 / 0 never leaves
             // rgb_to_hsl): no +inf to keep away from the tie bit, so the v_med3 of round_tie_prep (a half-rate instruction) is not needed
             auto tie = [](float v) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) | 1u); };
@@ -275,31 +266,14 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t* __restric
         for (int k = 0; k < 4; ++k) any_in |= (int)((v[k].x | v[k].y | v[k].z | v[k].w) >> 24);
         const bool live = sparse_mode == 2 ? __syncthreads_or(any_in) != 0 : true; // IN_PLACE: an unpopulated chunk is never visited
         int any_out = 0;
-        auto apply16 = [&](auto finite) {     // the 16 pixels of a lane as ONE basic block: their dependency chains interleave
-            constexpr bool F = decltype(finite)::value;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k].x = apply_px<OP, RHAI, F>(P, lut, v[k].x); v[k].y = apply_px<OP, RHAI, F>(P, lut, v[k].y);
-                v[k].z = apply_px<OP, RHAI, F>(P, lut, v[k].z); v[k].w = apply_px<OP, RHAI, F>(P, lut, v[k].w);
-#if PFX_PW_GROUP == 4
-                __builtin_amdgcn_sched_barrier(0);   // interleave the four pixels of a load, not all sixteen (86 VGPRs: five waves per SIMD instead of eight)
-#endif
-            }
-        };
-        if (live) {
-#if PFX_PW_GROUP == 1
-            apply16(std::false_type{});
-#else
-            if constexpr (!RHAI && (OP == PFXK_OP_HSL || OP == PFXK_OP_VIBRANCE)) {
-                if (P.p[11] != 0.0f) apply16(std::true_type{}); else apply16(std::false_type{});
-            } else apply16(std::false_type{});
-#endif
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = make_uint4(0u, 0u, 0u, 0u);
+        for (int k = 0; k < 4; ++k) {
+            if (live) {
+                v[k].x = apply_px<OP, RHAI>(P, lut, v[k].x); v[k].y = apply_px<OP, RHAI>(P, lut, v[k].y);
+                v[k].z = apply_px<OP, RHAI>(P, lut, v[k].z); v[k].w = apply_px<OP, RHAI>(P, lut, v[k].w);
+            } else v[k] = make_uint4(0u, 0u, 0u, 0u);
+            any_out |= (int)((v[k].x | v[k].y | v[k].z | v[k].w) >> 24);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) any_out |= (int)((v[k].x | v[k].y | v[k].z | v[k].w) >> 24);
         const bool drop = sparse_mode == 1 ? __syncthreads_or(any_out) == 0 : false; // FROM_FLAT: a chunk whose alpha is all zero is dropped
 #pragma unroll
         for (int k = 0; k < 4; ++k)
