@@ -7,6 +7,7 @@
 //   mode 1  raw buffer_load_dword, DEPTH layers in flight, v_cvt_f32_ubyteN + the two-operation div255        (12 VALU per pixel)
 //   mode 2  raw, DEPTH in flight, v_lshlrev_b32_sdwa (byte -> table offset) + ds_read_b32 from a 1 KB table   (4 VALU + 4 LDS reads; bank conflicts)
 //   mode 3  raw, DEPTH in flight, the same through a 32 KB table with one copy per bank (conflict-free)        (8 VALU + 4 LDS reads)
+//   mode 4  raw buffer_load_dword ... lds: DEPTH layers in flight in an LDS ring (no VGPR per pixel in flight), ds_read_b32 + v_cvt_f32_ubyteN + div255
 // Every mode's sum of converted channels is checked against the typed mode's (the conversions are the same function of the byte).
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -65,6 +66,8 @@ template <int MODE, int F, int DEPTH, int WPB, bool IL = false>
 __global__ __launch_bounds__(64 * WPB) void k(Layers L, int n_layers, uint32_t n_px, uint32_t units_per_wave, uint8_t* dst)
 {
     __shared__ float tab[MODE == 3 ? 256 * 32 : 256];
+    __shared__ uint32_t ring[MODE == 4 ? WPB : 1][MODE == 4 ? DEPTH : 1][3][64];
+    uint32_t rawv[3];
     if constexpr (MODE == 3) { for (uint32_t i = threadIdx.x; i < 256u * 32u; i += 64u * WPB) tab[i] = (float)(i >> 5) / 255.0f; }
     else { for (uint32_t i = threadIdx.x; i < 256u; i += 64u * WPB) tab[i] = (float)i / 255.0f; }
     __syncthreads();
@@ -96,6 +99,37 @@ __global__ __launch_bounds__(64 * WPB) void k(Layers L, int n_layers, uint32_t n
                 fetch(tA, l + 2);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) work<F>(acc[j], tB[j]);
+            }
+        } else if constexpr (MODE == 4) {
+            // the wave's ring: DEPTH layers x 3 groups x 64 dwords, filled by the loads themselves (M0 = slot base, lane l's dword lands at word l)
+            uint32_t (*slot)[3][64] = ring[wib];
+            auto fetch = [&](int sl, int l) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(L.p[l < n_layers ? l : n_layers]), 0, (int)bytes, (int)RAW32);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)&slot[sl][j][0], 4, voff[j], 0, 0, 0);
+            };
+#pragma unroll
+            for (int sl = 0; sl < DEPTH; ++sl) fetch(sl, sl);
+            for (int l = 0; l < n_layers; l += DEPTH) {
+#pragma unroll
+                for (int sl = 0; sl < DEPTH; ++sl) {
+                    // the oldest layer's three loads have landed when at most 3 (DEPTH - 1) are outstanding
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (DEPTH - 1)) : "memory");
+                    float t[3][4];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        uint32_t raw;
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(raw) : "v"((uint32_t)(uintptr_t)&slot[sl][j][lane]) : "memory");
+                        rawv[j] = raw;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) :: "memory");
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) convert<1>(t[j], rawv[j], tab, lane_base);
+                    fetch(sl, l + sl + DEPTH);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) work<F>(acc[j], t[j]);
+                }
             }
         } else {
             uint32_t raw[DEPTH][3];
@@ -183,6 +217,11 @@ int main(int argc, char** argv)
                 run<2, F, 4, 4, true>(L, n_px, dst, &ref, upw); run<2, F, 4, 8, true>(L, n_px, dst, &ref, upw); run<2, F, 8, 4, true>(L, n_px, dst, &ref, upw); run<2, F, 4, 4, false>(L, n_px, dst, &ref, upw);
         run<0, 0, 2, 1>(L, n_px, dst, &ref, upw);
         IROW(0) IROW(40) IROW(64)
+        return 0;
+    }
+    if (argc > 1 && atoi(argv[1]) < 0) {   // LDS-ring study
+#define LROW(F) run<0, F, 2, 1>(L, n_px, dst, &ref, 8); run<4, F, 4, 4>(L, n_px, dst, &ref, 8); run<4, F, 6, 4>(L, n_px, dst, &ref, 8); run<4, F, 8, 2>(L, n_px, dst, &ref, 8); run<4, F, 3, 4>(L, n_px, dst, &ref, 8);
+        LROW(0) LROW(40) LROW(64)
         return 0;
     }
     ROW(0) ROW(40) ROW(80) ROW(120)
