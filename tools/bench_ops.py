@@ -40,9 +40,14 @@ def main() -> int:
     def timed(name, timer_names, fn, px, alg_bytes_per_px, note=""):
         if args.only and args.only not in name:
             return
-        for _ in range(5):  # clocks ramp over the first launches
-            fn()
-        torch.cuda.synchronize()
+        import time
+        t_warm = time.perf_counter()  # clocks ramp over the first ~30 ms of load (bench.py's PREWARM standard)
+        while True:
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            if time.perf_counter() - t_warm >= 0.04:
+                break
         r.timing_reset()
         r.timing_enable(True)
         for _ in range(args.reps):
