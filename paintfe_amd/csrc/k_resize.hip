@@ -54,7 +54,16 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const float4* __restrict_
 // horizontal taps reach (h_left[first] .. h_left[last] + h_count[last], both monotone in the output column) into an f32 RGBA tile in
 // LDS, then the horizontal pass out of it.  The same operations in the same order as the two kernels above — bit-identical — without
 // the 16 B/sample intermediate in HBM (3/4 of the two-pass traffic at 8K -> 4K).
-constexpr int RZ_TOX = 64, RZ_TOY = 8;
+#ifndef PFX_RZ_ROWS_PER_WAVE
+#define PFX_RZ_ROWS_PER_WAVE 1
+#endif
+#ifndef PFX_RZ_TOX
+#define PFX_RZ_TOX 64
+#endif
+constexpr int RZ_TOX = PFX_RZ_TOX, RZ_TOY = 8;   // (128 output columns measured slower: 0.143 against 0.104 ms at 8K -> 4K bilinear)
+// Taps are taken four at a time: the four loads of a group are issued from clamped (always valid) indices before any of them is used, and the
+// accumulation — `t += v * w` in source order, one rounding per operation — skips the ones past the window under a block-uniform test.  With one load per
+// trip of a run-time-count loop every tap was a full memory (or LDS) round trip of its own (8K -> 4K bilinear 0.131 ms, 0.158 of the HBM roofline).
 __global__ __launch_bounds__(256) void resize_fused_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ v_left,
                                                            const uint32_t* __restrict__ v_count, const uint32_t* __restrict__ v_off, const float* __restrict__ v_wts,
                                                            const uint32_t* __restrict__ h_left, const uint32_t* __restrict__ h_count, const uint32_t* __restrict__ h_off,
@@ -63,18 +72,32 @@ __global__ __launch_bounds__(256) void resize_fused_kernel(const uint32_t* __res
     extern __shared__ float4 rz_tile[]; // [RZ_TOY][span_max]
     const int ox0 = blockIdx.x * RZ_TOX, oy0 = blockIdx.y * RZ_TOY, ox_last = min(ox0 + RZ_TOX, nw) - 1;
     const int L = (int)h_left[ox0], span = (int)(h_left[ox_last] + h_count[ox_last]) - L;
+#if PFX_RZ_ROWS_PER_WAVE
+    // a wave per output row (two rows each): oy stays wave-uniform — window bounds and weights come through scalar loads — and the four waves work on four
+    // rows at once instead of half the block idling over one row's ~130 source columns
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), x_first = (int)(threadIdx.x & 63u), x_step = 64;
+    for (int ry = wv; ry < RZ_TOY; ry += 4) {
+#else
+    const int x_first = (int)threadIdx.x, x_step = 256;
     for (int ry = 0; ry < RZ_TOY; ++ry) { // oy uniform: window bounds and weights come through scalar loads
+#endif
         const int oy = oy0 + ry;
         if (oy >= nh) break;
         const uint32_t l = v_left[oy], n = v_count[oy];
         const float* wp = v_wts + v_off[oy];
-        for (int xs = threadIdx.x; xs < span; xs += 256) {
+        for (int xs = x_first; xs < span; xs += x_step) {
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
             const uint32_t* p = src + (size_t)l * w + L + xs;
-            for (uint32_t i = 0; i < n; ++i, p += w) {
-                const uint32_t v = *p;
-                const float wt = wp[i];
-                t0 += ubyte0(v) * wt; t1 += ubyte1(v) * wt; t2 += ubyte2(v) * wt; t3 += ubyte3(v) * wt;
+            for (uint32_t i = 0; i < n; i += 4) {
+                uint32_t v[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) v[k] = p[(size_t)min(i + k, n - 1u) * w];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (i + k < n) {   // uniform
+                        const float wt = wp[i + k];
+                        t0 += ubyte0(v[k]) * wt; t1 += ubyte1(v[k]) * wt; t2 += ubyte2(v[k]) * wt; t3 += ubyte3(v[k]) * wt;
+                    }
             }
             rz_tile[ry * span_max + xs] = make_float4(t0, t1, t2, t3);
         }
@@ -88,10 +111,13 @@ __global__ __launch_bounds__(256) void resize_fused_kernel(const uint32_t* __res
         const float* wp = h_wts + h_off[ox];
         const float4* p = rz_tile + ry * span_max + ((int)h_left[ox] - L);
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-        for (uint32_t i = 0; i < n; ++i) {
-            const float4 v = p[i];
-            const float wt = wp[i];
-            t0 += v.x * wt; t1 += v.y * wt; t2 += v.z * wt; t3 += v.w * wt;
+        for (uint32_t i = 0; i < n; i += 4) {   // n varies by column (per lane): the guard below is a select per tap, the LDS reads are unconditional
+            float4 v[4]; float wt[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) { const uint32_t j = min(i + q, n - 1u); v[q] = p[j]; wt[q] = wp[j]; }
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q)
+                if (i + q < n) { t0 += v[q].x * wt[q]; t1 += v[q].y * wt[q]; t2 += v[q].z * wt[q]; t3 += v[q].w * wt[q]; }
         }
         dst[(size_t)oy * nw + ox] = pack_round_rgba(t0, t1, t2, t3); // NumCast::from(FloatNearest(clamp(t, 0, 255))): round half away from zero
     }
