@@ -153,12 +153,21 @@ PFX_DEV uint32_t fx_pixel(const uint32_t* __restrict__ src, uint32_t s, int x, i
         const int n = P.i[0];
         const float dx = (float)x - cx, dy = (float)y - cy;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f; // sums of integers < 2^24: exact in any order
-        for (int i = 0; i < n; ++i) {
-            const float t = 1.0f - st * ((float)i / (float)(n - 1));
-            const int sx = clampi(rs_i32(__builtin_roundf(cx + dx * t)), 0, w - 1);
-            const int sy = clampi(rs_i32(__builtin_roundf(cy + dy * t)), 0, h - 1);
-            const uint32_t p = src[(size_t)sy * w + sx];
-            s0 += ubyte0(p); s1 += ubyte1(p); s2 += ubyte2(p); s3 += ubyte3(p);
+        // samples in groups of four: the four gathers are issued (from the last sample's position past the end: always valid) before any is summed — with
+        // one load per trip of the run-time-count loop every sample was a memory round trip of its own
+        for (int i = 0; i < n; i += 4) {
+            uint32_t p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ik = min(i + k, n - 1);
+                const float t = 1.0f - st * ((float)ik / (float)(n - 1));
+                const int sx = clampi(rs_i32(__builtin_roundf(cx + dx * t)), 0, w - 1);
+                const int sy = clampi(rs_i32(__builtin_roundf(cy + dy * t)), 0, h - 1);
+                p[k] = src[(size_t)sy * w + sx];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n) { s0 += ubyte0(p[k]); s1 += ubyte1(p[k]); s2 += ubyte2(p[k]); s3 += ubyte3(p[k]); }   // uniform
         }
         float v[4] = {s0 * P.f[3], s1 * P.f[3], s2 * P.f[3], s3 * P.f[3]};
         if (P.f[9] > 0.001f) {
