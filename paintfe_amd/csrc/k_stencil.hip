@@ -105,31 +105,49 @@ __global__ __launch_bounds__(256) void box_v_kernel(const uint32_t* __restrict__
 // intermediate of the reference, rounded exactly as in box_h_kernel — and the vertical pass out of that.  Same integer arithmetic,
 // bit-identical to the two kernels above; the 4 B/px intermediate never reaches HBM and the halo (1.2x at r = 3) is recomputed.
 constexpr int BF_T = 64, BF_RUN = 8, BF_MAXR = 4; // r >= 5: the two passes (0.145 ms at 8K) beat the fused tile (0.16 .. 0.17 ms, 1.3x halo)
+// R is a template parameter (1 .. BF_MAXR): the tile geometry is a compile-time constant — the staging loop's index split is a multiply-shift, not a
+// run-time division, and the window loops are straight-line LDS reads at static offsets.  All of a lane's ~20 tile elements are loaded before the first is
+// stored: with one load per trip of the run-time-count loop every element was a memory round trip of its own (8K, r = 3: 0.123 ms).
+template <int R>
 __global__ __launch_bounds__(256) void box_fused_kernel(const uint32_t* __restrict__ src, const uint8_t* __restrict__ mask, uint32_t* __restrict__ dst,
-                                                        int r, uint32_t half, uint32_t magic, int w, int h)
+                                                        uint32_t half, uint32_t magic, int w, int h)
 {
     extern __shared__ uint32_t bf_lds[];
-    const int side = BF_T + 2 * r;                 // source tile is side x side, horizontal results are side rows x BF_T
-    const int sp = side | 1;                       // odd row pitches: the runs of 8 lanes working on consecutive rows start in different banks
+    constexpr int side = BF_T + 2 * R;             // source tile is side x side, horizontal results are side rows x BF_T
+    constexpr int sp = side | 1;                   // odd row pitches: the runs of 8 lanes working on consecutive rows start in different banks
     constexpr int HP = BF_T + 1;                   // (even pitches put them in 16 of 32 banks on the reads and ONE bank per column on the writes)
     uint32_t* s_src = bf_lds;                      // [side][sp]
     uint32_t* s_h = bf_lds + side * sp;            // [side][HP]
     const int bx = blockIdx.x * BF_T, by = blockIdx.y * BF_T;
-    for (int i = threadIdx.x; i < side * side; i += 256) {
-        const int ty = i / side, tx = i - ty * side;
-        s_src[ty * sp + tx] = src[(size_t)min(max(by - r + ty, 0), h - 1) * w + min(max(bx - r + tx, 0), w - 1)];
+    {
+        constexpr int NLD = (side * side + 255) / 256;   // 18 .. 21 elements per lane: ALL of a lane's loads are in flight before its first LDS store
+        uint32_t v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {            // elements past the tile's end read a clamped (valid) address and are not stored
+            const int i = (int)threadIdx.x + 256 * k, ty = i / side, tx = i - ty * side;
+            v[k] = src[(size_t)min(max(by - R + ty, 0), h - 1) * w + min(max(bx - R + tx, 0), w - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = (int)threadIdx.x + 256 * k, ty = i / side, tx = i - ty * side;
+            if (i < side * side) s_src[ty * sp + tx] = v[k];
+        }
     }
     __syncthreads();
     // horizontal: runs of BF_RUN outputs, sliding window (blur.rs:262-276)
     for (int run = threadIdx.x; run < side * (BF_T / BF_RUN); run += 256) {
         const int ty = run / (BF_T / BF_RUN), x0 = (run - ty * (BF_T / BF_RUN)) * BF_RUN;
         const uint32_t* row = s_src + ty * sp + x0; // window of output x0 + o = row[o .. o + 2r]
+        uint32_t px[BF_RUN + 2 * R];
+#pragma unroll
+        for (int k = 0; k < BF_RUN + 2 * R; ++k) px[k] = row[k];
         u4 s = {{0, 0, 0, 0}};
-        for (int k = 0; k <= 2 * r; ++k) add_px(s, row[k]);
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) add_px(s, px[k]);
 #pragma unroll
         for (int o = 0; o < BF_RUN; ++o) {
             s_h[ty * HP + x0 + o] = avg_px(s, half, magic);
-            if (o + 1 < BF_RUN) { sub_px(s, row[o]); add_px(s, row[o + 2 * r + 1]); }
+            if (o + 1 < BF_RUN) { sub_px(s, px[o]); add_px(s, px[o + 2 * R + 1]); }
         }
     }
     __syncthreads();
@@ -138,14 +156,16 @@ __global__ __launch_bounds__(256) void box_fused_kernel(const uint32_t* __restri
     const int x = bx + lx;
     if (x >= w) return;
     u4 s = {{0, 0, 0, 0}};
-    for (int k = 0; k <= 2 * r; ++k) add_px(s, s_h[(y0 + k) * HP + lx]);
+#pragma unroll
+    for (int k = 0; k <= 2 * R; ++k) add_px(s, s_h[(y0 + k) * HP + lx]);
+#pragma unroll 4
     for (int o = 0; o < BF_T / 4; ++o) {
         const int y = by + y0 + o;
         if (y >= h) break;
         const size_t i = (size_t)y * w + x;
         dst[i] = (mask && mask[i] == 0) ? src[i] : avg_px(s, half, magic); // blur.rs:296-303
         sub_px(s, s_h[(y0 + o) * HP + lx]);
-        add_px(s, s_h[(y0 + o + 2 * r + 1 < side ? y0 + o + 2 * r + 1 : side - 1) * HP + lx]);
+        add_px(s, s_h[(y0 + o + 2 * R + 1 < side ? y0 + o + 2 * R + 1 : side - 1) * HP + lx]);
     }
 }
 
@@ -510,11 +530,21 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
     if (radius <= BF_MAXR && g_box_two_pass == 0 && !force_two_pass && d_src != d_dst) { // small radii: both passes in one kernel (the halo recomputation stays below 1.6x)
         const int side = BF_T + 2 * radius;
         const size_t lds = (size_t)(side * (side | 1) + side * (BF_T + 1)) * 4;
-        hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e) return e;
-        box_fused_kernel<<<dim3((w + BF_T - 1) / BF_T, (h + BF_T - 1) / BF_T), 256, lds, s>>>((const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, half, magic,
-                                                                                           (int)w, (int)h);
-        return hipGetLastError();
+        auto go = [&](auto rc) -> hipError_t {
+            constexpr int R = decltype(rc)::value;
+            hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e) return e;
+            box_fused_kernel<R><<<dim3((w + BF_T - 1) / BF_T, (h + BF_T - 1) / BF_T), 256, lds, s>>>((const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, half, magic, (int)w, (int)h);
+            return hipGetLastError();
+        };
+        static_assert(BF_MAXR == 4, "box_fused_kernel is instantiated for radii 1 .. 4");
+        switch (radius) {
+        case 1: return go(std::integral_constant<int, 1>{});
+        case 2: return go(std::integral_constant<int, 2>{});
+        case 3: return go(std::integral_constant<int, 3>{});
+        case 4: return go(std::integral_constant<int, 4>{});
+        default: break;   // radius 0 never reaches the kernels (pfx_api.cpp copies); fall through to the two-pass path
+        }
     }
     // outputs per lane grow with the radius: a lane's first window costs 2r + 1 reads whatever it is followed by
     auto launch_h = [&](auto px_c) -> hipError_t {
