@@ -38,14 +38,24 @@ def test_doc_mode_two_ranks_contract():
 @pytest.mark.parametrize("nproc", [2, 3])
 def test_band_mode_is_the_default_and_matches_single_process(nproc):
     d = _run(nproc, ["--exact"], 29630 + nproc)  # no --shard: the driver's command line
-    assert d["scaling"] == "strong" and d["n_gpus"] == nproc and "all-gather" in d["config"]["sharding"]
+    assert d["scaling"] == "strong" and d["n_gpus"] == nproc and "stays sharded" in d["config"]["sharding"]
     assert d["ranks"]["world_size"] == nproc and len(d["ranks"]["per_rank_ms_per_step"]) == nproc and all(t > 0 for t in d["ranks"]["per_rank_ms_per_step"])
     assert d["check"]["band_blur_max_diff_vs_oracle"] == 0  # exact Gaussian: bit-identical to the unsharded pipeline
     assert abs(d["value"] - 640 * 400 / d["ms_per_step"] / 1e3) / d["value"] < 0.01  # ONE document per step for the whole job
     assert d["doc_mode"]["scaling"] == "weak" and d["doc_mode"]["value"] > 0
-    assert d["band_sharded_result"]["scaling"] == "strong" and d["band_sharded_result"]["value"] > 0  # the same pipeline without the all-gather
+    # the headline leaves the blurred result sharded (halo exchange only); the same pipeline + an all-gather into every rank is timed beside it
+    assert d["band_gathered_result"]["scaling"] == "strong" and d["band_gathered_result"]["value"] > 0 and "band_gathered_error" not in d
+    assert d["check"]["band_blur_checked_rows"] == "window of the gathered frame"
     d = _run(nproc, [], 29640 + nproc)
     assert d["check"]["band_blur_max_diff_vs_oracle"] <= 1  # matrix-core Gaussian: the stated +-1 LSB
+
+
+def test_band_mode_without_the_gathered_variant_checks_the_rank_own_band():
+    """--no-gather: the headline pipeline alone; rank 0's band (its edge rows depend on the received halo rows) against the oracle"""
+    d = _run(2, ["--exact", "--no-gather"], 29648)
+    assert d["scaling"] == "strong" and "band_gathered_result" not in d
+    assert d["check"]["band_blur_checked_rows"] == "own band" and d["check"]["band_blur_max_diff_vs_oracle"] == 0
+    assert abs(d["value"] - 640 * 400 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
 
 
 def test_failed_band_pipeline_still_reports_the_collective_free_mode():
@@ -81,7 +91,7 @@ def test_band_mode_with_split_flatten_matches_single_process():
 
 
 def test_band_mode_over_rccl_when_two_gpus_are_visible():
-    """the real thing: one rank per GPU over RCCL (backend "nccl"), halo rows by send/recv over xGMI, all-gather of the bands.
+    """the real thing: one rank per GPU over RCCL (backend "nccl"), halo rows by send/recv over xGMI (headline), then the all-gathered variant.
     Needs two visible devices; the driver's 8-GPU run uses exactly this command line."""
     import torch
     if torch.cuda.device_count() < 2:
