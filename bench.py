@@ -420,6 +420,8 @@ def main() -> int:
                     help="N>1: 'band' (default) = ONE document cut into row bands, RCCL halo exchange before the blur, result left "
                          "sharded (strong scaling; the all-gathered variant is timed beside it); 'doc' = one document per GPU, no collective (weak scaling)")
     ap.add_argument("--no-gather", action="store_true", help="band mode: skip the all-gathered variant (band_gathered_result)")
+    ap.add_argument("--band-split-edges", action="store_true",
+                    help="band mode (development / tests): unpipelined steps that flatten the band's edge chunk rows first and the interior under the halo exchange")
     ap.add_argument("--config", choices=["headline", "batch4k"], default="headline",
                     help="'batch4k' = BASELINE config 5 (S4): a batch of 3840x2160 images, per image Gaussian sigma=4 -> HSL -> 4-layer "
                          "flatten, streamed over PCIe with pinned double-buffering and sharded by image across the GPUs")
@@ -531,7 +533,8 @@ def main() -> int:
         stack = torch.empty((n, max(hh, 1), w, 4), dtype=torch.uint8, device=device)
         for k in range(n):
             stack[k, :hh] = synth_layer(torch, device, w, h, k, 0x5EED0002)[y0:y1]
-        pipe = S.BandPipeline(r, w, h, radius, args.sigma, device, gather=not args.no_gather)
+        pipe = S.BandPipeline(r, w, h, radius, args.sigma, device, gather=not args.no_gather, split_edges=args.band_split_edges,
+                              pipelined=not args.band_split_edges)
         ptrs = [stack[k].data_ptr() for k in range(n)]
 
         def step():
@@ -549,9 +552,10 @@ def main() -> int:
         band_gathered = None
         try:
             pipe.gather = False
-            elapsed, kern = timed(step)
+            elapsed, kern = timed(step)   # pipelined: step k's halo rows travel under step k + 1's flatten; K flattens + K blurs inside the timed region
+            pipe.finish()                 # the last step's blur
             flat_view = pipe.flat_band()
-            state["own_band"] = state["result"].clone()
+            state["own_band"] = pipe.last_result.clone()
             state["headline_step_ms"], state["headline_per_rank"] = state.get("step_ms"), state.get("per_rank_ms_per_step")
         except Exception as e:  # noqa: BLE001 — reported on the line, the process still exits non-zero
             state["band_error"] = f"{type(e).__name__}: {e}"[:500]
@@ -664,7 +668,8 @@ def main() -> int:
                       "width": w, "height": h, "layers": n, "sigma": args.sigma,
                       "gaussian_mode": "exact (f32, no FMA)" if args.exact else "matrix cores: one f16 per tap, horizontal result as two f16, f32 accumulate (+-1 LSB class)",
                       "sharding": ("ONE document in chunk-row bands: RCCL send/recv of %d halo rows before the blur; the blurred result stays sharded in "
-                                   "bands%s" % (radius, "" if args.no_gather else " (the all-gathered variant of the same run: band_gathered_result)")) if band_mode else
+                                   "bands%s%s" % (radius, "" if args.band_split_edges else "; back-to-back steps pipelined (a step's halo rows travel under the next step's flatten)",
+                                                "" if args.no_gather else " (the all-gathered variant of the same run: band_gathered_result)")) if band_mode else
                                   ("one independent document per GPU, no collective" if world > 1 else "single GPU")},
            "step_ms_hip_events": state.get("headline_step_ms", state.get("step_ms")),   # the headline's, not a secondary mode's
            "roofline": roofline}

@@ -136,7 +136,7 @@ class BandPipeline:
     """flatten -> halo exchange -> Gaussian (or box blur / median) -> all-gather of ONE document on this rank's band, buffers allocated once.
 
     Everything is enqueued on torch's current stream (the constructor points the renderer at it): the flatten writes straight into the centre of [top halo | band | bottom halo]
-    (edge rows first, so that the halo exchange overlaps the flatten of the band's interior), the halo rows arrive in place through one
+    (one launch; `split_edges` flattens the edge rows first so that the halo exchange overlaps the interior, `pipelined` overlaps it with the NEXT step's flatten instead), the halo rows arrive in place through one
     batched RCCL send/recv group (no concatenation, no host synchronisation), the blur
     runs on band + halo with its tiles on the whole image's grid (pfx_gaussian_blur_band_dev: results equal the single-GPU ones bit
     for bit), and the result bands are all-gathered into every rank.  Over RCCL the all-gather is asynchronous and double-buffered:
@@ -146,7 +146,8 @@ class BandPipeline:
 
     SETS = 2
 
-    def __init__(self, renderer, w: int, h: int, radius: int, sigma: float, device, gather: bool = True, group=None, filter: str = "gaussian"):
+    def __init__(self, renderer, w: int, h: int, radius: int, sigma: float, device, gather: bool = True, group=None, filter: str = "gaussian",
+                 split_edges: bool = False, pipelined: bool = False):
         """filter: "gaussian" (sigma; radius = ceil(3 sigma)), "box" (sigma carries the box radius; radius = ceil of it) or "median"
         (sigma carries the radius) — the three stencils whose vertical pass needs halo rows"""
         import torch
@@ -154,6 +155,14 @@ class BandPipeline:
 
         assert filter in ("gaussian", "box", "median")
         self.filter = filter
+        # split_edges: flatten the band's edge chunk rows first so that the halo exchange overlaps the interior's flatten.  OFF by default since round 4:
+        # a 64-row flatten launch is a chain of 32 dependent layer steps on a nearly empty chip (~0.06 ms each at 8K) — the three launches cost 0.12-0.17 ms
+        # more than one (tools/lab/band_step_cost.py: 8 GPUs' band 0.360 against 0.192 ms), the exchange they hide ~0.05.
+        # pipelined (result left sharded only): step k's halo exchange travels while step k + 1 is flattened into a second padded buffer; step() then
+        # returns the PREVIOUS step's blurred band (None on the first call) and finish() flushes the last one — back-to-back documents at
+        # flatten + blur per step with no exposed exchange.
+        self.split_edges, self.pipelined = split_edges, pipelined
+        self.inflight, self.last_result = None, None
         self.r, self.w, self.h, self.radius, self.sigma, self.group, self.gather = renderer, w, h, radius, sigma, group, gather
         # every kernel of a step and RCCL's ordering (req.wait(), the asynchronous all-gather) are relative to torch's CURRENT stream:
         # the renderer must launch there too, or the halo exchange races the flatten and the blur races the halo's arrival
@@ -168,7 +177,8 @@ class BandPipeline:
         self.bands = all_bands(h, self.world)
         self.max_rows = max(max(b1 - b0 for b0, b1 in self.bands), 1)
         self.padded = torch.empty((prow, w, 4), dtype=torch.uint8, device=device)
-        n_sets = self.SETS if gather else 1
+        self.padded_sets = [self.padded, torch.empty_like(self.padded)] if pipelined else [self.padded]
+        n_sets = self.SETS if (gather or pipelined) else 1
         # the blur output doubles as the all-gather's send buffer: rows [top, top + max_rows) — bands are ragged by at most one chunk
         # row, so the buffer carries that much slack and the gather needs no staging copy
         self.blurred = [torch.zeros((self.top + self.max_rows + radius + 1, w, 4), dtype=torch.uint8, device=device) for _ in range(n_sets)]
@@ -205,9 +215,63 @@ class BandPipeline:
         for (a, b, buf) in bufs:
             self.padded[a:b].copy_(buf)
 
+    def _start_exchange(self, pad):
+        """halo rows of `pad`: one batched send/recv group, ordered behind what the current stream holds so far; returns the requests to wait for"""
+        import torch.distributed as dist
+
+        if dist.get_backend(self.group) == "gloo" and pad.device.type == "cuda":
+            keep, self.padded = self.padded, pad
+            self._exchange_via_host()  # plumbing self-test on a 1-GPU box (gloo moves host memory); RCCL moves device memory
+            self.padded = keep
+            return []
+        ops = [dist.P2POp(dist.irecv, pad[a:b], src, self.group) for (src, a, b) in self.recvs]
+        ops += [dist.P2POp(dist.isend, pad[a:b], dst, self.group) for (dst, a, b) in self.sends]
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _filter(self, pad, blurred):
+        prow = self.top + self.rows + self.bottom
+        first = self.y0 - self.top
+        if self.filter == "gaussian":
+            self.r.gaussian_blur_dev(pad.data_ptr(), blurred.data_ptr(), self.w, prow, self.sigma, first_row=first)
+        elif self.filter == "box":
+            self.r.box_blur_band_dev(pad.data_ptr(), blurred.data_ptr(), self.w, prow, self.sigma, first_row=first)
+        else:
+            self.r.median_band_dev(pad.data_ptr(), blurred.data_ptr(), self.w, prow, int(self.sigma), first_row=first)
+
+    def _complete_inflight(self):
+        if self.inflight is None:
+            return None
+        s, reqs = self.inflight
+        self.inflight = None
+        for req in reqs:
+            req.wait()  # the compute stream waits for the halo rows; the host does not
+        if self.pending[s] is not None:
+            self.pending[s].wait()  # an all-gather of an earlier (gathered) step that still reads this output buffer
+            self.pending[s] = None
+        if self.rows:
+            self._filter(self.padded_sets[s], self.blurred[s])
+        self.last_result = self.blurred[s][self.top:self.top + self.rows]
+        return self.last_result
+
+    def _step_pipelined(self, layer_ptrs, info):
+        s = self.turn % 2
+        self.turn += 1
+        pad = self.padded_sets[s]
+        self.padded = pad  # flat_band() = the band flattened last
+        if self.rows:
+            self.r.flatten_dev(list(layer_ptrs), info, self.w, self.rows, pad[self.top:].data_ptr())
+        reqs = self._start_exchange(pad)     # travels while the previous step is blurred and the next one flattened
+        done = self._complete_inflight()     # the previous step: its halo rows have had a whole flatten to arrive
+        self.inflight = (s, reqs)
+        return done
+
     def step(self, layer_ptrs, info):
         import torch.distributed as dist
 
+        if self.pipelined and not self.gather:
+            return self._step_pipelined(layer_ptrs, info)
+        self._complete_inflight()  # a pipelined step left over from before the mode changed
+        self.padded = self.padded_sets[0]
         s = self.turn % len(self.blurred)
         self.turn += 1
         row_bytes = self.w * 4
@@ -217,22 +281,16 @@ class BandPipeline:
             if r1 > r0:
                 self.r.flatten_dev([p + r0 * row_bytes for p in layer_ptrs], info, self.w, r1 - r0, base + r0 * row_bytes)
 
-        # the rows the neighbours need (whole chunk rows covering `radius` at either edge of the band) are flattened first, the halo
+        # split_edges: the rows the neighbours need (whole chunk rows covering `radius` at either edge of the band) are flattened first, the halo
         # exchange starts on RCCL's stream, and the interior of the band is flattened while the halo rows travel
         edge = min(self.rows, 64 * ((self.radius + 63) // 64))
-        split = self.rows > 2 * edge and bool(self.sends or self.recvs)
+        split = self.split_edges and self.rows > 2 * edge and bool(self.sends or self.recvs)
         if split:
             flatten_rows(0, edge)
             flatten_rows(self.rows - edge, self.rows)
         else:
             flatten_rows(0, self.rows)
-        if dist.get_backend(self.group) == "gloo" and self.padded.device.type == "cuda":
-            self._exchange_via_host()  # plumbing self-test on a 1-GPU box (gloo moves host memory); RCCL moves device memory
-            reqs = []
-        else:
-            ops = [dist.P2POp(dist.irecv, self.padded[a:b], src, self.group) for (src, a, b) in self.recvs]
-            ops += [dist.P2POp(dist.isend, self.padded[a:b], dst, self.group) for (dst, a, b) in self.sends]
-            reqs = dist.batch_isend_irecv(ops) if ops else []  # ordered behind the edge rows' flatten (the current stream at this point)
+        reqs = self._start_exchange(self.padded)  # ordered behind the flatten so far (the current stream at this point)
         if split:
             flatten_rows(edge, self.rows - edge)
         for req in reqs:
@@ -242,16 +300,10 @@ class BandPipeline:
             self.pending[s] = None
         blurred = self.blurred[s]
         if self.rows:
-            prow = self.top + self.rows + self.bottom
-            first = self.y0 - self.top
-            if self.filter == "gaussian":
-                self.r.gaussian_blur_dev(self.padded.data_ptr(), blurred.data_ptr(), self.w, prow, self.sigma, first_row=first)
-            elif self.filter == "box":
-                self.r.box_blur_band_dev(self.padded.data_ptr(), blurred.data_ptr(), self.w, prow, self.sigma, first_row=first)
-            else:
-                self.r.median_band_dev(self.padded.data_ptr(), blurred.data_ptr(), self.w, prow, int(self.sigma), first_row=first)
+            self._filter(self.padded, blurred)
         if not self.gather:
-            return blurred[self.top:self.top + self.rows]
+            self.last_result = blurred[self.top:self.top + self.rows]
+            return self.last_result
         send = blurred[self.top:self.top + self.max_rows]
         self.last = s
         if dist.get_backend(self.group) == "gloo" and send.device.type == "cuda":
@@ -266,7 +318,8 @@ class BandPipeline:
         return self.slots[s]
 
     def finish(self):
-        """order the current stream behind every all-gather still in flight (the host does not block)"""
+        """order the current stream behind every all-gather still in flight and flush a pipelined step (the host does not block)"""
+        self._complete_inflight()
         for s, work in enumerate(self.pending):
             if work is not None:
                 work.wait()

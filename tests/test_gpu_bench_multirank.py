@@ -85,7 +85,7 @@ def test_gpus_flag_without_that_many_ranks_fails_loudly():
 def test_band_mode_with_split_flatten_matches_single_process():
     """bands taller than two edge regions: the edge rows are flattened first, the halo exchange starts, the interior follows (the overlap
     itself needs RCCL; here the ordering and the row-range pointer arithmetic are checked bit for bit)"""
-    d = _run(2, ["--exact"], 29655, height=900)
+    d = _run(2, ["--exact", "--band-split-edges"], 29655, height=900)
     assert d["check"]["band_blur_max_diff_vs_oracle"] == 0  # flatten + halo rows + exact Gaussian of rank 0's window, bit for bit
     assert abs(d["value"] - 640 * 900 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
 
@@ -177,3 +177,54 @@ def test_band_pipeline_over_rccl_single_rank():
     env["PFX_ROOT"] = ROOT
     p = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK.replace("PORT", "29683")], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert "RCCL_ONE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+_PIPELINED_TWO_RANKS = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PFX_ROOT"])
+from paintfe_amd import GpuRenderer, sharding as S
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+r = GpuRenderer(0); r.set_stream(torch.cuda.current_stream().cuda_stream)
+w, h, n, sigma, radius = 320, 450, 4, 3.0, 9
+g = torch.Generator(device=dev); g.manual_seed(5)     # every rank draws the same documents
+docs = [torch.randint(0, 256, (n, h, w, 4), dtype=torch.uint8, device=dev, generator=g) for _ in range(4)]
+info = [(k, 1.0 if k % 2 == 0 else 0.6, True, [0, 1, 8, 13][k]) for k in range(n)]
+y0, y1 = S.band_rows(h, world, rank)
+pipe = S.BandPipeline(r, w, h, radius, sigma, dev, gather=False, pipelined=True)
+got = []
+for d in docs:   # different documents back to back: a stale padded buffer, halo row or output set would show
+    band = d[:, y0:y1].contiguous()
+    res = pipe.step([band[k].data_ptr() for k in range(n)], info)
+    got.append(None if res is None else res.cpu().numpy().copy())
+    torch.cuda.synchronize()
+pipe.finish()
+got.append(pipe.last_result.cpu().numpy().copy())
+ok = got[0] is None and len(got) == 5
+flat = torch.empty((h, w, 4), dtype=torch.uint8, device=dev); blur = torch.empty_like(flat)
+for k, d in enumerate(docs):
+    r.flatten_dev([d[q].data_ptr() for q in range(n)], info, w, h, flat.data_ptr())
+    r.gaussian_blur_dev(flat.data_ptr(), blur.data_ptr(), w, h, sigma)
+    torch.cuda.synchronize()
+    ok = ok and np.array_equal(got[k + 1], blur[y0:y1].cpu().numpy())   # step k + 1 returns document k's band
+verdict = torch.tensor([1 if ok else 0])
+dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+if rank == 0:
+    print("PIPELINED_OK" if int(verdict) == 1 else "PIPELINED_MISMATCH")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_pipelined_band_steps_return_the_previous_document(nproc, tmp_path):
+    """BandPipeline(pipelined=True): step k's halo exchange travels under step k + 1's flatten (two padded buffers); step() hands back the
+    PREVIOUS document's blurred band and finish() the last — every band equal to the same rows of the single-process result, bit for bit"""
+    script = tmp_path / "pipelined.py"
+    script.write_text(_PIPELINED_TWO_RANKS)
+    env = dict(os.environ, PFX_ROOT=ROOT)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29690 + nproc), str(script)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert "PIPELINED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
