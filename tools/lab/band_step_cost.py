@@ -48,6 +48,11 @@ for N in (1, 2, 4, 8):
         t1 = time.perf_counter(); e1.record()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        print(f"N={N} band {rows} rows split={split}: host enqueue {1e3*(t1-t0)/K:.4f} ms/step, device {e0.elapsed_time(e1)/K:.4f} ms/step, wall {1e3*(t2-t0)/K:.4f}", flush=True)
+        r.timing_reset(); r.timing_enable(True)
+        for _ in range(20): step(split)
+        torch.cuda.synchronize(); r.timing_enable(False)
+        km = {k: r.timing_read(k) for k in ("flatten", "gauss_mfma")}
+        ks = ", ".join(f"{k} {ms / 20:.4f} ms/step in {int(c / 20)} launch(es)" for k, (ms, c) in km.items() if c)
+        print(f"N={N} band {rows} rows split={split}: host enqueue {1e3*(t1-t0)/K:.4f} ms/step, device {e0.elapsed_time(e1)/K:.4f} ms/step, wall {1e3*(t2-t0)/K:.4f}; {ks}", flush=True)
     del stack, padded, blurred
     torch.cuda.empty_cache()
