@@ -1245,8 +1245,15 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
                 SC.UA = SC.UB = SC.UC = std::min(dle_units > 0 ? (uint32_t)dle_units : 8u, umax);
                 SC.wavesA = (units + SC.UA - 1) / SC.UA;
             } else {
-                // the long streams fill the chip about once (256 CUs x 24 waves): measured best (profiles/r03_tuning.md)
-                const uint32_t ua_auto = std::max(((uint32_t)((uint64_t)units * (uint32_t)fracA / 100u) + 6143u) / 6144u, 4u);
+                // the long streams fill the chip about once (256 CUs x 24 waves): measured best (profiles/r03_tuning.md).  No floor: a floor of 4 units left small
+                // launches (a 64-row dirty rectangle, a thin band of a sharded document) with a quarter of the waves the chip holds — 8K x 64 rows 0.091 -> 0.037 ms,
+                // 8K x 256 rows 0.115 -> 0.081 (tools/lab/band_units_sweep.py, profiles/r04_band_units_sweep.txt)
+                // No ceiling above 8 either since the class-sorting kernel (no queue across units: a stream's length only sets how the launch drains): at 8K
+                // 22 units per wave left the long streams at 0.82 of a chip-full, 8 runs 1.1 % faster (18 — a hair over one chip-full — 3 % slower),
+                // 8K x 2176 rows 11 -> 8: -1.4 % (tools/lab/units_ab.py, randomised order, profiles/r04_units_ab.txt)
+                // (round 3's queue kernel keeps its rule: its compacted rounds need long streams)
+                const uint32_t ua_fill = ((uint32_t)((uint64_t)units * (uint32_t)fracA / 100u) + 6143u) / 6144u;
+                const uint32_t ua_auto = srt_kernel ? std::min(std::max(ua_fill, 1u), 8u) : std::max(ua_fill, 4u);
                 SC.UA = std::min(dle_units > 0 ? (uint32_t)dle_units : ua_auto, umax);
                 SC.UB = std::max(SC.UA / 4u, 1u);
                 SC.UC = 1u;
