@@ -621,7 +621,9 @@ def main() -> int:
     pipeline_bytes = (4 * n + 4 + 8) * px_per_step
     pmc = pmc_profile(w, h, n)
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (pmc or {}).get("flatten", {}).get("hbm_bytes"),
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # PMC traffic of one whole-frame launch (committed counter pass); a rank's band launch of an N > 1 run has no counter pass of its own
+                "traffic": (pmc or {}).get("flatten", {}).get("hbm_bytes") if world == 1 else None,
                 "kernel_ms": {k: round(v[0], 4) for k, v in kern.items()},
                 **({"flatten_launches_per_step": per_step} if per_step > 1 else {}),
                 "pipeline_achieved_GBs": round(pipeline_bytes * args.steps * docs / elapsed / 1e9, 1),
