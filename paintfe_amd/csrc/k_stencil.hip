@@ -516,8 +516,12 @@ int g_median_search1 = 0; // pfxk_median_set_search1: the value search with one 
 extern "C" void pfxk_median_set_search1(int on) { g_median_search1 = on; }
 int g_median_single = 0; // pfxk_median_set_single: the one-window-per-lane networks for radii 2 and 3
 extern "C" void pfxk_median_set_single(int on) { g_median_single = on; }
-int g_box_px_switch = 24, g_box_py_switch = 24; // radii from which a lane takes 16 columns / 128 rows instead of 8 / 32
+// radii from which a lane takes 16 columns instead of 8 / 64 rows instead of 16 (128 rows from twice that radius on).  Round-4 sweep of 3 x 4 shapes per radius
+// (tools/lab/box_sweep.py, profiles/r04_box_sweep.txt): 8K r = 5 / 9 / 16 / 24 0.132 / 0.145 / 0.157 / 0.171 -> 0.128 / 0.139 / 0.151 / 0.165 ms; r >= 48 unchanged
+int g_box_px_switch = 12, g_box_py_switch = 20;
 extern "C" void pfxk_box_set_switch(int px, int py) { if (px >= 0) g_box_px_switch = px; if (py >= 0) g_box_py_switch = py; }
+int g_box_px_force = 0, g_box_py_force = 0; // development sweep (pfx_tune "box_px" / "box_py"): 0 = by radius
+extern "C" void pfxk_box_set_force(int px, int py) { if (px >= 0) g_box_px_force = px; if (py >= 0) g_box_py_force = py; }
 int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
 extern "C" void pfxk_box_set_two_pass(int on) { g_box_two_pass = on; }
 extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst,
@@ -556,10 +560,12 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
         box_h_kernel<PX><<<dim3((w + BX_THREADS * PX - 1) / (BX_THREADS * PX), h), BX_THREADS, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_tmp, radius, half, magic, (int)w, (int)h);
         return hipGetLastError();
     };
-    hipError_t e = radius < g_box_px_switch ? launch_h(std::integral_constant<int, 8>{}) : launch_h(std::integral_constant<int, 16>{});
+    const int px = g_box_px_force ? g_box_px_force : (radius < g_box_px_switch ? 8 : 16);
+    hipError_t e = px == 4 ? launch_h(std::integral_constant<int, 4>{}) : (px == 8 ? launch_h(std::integral_constant<int, 8>{}) : launch_h(std::integral_constant<int, 16>{}));
     if (e) return e;
 #define PFX_BV(PY) box_v_kernel<PY><<<dim3((w + 63) / 64, (h + 4 * PY - 1) / (4 * PY)), 256, 0, s>>>((const uint32_t*)d_tmp, (const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, half, magic, (int)w, (int)h)
-    if (radius < g_box_py_switch) PFX_BV(32); else PFX_BV(128);
+    const int py = g_box_py_force ? g_box_py_force : (radius < g_box_py_switch ? 16 : (radius < 2 * g_box_py_switch ? 64 : 128));
+    if (py == 16) PFX_BV(16); else if (py == 32) PFX_BV(32); else if (py == 64) PFX_BV(64); else PFX_BV(128);
 #undef PFX_BV
     return hipGetLastError();
 }

@@ -912,20 +912,21 @@ def test_box_blur_fused_equals_two_pass_and_oracle(gpu, radius, size):
 @pytest.mark.parametrize("radius", [5.0, 23.0, 24.0, 60.0, 130.0])
 @pytest.mark.parametrize("size", [(2049, 40), (4100, 9), (300, 300), (33, 1), (1, 70)])
 def test_box_blur_two_pass_lane_runs(gpu, radius, size):
-    """the two-pass kernels: 8 / 16 columns per lane in the horizontal pass (2048- and 4096-pixel row tiles: widths either side of one and
-    two tiles), 32 / 128 rows per lane in the vertical pass with the window's rows requested eight outputs ahead (heights below one run,
-    bands that end inside an 8-row group), both run lengths forced on every radius through pfx_tune"""
+    """the two-pass kernels: 4 / 8 / 16 columns per lane in the horizontal pass (1024-, 2048- and 4096-pixel row tiles: widths either side of one and
+    two tiles), 16 / 32 / 64 / 128 rows per lane in the vertical pass with the window's rows requested eight outputs ahead (heights below one run,
+    bands that end inside an 8-row group): the shapes the radius rule picks, and every shape forced on every radius through pfx_tune"""
     w, h = size
     img = I.random_rgba(w, h, 777 + w + int(radius))
     ref = O.box_blur(img, radius)
-    for px_sw, py_sw in ((24, 24), (0, 0), (4000, 4000)):
-        gpu.r.tune("box_px_switch", px_sw)
-        gpu.r.tune("box_py_switch", py_sw)
+    assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} (shapes by radius)")
+    for px, py in ((4, 16), (8, 32), (16, 64), (16, 128), (8, 16), (4, 128)):
+        gpu.r.tune("box_px", px)
+        gpu.r.tune("box_py", py)
         try:
-            assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} switches {px_sw}/{py_sw}")
+            assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} lane runs {px}/{py}")
         finally:
-            gpu.r.tune("box_px_switch", 24)
-            gpu.r.tune("box_py_switch", 24)
+            gpu.r.tune("box_px", 0)
+            gpu.r.tune("box_py", 0)
 
 
 @pytest.mark.parametrize("params", [(30.0, -20.0, float("inf")), (30.0, -20.0, float("-inf")), (float("nan"), 10.0, 5.0), (10.0, float("inf"), 0.0),
