@@ -66,6 +66,82 @@ __global__ __launch_bounds__(BX_THREADS) void box_h_kernel(const uint32_t* __res
     for (int i = threadIdx.x; i < n_out; i += BX_THREADS) out[i] = out_tile[bx_pad(i)];
 }
 
+// Horizontal pass for large radii: window sums as differences of a per-channel prefix sum over the row tile, so an output costs two LDS reads per channel
+// whatever the radius (box_h_kernel's sliding window pays (2r + 1 + 2 PX) / PX reads per output: 14 at r = 48).  A lane sums a contiguous chunk of the staged
+// tile, the 256 chunk sums are scanned (wave shuffles + one LDS hop across the four waves), the lane writes its chunk's exclusive prefixes (one plane per
+// channel, padded like the tile), and output o = P[o + 2r + 1] - P[o] — integer sums, order-independent: bit-identical to the sliding window (blur.rs:262-276).
+constexpr int BXP_TILE = 1024;
+PFX_DEV int bxp_words(int r) { return bx_pad(BXP_TILE + 2 * r + 1) + 1; }
+__global__ __launch_bounds__(BX_THREADS) void box_h_prefix_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                                 int r, uint32_t half, uint32_t magic, int w, int h)
+{
+    extern __shared__ uint32_t sm[];
+    const int words = bxp_words(r);
+    uint32_t* const raw = sm;                  // staged pixels
+    uint32_t* const P = sm + words;            // P[c * words + bx_pad(i)] = sum over inputs [0, i) of channel c
+    uint32_t* const wt = sm + 5 * words;       // [4 waves][4 channels]
+    const int tid = threadIdx.x, y = blockIdx.y, x_tile = blockIdx.x * BXP_TILE;
+    const int n_out = min(BXP_TILE, w - x_tile), n_in = n_out + 2 * r;
+    const uint32_t* row = src + (size_t)y * w;
+    {   // all of a lane's loads are requested before the first LDS store (a load per loop trip is a chain of memory round trips: profiles/r04_tuning.md)
+        constexpr int MAXT = 12;
+        uint32_t v[MAXT];
+#pragma unroll
+        for (int k = 0; k < MAXT; ++k)
+            if (k * BX_THREADS < n_in) v[k] = row[min(max(x_tile - r + min(tid + k * BX_THREADS, n_in - 1), 0), w - 1)];
+#pragma unroll
+        for (int k = 0; k < MAXT; ++k)
+            if (k * BX_THREADS < n_in && tid + k * BX_THREADS < n_in) raw[bx_pad(tid + k * BX_THREADS)] = v[k];
+        for (int i = tid + MAXT * BX_THREADS; i < n_in; i += BX_THREADS) raw[bx_pad(i)] = row[min(max(x_tile - r + i, 0), w - 1)];
+    }
+    __syncthreads();
+    const int per = (n_in + BX_THREADS - 1) / BX_THREADS;
+    const int i0 = min(tid * per, n_in), i1 = min(i0 + per, n_in);
+    u4 s = {{0, 0, 0, 0}};
+    for (int i = i0; i < i1; ++i) add_px(s, raw[bx_pad(i)]);
+    u4 inc = s;                                // inclusive scan over the wave's 64 chunk sums
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc.c[c], d, 64);
+            if ((tid & 63) >= d) inc.c[c] += t;
+        }
+    }
+    if ((tid & 63) == 63) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wt[(tid >> 6) * 4 + c] = inc.c[c];
+    }
+    __syncthreads();
+    u4 run;                                    // exclusive prefix of this lane's chunk
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t base = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv) base += wt[wv * 4 + c];
+        run.c[c] = base + inc.c[c] - s.c[c];
+    }
+    for (int i = i0; i < i1; ++i) {
+        const int pi = bx_pad(i);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) P[c * words + pi] = run.c[c];
+        add_px(run, raw[pi]);
+    }
+    if (i1 == n_in && i0 < n_in) {             // the one lane whose chunk ends the tile also writes the total
+        const int pi = bx_pad(n_in);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) P[c * words + pi] = run.c[c];
+    }
+    __syncthreads();
+    uint32_t* const out = dst + (size_t)y * w + x_tile;
+    for (int o = tid; o < n_out; o += BX_THREADS) {
+        const int a = bx_pad(o), b = bx_pad(o + 2 * r + 1);
+        u4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v.c[c] = P[c * words + b] - P[c * words + a];
+        out[o] = avg_px(v, half, magic);
+    }
+}
+
 // Vertical pass: a lane owns PY consecutive rows of one column.  The rows entering and leaving the window are requested eight outputs ahead
 // (16 loads in flight per lane): with the loads inside the per-output loop every iteration waited out a memory round trip
 constexpr int BV_U = 8;
@@ -520,6 +596,11 @@ extern "C" void pfxk_median_set_single(int on) { g_median_single = on; }
 // (tools/lab/box_sweep.py, profiles/r04_box_sweep.txt): 8K r = 5 / 9 / 16 / 24 0.132 / 0.145 / 0.157 / 0.171 -> 0.128 / 0.139 / 0.151 / 0.165 ms; r >= 48 unchanged
 int g_box_px_switch = 12, g_box_py_switch = 20;
 extern "C" void pfxk_box_set_switch(int px, int py) { if (px >= 0) g_box_px_switch = px; if (py >= 0) g_box_py_switch = py; }
+// radii from which the horizontal pass uses prefix sums (pfx_tune "box_prefix_from"; 0 = never).  8K, tools/lab/box_prefix_ab.py: the prefix pass costs ~0.115 ms whatever the
+// radius (three barriers, a 6-step scan), the sliding window 0.06 ms at r = 9 and 0.15 at r = 100: r = 48 0.201 / 0.221 ms, r = 100 0.276 / 0.237, r = 300 0.570 / 0.339
+int g_box_prefix_from = 72;
+extern "C" void pfxk_box_set_prefix_from(int r) { g_box_prefix_from = r; }
+inline int bxp_words_host(int r) { const int i = BXP_TILE + 2 * r + 1; return i + (i >> 5) + 1; }
 int g_box_px_force = 0, g_box_py_force = 0; // development sweep (pfx_tune "box_px" / "box_py"): 0 = by radius
 extern "C" void pfxk_box_set_force(int px, int py) { if (px >= 0) g_box_px_force = px; if (py >= 0) g_box_py_force = py; }
 int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
@@ -561,8 +642,22 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
         return hipGetLastError();
     };
     const int px = g_box_px_force ? g_box_px_force : (radius < g_box_px_switch ? 8 : 16);
+    if (g_box_prefix_from > 0 && radius >= g_box_prefix_from && g_box_px_force == 0) {
+        const size_t lds = ((size_t)5 * bxp_words_host(radius) + 16) * 4;
+        if (lds <= 160u * 1024u) {
+            hipError_t e0 = hipFuncSetAttribute((const void*)box_h_prefix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e0) return e0;
+            box_h_prefix_kernel<<<dim3((w + BXP_TILE - 1) / BXP_TILE, h), BX_THREADS, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_tmp, radius, half, magic, (int)w, (int)h);
+            e0 = hipGetLastError();
+            if (e0) return e0;
+            goto vertical;
+        }
+    }
+    {
     hipError_t e = px == 4 ? launch_h(std::integral_constant<int, 4>{}) : (px == 8 ? launch_h(std::integral_constant<int, 8>{}) : launch_h(std::integral_constant<int, 16>{}));
     if (e) return e;
+    }
+vertical:
 #define PFX_BV(PY) box_v_kernel<PY><<<dim3((w + 63) / 64, (h + 4 * PY - 1) / (4 * PY)), 256, 0, s>>>((const uint32_t*)d_tmp, (const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, half, magic, (int)w, (int)h)
     const int py = g_box_py_force ? g_box_py_force : (radius < g_box_py_switch ? 16 : (radius < 2 * g_box_py_switch ? 64 : 128));
     if (py == 16) PFX_BV(16); else if (py == 32) PFX_BV(32); else if (py == 64) PFX_BV(64); else PFX_BV(128);

@@ -1286,6 +1286,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "outline_bits") == 0) { ctx->outline_bits = value != 0; return PFX_OK; }
     if (std::strcmp(key, "median_bits_min") == 0) { ctx->median_bits_min = value; return PFX_OK; } // smallest radius on the bit-plane kernel (8: never)
     if (std::strcmp(key, "median_single") == 0) { pfxk_median_set_single(value); return PFX_OK; }
+    if (std::strcmp(key, "box_prefix_from") == 0) { pfxk_box_set_prefix_from(value); return PFX_OK; }
     if (std::strcmp(key, "box_px") == 0) { pfxk_box_set_force(value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_py") == 0) { pfxk_box_set_force(-1, value); return PFX_OK; }
     if (std::strcmp(key, "box_px_switch") == 0) { pfxk_box_set_switch(value, -1); return PFX_OK; }

@@ -113,6 +113,7 @@ hipError_t pfxk_minmax_rgb(hipStream_t s, const uint8_t* d_src, const uint8_t* d
 
 // ---- k_stencil.hip ---- box blur / median / pixelate
 void pfxk_box_set_two_pass(int on);
+void pfxk_box_set_prefix_from(int radius); // two-pass box blur: radii from which the horizontal pass uses prefix sums (0 = never)
 void pfxk_box_set_force(int px, int py); // development sweep: outputs per lane of the two passes (0 = by radius, -1: keep)
 void pfxk_box_set_switch(int px_radius, int py_radius); // two-pass box blur: radii from which a lane takes 32 columns / 128 rows (-1: keep)
 void pfxk_median_set_search1(int on); // value search (radii 5..24, and 4 with median_single) with one pixel per lane instead of four

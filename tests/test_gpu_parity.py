@@ -909,8 +909,8 @@ def test_box_blur_fused_equals_two_pass_and_oracle(gpu, radius, size):
         assert_same(fused, O.box_blur(img, radius, m), 0, f"box blur r={radius} {size}")
 
 
-@pytest.mark.parametrize("radius", [5.0, 23.0, 24.0, 60.0, 130.0])
-@pytest.mark.parametrize("size", [(2049, 40), (4100, 9), (300, 300), (33, 1), (1, 70)])
+@pytest.mark.parametrize("radius", [5.0, 23.0, 24.0, 60.0, 130.0, 700.0])
+@pytest.mark.parametrize("size", [(2049, 40), (4100, 9), (1024, 3), (1025, 2), (300, 300), (33, 1), (1, 70)])
 def test_box_blur_two_pass_lane_runs(gpu, radius, size):
     """the two-pass kernels: 4 / 8 / 16 columns per lane in the horizontal pass (1024-, 2048- and 4096-pixel row tiles: widths either side of one and
     two tiles), 16 / 32 / 64 / 128 rows per lane in the vertical pass with the window's rows requested eight outputs ahead (heights below one run,
@@ -919,6 +919,11 @@ def test_box_blur_two_pass_lane_runs(gpu, radius, size):
     img = I.random_rgba(w, h, 777 + w + int(radius))
     ref = O.box_blur(img, radius)
     assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} (shapes by radius)")
+    gpu.r.tune("box_prefix_from", 1)   # the prefix-sum horizontal pass (default: radii from 72) on every radius and tile shape
+    try:
+        assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} prefix-sum horizontal pass")
+    finally:
+        gpu.r.tune("box_prefix_from", 72)
     for px, py in ((4, 16), (8, 32), (16, 64), (16, 128), (8, 16), (4, 128)):
         gpu.r.tune("box_px", px)
         gpu.r.tune("box_py", py)
