@@ -1202,7 +1202,7 @@ extern "C" hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const u
 extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                                    const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active,
                                    int chunk_active_ready, uint32_t w, uint32_t h, uint8_t* d_dst, const pfxk_preview* preview, const pfxk_region* region,
-                                   const pfxk_dle_cands* cands, const uint8_t* d_chunk_start, int typed_store_ok)
+                                   const pfxk_dle_cands* cands, const uint8_t* d_chunk_start, int typed_store_ok, int mode_class)
 {
     size_t n_quads = ((size_t)w * h + 3) / 4;
     if (n_quads == 0) return hipSuccess;
@@ -1225,7 +1225,16 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
         // walk the image with a grid stride instead of taking one tile each (a 4-layer tile is over before its launch cost is: -5 .. -10 % more)
         int variant = flatten_variant % 10;
         bool stride = flatten_variant >= 10;
-        if (flatten_variant == 0 || flatten_variant == 8) { variant = 1; stride = n_layers <= 16; }
+        if (flatten_variant == 0 || flatten_variant == 8) {
+            variant = 1; stride = n_layers <= 16;
+            // Round 4, tools/lab/shallow_modes_ab.py (8K, 9 and 12 layers, every mode, S2 data; profiles/r04_shallow_modes_ab.txt) and tools/ab_shallow.py (2 .. 9 layers):
+            // 4 pixels per lane pay where the blend arithmetic is light — Normal, Multiply, Additive, Difference, Lighten / Darken, Overwrite, Subtract, Linear Burn:
+            // one tile per wave -5 .. -7 % from 7 layers up (Normal at 9 layers 0.312 -> 0.290 ms), grid-stride -2 .. -3 % at 5 - 6 layers and for the medium modes
+            // (Screen, Overlay, Negation, Hard Light, Exclusion, Linear Light, Hard Mix); the heavy modes (Reflect .. Color Dodge, Xor, Soft Light, Divide, Vivid
+            // Light, Pin Light) keep 2 pixels per lane (Vivid Light +9 % with 4), and so do stacks of up to 4 layers
+            if (n_layers >= 5 && mode_class == 2) { variant = 3; stride = n_layers < 7; }
+            else if (n_layers >= 5 && mode_class == 1) { variant = 3; stride = true; }
+        }
         auto grid = [&](uint32_t px_per_wave) {
             size_t tiles = (n_px + px_per_wave - 1) / px_per_wave, b = (tiles + 3) / 4;
             const size_t lim = stride ? cap : (size_t)1 << 20;

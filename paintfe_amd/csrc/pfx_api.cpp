@@ -224,6 +224,12 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
             std::memcpy(chunk_meta->data() + desc.size() * sizeof(void*), want.data(), desc.size());
         }
     }
+    {   // arithmetic weight of the stack's blend modes (k_blend.h instruction counts, profiles/r03_blend_isa.md): the streaming compositor's register shape follows it
+        static const uint8_t cls_of_mode[25] = {2, 2, 1, 2, 0, 0, 0, 0, 1, 2, 1, 2, 2, 0, 2, 1, 0, 1, 2, 0, 2, 0, 1, 0, 1};
+        int cls = 2;
+        for (const pfxk_layer_desc& d : desc) cls = std::min(cls, d.kind == PFX_LAYER_RASTER && d.mode < 25u ? (int)cls_of_mode[d.mode] : 0);
+        ctx->stack_mode_class = desc.empty() ? 0 : cls;
+    }
     if (cands) {
         // reset layers (k_flatten.hip: dead-layer elimination): the topmost PFXK_DLE_MAX raster layers above the bottom one that are
         // Overwrite (canvas_state.rs:1275) or Normal at opacity >= 1 (:1258); only used by the raster-only streaming path
@@ -359,7 +365,7 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
     pfx_timer t(ctx, "flatten");
     PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
                               general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region, &cands, d_chunk_start,
-                              parking_ok));
+                              parking_ok, ctx->stack_mode_class));
     return PFX_OK;
 }
 

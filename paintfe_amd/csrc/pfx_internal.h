@@ -63,6 +63,7 @@ struct pfx_ctx {
     uint32_t wts_sigma_bits = 0, wsplit_sigma_bits = 0;
     bool use_chunk_start = true; // stored layers: per-chunk start table from their alpha summaries (pfx_tune "chunk_start")
     int unorm_store_ok = -1;  // -1 not checked yet, 1 = typed UNORM8 stores round-trip RN(k / 255) exactly on this device (pfxk_unorm_store_check), 0 = they do not
+    int stack_mode_class = 0; // set by build_stack: 0 heavy / unknown, 1 medium, 2 light blend arithmetic (pfxk_flatten picks the streaming kernel's shape from it)
     int dle_min_layers = 16;  // stacks at least this deep may take the compositor's dead-layer elimination kernel (pfx_api.cpp:build_stack)
     bool wts_valid = false, wsplit_valid = false; // explicit flags: every 32-bit pattern is some sigma (0xffffffff is a NaN)
     float wsplit_inv_scale = 1.0f, wsplit_bias = 0.0f, wsplit_bias_single = 0.0f;

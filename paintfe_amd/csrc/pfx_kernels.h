@@ -56,7 +56,8 @@ hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uin
                         const pfxk_region* region /* may be NULL */, const pfxk_dle_cands* cands /* may be NULL: no elimination */,
                         const uint8_t* d_chunk_start /* may be NULL: per-chunk first layer that can show (pfxk_chunk_start) */,
                         int typed_store_ok /* the device's float -> UNORM8 typed-store conversion is verified (pfxk_unorm_store_check): the class-sorting
-                                              kernel may write its result that way (k_flatten.hip: flatten_srt_kernel) */);
+                                              kernel may write its result that way (k_flatten.hip: flatten_srt_kernel) */,
+                        int mode_class /* arithmetic weight of the stack's blend modes: 0 heavy (or unknown), 1 medium, 2 light: picks the streaming kernel's shape */);
 // per-chunk alpha summary of a stored layer (bit 0: all 255, bit 1: none 0) over the chunk rectangle [cx0, cx0+ncx) x [cy0, cy0+ncy), and the
 // per-chunk start table of a stack (want[k]: 1 = Normal at opacity >= 1 needs bit 0, 2 = Overwrite needs bit 1, 0 = layer k never resets)
 hipError_t pfxk_chunk_alpha_flags(hipStream_t s, const uint8_t* d_px, uint32_t w, uint32_t h, uint32_t cx0, uint32_t cy0, uint32_t ncx, uint32_t ncy,
