@@ -226,6 +226,22 @@ def test_streaming_kernel_shapes_agree_with_the_oracle(gpu, n):
             gpu.r.tune("flatten_variant", 0)
 
 
+@pytest.mark.parametrize("n", [4, 5, 6, 7, 9, 17])
+@pytest.mark.parametrize("cls", ["light", "medium", "heavy", "mixed"])
+def test_streaming_kernel_shape_by_mode_class(gpu, n, cls):
+    """the automatic shape (flatten_variant 0) follows the heaviest blend mode of the stack (pfx_api.cpp: build_stack -> pfxk_flatten mode_class): light and medium
+    stacks of 5+ layers run 4 pixels per lane (one tile per wave from 7 layers, grid-stride below / for medium), heavy ones and stacks of up to 4 layers 2 — every
+    class at the depths where the rule switches, on a width that leaves a ragged last tile"""
+    w, h = 397, 71
+    stack, _, opac = I.layer_stack(w, h, n, seed=90 + n)
+    pool = {"light": [0, 1, 3, 9, 11, 12, 18, 20], "medium": [2, 8, 10, 15, 17, 22, 24, 1], "heavy": [4, 5, 6, 7, 13, 16, 19, 21, 23],
+            "mixed": [0, 2, 21, 1, 16, 8, 3, 23]}[cls]
+    modes = [pool[k % len(pool)] for k in range(n)]
+    opac = [o if o < 1.0 else 0.97 for o in opac]                        # no Normal-at-100 % reset candidates: the streaming kernel runs
+    gpu.r.tune("flatten_variant", 0)
+    check(gpu, stack, modes, list(opac), f"{n} layers, {cls} modes, automatic shape")
+
+
 def test_switched_off_and_general_path_agree(gpu):
     """the same stack through the plain streaming kernel (variant 8), the general kernel (variant 9) and with a live mask on the
     reset layer (the mask can lower alpha to 0: the host must not list that layer)"""
