@@ -312,7 +312,7 @@ class BandPipeline:
             for k in range(self.world):
                 self.slots[s][k].copy_(outs[k])
         elif dist.get_backend(self.group) == "gloo":
-            dist.all_gather_into_tensor(self.slots[s], send, group=self.group)
+            dist.all_gather(list(self.slots[s].unbind(0)), send, group=self.group)  # gloo's all_gather_into_tensor refuses the stacked (world, rows, w, 4) layout RCCL takes
         else:
             self.pending[s] = dist.all_gather_into_tensor(self.slots[s], send, group=self.group, async_op=True)
         return self.slots[s]

@@ -180,3 +180,71 @@ def test_halo_plan_covers_radius():
             rows.update(range(s0, s1))
         want = set(range(max(0, y0 - r), y0)) | set(range(y1, min(h, y1 + r)))
         assert rows == want
+
+
+class _CpuBandRenderer:
+    """CPU stand-in for the two entry points BandPipeline.step calls (tests only): the oracle on the host buffers behind the raw pointers"""
+
+    @staticmethod
+    def _view(ptr, rows, w):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint8 * (rows * w * 4)).from_address(ptr)).reshape(rows, w, 4)
+
+    def flatten_dev(self, ptrs, info, w, rows, dst_ptr):
+        stack = np.stack([self._view(p, rows, w) for p in ptrs])
+        modes = np.array([i[3] for i in info], np.uint8)
+        opac = np.array([i[1] for i in info], np.float32)
+        self._view(dst_ptr, rows, w)[...] = O.flatten_stack(stack, modes, opac, threads=1)
+
+    def gaussian_blur_dev(self, src_ptr, dst_ptr, w, prow, sigma, first_row=0):
+        # a band with its halo rows: rows at least `radius` from the buffer's ends equal the whole image's (clamp-to-edge only matters at true image edges)
+        self._view(dst_ptr, prow, w)[...] = O.gaussian_blur(self._view(src_ptr, prow, w).copy(), sigma, threads=1)
+
+
+def _pipeline_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        radius = len(O.gaussian_kernel(SIGMA)) // 2
+        y0, y1 = S.band_rows(H, world, rank)
+        docs = [I.layer_stack(W, H, NL, seed=21 + d) for d in range(3)]
+        bands = [torch.from_numpy(np.ascontiguousarray(st[:, y0:y1])) for (st, _, _) in docs]
+        infos = [[(k, float(op[k]), True, int(md[k])) for k in range(NL)] for (_, md, op) in docs]
+        # (a) pipelined, result left sharded: step k + 1 hands back document k's band, finish() the last one
+        pipe = S.BandPipeline(_CpuBandRenderer(), W, H, radius, SIGMA, "cpu", gather=False, pipelined=True)
+        got = []
+        for b, info in zip(bands, infos):
+            res = pipe.step([b[k].data_ptr() for k in range(NL)], info)
+            got.append(None if res is None else res.numpy().copy())
+        pipe.finish()
+        got.append(pipe.last_result.numpy().copy())
+        assert got[0] is None
+        np.save(os.path.join(out_dir, f"p{rank}.npy"), np.stack(got[1:]))
+        # (b) unpipelined with the all-gather, and the edge-first split
+        pipe2 = S.BandPipeline(_CpuBandRenderer(), W, H, radius, SIGMA, "cpu", gather=True, split_edges=(rank % 2 == 0))
+        fulls = []
+        for b, info in zip(bands, infos):
+            pipe2.step([b[k].data_ptr() for k in range(NL)], info)
+            fulls.append(pipe2.assemble().numpy().copy())
+        np.save(os.path.join(out_dir, f"g{rank}.npy"), np.stack(fulls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_pipeline_class_pipelined_and_gathered(tmp_path, world):
+    """paintfe_amd.sharding.BandPipeline itself over gloo on CPU (the oracle behind the renderer's two entry points): the pipelined form bench.py --gpus N times
+    (a step's halo rows travel under the next step's flatten; results arrive one step late) and the gathered form, three different documents back to back"""
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    refs = []
+    for d in range(3):
+        stack, modes, opac = I.layer_stack(W, H, NL, seed=21 + d)
+        refs.append(O.gaussian_blur(O.flatten_stack(stack, modes, opac, threads=2), SIGMA, threads=2))
+    for r in range(world):
+        y0, y1 = S.band_rows(H, world, r)
+        p, g = np.load(tmp_path / f"p{r}.npy"), np.load(tmp_path / f"g{r}.npy")
+        for d in range(3):
+            assert np.array_equal(p[d], refs[d][y0:y1]), f"rank {r} document {d}: pipelined band differs"
+            assert np.array_equal(g[d], refs[d]), f"rank {r} document {d}: gathered frame differs"
