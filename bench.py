@@ -306,18 +306,24 @@ def other_configs(args, torch, r, device, O, flat, blurred):
     pool, overlays, modes = s4_inputs(w4, h4)
     dev_index = device.index or 0
     run_batch([dev_index], 8, pool, overlays, modes, sigma=4.0, slots=args.slots)
+    # the timed stream runs the pipeline's default: the bit-exact Gaussian (pfx_batch_params.fast_gaussian = 0) — the blur feeds HSL, which amplifies a +-1 LSB
+    # input, and the stream is PCIe-bound either way; the opt-in fast mode (f16 taps) is timed beside it and gated by its error bound
     res = run_batch([dev_index], 256, pool, overlays, modes, sigma=4.0, slots=args.slots, keep=[0])
-    ok, chk = s4_check(O, pool[0], overlays, modes, res["kept"][0], exact=False)
-    res_x = run_batch([dev_index], 4, pool, overlays, modes, sigma=4.0, slots=args.slots, keep=[1], exact=True)
-    ok_x, chk_x = s4_check(O, pool[1], overlays, modes, res_x["kept"][1], exact=True)
+    ok, chk = s4_check(O, pool[0], overlays, modes, res["kept"][0], exact=True)
+    res_x = run_batch([dev_index], 256, pool, overlays, modes, sigma=4.0, slots=args.slots, keep=[1], fast=True)
+    ok_x, chk_x = s4_check(O, pool[1], overlays, modes, res_x["kept"][1], exact=False)
     gbs = res["images_per_s"] * w4 * h4 * 4 / 1e9
     out["config5_batch_4k_slice"] = {"images": 256, "images_per_s": round(res["images_per_s"], 1), "mpixels_per_s": round(res["images_per_s"] * w4 * h4 / 1e6, 1),
                                      "resident_kernel_ms_per_image": round(res["kernel_ms_per_image"], 4), "alg_bytes_per_image": 36 * w4 * h4,
                                      "bound": "pcie", "GBs_each_direction": round(gbs, 2), "frac": round(gbs / PCIE_GEN5_X16_GBS, 3),
                                      "frac_of": f"PCIe Gen5 x16, {PCIE_GEN5_X16_GBS:g} GB/s per direction",
-                                     "check": {"image0_vs_oracle": chk, "exact_gaussian_image1_vs_oracle": chk_x}}
+                                     "gaussian": "bit-exact f32 (the pipeline's default)",
+                                     "fast_gaussian_variant": {"images_per_s": round(res_x["images_per_s"], 1),
+                                                               "resident_kernel_ms_per_image": round(res_x["kernel_ms_per_image"], 4),
+                                                               "what": "pfx_batch_params.fast_gaussian = 1: f16 taps on the matrix cores, +-1 LSB before HSL"},
+                                     "check": {"image0_vs_oracle": chk, "fast_gaussian_image1_vs_oracle": chk_x}}
     if not ok: failed.append("config5_image0")
-    if not ok_x: failed.append("config5_exact_image1")
+    if not ok_x: failed.append("config5_fast_image1")
 
     # ---- config 1 (BASELINE configs[0], the reference's own CPU-runnable case): the batch tool on a 1024 x 1024 PNG with `apply_blur(4.0);` —
     # process start, context creation, PNG decode, script, PNG encode; wall clock of the whole process (src/cli.rs:105-215) ----
@@ -395,7 +401,7 @@ def run_batch4k(args, torch, dist, rank, world, dev_index, device) -> int:
     failed = []
     if rank == 0:
         from tests import oracle_lib as O
-        ok, chk = s4_check(O, pool[0], overlays, modes, res["kept"][0], exact=False)
+        ok, chk = s4_check(O, pool[0], overlays, modes, res["kept"][0], exact=True)   # the pipeline's default is the bit-exact Gaussian
         out["check"] = {"image0_vs_oracle": chk}
         if not ok:
             failed.append("image0_vs_oracle")

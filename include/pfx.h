@@ -104,8 +104,9 @@ int pfx_median_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, 
 /* pixelate_core (ref: src/ops/effects/distort.rs:333-373) */
 int pfx_pixelate_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, uint32_t block_size,
                       const uint8_t* mask);
-/* effects that reuse the same kernels.  sharpen / glow run the Gaussian in the context's numeric mode:
- * bit-exact with the CPU path after pfx_ctx_set_exact(ctx, 1), otherwise the Gaussian's +-1 LSB enters `amount` times. */
+/* effects that reuse the same kernels.  sharpen / glow / drop shadow feed a Gaussian into a gain, so they run the BIT-EXACT Gaussian in every
+ * context (the reference's tests hold them at tolerance 0: tests/visual_filters.rs:43-55,154-165); pfx_tune(ctx, "gauss_fast_effects", 1) opts a context into the
+ * default-mode Gaussian there too (faster; its +-1 LSB then enters `amount` / `intensity` times). */
 /* sharpen_core(flat, amount, radius, mask) (ref: src/ops/effects/stylize.rs:96-143) */
 int pfx_sharpen_core(pfx_ctx* ctx, const uint8_t* src, uint8_t* dst, uint32_t w, uint32_t h, float amount, float radius,
                      const uint8_t* mask);
@@ -490,6 +491,11 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value);
  * synchronises the device): out[0] compacted rounds, [1] pixels in them, [2] sum of layers over rounds, [3] natural 192-pixel units,
  * [4] sum of layers over natural units, [5] candidate alpha reads (units), [6] units that used the queue, [7] reserved */
 int pfx_flatten_stats(pfx_ctx* ctx, uint64_t out[8], int reset);
+/* diagnostic build of the class-sorting compositor (pfx_tune "dle_stats" = 4; results stay bit-exact, the launch is slower): wave clocks (s_memtime) summed over
+ * the waves of the launches since the last reset — out[0] wave lifetimes, [1] waves, [8] classification, [9] deal + early passes, [10] natural passes,
+ * [11] lane order + store, [12] / [13] waiting for layer pixels / blending in the early passes, [14] / [15] the same in the natural passes.  The stand-in for an
+ * instruction-level thread trace: rocprofv3 --att needs the rocprof-trace-decoder library, which this image does not hold (profiles/r05_tuning.md) */
+int pfx_flatten_trace(pfx_ctx* ctx, uint64_t out[16], int reset);
 
 /* per-launch timing of the most recent `_dev` call family, measured with HIP events on the context stream
  * (used by bench.py for the roofline line).  Enable, run, then read the accumulated milliseconds / launches. */
@@ -710,7 +716,8 @@ typedef struct pfx_batch_params {
     uint32_t n_keep;
     const uint32_t* keep_indices;
     uint8_t* const* keep_out;
-    uint32_t exact_gaussian;              /* 1 = the bit-exact f32 Gaussian (pfx_ctx_set_exact): every kept result equals the CPU path exactly */
+    uint32_t fast_gaussian;               /* 0 (default) = the bit-exact f32 Gaussian: every result equals the CPU path exactly (the blur feeds HSL, which amplifies
+                                             a +-1 LSB input, and the stream is PCIe-bound either way); 1 = the default-mode Gaussian (f16 taps, +-1 LSB before HSL) */
 } pfx_batch_params;
 typedef struct pfx_batch_stats {
     double   seconds;              /* first enqueue .. last result back on the host, slowest device */

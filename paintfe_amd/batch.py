@@ -14,7 +14,7 @@ class BatchParams(C.Structure):
     _fields_ = [("w", C.c_uint32), ("h", C.c_uint32), ("sigma", C.c_float), ("hue", C.c_float), ("saturation", C.c_float),
                 ("lightness", C.c_float), ("n_overlays", C.c_uint32), ("overlays_host", C.POINTER(C.c_void_p)),
                 ("overlay_modes", C.c_void_p), ("overlay_opacity", C.c_void_p), ("slots", C.c_uint32), ("n_keep", C.c_uint32),
-                ("keep_indices", C.c_void_p), ("keep_out", C.POINTER(C.c_void_p)), ("exact_gaussian", C.c_uint32)]
+                ("keep_indices", C.c_void_p), ("keep_out", C.POINTER(C.c_void_p)), ("fast_gaussian", C.c_uint32)]
 
 
 class BatchStats(C.Structure):
@@ -23,8 +23,9 @@ class BatchStats(C.Structure):
 
 
 def run_batch(devices: Sequence[int], n_images: int, pool: List[np.ndarray], overlays: List[np.ndarray], overlay_modes: Sequence[int],
-              sigma: float, hsl=(30.0, -20.0, 10.0), slots: int = 3, keep: Sequence[int] = (), exact: bool = False) -> Dict:
-    """Runs the S4 pipeline on `n_images` images (image i = pool[i % len(pool)]); returns the stats and the kept results."""
+              sigma: float, hsl=(30.0, -20.0, 10.0), slots: int = 3, keep: Sequence[int] = (), fast: bool = False) -> Dict:
+    """Runs the S4 pipeline on `n_images` images (image i = pool[i % len(pool)]); returns the stats and the kept results.
+    fast=False (default): the bit-exact Gaussian, results equal the CPU path; fast=True: the default-mode Gaussian (+-1 LSB before HSL)."""
     lib = L.load()
     h, w = pool[0].shape[:2]
     pool = [np.ascontiguousarray(p, dtype=np.uint8) for p in pool]
@@ -40,7 +41,7 @@ def run_batch(devices: Sequence[int], n_images: int, pool: List[np.ndarray], ove
     P.overlay_modes = modes.ctypes.data
     P.overlay_opacity = None
     P.slots = slots
-    P.exact_gaussian = 1 if exact else 0
+    P.fast_gaussian = 1 if fast else 0
     keep_idx = np.asarray(list(keep), np.uint32)
     outs = [np.zeros((h, w, 4), np.uint8) for _ in keep_idx]
     out_ptrs = (C.c_void_p * max(len(outs), 1))(*[o.ctypes.data for o in outs])

@@ -501,6 +501,108 @@ PFX_DEV void blend_layer_nx_groups(uint32_t mode, float (&acc)[PX][4], const flo
     else blend_nx_dispatch_lead<PX, 1>(mode, acc, top, opc, opc);
 #endif
 }
+// ---- two-stage form (round 5) ----
+// The one-switch form above instantiates every (class variant, mode) pair: 125 bodies, 266 KB of code for three pixels per lane, a compare tree eight levels deep,
+// and — what costs issue slots — a 125-way join whose twelve accumulator registers the register allocator no longer coalesces: every layer step ended in 12 to 24
+// v_mov_b32 (7 - 13 % of the executed VALU instructions, profiles/r05_tuning.md).  blend_pixel_static factors: the blend function f(base_c, top_c) of the mode
+// (:1302-1405) depends on no alpha, and the compositing around it (:1407-1421) on no mode.  Stage A switches over the mode and leaves f for the 3 PX colour
+// channels in fresh registers (nothing to merge: the values are born in the cases); stage B switches over the class variant and updates the accumulators in
+// place.  23 + 5 small bodies; the same IEEE operations on the same operands in the same order per pixel as blend_nx — only the instruction schedule changes.
+// Xor and Overwrite have no f and keep their blend_nx bodies (a two-way branch in front).
+template <int OB>
+PFX_DEV void comp_nx(float (&acc)[4], const float (&top)[4], const float (&f)[3], float opc)
+{
+    if constexpr (OB == 2) { // opaque accumulator, opaque layer pixel, opacity >= 1 (wave-uniform).  Normal: requant(top_c) == top_c for byte values
+        acc[0] = requant(f[0]); acc[1] = requant(f[1]); acc[2] = requant(f[2]); acc[3] = 1.0f;
+        return;
+    }
+    const float top_a = top[3] * opc;                                  // :1272
+    const float ita = 1.0f - top_a;
+    if constexpr (OB == 1) {                                           // out_a == 1.0 exactly (see blend_px); no select for a transparent layer pixel (see blend_nx)
+        acc[0] = requant(f[0] * top_a + acc[0] * ita);
+        acc[1] = requant(f[1] * top_a + acc[1] * ita);
+        acc[2] = requant(f[2] * top_a + acc[2] * ita);
+    } else {
+        const bool skip = (top[3] == 0.0f);                            // :1253  -> keep base
+        const float base_a = acc[3];
+        const float den = top_a + base_a * ita;                        // :1407
+        const float nr = f[0] * top_a + acc[0] * base_a * ita;         // :1412
+        const float ng = f[1] * top_a + acc[1] * base_a * ita;
+        const float nb = f[2] * top_a + acc[2] * base_a * ita;
+        const rdiv k = rdiv_prepare(den);
+        const float o0 = requant(rdiv_apply(k, nr)), o1 = requant(rdiv_apply(k, ng)), o2 = requant(rdiv_apply(k, nb)), o3 = requant(den);
+        acc[0] = skip ? acc[0] : o0; acc[1] = skip ? acc[1] : o1; acc[2] = skip ? acc[2] : o2; acc[3] = skip ? acc[3] : o3;
+    }
+}
+template <uint32_t M, int PX>
+PFX_DEV void fN_nx(float (&f)[PX][3], const float (&acc)[PX][4], const float (&top)[PX][4])
+{
+#pragma unroll
+    for (int p = 0; p < PX; ++p)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[p][c] = blend_fn_nx<M>(acc[p][c], top[p][c]);
+}
+template <int PX, int LEAD, int OBL, int OBR> // pixels [0, LEAD) composite with OBL, the rest with OBR
+PFX_DEV void compN_nx(float (&acc)[PX][4], const float (&top)[PX][4], const float (&f)[PX][3], float opc)
+{
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        if (p < LEAD) comp_nx<OBL>(acc[p], top[p], f[p], opc);
+        else comp_nx<OBR>(acc[p], top[p], f[p], opc);
+    }
+}
+// `v`: 0 .. PX - 1 = that many leading opaque groups, 3 = every group opaque, 4 = and the layer's pixels are opaque at 100 % (blend_layer_nx_groups)
+template <int PX>
+PFX_DEV void blend_two_stage(uint32_t m, uint32_t v, float (&acc)[PX][4], const float (&top)[PX][4], float opc)
+{
+    if (m == M_XOR || m == M_OVERWRITE) {
+        switch (v * 2u + (m == M_XOR ? 1u : 0u)) {
+#define PFX_CASE2(V, BODY) case V * 2u: { constexpr uint32_t M = M_OVERWRITE; BODY; } break; case V * 2u + 1u: { constexpr uint32_t M = M_XOR; BODY; } break;
+            PFX_CASE2(0u, (blendN_nx<M, PX, 0>(acc, top, opc, opc)))
+            PFX_CASE2(1u, (blendN_nx_lead<M, PX, 1>(acc, top, opc, opc)))
+            PFX_CASE2(2u, (blendN_nx_lead<M, PX, (PX == 3 ? 2 : 1)>(acc, top, opc, opc)))
+            PFX_CASE2(3u, (blendN_nx<M, PX, 1>(acc, top, opc, opc)))
+            PFX_CASE2(4u, (blendN_nx<M, PX, 2>(acc, top, opc, opc)))
+#undef PFX_CASE2
+        default: break;
+        }
+        return;
+    }
+    float f[PX][3];
+    switch (m) {
+#define PFX_CASE(M) case M: fN_nx<M, PX>(f, acc, top); break;
+        PFX_CASE(M_MULTIPLY) PFX_CASE(M_SCREEN) PFX_CASE(M_ADDITIVE) PFX_CASE(M_REFLECT)
+        PFX_CASE(M_GLOW) PFX_CASE(M_COLOR_BURN) PFX_CASE(M_COLOR_DODGE) PFX_CASE(M_OVERLAY) PFX_CASE(M_DIFFERENCE)
+        PFX_CASE(M_NEGATION) PFX_CASE(M_LIGHTEN) PFX_CASE(M_DARKEN)
+        PFX_CASE(M_HARD_LIGHT) PFX_CASE(M_SOFT_LIGHT) PFX_CASE(M_EXCLUSION) PFX_CASE(M_SUBTRACT) PFX_CASE(M_DIVIDE)
+        PFX_CASE(M_LINEAR_BURN) PFX_CASE(M_VIVID_LIGHT) PFX_CASE(M_LINEAR_LIGHT) PFX_CASE(M_PIN_LIGHT)
+        PFX_CASE(M_HARD_MIX)
+#undef PFX_CASE
+    default: fN_nx<M_NORMAL, PX>(f, acc, top); break;   // Normal, and BlendMode::from_u8's fallback (layers.rs:183)
+    }
+    switch (v) {
+    case 0u: compN_nx<PX, 0, 0, 0>(acc, top, f, opc); break;
+    case 1u: compN_nx<PX, 1, 1, 0>(acc, top, f, opc); break;
+    case 2u: compN_nx<PX, (PX == 3 ? 2 : 1), 1, 0>(acc, top, f, opc); break;
+    case 3u: compN_nx<PX, PX, 1, 1>(acc, top, f, opc); break;
+    default: compN_nx<PX, PX, 2, 2>(acc, top, f, opc); break;
+    }
+}
+#if !defined(PFX_TWO_STAGE)
+#define PFX_TWO_STAGE 1
+#endif
+// one layer on PX groups (PX = 1: the early groups' one-pixel-per-lane pass), `lead` as in blend_layer_nx_groups
+template <int PX>
+PFX_DEV void blend_layer_nx_two_stage(uint32_t mode, float (&acc)[PX][4], const float (&top)[PX][4], float opc, uint32_t lead)
+{
+    uint32_t v = lead;
+    if (lead == (uint32_t)PX) {
+        const float tmin = alpha_min<PX>(top);
+        v = (opc >= 1.0f && __all(tmin == 1.0f)) ? 4u : 3u;
+    }
+    blend_two_stage<PX>(mode > 24u ? 0u : mode, v, acc, top, opc);
+}
+
 // number of leading groups whose accumulators are all opaque (three compares and scalar counting)
 template <int PX>
 PFX_DEV uint32_t count_lead(const float (&acc)[PX][4])

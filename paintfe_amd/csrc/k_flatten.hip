@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, MINW) void flatten_stream_kernel(const pfxk_la
 // HBM traffic: the candidates' alpha is read once more (+4 bytes per pixel and candidate actually inspected).
 // work counters of the last launches (pfxk_flatten_dle_stats): [0] compacted rounds, [1] pixels in them, [2] layers x rounds,
 // [3] natural units, [4] layers x natural units, [5] candidate alpha reads (units), [6] units that used the queue
-__device__ unsigned long long g_dle_stats[8];
+__device__ unsigned long long g_dle_stats[16];
 
 #ifndef PFX_DLE_SGPR_ATTR
 #define PFX_DLE_SGPR_ATTR
@@ -650,7 +650,9 @@ template <int PX>
 PFX_DEV void stream_layer_groups(float (&acc)[PX][4], const float (&t)[PX][4], uint32_t mode, float opacity, uint32_t lead)
 {
     const float amax = alpha_max<PX>(t);
-#if PFX_SRT_GROUPS
+#if PFX_TWO_STAGE
+    if (__any(amax != 0.0f)) blend_layer_nx_two_stage<PX>(mode, acc, t, opacity, lead);
+#elif PFX_SRT_GROUPS
     if (__any(amax != 0.0f)) blend_layer_nx_groups<PX>(mode, acc, t, opacity, lead);
 #else
     if (__any(amax != 0.0f)) blend_layer_nx<PX>(mode, acc, t, opacity);
@@ -661,12 +663,14 @@ PFX_DEV void stream_layer_groups(float (&acc)[PX][4], const float (&t)[PX][4], u
 // pixels to the lanes when that completes another wave-uniform opaque group.  A re-deal moves the accumulators, the pixel offsets and the one layer
 // that is already in flight (requested with the old offsets) through the LDS tile; the next request uses the new offsets.
 // Scalar work per layer is kept short — the CU's one scalar unit serves all 24 waves, and round 4's counters show it more than half busy: the descriptor
-// pointer advances instead of being indexed, nothing clamps it (the host appends two copies of the last descriptor: pfx_api.cpp:build_stack; what is
+// pointer advances instead of being indexed, nothing clamps it (the host appends PFXK_DESC_PAD = 3 copies of the last descriptor: pfx_api.cpp:build_stack; a pass reads up to descriptor le + 2; what is
 // fetched through them or beyond `le` is never blended), the whole 32-byte descriptor comes with one scalar load, the resource needs no mask.
 // NOBLEND (diagnostic, pfx_tune "dle_stats" = 2): the load stream without the arithmetic — results are garbage.
-template <int PX, bool NOBLEND = false>
+// TR (diagnostic build, pfx_tune "dle_stats" = 4): wave clock spent in front of each blend waiting for the layer's pixels (an explicit s_waitcnt bracketed by
+// s_memtime) and inside the blends, accumulated into tr[0] / tr[1]
+template <int PX, bool NOBLEND = false, bool TR = false>
 PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__ layers, uint32_t lb, uint32_t le, uint32_t bytes, int (&voff)[PX],
-                        uint32_t s1, uint32_t seg, float4* s_x, uint32_t* s_v, uint32_t& st_moves)
+                        uint32_t s1, uint32_t seg, float4* s_x, uint32_t* s_v, uint32_t& st_moves, unsigned long long* tr = nullptr)
 {
     float t[2][PX][4];
     uint32_t m[2], o[2];
@@ -690,15 +694,31 @@ PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
     auto blend = [&](auto SET, uint32_t K) {
         constexpr int S = decltype(SET)::value;
         if (K < le) {
+            unsigned long long c0 = 0, c1 = 0;
+            if constexpr (TR) {
+                c0 = __builtin_amdgcn_s_memtime();
+                if constexpr (PX == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if constexpr (PX == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                c1 = __builtin_amdgcn_s_memtime();
+                tr[0] += c1 - c0;
+            }
             if constexpr (NOBLEND) {
 #pragma unroll
                 for (int j = 0; j < PX; ++j) { acc[j][0] += t[S][j][0]; acc[j][1] += t[S][j][1]; acc[j][2] += t[S][j][2]; acc[j][3] = t[S][j][3]; }
-            } else if constexpr (PX == 1) {
+            } else if constexpr (PX == 1 && !PFX_TWO_STAGE) {
                 stream_layer<1>(acc, t[S], m[S], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(o[S])));
             } else {
                 if (recount) { lead = count_lead<PX>(acc); recount = false; }
                 stream_layer_groups<PX>(acc, t[S], m[S], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(o[S])), lead);
                 recount = m[S] == M_XOR || m[S] == M_OVERWRITE;
+            }
+            if constexpr (TR) {
+                float sink = 0.0f;                      // the blend's results must exist before the clock is read
+#pragma unroll
+                for (int j = 0; j < PX; ++j) sink += acc[j][0] + acc[j][3];
+                asm volatile("" :: "v"(sink));
+                tr[1] += __builtin_amdgcn_s_memtime() - c1;
             }
         }
     };
@@ -760,6 +780,71 @@ PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
     }
 }
 
+// The early groups' pass (one pixel per lane, layers [lb, le) below the split): a set is four registers here, so NB sets keep NB - 1 layers in flight for the
+// price of two of the natural pass's.  The pass is short on arithmetic (a third of a natural step) and long on memory time — the group's lanes sit on a random
+// quarter of the unit's pixels, so every layer's load still touches all of the unit's cache lines — i.e. it is paced by how many loads a wave has in flight.
+// Descriptors are read ahead without clamping like srt_layers: up to descriptor le + 2 NB - 2 (the host pads the table: PFXK_DESC_PAD).
+template <int NB, bool NOBLEND = false, bool TR = false>
+PFX_DEV void srt_early(float (&acc)[1][4], const pfxk_layer_desc* __restrict__ layers, uint32_t lb, uint32_t le, uint32_t bytes, int voff, unsigned long long* tr = nullptr)
+{
+    static_assert(NB >= 2 && 2 * NB - 2 <= PFXK_DESC_PAD, "descriptor padding");
+    float t[NB][1][4];
+    uint32_t m[NB], o[NB];
+    const pfxk_layer_desc* nptr = layers + lb;
+    pfxk_layer_desc nd = *nptr;
+    uint32_t lead = 0u;
+    bool recount = true;
+    auto fetch = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+        m[S] = nd.mode; o[S] = nd.adj_off;
+        const pfx_v4i rs = make_rsrc_canonical(nd.pixels, bytes, PFX_RSRC_UNORM8X4);
+        const pfx_v4f v = pfx_buffer_load_format_v4f32(rs, voff, 0, 0);
+        t[S][0][0] = v.x; t[S][0][1] = v.y; t[S][0][2] = v.z; t[S][0][3] = v.w;
+        nptr += 1;
+        nd = *nptr;
+    };
+    auto blend = [&](auto SET, uint32_t K) {
+        constexpr int S = decltype(SET)::value;
+        if (K < le) {
+            unsigned long long c0 = 0, c1 = 0;
+            if constexpr (TR) {
+                c0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NB - 1) : "memory");
+                c1 = __builtin_amdgcn_s_memtime();
+                tr[0] += c1 - c0;
+            }
+            if constexpr (NOBLEND) { acc[0][0] += t[S][0][0]; acc[0][1] += t[S][0][1]; acc[0][2] += t[S][0][2]; acc[0][3] = t[S][0][3]; }
+            else {
+                if (recount) { lead = count_lead<1>(acc); recount = false; }
+                stream_layer_groups<1>(acc, t[S], m[S], __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(o[S])), lead);
+                recount = true; // one compare: cheaper than tracking which modes can change a single group's class
+            }
+            if constexpr (TR) {
+                const float sink = acc[0][0] + acc[0][3];
+                asm volatile("" :: "v"(sink));
+                tr[1] += __builtin_amdgcn_s_memtime() - c1;
+            }
+        }
+    };
+    auto seq = [&](auto self, auto I, uint32_t li) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < NB) {
+            fetch(std::integral_constant<int, (i + NB - 1) % NB>{});
+            blend(std::integral_constant<int, i>{}, li + (uint32_t)i);
+            self(self, std::integral_constant<int, i + 1>{}, li);
+        }
+    };
+    auto pre = [&](auto self, auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < NB - 1) { fetch(std::integral_constant<int, i>{}); self(self, std::integral_constant<int, i + 1>{}); }
+    };
+    pre(pre, std::integral_constant<int, 0>{});
+    for (uint32_t li = lb; li < le; li += (uint32_t)NB) seq(seq, std::integral_constant<int, 0>{}, li);
+}
+#ifndef PFX_EARLY_NB
+#define PFX_EARLY_NB 2   // 8K x 32 layers (S2), one box: 2 sets 0.990-1.010 ms, 4 sets 1.013-1.018, 6 / 8 sets 1.04-1.05, srt_layers<1> 1.044-1.048 (profiles/r05_tuning.md)
+#endif
+
 // ---- class sorting inside a unit (round 4) -------------------------------------------------------------------------------------------------------
 // Two per-pixel properties decide how much a layer costs a pixel: whether the layer is dead for it (below its topmost reset layer: dead-layer
 // elimination, above) and whether its accumulator is opaque (out_a == 1: no division, no base-alpha products, no alpha re-quantisation, no select for
@@ -780,8 +865,19 @@ PFX_DEV void srt_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
 // pfxk_unorm_store_check, still gates this kernel — it reads every layer through the same conversions).
 struct dle_plan { uint32_t s1, seg; }; // re-deal attempts in front of layers s1, s1 + seg, s1 + 2 seg, ... (seg == 0: none)
 
-template <int PX, bool NOBLEND = false>
-__global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers, uint32_t n_px,
+// 63 VGPRs and no spills once the uniform regions are left unstructurized (Makefile: FLAGS_k_flatten): the eighth wave per SIMD
+#ifndef PFX_SRT_WAVES
+#define PFX_SRT_WAVES 8
+#endif
+#if PFX_SRT_WAVES == 8
+#define PFX_SRT_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#elif PFX_SRT_WAVES == 7
+#define PFX_SRT_ATTR __attribute__((amdgpu_waves_per_eu(7, 7)))
+#else
+#define PFX_SRT_ATTR
+#endif
+template <int PX, bool NOBLEND = false, bool TR = false>
+__global__ __launch_bounds__(64) PFX_SRT_ATTR void flatten_srt_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t n_layers, uint32_t n_px,
                                                                          uint8_t* __restrict__ dst, const pfxk_dle_cands C, const dle_sched SC,
                                                                          const dle_plan P)
 {
@@ -809,7 +905,11 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
     const uint32_t s1 = P.seg != 0u ? P.s1 : 0xFFFFFFFFu;
     uint32_t st_egroups = 0, st_elay = 0, st_nlay = 0, st_reads = 0, st_cunits = 0, st_moves = 0;
     uint32_t probe_fail = 0, skip_left = 0;      // classification back-off (flatten_dle_kernel)
+    // TR: [0] classification, [1] deal + early passes, [2] natural pass, [3] back to lane order + store; waits / blends of the early ([4], [5]) and natural ([6], [7]) passes
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc0 = 0;
+    const unsigned long long t_birth = TR ? __builtin_amdgcn_s_memtime() : 0ull;
     for (uint32_t u = 0; u < nu; ++u) {
+        if constexpr (TR) tc0 = __builtin_amdgcn_s_memtime();
         int voff[PX];
         float acc[PX][4];
 #pragma unroll
@@ -866,6 +966,7 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
             if (best != 0u || s_u != 0u) probe_fail = 0u;
             else if (++probe_fail >= 2u) { probe_fail = 0u; skip_left = 14u; }
         }
+        if constexpr (TR) { const unsigned long long c = __builtin_amdgcn_s_memtime(); tph[0] += c - tc0; tc0 = c; }
         if (best != 0u) {
             // ---- early pixels to the leading groups (the accumulators are all (0,0,0,0): only the offsets move), then their layers [s_u, r) ----
             st_cunits += 1u;
@@ -890,7 +991,12 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
 #pragma unroll
                 for (int j = 1; j < PX; ++j) v1[0] = g == (uint32_t)j ? voff[j] : v1[0];
                 uint32_t none = 0u;
-                srt_layers<1, NOBLEND>(a1, layers, s_u, r, bytes, v1, 0xFFFFFFFFu, 0u, s_x, s_v, none);
+#if PFX_EARLY_NB > 0
+                (void)none;
+                srt_early<PFX_EARLY_NB, NOBLEND, TR>(a1, layers, s_u, r, bytes, v1[0], tph + 4);
+#else
+                srt_layers<1, NOBLEND, TR>(a1, layers, s_u, r, bytes, v1, 0xFFFFFFFFu, 0u, s_x, s_v, none, tph + 4);
+#endif
 #pragma unroll
                 for (int j = 0; j < PX; ++j)
                     if (g == (uint32_t)j) { acc[j][0] = a1[0][0]; acc[j][1] = a1[0][1]; acc[j][2] = a1[0][2]; acc[j][3] = a1[0][3]; }
@@ -900,7 +1006,9 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
         // ---- natural pass: every group from r on, re-dealt by accumulator class on the way ----
         st_nlay += n_layers - r;
         const uint32_t moves_before = st_moves;
-        srt_layers<PX, NOBLEND>(acc, layers, r, n_layers, bytes, voff, s1, P.seg, s_x, s_v, st_moves);
+        if constexpr (TR) { const unsigned long long c = __builtin_amdgcn_s_memtime(); tph[1] += c - tc0; tc0 = c; }
+        srt_layers<PX, NOBLEND, TR>(acc, layers, r, n_layers, bytes, voff, s1, P.seg, s_x, s_v, st_moves, tph + 6);
+        if constexpr (TR) { const unsigned long long c = __builtin_amdgcn_s_memtime(); tph[2] += c - tc0; tc0 = c; }
         // A dealt unit goes back to lane order before it is stored (three 16-byte LDS writes and reads per unit): whole-line stores instead of three
         // stores that each cover a third of every 64-byte piece.  Worth ~1 % of the step on one box (tools/r4_s6.sh), nothing in WRITE_SIZE.
         if (PFX_SRT_NATSTORE && (best != 0u || st_moves != moves_before)) {
@@ -929,6 +1037,16 @@ __global__ __launch_bounds__(64) PFX_DLE_SGPR_ATTR void flatten_srt_kernel(const
             pfx_buffer_store_i32((int)px, rs_dst, voff[j], 0, 0);
 #endif
         }
+        if constexpr (TR) { const unsigned long long c = __builtin_amdgcn_s_memtime(); tph[3] += c - tc0; tc0 = c; }
+    }
+    if constexpr (TR) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_dle_stats[8 + i], tph[i]);
+            atomicAdd(&g_dle_stats[0], __builtin_amdgcn_s_memtime() - t_birth); // wave lifetime (the work counters are not taken in this build)
+            atomicAdd(&g_dle_stats[1], 1ull);
+        }
+        return;
     }
     if (lane == 0 && (C.stats & 1u)) {
         // [0] early groups run, [1] pixels in them (64 each), [2] layers x early groups, [3] units, [4] layers x units of the natural passes,
@@ -1123,12 +1241,12 @@ extern "C" hipError_t pfxk_chunk_start(hipStream_t s, const uint8_t* const* d_fl
     chunk_start_kernel<<<(n_chunks + 255) / 256, 256, 0, s>>>(d_flag_ptrs, d_want, n_layers, n_chunks, d_start, useful_pinned, tag);
     return hipGetLastError();
 }
-extern "C" hipError_t pfxk_flatten_dle_stats(unsigned long long* out8, int reset)
+extern "C" hipError_t pfxk_flatten_dle_stats(unsigned long long* out16, int reset)
 {
     hipError_t e = hipSuccess;
-    if (out8) e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dle_stats), 8 * sizeof(unsigned long long));
+    if (out16) e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dle_stats), 16 * sizeof(unsigned long long));
     if (e == hipSuccess && reset) {
-        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long z[16] = {};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_dle_stats), z, sizeof z);
     }
     return e;
@@ -1282,7 +1400,8 @@ extern "C" hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_
                 P.seg = o2 < 0 ? 3u : (o2 == 0 ? 1000u : (uint32_t)o2);   // 0: a single attempt
                 if (o1 == 0) P.seg = 0u;                                   // no attempts at all: round 3's natural pass + parking in the destination
 #define PFX_ARGS <<<waves, 64, 0, stream>>>(d_layers, n_layers, (uint32_t)n_px, d_dst, C, SC, P)
-                if (C.stats & 2u) flatten_srt_kernel<3, true> PFX_ARGS;      // diagnostic: the load stream without the arithmetic
+                if (C.stats & 4u) flatten_srt_kernel<3, false, true> PFX_ARGS; // diagnostic: per-phase wave clocks (tools/lab/srt_phases.py)
+                else if (C.stats & 2u) flatten_srt_kernel<3, true> PFX_ARGS;   // diagnostic: the load stream without the arithmetic
                 else if (dle_cfg == 1) flatten_srt_kernel<2> PFX_ARGS;
                 else flatten_srt_kernel<3> PFX_ARGS;
 #undef PFX_ARGS

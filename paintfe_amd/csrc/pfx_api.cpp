@@ -254,9 +254,11 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
             cands->n++;
         }
     }
-    // two copies of the last descriptor behind the stack: the class-sorting compositor requests a layer's descriptor two stages ahead without clamping
-    // the index (k_flatten.hip: srt_layers; what it fetches through them is never blended)
-    if (!desc.empty()) { desc.push_back(desc.back()); desc.push_back(desc.back()); }
+    // PFXK_DESC_PAD copies of the last descriptor behind the stack: the class-sorting compositor requests descriptors ahead of the layer it blends without
+    // clamping the index (k_flatten.hip: srt_layers: every fetch() loads the next descriptor, and the loop runs its fetches in pairs, so a pass over an
+    // odd number of layers that ends at the top of the stack has read descriptor n + 2; srt_early<NB> runs NB - 1 layers ahead in groups of NB; what is
+    // fetched through the copies is never blended)
+    if (!desc.empty()) { const pfxk_layer_desc last = desc.back(); desc.insert(desc.end(), PFXK_DESC_PAD, last); }
     // the tables only travel when they differ from what the device already holds (a render loop re-composites the same stack: the
     // small pageable-memory copy in front of every launch was a ~10 us bubble on the stream)
     const size_t desc_bytes = desc.size() * sizeof(pfxk_layer_desc), adj_bytes = adj.size() * sizeof(float);
@@ -1298,6 +1300,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "box_px_switch") == 0) { pfxk_box_set_switch(value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_py_switch") == 0) { pfxk_box_set_switch(-1, value); return PFX_OK; }
     if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
+    if (std::strcmp(key, "gauss_fast_effects") == 0) { ctx->gauss_fast_effects = value != 0; return PFX_OK; } // sharpen / glow / shadow on the default-mode Gaussian (+-amount LSB)
     if (std::strcmp(key, "resize_two_pass") == 0) { ctx->resize_two_pass = value != 0; return PFX_OK; } // A/B and the parity test of the fused kernel
     return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_tune: unknown key %s", key);
 }
@@ -1307,6 +1310,16 @@ int pfx_flatten_stats(pfx_ctx* ctx, uint64_t out[8], int reset)
     if (!ctx) return PFX_ERR_INVALID;
     PFX_TRY(pfx_sync(ctx));
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+    unsigned long long all[16];
+    PFX_HIP(ctx, pfxk_flatten_dle_stats(all, reset));
+    for (int i = 0; i < 8; ++i) out[i] = all[i];
+    return PFX_OK;
+}
+
+int pfx_flatten_trace(pfx_ctx* ctx, uint64_t out[16], int reset)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    PFX_TRY(pfx_sync(ctx));
     PFX_HIP(ctx, pfxk_flatten_dle_stats((unsigned long long*)out, reset));
     return PFX_OK;
 }

@@ -67,7 +67,7 @@ void run_device_body(int device, uint32_t rank, uint32_t world, uint32_t n_image
 
     if (!hip(hipSetDevice(device), "hipSetDevice")) return;
     if (pfx_ctx_create(device, &ctx) != PFX_OK) fail(PFX_ERR_HIP, "pfx_ctx_create failed");
-    else if (P.exact_gaussian) (void)pfx_ctx_set_exact(ctx, 1);
+    else if (!P.fast_gaussian) (void)pfx_ctx_set_exact(ctx, 1);
     if (R.status == PFX_OK) {
         (void)(hip(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking), "hipStreamCreate") && hip(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking), "hipStreamCreate") &&
                hip(hipMalloc(&d_a, bytes), "hipMalloc") && hip(hipMalloc(&d_b, bytes), "hipMalloc"));

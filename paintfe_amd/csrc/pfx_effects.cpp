@@ -22,13 +22,26 @@ int check2(pfx_ctx* ctx, const void* a, const void* b, uint32_t w, uint32_t h, c
 
 inline int32_t f32_as_i32(float v) { return v != v ? 0 : (v >= 2147483648.0f ? 2147483647 : (v <= -2147483648.0f ? (-2147483647 - 1) : (int32_t)v)); }
 
+// The Gaussian inside a composite effect: bit-exact unless the caller opted out (pfx_internal.h: gauss_fast_effects).  The reference's tests hold these
+// effects at tolerance 0 (tests/visual_filters.rs:43-55,154-165), and the default-mode Gaussian's +-1 LSB would be multiplied by `amount` / `intensity`.
+struct exact_gauss_scope {
+    pfx_ctx* c; bool saved;
+    explicit exact_gauss_scope(pfx_ctx* ctx) : c(ctx), saved(ctx->exact) { if (!ctx->gauss_fast_effects) ctx->exact = true; }
+    ~exact_gauss_scope() { c->exact = saved; }
+};
+int effect_gaussian(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius)
+{
+    exact_gauss_scope g(ctx);
+    return pfx_gaussian_blur_dev(ctx, src_dev, dst_dev, w, h, radius, nullptr);
+}
+
 // Gaussian of src into the context scratch, then the two-input pass (stylize.rs: `blurred = parallel_gaussian_blur_pub(flat, radius)`)
 int blur_then_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float radius, int op, float p0,
                       const void* mask_dev, const char* timer)
 {
     const size_t bytes = (size_t)w * h * 4;
     PFX_TRY(pfx_reserve(ctx, ctx->st_aux2, bytes));
-    PFX_TRY(pfx_gaussian_blur_dev(ctx, src_dev, ctx->st_aux2.p, w, h, radius, nullptr));
+    PFX_TRY(effect_gaussian(ctx, src_dev, ctx->st_aux2.p, w, h, radius));
     pfx_timer t(ctx, timer);
     PFX_HIP(ctx, pfxk_combine(ctx->stream, (const uint8_t*)src_dev, (const uint8_t*)ctx->st_aux2.p, (const uint8_t*)mask_dev,
                               (uint8_t*)dst_dev, w, h, op, p0));
@@ -378,7 +391,7 @@ int pfx_shadow_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w,
     }
     if (blur_radius > 0.5f) { // render.rs:297
         PFX_TRY(pfx_reserve(ctx, ctx->st_aux2, 4 * n));
-        PFX_TRY(pfx_gaussian_blur_dev(ctx, ctx->fx_b.p, ctx->st_aux2.p, w, h, blur_radius, nullptr));
+        PFX_TRY(effect_gaussian(ctx, ctx->fx_b.p, ctx->st_aux2.p, w, h, blur_radius));
         alpha_img = ctx->st_aux2.p;
     }
     pfxk_fx_params P{};

@@ -35,6 +35,9 @@ struct pfx_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool exact = false;
+    // sharpen / glow / drop shadow feed a Gaussian into a gain (stylize.rs:96-143, :26-70, render.rs:297): a +-1 LSB input would come out as +-amount, so these
+    // effects run the bit-exact Gaussian whatever `exact` says, unless the caller opts out (pfx_tune "gauss_fast_effects" = 1)
+    bool gauss_fast_effects = false;
     bool resize_two_pass = false;       // pfx_tune("resize_two_pass"): keep the resamplers' f32 intermediate in HBM (the pre-fusion path)
     std::string err;
     // staging for the host-buffer tier (the reference keeps cached staging/ping-pong textures the same way,

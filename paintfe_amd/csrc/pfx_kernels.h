@@ -49,6 +49,7 @@ typedef struct pfxk_region { uint32_t x0, y0, rw, rh; } pfxk_region;
 // below them wherever their alpha qualifies — kind 0: Overwrite, alpha != 0 (canvas_state.rs:1275-1281); kind 1: Normal at
 // opacity >= 1, alpha == 255 (:1258).  The compositor skips the layers below a pixel's topmost reset (k_flatten.hip, flatten_dle_kernel).
 #define PFXK_DLE_MAX 4
+#define PFXK_DESC_PAD 16 /* copies of the last layer descriptor the host appends: srt_layers (k_flatten.hip) reads up to descriptor n + 2, srt_early<NB> up to n + 2 NB - 3 */
 typedef struct pfxk_dle_cands { uint32_t n; uint32_t layer[PFXK_DLE_MAX]; uint32_t kind[PFXK_DLE_MAX]; uint32_t stats; /* set by the launcher */ } pfxk_dle_cands;
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                         const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, int chunk_active_ready, uint32_t w,
@@ -65,7 +66,7 @@ hipError_t pfxk_chunk_alpha_flags(hipStream_t s, const uint8_t* d_px, uint32_t w
 hipError_t pfxk_chunk_start(hipStream_t s, const uint8_t* const* d_flag_ptrs, const uint8_t* d_want, uint32_t n_layers, uint32_t n_chunks,
                             uint8_t* d_start, uint32_t* useful_pinned /* may be NULL: receives `tag` if any chunk starts above layer 0 */, uint32_t tag);
 void       pfxk_flatten_set_dle(int units_per_wave /* 0 = default, < 0 = keep */, int ring_log2 /* 10 | 11, else keep */);
-hipError_t pfxk_flatten_dle_stats(unsigned long long* out8 /* may be NULL */, int reset); // synchronises the device
+hipError_t pfxk_flatten_dle_stats(unsigned long long* out16 /* may be NULL */, int reset); // synchronises the device
 void       pfxk_flatten_set_dle_dev(int stats_on /* < 0 keep */, int cfg /* < 0 keep */);
 void       pfxk_flatten_set_dle_sched(int sched /* 0 equal streams, 1 shrinking */, int fracA, int fracB); // < 0 keeps
 void       pfxk_flatten_set_dle_plan(int kernel /* 0 class sorting, 1 round-3 kernel; < 0 keeps */, int s1 /* first re-deal attempt, layers above the topmost candidate: -1 = 1, 0 = never; < -1 keeps */,

@@ -665,6 +665,14 @@ class GpuRenderer:
         keys = ("rounds", "round_px", "round_layers", "nat_units", "nat_layers", "alpha_reads", "queue_units", "reserved")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def flatten_trace(self, reset: bool = False):
+        """per-phase wave clocks of the class-sorting compositor's diagnostic build (pfx_flatten_trace; tune("dle_stats", 4) first)"""
+        out = (C.c_uint64 * 16)()
+        self._check(self._lib.pfx_flatten_trace(self._h, out, C.c_int(int(reset))))
+        v = [int(x) for x in out]
+        keys = ("classify", "deal_early", "natural", "store", "early_wait", "early_blend", "natural_wait", "natural_blend")
+        return {"wave_clocks": v[0], "waves": v[1], **dict(zip(keys, v[8:16]))}
+
     def timing_enable(self, on: bool):
         self._check(self._lib.pfx_timing_enable(self._h, C.c_int(int(on))))
 

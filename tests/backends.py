@@ -131,19 +131,13 @@ class GpuBackend:
     def pixelate(self, img, block, mask=None):
         return self.r.pixelate_core(img, block, mask)
 
+    # sharpen / glow / shadow run in the context's DEFAULT mode here: the library itself takes the bit-exact Gaussian inside composite effects
+    # (pfx_effects.cpp: effect_gaussian; the reference holds them at tolerance 0, tests/visual_filters.rs:43-55,154-165)
     def sharpen(self, img, amount, radius, mask=None):
-        self.r.set_exact(True)  # composite effects amplify the Gaussian's +-1 LSB; goldens are held at tolerance 0
-        try:
-            return self.r.sharpen_core(img, amount, radius, mask)
-        finally:
-            self.r.set_exact(False)
+        return self.r.sharpen_core(img, amount, radius, mask)
 
     def glow(self, img, radius, intensity, mask=None):
-        self.r.set_exact(True)
-        try:
-            return self.r.glow_core(img, radius, intensity, mask)
-        finally:
-            self.r.set_exact(False)
+        return self.r.glow_core(img, radius, intensity, mask)
 
     def bokeh_blur(self, img, radius, mask=None):
         return self.r.bokeh_blur_core(img, radius, mask)
@@ -166,12 +160,7 @@ class GpuBackend:
         return self.composite([dict(pixels=layer)], w, h) if composite else layer
 
     def effect(self, name, img, **kw):
-        if name == "shadow":  # Gaussian inside: goldens are held at tolerance 0
-            self.r.set_exact(True)
-        try:
-            return getattr(self.r, name + "_core")(img, **kw)
-        finally:
-            self.r.set_exact(False)
+        return getattr(self.r, name + "_core")(img, **kw)
 
     def rhai_adjust(self, img, op, params=()):
         return self.r.rhai_adjust(img, op, params)

@@ -374,3 +374,25 @@ def test_destination_that_aliases_a_layer(gpu):
     finally:
         for b in bufs:
             r.dev_free(b)
+
+
+@pytest.mark.parametrize("n", [125, 126, 253, 254])
+@pytest.mark.parametrize("odd_pass", [True, False])
+def test_descriptor_table_that_ends_on_a_page_boundary(gpu, n, odd_pass):
+    """srt_layers reads layer descriptors ahead of the layer it blends without clamping (up to descriptor n + 2 when a pass over an odd number of layers
+    ends at the top of the stack); the host pads the table (PFXK_DESC_PAD).  (n + pad) * 32 bytes = 4096 / 8192 for these n with the round-4 / round-5
+    padding: a read past the padding would cross the allocation's page.  Both parities of the natural pass's length."""
+    rng = np.random.default_rng(1000 + n)
+    w, h = 200, 3
+    stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    for k in range(n):
+        stack[k, ..., 3] = noise_alpha(rng, h, w, 0.3, 0.3)
+    stack[0, ..., 3] = 255
+    modes = [k % 25 if k % 25 not in (OVERWRITE,) else 1 for k in range(n)]
+    modes = [m if not (m == NORMAL) else 2 for m in modes]
+    opac = [1.0 if k % 2 == 0 else 0.6 for k in range(n)]
+    r = n - 9 if ((n - (n - 9)) % 2 == 1) == odd_pass else n - 10   # the one reset layer: the natural pass covers layers [r, n)
+    modes[r] = OVERWRITE
+    stack[r, ..., 3] = 255                                         # no holes: every unit starts its natural pass exactly at r
+    modes[0] = NORMAL
+    check(gpu, stack, modes, opac, f"{n} layers, natural pass of {n - r}")

@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """tools/dle_stats.py — work counters and timing of the compositor's dead-layer elimination on the bench stack (8K x 32 layers, S2).
-Usage: python tools/dle_stats.py [key=value ...]   (pfx_tune knobs: dle_units, dle_ring, flatten_variant)"""
+Usage: python tools/dle_stats.py [key=value ...]   (pfx_tune knobs: dle_units, dle_ring, flatten_variant; mode=M: one blend mode on layers 1-13, 15-31)"""
 import os, sys, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from paintfe_amd import GpuRenderer
 r = GpuRenderer(0); r.set_stream(torch.cuda.current_stream().cuda_stream)
+one_mode = None
 for kv in sys.argv[1:]:
-    k, v = kv.split("="); r.tune(k, int(v))
+    k, v = kv.split("=")
+    if k == "mode": one_mode = int(v)   # every layer but 0 and 14 (S2's reset layers) blends with this one mode: same elimination, one mode's code
+    else: r.tune(k, int(v))
 w, h, n = 7680, 4320, 32
 dev = torch.device("cuda", 0)
 stack, modes, opac = bench.synth_stack(torch, dev, w, h, n, seed=0x5EED0002)
 flat = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+if one_mode is not None:
+    modes = [int(modes[k]) if k in (0, 14) else one_mode for k in range(n)]
 ptrs = [stack[k].data_ptr() for k in range(n)]
 info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
 for _ in range(20): r.flatten_dev(ptrs, info, w, h, flat.data_ptr())
