@@ -684,6 +684,12 @@ int         pfx_group_synchronize(pfx_group* g);
  * PEER.  timeout_ms == 0 switches it off.  Selecting PFX_GROUP_RCCL arms it for the first two calls (20 s) unless it was configured before. */
 int         pfx_group_set_watchdog(pfx_group* g, uint32_t timeout_ms, uint32_t calls);
 int         pfx_group_synchronize_timeout(pfx_group* g, uint32_t timeout_ms); /* pfx_group_synchronize with the same bounded wait and report */
+/* Per-phase clocks of the pipeline calls (off by default): with timing on, every member records HIP events around its phases, and pfx_group_phase_ms returns
+ * for member `rank` of the LAST call (it waits for that member's work): out_ms[0] flatten, [1] from the end of its flatten to the arrival of its last halo row
+ * (waiting for the neighbours' flattens + the transfer), [2] the band filter, [3] its all-gather pushes (0 without all_gather).  What a first run on a real
+ * multi-GPU node should print beside the step time (bench.py --gpus N: "c_abi_group"). */
+int         pfx_group_set_phase_timing(pfx_group* g, int on);
+int         pfx_group_phase_ms(pfx_group* g, uint32_t rank, double out_ms[4]);
 /* Warps of the sharded document ("replicate the source, warp bands of the output"; ref: src/ops/transform.rs:1288-1345, 1687-1761): the
  * flattened bands are all-gathered so that every member holds the whole source, then every member warps its band of the output with
  * pfx_warp_displacement_band_dev (`disp_host` = w*h xy pairs, scattered to the members by rows; blocking until the field has been copied) or

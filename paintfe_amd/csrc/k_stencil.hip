@@ -245,6 +245,167 @@ __global__ __launch_bounds__(256) void box_fused_kernel(const uint32_t* __restri
     }
 }
 
+// Both passes in one kernel for radii 5 .. BS_MAXR (round 5): a column-strip walk.  A workgroup owns BS_W output columns of a segment of rows and walks down in
+// blocks of BS_RB rows:
+//  (1) horizontal pass (blur.rs:262-276), one wave per source row, no staging: a lane loads 4 consecutive pixels of the row's BS_W + 2r columns straight from
+//      global memory (16 bytes per lane), the wave scans them (DPP: row_shr 1/2/4/8, row_bcast 15/31) into per-pixel exclusive prefix sums P — two channels
+//      per register as 16-bit lanes: a 256-pixel row tile sums to <= 65 280 — and output x is (P[x + 2r + 1] - P[x] + d/2) / d: a cost per pixel that does not
+//      depend on the radius.  The block's BS_RB rows of the reference's u8 intermediate go into an LDS RING of 2r + 1 + BS_RB rows;
+//  (2) vertical pass (blur.rs:294-312): one running column sum per lane — add the row entering the window, emit the output row r rows behind, subtract the row
+//      leaving, both read from the ring.
+// The 4 B/px intermediate never reaches HBM (the two-pass path moves 16 B/px for 8 algorithmic ones).  Recomputed: 2r rows of run-in per segment and the
+// strips' 2r-column halos; the halo columns are read by the neighbouring strip's workgroup too, so the launcher puts neighbouring strips on the SAME XCD (block b
+// runs on XCD b % 8) where the second read is an L2 hit.  Integer sums are order-independent: bit-identical to box_h_kernel + box_v_kernel.
+constexpr int BS_W = 128, BS_RB = 16, BS_MAXR = 60, BS_RP = BS_W + 1;
+__host__ __device__ inline int bs_pp(int r) { return 2 * ((BS_W + 2 * r + 1 + 3) & ~3); }   // words per row of prefix pairs: BS_W + 2r entries + the total's slot, rounded to the lanes' 4-entry groups
+PFX_DEV uint32_t bs_pair(uint32_t px, uint32_t sel) { return __builtin_amdgcn_perm(0u, px, sel); }            // two channels of a pixel as 16-bit lanes
+constexpr uint32_t BS_SEL_RG = 0x0c010c00u, BS_SEL_BA = 0x0c030c02u;
+PFX_DEV uint32_t bs_wave_scan(uint32_t v)   // inclusive add-scan over the 64 lanes
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+PFX_DEV void bs_wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// ((sum + d/2) / d) as u8 for an ODD d, written into byte `b` of `acc`: with d/2 = (d - 1)/2 the quotient is sum/d rounded to nearest, and a tie cannot occur
+// (the fractional part of sum/d is a multiple of 1/d, never 1/2): the nearest integer stays nearest under any error below 1/(2d), and float(sum) * RN(1/d) is off
+// by < 255.5 * 2^-23 — so the conversion's round-to-nearest (v_cvt_pk_u8_f32) yields the reference's integer division exactly (sum <= 65535 is exact in f32).
+// Three full-rate instructions per channel and no packing arithmetic, where v_mul_hi_u32 alone is a quarter-rate one (tests: every radius against the oracle).
+PFX_DEV uint32_t bs_avg_into(uint32_t sum16, float inv_d, uint32_t b, uint32_t acc) { return __builtin_amdgcn_cvt_pk_u8_f32((float)sum16 * inv_d, b, acc); }
+} // namespace
+typedef int bs_v4i __attribute__((ext_vector_type(4)));
+__device__ bs_v4i bs_buffer_load_v4i32(bs_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+__device__ int bs_buffer_load_i32(bs_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+__device__ void bs_buffer_store_i32(int data, bs_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
+namespace {
+PFX_DEV bs_v4i bs_rsrc(const void* base, uint32_t bytes)
+{
+    const uint64_t a = (uint64_t)base;
+    bs_v4i r; r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = (int)(0xFACu | (7u << 12) | (4u << 15)); // untyped dword access
+    return r;
+}
+template <bool MASK>
+__global__ __launch_bounds__(256) void box_strip_kernel(const uint32_t* __restrict__ src, const uint8_t* __restrict__ mask, uint32_t* __restrict__ dst, int r,
+                                                        float inv_d, int w, int h, int seg_rows, int nseg, int strips)
+{
+    extern __shared__ uint32_t bs_lds[];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware item order: XCD k owns a contiguous group of strips, and its blocks walk that group strip by strip within a segment
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+    const int s_lo = strips * xcd / 8, s_hi = strips * (xcd + 1) / 8, sg = s_hi - s_lo;
+    if (sg == 0 || j >= sg * nseg) return;
+    const int seg = j / sg, strip = s_lo + (j - seg * sg);
+    const int x0 = strip * BS_W, y0 = seg * seg_rows, y1 = min(y0 + seg_rows, h);
+    if (y0 >= h) return;
+    const int RR = 2 * r + 1 + BS_RB, d = 2 * r + 1, sw = BS_W + 2 * r;
+    uint32_t* const s_ring = bs_lds;                                  // [RR][BS_RP]: intermediate row v lives in slot (v - v_begin) mod RR
+    const int PP = bs_pp(r);
+    uint2* const Pw = reinterpret_cast<uint2*>(bs_lds + ((RR * BS_RP + 3) & ~3) + wave * (2 * PP)); // this wave's prefix pairs {R|G, B|A} for two rows, 16-byte aligned
+    const int v_begin = y0 - r, v_end = y1 + r;                       // intermediate ("virtual") rows this segment needs; row v is the H pass of source row clamp(v)
+    const uint32_t bytes = (uint32_t)w * (uint32_t)h * 4u;
+    const bs_v4i rs_src = bs_rsrc(src, bytes), rs_dst = bs_rsrc(dst, bytes);
+    // horizontal-pass role: wave = 4 rows of the block, lane = 4 consecutive staged columns
+    const int lx = x0 - r + 4 * lane;
+    const bool interior = x0 - r >= 0 && x0 - r + sw <= w;            // the strip's staged columns lie inside the row (lanes past them read what follows: never used)
+    auto load_rows = [&](int vb, bs_v4i (&px)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row_off = __builtin_amdgcn_readfirstlane(min(max(vb + wave * 4 + q, 0), h - 1) * w * 4);
+            if (interior) px[q] = bs_buffer_load_v4i32(rs_src, lx * 4, row_off, 0);
+            else {
+                px[q].x = bs_buffer_load_i32(rs_src, min(max(lx + 0, 0), w - 1) * 4, row_off, 0); px[q].y = bs_buffer_load_i32(rs_src, min(max(lx + 1, 0), w - 1) * 4, row_off, 0);
+                px[q].z = bs_buffer_load_i32(rs_src, min(max(lx + 2, 0), w - 1) * 4, row_off, 0); px[q].w = bs_buffer_load_i32(rs_src, min(max(lx + 3, 0), w - 1) * 4, row_off, 0);
+            }
+        }
+    };
+    // vertical-pass role: lane = (column, channel pair)
+    const int col = tid >> 1, x = x0 + col;
+    const uint32_t vsel = (tid & 1) ? BS_SEL_BA : BS_SEL_RG, vb0 = (tid & 1) ? 2u : 0u;
+    const int vx = (x < w && (tid & 1) == 0) ? x * 4 : (int)0x7fffffff;   // the odd lane of a column and columns past the row store out of range: dropped by the buffer check
+    uint32_t vsum = 0u;
+    int base = 0;                                                     // ring slot of the block's first row
+    bs_v4i cur[4], nxt[4];
+    load_rows(v_begin, nxt);
+    for (int vb = v_begin; vb < v_end; vb += BS_RB) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        // (1) horizontal: two rows at a time (two independent scans in flight)
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const bs_v4i c = cur[q + qq];
+                uint32_t e[2][3], ex[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const uint32_t sel = pl ? BS_SEL_BA : BS_SEL_RG;
+                    e[pl][0] = bs_pair((uint32_t)c.x, sel); e[pl][1] = e[pl][0] + bs_pair((uint32_t)c.y, sel); e[pl][2] = e[pl][1] + bs_pair((uint32_t)c.z, sel);
+                    const uint32_t tot = e[pl][2] + bs_pair((uint32_t)c.w, sel);
+                    ex[pl] = bs_wave_scan(tot) - tot;             // sum of the pixels left of this lane's four
+                }
+                if (4 * lane <= sw) {                             // entries 0 .. sw (lanes past them hold pixels no window reaches)
+                    uint4* out = reinterpret_cast<uint4*>(Pw + qq * (PP / 2) + 4 * lane);
+                    out[0] = make_uint4(ex[0], ex[1], ex[0] + e[0][0], ex[1] + e[1][0]);
+                    out[1] = make_uint4(ex[0] + e[0][1], ex[1] + e[1][1], ex[0] + e[0][2], ex[1] + e[1][2]);
+                }
+            }
+            bs_wave_lds_sync();
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                int slot = base + wave * 4 + q + qq; slot = slot >= RR ? slot - RR : slot;
+                const uint2* P = Pw + qq * (PP / 2);
+#pragma unroll
+                for (int hx = 0; hx < 2; ++hx) {
+                    const int ox = lane + 64 * hx;                // window of output ox = staged columns [ox, ox + 2r]
+                    const uint2 lo = P[ox], hi = P[ox + d];
+                    const uint32_t s0 = hi.x - lo.x, s1 = hi.y - lo.y;
+                    uint32_t o = bs_avg_into(s0 & 0xffffu, inv_d, 0u, 0u);
+                    o = bs_avg_into(s0 >> 16, inv_d, 1u, o); o = bs_avg_into(s1 & 0xffffu, inv_d, 2u, o); o = bs_avg_into(s1 >> 16, inv_d, 3u, o);
+                    s_ring[slot * BS_RP + ox] = o;
+                }
+            }
+            bs_wave_lds_sync();                                   // the next pair of rows overwrites the planes
+        }
+        __syncthreads();
+        if (vb + BS_RB < v_end) load_rows(vb + BS_RB, nxt);       // the next block's rows travel under the vertical pass
+        // (2) vertical: all of the block's ring reads are requested before the running sum walks through them
+        {
+            uint32_t rin[BS_RB], rout[BS_RB];
+#pragma unroll
+            for (int k = 0; k < BS_RB; ++k) {
+                int sn = base + k; sn = sn >= RR ? sn - RR : sn;
+                int so = sn - 2 * r; so = so < 0 ? so + RR : so;  // row v - 2r = y - r leaves the window behind output y = v - r
+                rin[k] = s_ring[sn * BS_RP + col];
+                rout[k] = s_ring[so * BS_RP + col];               // (a slot not yet written during the run-in: read, never used)
+            }
+#pragma unroll
+            for (int k = 0; k < BS_RB; ++k) {
+                const int v = vb + k;
+                if (v < v_end) {
+                    vsum += bs_pair(rin[k], vsel);
+                    if (v >= y0 + r) {                            // the window of output row y = v - r is complete
+                        const int row_off = (v - r) * w * 4;
+                        uint32_t mine = bs_avg_into(vsum & 0xffffu, inv_d, vb0, 0u);
+                        mine = bs_avg_into(vsum >> 16, inv_d, vb0 + 1u, mine);
+                        uint32_t o = mine | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]: the column's other channel pair
+                        if constexpr (MASK) {                     // blur.rs:296-303: unselected pixels keep the source
+                            if (vx != (int)0x7fffffff && mask[(size_t)(v - r) * w + x] == 0) o = (uint32_t)bs_buffer_load_i32(rs_src, vx, row_off, 0);
+                        }
+                        bs_buffer_store_i32((int)o, rs_dst, vx, row_off, 0);
+                        vsum -= bs_pair(rout[k], vsel);
+                    }
+                }
+            }
+        }
+        base += BS_RB; base = base >= RR ? base - RR : base;
+        __syncthreads();                                          // the next block's horizontal pass writes ring slots this vertical pass has read
+    }
+}
+
 // ---------------------------------------------------------------- median
 constexpr int MD_TX = 32, MD_TY = 8; // outputs per block: one per lane
 
@@ -605,6 +766,8 @@ int g_box_px_force = 0, g_box_py_force = 0; // development sweep (pfx_tune "box_
 extern "C" void pfxk_box_set_force(int px, int py) { if (px >= 0) g_box_px_force = px; if (py >= 0) g_box_py_force = py; }
 int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
 extern "C" void pfxk_box_set_two_pass(int on) { g_box_two_pass = on; }
+int g_box_strip = 1, g_box_strip_fill = 100, g_box_strip_nseg = 0; // pfxk_box_set_strip: the fused strip walk for radii 5 .. BS_MAXR (0 = two passes); chip fill in % of one wave of workgroups; forced segment count
+extern "C" void pfxk_box_set_strip(int on, int fill, int nseg) { if (on >= 0) g_box_strip = on; if (fill > 0) g_box_strip_fill = fill; if (nseg >= 0) g_box_strip_nseg = nseg; }
 extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst,
                                     const uint8_t* d_mask, int radius, uint32_t w, uint32_t h, int force_two_pass)
 {
@@ -630,6 +793,30 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
         case 4: return go(std::integral_constant<int, 4>{});
         default: break;   // radius 0 never reaches the kernels (pfx_api.cpp copies); fall through to the two-pass path
         }
+    }
+    if (radius > BF_MAXR && radius <= BS_MAXR && g_box_strip && g_box_two_pass == 0 && !force_two_pass && d_src != d_dst && (uint64_t)w * h < (1ull << 29)) { // fused strip walk, no intermediate in HBM
+        const int RR = 2 * radius + 1 + BS_RB;
+        const size_t lds = (size_t)(((RR * BS_RP + 3) & ~3) + 4 * 2 * bs_pp(radius)) * 4;   // the ring, then two rows of prefix pairs per wave on a 16-byte boundary
+        const int strips = (int)((w + BS_W - 1) / BS_W);
+        // One round of workgroups per XCD: an XCD owns ceil(strips / 8) strips at most and holds 32 CUs x (workgroups the LDS footprint allows) at a time; a
+        // second, partly filled round would double the launch's time.  Segments are at least 6r rows (the 2r rows of run-in stay below a third).
+        const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / lds));
+        const int sg_max = (strips + 7) / 8;
+        int nseg = std::max(1, 32 * wg_per_cu * g_box_strip_fill / 100 / sg_max);
+        nseg = std::min(nseg, std::max(1, (int)h / std::max(64, 6 * radius)));
+        if (g_box_strip_nseg > 0) nseg = g_box_strip_nseg;
+        const int seg_rows = ((int)h + nseg - 1) / nseg;
+        nseg = ((int)h + seg_rows - 1) / seg_rows;
+        const float inv_d = 1.0f / (float)d;
+        auto go = [&](auto mk) -> hipError_t {
+            constexpr bool MK = decltype(mk)::value;
+            hipError_t e = hipFuncSetAttribute((const void*)box_strip_kernel<MK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e) return e;
+            box_strip_kernel<MK><<<dim3(8u * (uint32_t)(sg_max * nseg)), 256, lds, s>>>((const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, inv_d, (int)w, (int)h,
+                                                                                      seg_rows, nseg, strips);
+            return hipGetLastError();
+        };
+        return d_mask ? go(std::true_type{}) : go(std::false_type{});
     }
     // outputs per lane grow with the radius: a lane's first window costs 2r + 1 reads whatever it is followed by
     auto launch_h = [&](auto px_c) -> hipError_t {

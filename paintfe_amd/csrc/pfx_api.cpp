@@ -1299,6 +1299,9 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "box_py") == 0) { pfxk_box_set_force(-1, value); return PFX_OK; }
     if (std::strcmp(key, "box_px_switch") == 0) { pfxk_box_set_switch(value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_py_switch") == 0) { pfxk_box_set_switch(-1, value); return PFX_OK; }
+    if (std::strcmp(key, "box_strip") == 0) { pfxk_box_set_strip(value, 0, -1); return PFX_OK; }          // 0 = radii >= 5 through the two-pass kernels
+    if (std::strcmp(key, "box_strip_fill") == 0) { pfxk_box_set_strip(-1, value, -1); return PFX_OK; }
+    if (std::strcmp(key, "box_strip_nseg") == 0) { pfxk_box_set_strip(-1, 0, value); return PFX_OK; }
     if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
     if (std::strcmp(key, "gauss_fast_effects") == 0) { ctx->gauss_fast_effects = value != 0; return PFX_OK; } // sharpen / glow / shadow on the default-mode Gaussian (+-amount LSB)
     if (std::strcmp(key, "resize_two_pass") == 0) { ctx->resize_two_pass = value != 0; return PFX_OK; } // A/B and the parity test of the fused kernel

@@ -83,6 +83,10 @@ struct pfx_group_member {
     hipEvent_t ev_gin = nullptr;        // every H2D of a gather INTO this member finished (its copy stream)
     bool gin_pending = false;
     ncclComm_t comm = nullptr;          // RCCL transport
+    // per-phase clocks of the last pipeline call (pfx_group_set_phase_timing): timing-enabled events on the compute stream in front of the flatten, behind it,
+    // behind the last halo row's arrival, behind the filter, and on the copy stream behind the member's all-gather pushes
+    hipEvent_t tm[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool tm_valid = false, tm_gather = false;
 };
 
 struct pfx_group {
@@ -96,6 +100,9 @@ struct pfx_group {
     // watchdog (pfx_group_set_watchdog): the next `watch_calls` pipeline calls end with a bounded host-side wait for every member's work; a member
     // that does not finish in time turns a hang (a deadlocked RCCL group, a peer that never sends) into PFX_ERR_HIP naming the pairs involved
     uint32_t watch_ms = 0, watch_calls = 0;
+    bool watch_configured = false;      // pfx_group_set_watchdog was called (an explicit "off" must survive selecting RCCL)
+    bool phase_timing = false;
+    int test_stall_ms = 0;              // PFX_GROUP_TEST_STALL_MS, read once at creation (tests: a member that is late)
     struct halo_piece { uint32_t i, j, s0, s1; };
     std::vector<halo_piece> last_pieces; // halo transfers of the last call (consumer i <- producer j, image rows [s0, s1)): the watchdog's report
     std::string err;
@@ -294,6 +301,7 @@ static int group_create_impl(const int* devices, uint32_t n, pfx_group** out)
     // direct xGMI access between every pair of distinct devices.  A pair whose access cannot be enabled (no link, IOMMU / container
     // restrictions, PFX_GROUP_DENY_PEER=1 for tests) is served by staged copies through pinned host memory instead — the calls keep
     // working, only slower.
+    if (const char* stall = std::getenv("PFX_GROUP_TEST_STALL_MS")) g->test_stall_ms = std::max(0, std::atoi(stall));
     const char* deny = getenv("PFX_GROUP_DENY_PEER");
     const bool deny_peer = deny && deny[0] == '1';
     g->peer_ok.assign((size_t)n * n, 0);
@@ -326,6 +334,7 @@ void pfx_group_destroy(pfx_group* g)
         if (mem.ev_staged_halo) (void)hipEventDestroy(mem.ev_staged_halo);
         if (mem.ev_staged_band) (void)hipEventDestroy(mem.ev_staged_band);
         if (mem.ev_gin) (void)hipEventDestroy(mem.ev_gin);
+        for (hipEvent_t& e : mem.tm) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (mem.comm && rccl().ok) (void)rccl().CommDestroy(mem.comm);
         if (mem.ctx) pfx_ctx_destroy(mem.ctx);
     }
@@ -410,7 +419,7 @@ int pfx_group_set_transport(pfx_group* g, int transport)
         for (size_t k = 0; k < n; ++k) g->m[k].comm = comms[k];
         g->rccl_ready = true;
         // the first exchanges over fresh communicators are where a mis-paired group would hang: watch them unless the caller configured otherwise
-        if (g->watch_ms == 0) { g->watch_ms = 20000; g->watch_calls = 2; }
+        if (!g->watch_configured) { g->watch_ms = 20000; g->watch_calls = 2; }
     }
     g->transport = transport;
     return PFX_OK;
@@ -454,7 +463,9 @@ static int wait_bounded(pfx_group* g, uint32_t timeout_ms, const char* what)
     static const char* const tname[] = {"PEER", "RCCL", "STAGED"};
     const int t = g->transport;
     if (t == PFX_GROUP_RCCL && g->rccl_ready) {
-        if (rccl().CommAbort) for (auto& mem : g->m) if (mem.comm) { (void)rccl().CommAbort(mem.comm); mem.comm = nullptr; }
+        // without ncclCommAbort the communicators cannot be torn down while a collective hangs on them: they are dropped (a later RCCL selection builds new
+        // ones; the hung ones are the price of the hang), never left dangling in the members
+        for (auto& mem : g->m) if (mem.comm) { if (rccl().CommAbort) (void)rccl().CommAbort(mem.comm); mem.comm = nullptr; }
         g->rccl_ready = false;
         g->transport = PFX_GROUP_PEER;
     }
@@ -604,12 +615,20 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
             mem.gather_pending = false;
         }
     }
+    g->last_pieces.clear();   // a call without a halo has no transfers to report
+    auto mark = [&](pfx_group_member& mem, int k, hipStream_t st) -> hipError_t {   // phase clocks (off by default: five more events per member and call)
+        if (!g->phase_timing) return hipSuccess;
+        if (!mem.tm[k]) { const hipError_t e = hipEventCreate(&mem.tm[k]); if (e != hipSuccess) return e; }
+        return hipEventRecord(mem.tm[k], st);
+    };
     // 1. every member flattens its band straight into the centre of its padded buffer
     for (auto& mem : g->m) {
         const uint32_t rows = mem.y1 - mem.y0;
         mem.top = std::min(halo, mem.y0);
         mem.bottom = std::min(halo, h - mem.y1);
         PFXG_HIP(g, hipSetDevice(mem.device));
+        mem.tm_valid = false; mem.tm_gather = false;
+        PFXG_HIP(g, mark(mem, 0, stream_of(mem)));
         if (rows) {
             std::vector<const void*> ptrs(n_layers, nullptr);
             std::vector<pfx_layer_info> li(layers, layers + n_layers);
@@ -619,18 +638,18 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
                                              (uint8_t*)mem.padded + (size_t)mem.top * row_bytes));
         }
         if (&mem == &g->m.back()) {
-            // test hook: a peer that is late (PFX_GROUP_TEST_STALL_MS): its stream sleeps in a host function in front of the event its neighbours wait for
-            const char* stall = std::getenv("PFX_GROUP_TEST_STALL_MS");
-            if (stall && std::atoi(stall) > 0) PFXG_HIP(g, hipLaunchHostFunc(stream_of(mem), stall_host_fn, (void*)(intptr_t)std::atoi(stall)));
+            // test hook: a peer that is late (PFX_GROUP_TEST_STALL_MS, read when the group was created): its stream sleeps in a host function in front of the
+            // event its neighbours wait for
+            if (g->test_stall_ms > 0) PFXG_HIP(g, hipLaunchHostFunc(stream_of(mem), stall_host_fn, (void*)(intptr_t)g->test_stall_ms));
         }
         PFXG_HIP(g, hipEventRecord(mem.ev_flat, stream_of(mem)));
+        PFXG_HIP(g, mark(mem, 1, stream_of(mem)));
     }
     if (blur) {
         // 2. halo rows: member i needs rows [y0 - top, y0) and [y1, y1 + bottom) from whichever members own them.
         // Every (consumer i, producer j, image rows [s0, s1)) piece is listed once and then moved by the transport in use.
         using piece = pfx_group::halo_piece;
         std::vector<piece>& pieces = g->last_pieces;
-        pieces.clear();
         for (uint32_t i = 0; i < world; ++i) {
             const auto& mem = g->m[i];
             if (mem.y1 == mem.y0) continue;
@@ -708,6 +727,7 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
             auto& mem = g->m[i];
             if (mem.y1 == mem.y0) continue;
             PFXG_HIP(g, hipSetDevice(mem.device));
+            PFXG_HIP(g, mark(mem, 2, stream_of(mem)));   // every halo row has arrived (the transfers above sit on this stream or are waited for by it)
             if (mem.gather_pending) { PFXG_HIP(g, hipStreamWaitEvent(stream_of(mem), mem.ev_gather, 0)); mem.gather_pending = false; }
             const uint32_t prow = mem.top + (mem.y1 - mem.y0) + mem.bottom, first = mem.y0 - mem.top;
             if (filter == PFX_BAND_GAUSSIAN) PFXG_CTX(g, mem, pfx_gaussian_blur_band_dev(mem.ctx, mem.padded, mem.blurred, w, prow, param, nullptr, first));
@@ -719,11 +739,20 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
     for (auto& mem : g->m) {
         PFXG_HIP(g, hipSetDevice(mem.device));
         PFXG_HIP(g, hipEventRecord(mem.ev_done, stream_of(mem)));
+        if (!blur) PFXG_HIP(g, mark(mem, 2, stream_of(mem)));
+        PFXG_HIP(g, mark(mem, 3, stream_of(mem)));
+        mem.tm_valid = g->phase_timing;
     }
     // 4. all-gather (gather_result above)
     if (all_gather) {
         const int gs = gather_result(g, blur);
         if (gs != PFX_OK) return gs;
+        for (auto& mem : g->m) {
+            if (!mem.gather_pending) continue;
+            PFXG_HIP(g, hipSetDevice(mem.device));
+            PFXG_HIP(g, mark(mem, 4, mem.s_copy));
+            mem.tm_gather = g->phase_timing;
+        }
     }
     g->have_result = true;
     return PFX_OK;
@@ -750,6 +779,36 @@ int pfx_group_set_watchdog(pfx_group* g, uint32_t timeout_ms, uint32_t calls)
     if (!g) return PFX_ERR_INVALID;
     g->watch_ms = timeout_ms;
     g->watch_calls = timeout_ms ? calls : 0u;
+    g->watch_configured = true;
+    return PFX_OK;
+}
+
+int pfx_group_set_phase_timing(pfx_group* g, int on)
+{
+    if (!g) return PFX_ERR_INVALID;
+    g->phase_timing = on != 0;
+    return PFX_OK;
+}
+
+int pfx_group_phase_ms(pfx_group* g, uint32_t rank, double out_ms[4])
+{
+    if (!g || !out_ms || rank >= g->m.size()) return PFX_ERR_INVALID;
+    auto& mem = g->m[rank];
+    out_ms[0] = out_ms[1] = out_ms[2] = out_ms[3] = 0.0;
+    if (!mem.tm_valid) return gfail(g, PFX_ERR_INVALID, "no phase clocks: pfx_group_set_phase_timing(g, 1) before the pipeline call");
+    PFXG_HIP(g, hipSetDevice(mem.device));
+    PFXG_HIP(g, hipEventSynchronize(mem.tm[3]));
+    for (int k = 0; k < 3; ++k) {
+        float ms = 0.0f;
+        PFXG_HIP(g, hipEventElapsedTime(&ms, mem.tm[k], mem.tm[k + 1]));
+        out_ms[k] = ms;
+    }
+    if (mem.tm_gather) {
+        float ms = 0.0f;
+        PFXG_HIP(g, hipEventSynchronize(mem.tm[4]));
+        PFXG_HIP(g, hipEventElapsedTime(&ms, mem.tm[3], mem.tm[4]));
+        out_ms[3] = ms;
+    }
     return PFX_OK;
 }
 

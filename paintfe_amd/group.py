@@ -106,6 +106,15 @@ class GpuGroup:
     def synchronize_timeout(self, timeout_ms: int):
         self._check(self.lib.pfx_group_synchronize_timeout(self.g, C.c_uint32(timeout_ms)))
 
+    def set_phase_timing(self, on: bool):
+        self._check(self.lib.pfx_group_set_phase_timing(self.g, C.c_int(1 if on else 0)))
+
+    def phase_ms(self, rank: int):
+        """(flatten, halo wait, filter, gather) of the last pipeline call on member `rank`, in ms (pfx_group_phase_ms)"""
+        out = (C.c_double * 4)()
+        self._check(self.lib.pfx_group_phase_ms(self.g, C.c_uint32(rank), out))
+        return {"flatten": out[0], "halo_wait": out[1], "filter": out[2], "gather": out[3]}
+
     def set_transport(self, transport: int):
         self._check(self.lib.pfx_group_set_transport(self.g, C.c_int(transport)))
 

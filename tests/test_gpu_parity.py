@@ -918,7 +918,16 @@ def test_box_blur_two_pass_lane_runs(gpu, radius, size):
     w, h = size
     img = I.random_rgba(w, h, 777 + w + int(radius))
     ref = O.box_blur(img, radius)
-    assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} (shapes by radius)")
+    assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} (kernel by radius)")
+    gpu.r.tune("box_strip", 0)         # radii 5 .. 64 take the fused strip walk by default (test_box_blur_strip_walk); here: the two-pass kernels on every radius
+    try:
+        _two_pass_shapes(gpu, img, ref, radius, size)
+    finally:
+        gpu.r.tune("box_strip", 1)
+
+
+def _two_pass_shapes(gpu, img, ref, radius, size):
+    assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} (two-pass shapes by radius)")
     gpu.r.tune("box_prefix_from", 1)   # the prefix-sum horizontal pass (default: radii from 72) on every radius and tile shape
     try:
         assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} prefix-sum horizontal pass")
@@ -932,6 +941,32 @@ def test_box_blur_two_pass_lane_runs(gpu, radius, size):
         finally:
             gpu.r.tune("box_px", 0)
             gpu.r.tune("box_py", 0)
+
+
+@pytest.mark.parametrize("radius", [5.0, 6.5, 9.0, 16.0, 33.0, 48.0, 60.0, 64.0])
+@pytest.mark.parametrize("size", [(300, 300), (129, 200), (128, 64), (1, 70), (33, 1), (700, 37), (260, 1000), (1100, 130)])
+def test_box_blur_strip_walk(gpu, radius, size):
+    """radii 5 .. 64: both passes in one kernel, a column-strip walk with the u8 intermediate in an LDS ring (k_stencil.hip: box_strip_kernel).  Bit-identical
+    to the oracle and to the two-pass kernels for every way of cutting the image into strips (128 columns: widths either side of one, two, eight and nine
+    strips — the XCD grouping) and segments (forced counts: one segment, segments shorter than the window, the launcher's own choice), with and without a
+    selection mask; images smaller than the window in either direction"""
+    w, h = size
+    img = I.random_rgba(w, h, 999 + w + int(radius))
+    mask = (np.random.default_rng(w + h).random((h, w)) < 0.5).astype(np.uint8) * 255
+    ref, ref_m = O.box_blur(img, radius), O.box_blur(img, radius, mask)
+    try:
+        for nseg in (0, 1, 2, 7, 40):
+            gpu.r.tune("box_strip_nseg", nseg)
+            assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} strip walk, {nseg or 'auto'} segments")
+        gpu.r.tune("box_strip_nseg", 3)
+        assert_same(gpu.box_blur(img, radius, mask), ref_m, 0, f"box blur r={radius} {size} strip walk, masked")
+    finally:
+        gpu.r.tune("box_strip_nseg", 0)
+    gpu.r.tune("box_strip", 0)
+    try:
+        assert_same(gpu.box_blur(img, radius), ref, 0, f"box blur r={radius} {size} two-pass")
+    finally:
+        gpu.r.tune("box_strip", 1)
 
 
 @pytest.mark.parametrize("params", [(30.0, -20.0, float("inf")), (30.0, -20.0, float("-inf")), (float("nan"), 10.0, 5.0), (10.0, float("inf"), 0.0),

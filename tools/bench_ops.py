@@ -85,8 +85,8 @@ def main() -> int:
     timed("levels/curves LUT apply", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "lut_rgba", lut=lut), px, 8)
     timed("vibrance", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "vibrance", [50.0]), px, 8)
     timed("box blur r=3", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 3.0), px, 8, "both passes in one kernel on 64 x 64 tiles (r <= 4)")
-    timed("box blur r=9", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 9.0), px, 8, "two passes, u8 intermediate (+8 B/px)")
-    timed("box blur r=48", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 48.0), px, 8, "two passes")
+    timed("box blur r=9", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 9.0), px, 8, "fused column-strip walk, u8 intermediate in an LDS ring (radii 5 .. 60)")
+    timed("box blur r=48", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 48.0), px, 8, "fused column-strip walk")
     timed("median r=1", ["median"], lambda: r.median_dev(s, d, w, h, 1), px, 8)
     timed("median r=2", ["median"], lambda: r.median_dev(s, d, w, h, 2), px, 8)
     timed("median r=3", ["median"], lambda: r.median_dev(s, d, w, h, 3), px, 8, "bit-plane radix select (k_median_bits.hip), incl. the planes pre-pass")

@@ -15,12 +15,12 @@ dur=collections.defaultdict(list)
 for d in "abcd":
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv"%d, recursive=True):
         for row in csv.DictReader(open(f)):
-            k=re.sub(r"\(.*","",row["Kernel_Name"]); k=re.sub(r"^void ","",k); k=k.replace("(anonymous namespace)::","")
+            k=row["Kernel_Name"].replace("(anonymous namespace)::",""); k=re.sub(r"^void ","",k); k=re.sub(r"\(.*","",k)
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for f in glob.glob("$OUT/%s/**/*kernel_trace.csv"%d, recursive=True):
         if d!="a": continue
         for row in csv.DictReader(open(f)):
-            k=re.sub(r"\(.*","",row["Kernel_Name"]); k=re.sub(r"^void ","",k); k=k.replace("(anonymous namespace)::","")
+            k=row["Kernel_Name"].replace("(anonymous namespace)::",""); k=re.sub(r"^void ","",k); k=re.sub(r"\(.*","",k)
             dur[k].append(float(row["End_Timestamp"])-float(row["Start_Timestamp"]))
 print(f"{'kernel':58s} {'ms':>7s} {'GHz':>5s} {'VALU':>5s} {'SALU':>5s} {'LDS':>5s} {'confl':>5s} {'TA':>5s} {'waves':>5s} {'rdGB':>6s} {'wrGB':>6s}")
 for k,c in sorted(acc.items(), key=lambda kv: -sum(dur.get(kv[0],[0]))):
