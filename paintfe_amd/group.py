@@ -106,6 +106,11 @@ class GpuGroup:
     def synchronize_timeout(self, timeout_ms: int):
         self._check(self.lib.pfx_group_synchronize_timeout(self.g, C.c_uint32(timeout_ms)))
 
+    def set_exact(self, on: bool):
+        """pfx_ctx_set_exact on every member's context (the bit-exact Gaussian)"""
+        for k in range(self.n):
+            self._check(self.lib.pfx_ctx_set_exact(C.c_void_p(self.ctx(k)), C.c_int(1 if on else 0)))
+
     def set_phase_timing(self, on: bool):
         self._check(self.lib.pfx_group_set_phase_timing(self.g, C.c_int(1 if on else 0)))
 

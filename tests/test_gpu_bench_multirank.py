@@ -45,7 +45,13 @@ def test_band_mode_is_the_default_and_matches_single_process(nproc):
     assert d["doc_mode"]["scaling"] == "weak" and d["doc_mode"]["value"] > 0
     # the headline leaves the blurred result sharded (halo exchange only); the same pipeline + an all-gather into every rank is timed beside it
     assert d["band_gathered_result"]["scaling"] == "strong" and d["band_gathered_result"]["value"] > 0 and "band_gathered_error" not in d
-    assert d["check"]["band_blur_checked_rows"] == "window of the gathered frame"
+    # the timed headline's own band is always checked, and the gathered variant's window beside it
+    assert d["check"]["band_blur_checked_rows"].startswith("own band") and d["check"]["gathered_window_max_diff_vs_oracle"] == 0
+    # the C-ABI single-process leg over the same ranks' devices (here: the one GPU twice / three times), bit-identical under every variant
+    ga = d["c_abi_group"]
+    assert ga["members"] == nproc and ga["check"]["window_max_diff_vs_oracle"] == 0
+    assert ga["peer"]["sharded"]["value"] > 0 and ga["peer"]["gathered"]["identical_to_first_variant"] is True
+    assert len(ga["peer"]["sharded"]["phase_ms_per_member"]) == nproc and all(p["flatten"] > 0 and p["filter"] > 0 for p in ga["peer"]["sharded"]["phase_ms_per_member"])
     d = _run(nproc, [], 29640 + nproc)
     assert d["check"]["band_blur_max_diff_vs_oracle"] <= 1  # matrix-core Gaussian: the stated +-1 LSB
 
@@ -54,7 +60,7 @@ def test_band_mode_without_the_gathered_variant_checks_the_rank_own_band():
     """--no-gather: the headline pipeline alone; rank 0's band (its edge rows depend on the received halo rows) against the oracle"""
     d = _run(2, ["--exact", "--no-gather"], 29648)
     assert d["scaling"] == "strong" and "band_gathered_result" not in d
-    assert d["check"]["band_blur_checked_rows"] == "own band" and d["check"]["band_blur_max_diff_vs_oracle"] == 0
+    assert d["check"]["band_blur_checked_rows"].startswith("own band") and d["check"]["band_blur_max_diff_vs_oracle"] == 0
     assert abs(d["value"] - 640 * 400 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
 
 

@@ -222,17 +222,17 @@ def test_group_watchdog_names_the_late_member(monkeypatch):
     w, h, n, world = 128, 400, 3, 3
     stack, modes, opac = I.layer_stack(w, h, n, seed=77)
     infos = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+    monkeypatch.setenv("PFX_GROUP_TEST_STALL_MS", "700")      # read once, when the group is created: every pipeline call of THIS group stalls its last member
     g = GpuGroup(_devices(world))
+    monkeypatch.delenv("PFX_GROUP_TEST_STALL_MS")
     g.set_document(w, h, n)
     for k in range(n):
         g.upload_layer(k, stack[k])
-    g.flatten_blur(infos, 3.0)                                 # warm: allocations, first launches
+    g.flatten_blur(infos, 3.0)                                 # warm: allocations, first launches (no watchdog yet: it simply takes 700 ms)
     g.synchronize()
     g.set_watchdog(60, 1)
-    monkeypatch.setenv("PFX_GROUP_TEST_STALL_MS", "700")
     with pytest.raises(PfxError) as e:
         g.flatten_blur(infos, 3.0)
-    monkeypatch.delenv("PFX_GROUP_TEST_STALL_MS")
     assert e.value.status == ERR_HIP
     msg = str(e.value)
     assert "did not finish within 60 ms" in msg and "member(s)" in msg and "<-" in msg and "2 (device" in msg, msg
