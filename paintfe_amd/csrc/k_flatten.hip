@@ -262,13 +262,23 @@ PFX_DEV void stream_fetch(float (&t)[PX][4], const uint8_t* pixels, uint32_t byt
     }
 }
 
+#ifndef PFX_STREAM_TWO_STAGE
+#define PFX_STREAM_TWO_STAGE 1   // round 5, 9-layer stacks per mode on one box: -1 .. -8 % (Xor, Vivid Light, Overlay, Hard Light, Glow most), none slower (tools/lab/ab_ops_libs.sh)
+#endif
 template <int PX>
 PFX_DEV void stream_layer(float (&acc)[PX][4], const float (&t)[PX][4], uint32_t mode, float opacity)
 {
     const float amax = alpha_max<PX>(t);
     // a wave whose 64*PX pixels are all transparent in this layer (sparse layers of real documents; the TiledImage analogue
     // is a missing chunk, canvas_state.rs:600) skips the blend entirely
+#if PFX_STREAM_TWO_STAGE
+    if (__any(amax != 0.0f)) {
+        const float amin = alpha_min<PX>(acc);   // every accumulator opaque: the class variants 3 / 4 of the two-stage form, else the general one
+        blend_layer_nx_two_stage<PX>(mode, acc, t, opacity, __all(amin == 1.0f) ? (uint32_t)PX : 0u);
+    }
+#else
     if (__any(amax != 0.0f)) blend_layer_nx<PX>(mode, acc, t, opacity);
+#endif
 }
 
 template <int PX, int NB, int MINW>

@@ -339,9 +339,19 @@ static_assert(MESH_WALK <= 64 && (MESH_WX == 1 || MESH_WX == 2 || MESH_WX == 4),
 template <bool IN_LDS, int D, bool PAIR, bool BUF32>
 __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restrict__ src, const float2* __restrict__ g_orig, const float2* __restrict__ g_def,
                                                         uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint32_t* __restrict__ dst, uint32_t y_off,
-                                                        uint32_t h_full)
+                                                        uint32_t h_full, uint32_t gx, uint32_t gy)
 {
     constexpr uint32_t WALK = MESH_WALK, WX = MESH_WX; // rows per lane; a workgroup covers (64 WX) x (WALK 4 / WX) pixels
+    // Tile of this workgroup.  gx != 0: a one-dimensional launch with an XCD-aware order (round 5) — block b runs on XCD b % 8 and each XCD has its own L2, so
+    // XCD k takes the k-th eighth of the tile rows and walks it in raster order: the workgroups resident on an XCD at one time are neighbours, and the source
+    // texels their footprints share (the smooth field moves a tile's window by a fraction of its size) are fetched into that L2 once instead of into several.
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (gx != 0u) {
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const uint32_t r0 = gy * xcd / 8u, r1 = gy * (xcd + 1u) / 8u;
+        if (j >= (r1 - r0) * gx) return;
+        by = r0 + j / gx; bx = j - (j / gx) * gx;
+    }
     extern __shared__ __attribute__((aligned(16))) uint8_t mesh_lds[];
     float2* const s_orig = reinterpret_cast<float2*>(mesh_lds);
     float2* const s_def = s_orig + (IN_LDS ? (cols + 1u) * (rows + 1u) : 0u);
@@ -357,8 +367,8 @@ __global__ __launch_bounds__(256) void mesh_roll_kernel(const uint32_t* __restri
     const float2* p_orig = IN_LDS ? s_orig : g_orig;
     // the wave's first row as a scalar: row counters, the rows' v_readlane indices and the end-of-image tests then stay on the scalar unit
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t lane = threadIdx.x & 63u, x_lane = (blockIdx.x * WX + wave % WX) * 64u + lane;
-    const uint32_t y_walk = (blockIdx.y * (4u / WX) + wave / WX) * WALK;
+    const uint32_t lane = threadIdx.x & 63u, x_lane = (bx * WX + wave % WX) * 64u + lane;
+    const uint32_t y_walk = (by * (4u / WX) + wave / WX) * WALK;
     if (y_walk >= h) return;               // whole wave
     const bool x_valid = x_lane < w;
     const uint32_t x = x_valid ? x_lane : w - 1u;
@@ -501,6 +511,8 @@ extern "C" hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig,
     return hipGetLastError();
 }
 
+int g_mesh_xcd = 1; // pfxk_warp_set_mesh_xcd (pfx_tune "mesh_xcd"): XCD-aware tile order of the fused mesh warp
+extern "C" void pfxk_warp_set_mesh_xcd(int on) { g_mesh_xcd = on; }
 // band form: d_dst holds rows [first_row, first_row + h) of an h_full-row result; d_src is the whole w x h_full source
 extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const float* d_orig, const float* d_def,
                                      uint32_t cols, uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst, uint32_t first_row, uint32_t h_full)
@@ -512,7 +524,12 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
     const size_t lds = (size_t)(cols + 1u) * (rows + 1u) * 16u;
     const bool in_lds = (cols + 1u) * (rows + 1u) <= MESH_LDS_PTS;
     const bool buf32 = w >= 2u && w < (1u << 24) && h_full < (1u << 24) && (uint64_t)w * h_full * 4u < (1ull << 32);
-#define PFX_ROLL(L, P, B) mesh_roll_kernel<L, ROLL, P, B><<<g, 256, (L) ? lds : 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full)
+    uint32_t gx = 0u, gy = 0u;
+    if (g_mesh_xcd && g.y >= 16u) {   // XCD-aware tile order (mesh_roll_kernel); small launches keep the plain 2-D grid
+        gx = g.x; gy = g.y;
+        g = dim3(8u * ((gy + 7u) / 8u) * gx, 1u);
+    }
+#define PFX_ROLL(L, P, B) mesh_roll_kernel<L, ROLL, P, B><<<g, 256, (L) ? lds : 0, s>>>((const uint32_t*)d_src, (const float2*)d_orig, (const float2*)d_def, cols, rows, w, h, (uint32_t*)d_dst, first_row, h_full, gx, gy)
     if (in_lds) { if (buf32) PFX_ROLL(true, true, true); else if (w >= 2u) PFX_ROLL(true, true, false); else PFX_ROLL(true, false, false); }
     else { if (buf32) PFX_ROLL(false, true, true); else if (w >= 2u) PFX_ROLL(false, true, false); else PFX_ROLL(false, false, false); }
 #undef PFX_ROLL

@@ -1299,6 +1299,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "box_py") == 0) { pfxk_box_set_force(-1, value); return PFX_OK; }
     if (std::strcmp(key, "box_px_switch") == 0) { pfxk_box_set_switch(value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_py_switch") == 0) { pfxk_box_set_switch(-1, value); return PFX_OK; }
+    if (std::strcmp(key, "mesh_xcd") == 0) { pfxk_warp_set_mesh_xcd(value); return PFX_OK; }            // 0 = the fused mesh warp's plain 2-D tile order
     if (std::strcmp(key, "box_strip") == 0) { pfxk_box_set_strip(value, 0, -1); return PFX_OK; }          // 0 = radii >= 5 through the two-pass kernels
     if (std::strcmp(key, "box_strip_fill") == 0) { pfxk_box_set_strip(-1, value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_strip_nseg") == 0) { pfxk_box_set_strip(-1, 0, value); return PFX_OK; }

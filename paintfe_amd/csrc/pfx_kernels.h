@@ -204,6 +204,7 @@ hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src, uint32_t 
 hipError_t pfxk_mesh_displacement(hipStream_t s, const float* d_orig, const float* d_def, uint32_t cols, uint32_t rows,
                                   uint32_t w, uint32_t h, float* d_disp);
 // d_dst = rows [first_row, first_row + h) of the h_full-row result; d_src = the whole w x h_full source (first_row = 0, h_full = h: whole image)
+void pfxk_warp_set_mesh_xcd(int on);
 hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const float* d_orig, const float* d_def, uint32_t cols,
                           uint32_t rows, uint32_t w, uint32_t h, uint8_t* d_dst, uint32_t first_row, uint32_t h_full);
 
