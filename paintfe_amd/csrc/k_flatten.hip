@@ -651,7 +651,7 @@ __global__ __launch_bounds__(64 * WPB) PFX_DLE_SGPR_ATTR void flatten_dle_kernel
 #endif
 #ifndef PFX_SRT_TYPED_STORE
 #define PFX_SRT_TYPED_STORE 0 // development A/B: 1 = the result leaves through buffer_store_format_xyzw (float -> UNORM8 in the texture path, no pack arithmetic):
-                              // 1.120-1.124 ms against 1.106-1.112 for four v_cvt_pk_u8_f32 and a dword store, two alternations on one box (tools/r4_s10.sh)
+                              // 1.120-1.124 ms against 1.106-1.112 for four v_cvt_pk_u8_f32 and a dword store, two alternations on one box (profiles/r04_tuning.md)
 #endif
 #ifndef PFX_SRT_NATSTORE
 #define PFX_SRT_NATSTORE 1 // development A/B: 0 = a dealt unit is stored in dealt order
@@ -876,6 +876,9 @@ PFX_DEV void srt_early(float (&acc)[1][4], const pfxk_layer_desc* __restrict__ l
 struct dle_plan { uint32_t s1, seg; }; // re-deal attempts in front of layers s1, s1 + seg, s1 + 2 seg, ... (seg == 0: none)
 
 // 63 VGPRs and no spills once the uniform regions are left unstructurized (Makefile: FLAGS_k_flatten): the eighth wave per SIMD
+#ifndef PFX_SRT_PRIO
+#define PFX_SRT_PRIO 0   // development A/B: bits 0-1 = wave priority in the early passes, bits 2-3 = in the natural pass
+#endif
 #ifndef PFX_SRT_WAVES
 #define PFX_SRT_WAVES 8
 #endif
@@ -1001,6 +1004,9 @@ __global__ __launch_bounds__(64) PFX_SRT_ATTR void flatten_srt_kernel(const pfxk
 #pragma unroll
                 for (int j = 1; j < PX; ++j) v1[0] = g == (uint32_t)j ? voff[j] : v1[0];
                 uint32_t none = 0u;
+#if PFX_SRT_PRIO
+                __builtin_amdgcn_s_setprio(PFX_SRT_PRIO & 3);
+#endif
 #if PFX_EARLY_NB > 0
                 (void)none;
                 srt_early<PFX_EARLY_NB, NOBLEND, TR>(a1, layers, s_u, r, bytes, v1[0], tph + 4);
@@ -1017,10 +1023,13 @@ __global__ __launch_bounds__(64) PFX_SRT_ATTR void flatten_srt_kernel(const pfxk
         st_nlay += n_layers - r;
         const uint32_t moves_before = st_moves;
         if constexpr (TR) { const unsigned long long c = __builtin_amdgcn_s_memtime(); tph[1] += c - tc0; tc0 = c; }
+#if PFX_SRT_PRIO
+        __builtin_amdgcn_s_setprio((PFX_SRT_PRIO >> 2) & 3);
+#endif
         srt_layers<PX, NOBLEND, TR>(acc, layers, r, n_layers, bytes, voff, s1, P.seg, s_x, s_v, st_moves, tph + 6);
         if constexpr (TR) { const unsigned long long c = __builtin_amdgcn_s_memtime(); tph[2] += c - tc0; tc0 = c; }
         // A dealt unit goes back to lane order before it is stored (three 16-byte LDS writes and reads per unit): whole-line stores instead of three
-        // stores that each cover a third of every 64-byte piece.  Worth ~1 % of the step on one box (tools/r4_s6.sh), nothing in WRITE_SIZE.
+        // stores that each cover a third of every 64-byte piece.  Worth ~1 % of the step on one box (profiles/r04_tuning.md), nothing in WRITE_SIZE.
         if (PFX_SRT_NATSTORE && (best != 0u || st_moves != moves_before)) {
             const uint32_t ub = (base_px + u * UPX) * 4u;
 #pragma unroll

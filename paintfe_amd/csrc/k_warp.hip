@@ -519,7 +519,7 @@ extern "C" hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const 
 {
     if (w == 0 || h == 0) return hipSuccess;
     dim3 g((w + 64 * MESH_WX - 1) / (64 * MESH_WX), (h + MESH_WALK * (4 / MESH_WX) - 1) / (MESH_WALK * (4 / MESH_WX)));
-    // rows in flight per lane: 2 measured best at 16K (tools/r4_s9.sh: 0.565 ms against 0.573-0.59 for 3 / 4, 0.63 for 6 and for round 3's batches of 8)
+    // rows in flight per lane: 2 measured best at 16K (profiles/r04_tuning.md: 0.565 ms against 0.573-0.59 for 3 / 4, 0.63 for 6 and for round 3's batches of 8)
     constexpr int ROLL = PFX_MESH_ROLL;
     const size_t lds = (size_t)(cols + 1u) * (rows + 1u) * 16u;
     const bool in_lds = (cols + 1u) * (rows + 1u) <= MESH_LDS_PTS;

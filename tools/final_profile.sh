@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r4_final.sh <commit> — the judged artefacts of one build from ONE box: driver-style bench line, rocprofv3 kernel stats + PMC passes, operation table
+# tools/final_profile.sh <commit> — the judged artefacts of one build from ONE box: driver-style bench line, rocprofv3 kernel stats + PMC passes, operation table
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final; rm -rf $OUT; mkdir -p $OUT
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"

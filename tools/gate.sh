@@ -1,7 +1,7 @@
 #!/bin/bash
-# full GPU gate + bench line (round-5 checkpoints)
+# tools/gate.sh — the full GPU gate (pytest -m gpu) + one default bench line, as the driver runs them at round end
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-O=$ROOT/gpurun_out/r5gate; mkdir -p $O
+O=$ROOT/gpurun_out/gate; mkdir -p $O
 cd $ROOT
 timeout 2400 python -m pytest tests -m gpu -x -q > $O/gpu_tests.txt 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.txt
 tail -5 $O/gpu_tests.txt

@@ -28,5 +28,10 @@ for k,c in sorted(acc.items(), key=lambda kv: -sum(dur.get(kv[0],[0]))):
     cyc=m("GRBM_GUI_ACTIVE")/8
     if cyc<20000: continue
     ms=(sum(dur[k])/len(dur[k])/1e6) if dur.get(k) else 0
+    # GRBM_GUI_ACTIVE / duration is a clock only when the launch is long against the counter's start / stop latency: a derived clock above the 2.4 GHz
+    # spec means the launch was too short for it, and every "busy" fraction built on that clock with it
+    if ms and cyc/(ms*1e6) > 2.45:
+        print(f"{k[:58]:58s} {ms:7.3f}  launch too short for the busy fractions (derived clock {cyc/(ms*1e6):.2f} GHz > 2.4 spec); rdGB {m('FETCH_SIZE')*2048/1e9:.2f} wrGB {m('WRITE_SIZE')*1024/1e9:.2f}")
+        continue
     print(f"{k[:58]:58s} {ms:7.3f} {cyc/(ms*1e6) if ms else 0:5.2f} {m('SQ_INSTS_VALU')*2/(1024*cyc):5.2f} {m('SQ_INSTS_SALU')/(256*cyc):5.2f} {m('SQ_LDS_IDX_ACTIVE')/(256*cyc):5.2f} {m('SQ_LDS_BANK_CONFLICT')/max(m('SQ_LDS_IDX_ACTIVE'),1):5.2f} {m('TA_BUSY_avr')/cyc:5.2f} {m('SQ_WAVE_CYCLES')*4/(1024*cyc):5.1f} {m('FETCH_SIZE')*2048/1e9:6.2f} {m('WRITE_SIZE')*1024/1e9:6.2f}")
 PY
