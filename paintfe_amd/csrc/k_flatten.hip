@@ -453,14 +453,6 @@ PFX_DEV void dle_layers(float (&acc)[PX][4], const pfxk_layer_desc* __restrict__
     }
 }
 
-// v with lane `idx` replaced by `val` (both wave-uniform).  hipcc has no builtin for v_writelane_b32 here; inline asm sits outside the compiler's hazard
-// bookkeeping, so the wait states a VALU-written SGPR needs before it may select a lane are spelled out (rare instruction: once per round).
-PFX_DEV uint32_t lane_write(uint32_t v, uint32_t val, uint32_t idx)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(idx) : "m0"); // one SGPR per VALU instruction: the lane select travels in M0
-    return v;
-}
-
 PFX_DEV void wave_lds_sync()
 {
     // LDS operations of one wave execute in order; this only keeps the compiler from moving them across the hand-over

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "k_common.h"
+#include <atomic>
 #include "pfx_kernels.h"
 
 using namespace pfxk;
@@ -187,7 +188,7 @@ int g_mfma_seg = 0; // tuning knob (pfxk_gauss_set_mfma_segments): row segments 
 // 0.243 -> 0.190; channels that differ (all by 1): uniform noise 4.9e-5 -> 3.6e-4, photograph-like ramps + noise 5.0e-5 -> 4.8e-5, smooth ramps
 // 1e-7 -> 8e-9.  One piece for both (pfx_tune "gauss_parts" = 11) runs sigma 16 in 0.114 ms but rounds the horizontal result to 11 bits — 0.125 LSB
 // steps at the bright end: 2 % of a smooth ramp's channels come out one off; kept as a measured variant, not shipped.
-int g_mfma_wp = 1, g_mfma_hp = 2;
+std::atomic<int> g_mfma_wp{1}, g_mfma_hp{2};   // process-wide development knobs read by batch workers' threads
 
 template <bool EXACT>
 hipError_t launch_v(hipStream_t stream, const float4* tmp, uint8_t* d_dst, const float* wts, int radius, uint32_t w, uint32_t h)

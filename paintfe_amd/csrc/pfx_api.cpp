@@ -287,6 +287,12 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
 {
     PFX_REQUIRE(ctx, n_layers <= PFX_MAX_LAYERS, "too many layers");
     PFX_REQUIRE(ctx, n_layers == 0 || layers, "null layer list");
+    // in place is allowed — dst may BE one of the layers (every kernel reads a pixel of every layer before it writes that pixel) — a partial overlap is not:
+    // a workgroup would read pixels another one has already replaced
+    if (!from_store && layer_ptrs && dst_dev)
+        for (uint32_t l = 0; l < n_layers; ++l)
+            if (layer_ptrs[l] && layer_ptrs[l] != dst_dev && ranges_overlap(layer_ptrs[l], dst_dev, img_bytes(w, h)))
+                return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_flatten_dev: dst partially overlaps layer %u (it may be a layer, or disjoint from all)", l);
     uint32_t n_desc = 0, active_pos = 0xFFFFFFFFu;
     const uint8_t* active_pixels = nullptr;
     bool general = false, has_adj = false;
@@ -349,8 +355,9 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
         }
         if (ctx->chunk_state != 3) d_chunk_start = (const uint8_t*)ctx->d_chunk_start.p; // pending or useful: the table of THIS stack is in the buffer
     }
-    // The class-sorting compositor (k_flatten.hip: flatten_srt_kernel) writes its result with typed UNORM8 buffer stores: the device's float -> UNORM8
-    // conversion must return k for RN(k / 255), which is checked once per context on the device itself.  Otherwise round 3's kernel runs.
+    // The class-sorting compositor (k_flatten.hip: flatten_srt_kernel) reads every layer through typed UNORM8 buffer loads and keeps its accumulators as
+    // RN(k / 255); its result leaves as v_cvt_pk_u8_f32 + dword stores (the typed format store measured 1 % slower).  The device's UNORM8 <-> float
+    // conversions must be exact for all 256 byte values, which is checked once per context on the device itself.  Otherwise round 3's kernel runs.
     int parking_ok = 0;
     if (cands.n > 0 && !general && fast_div && !region && !PV.pixels) {
         if (ctx->unorm_store_ok < 0) {

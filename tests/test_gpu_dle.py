@@ -396,3 +396,39 @@ def test_descriptor_table_that_ends_on_a_page_boundary(gpu, n, odd_pass):
     stack[r, ..., 3] = 255                                         # no holes: every unit starts its natural pass exactly at r
     modes[0] = NORMAL
     check(gpu, stack, modes, opac, f"{n} layers, natural pass of {n - r}")
+
+
+@pytest.mark.parametrize("which", ["srt", "stream", "general"])
+def test_in_place_flatten_on_every_kernel_and_partial_overlap_refused(gpu, which):
+    """include/pfx.h: dst may BE one of the layers (in place) but must not partially overlap any.  In place on the class-sorting kernel (a reset layer), the plain
+    streaming kernel (none) and the general kernel (a masked layer); a destination shifted into a layer by one row is PFX_ERR_INVALID"""
+    from paintfe_amd._lib import PfxError
+    rng = np.random.default_rng(31)
+    w, h, n = 256, 80, 18
+    stack, modes, opac = class_stack(rng, w, h, n, 6, 0.3, {})
+    if which != "srt":
+        modes = [m if m not in (OVERWRITE, NORMAL) else 1 for m in modes]
+        modes[0] = NORMAL
+        opac = [0.7 if (m == NORMAL and k) else o for k, (m, o) in enumerate(zip(modes, opac))]
+    ref = O.flatten_stack(stack, np.asarray(modes, np.uint8), np.asarray(opac, np.float32))
+    r = gpu.r
+    big = r.dev_alloc(w * h * 4 * (n + 1))
+    try:
+        ptrs = [big + k * w * h * 4 for k in range(n)]
+        for k in range(n):
+            r.dev_upload(ptrs[k], stack[k])
+        info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+        masks = None
+        if which == "general":   # a live mask that conceals nothing (canvas_state.rs:660-665: alpha * (255 - 0) / 255) changes no pixel and moves the stack to the general kernel
+            mbuf = r.dev_alloc(w * h)
+            r.dev_upload(mbuf, np.zeros((h, w), np.uint8))
+            masks = [0] * n
+            masks[3] = mbuf
+        with pytest.raises(PfxError):
+            r.flatten_dev(ptrs, info, w, h, ptrs[4] + w * 4, mask_ptrs=masks)      # one row into layer 4 (and into layer 5 at its end)
+        r.flatten_dev(ptrs, info, w, h, ptrs[9], mask_ptrs=masks)
+        assert np.array_equal(r.dev_download(ptrs[9], (h, w, 4)), ref)
+    finally:
+        r.dev_free(big)
+        if which == "general":
+            r.dev_free(mbuf)

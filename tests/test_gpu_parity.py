@@ -69,8 +69,9 @@ def test_blend_pixels_exhaustive_alpha_lattice(gpu):
 
 
 def test_typed_unorm8_store_and_load_round_trip_every_byte_value(gpu):
-    """the class-queue compositor parks accumulators RN(k / 255) in the destination with typed UNORM8 buffer stores and reads them back with typed
-    loads (k_flatten.hip: flatten_cls_kernel): both conversions must be exact for all 256 byte values on every channel"""
+    """the streaming compositors read every layer through typed UNORM8 buffer loads and hold their accumulators as RN(k / 255) (k_flatten.hip:
+    flatten_srt_kernel / flatten_stream_kernel; round 3's kernel also parks accumulators with typed stores): the texture path's conversions must be exact
+    in both directions for all 256 byte values on every channel"""
     assert gpu.r.selftest_unorm_store() == 0
 
 
