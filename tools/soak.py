@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/soak.py [--seconds S] [--seed N] — randomized parity soak on the GPU against the oracle (test infrastructure, like tests/): random layer stacks
 (sizes, depths, modes, opacities, alpha structure: noise, opaque / transparent runs and blocks, reset layers at random depths) through pfx_composite — which
-picks the class-sorting, streaming or general compositor by itself —, random-sigma Gaussians in the default (<= 1 LSB) and exact (bit-exact) modes, random
+picks the class-sorting, streaming or general compositor by itself —, random-sigma Gaussians in the default (<= 1 LSB) and exact (bit-exact) modes, random-radius box blurs (bit-exact), random
 displacement and mesh warps (bit-exact).  Prints one JSON line; exits 1 on the first mismatch with the case's seed."""
 import argparse, json, os, sys, time
 import numpy as np
@@ -16,7 +16,7 @@ ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 r = GpuRenderer(0)
 t_end = time.time() + a.seconds
-counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0}
+counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0}
 case = a.seed * 1000003
 
 
@@ -41,7 +41,7 @@ def alpha_plane(rng, w, h):
 while time.time() < t_end:
     case += 1
     rng = np.random.default_rng(case)
-    what = rng.integers(0, 10)
+    what = rng.integers(0, 11)
     try:
         if what < 6:
             w, h = int(rng.integers(1, 700)), int(rng.integers(1, 120))
@@ -72,6 +72,13 @@ while time.time() < t_end:
             finally:
                 r.set_exact(False)
             counts["gauss"] += 1
+        elif what == 10:   # box blur: the fused tile (r <= 4), the fused strip walk (r <= 60) and the two-pass kernels, with and without a selection
+            w, h = int(rng.integers(1, 900)), int(rng.integers(1, 400))
+            radius = float(rng.choice([0.6, 1.0, 2.0, 4.0, 4.5, 5.0, 7.0, 9.0, 13.0, 24.0, 37.0, 48.0, 60.0, 61.0, 90.0])) - (0.3 if rng.random() < 0.3 else 0.0)
+            img = I.random_rgba(w, h, case)
+            mask = None if rng.random() < 0.6 else ((rng.random((h, w)) < 0.5).astype(np.uint8) * 255)
+            if not np.array_equal(r.box_blur_core(img, radius, mask), O.box_blur(img, radius, mask)): raise AssertionError(f"box blur {w}x{h} radius {radius} mask {mask is not None}")
+            counts["box"] += 1
         elif what == 8:
             w, h = int(rng.integers(1, 600)), int(rng.integers(1, 200))
             sw, sh = (w, h) if rng.random() < 0.6 else (int(rng.integers(1, 600)), int(rng.integers(1, 200)))
