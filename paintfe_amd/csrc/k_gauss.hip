@@ -22,6 +22,7 @@
 
 #include "k_common.h"
 #include <atomic>
+#include <algorithm>
 #include "pfx_kernels.h"
 
 using namespace pfxk;

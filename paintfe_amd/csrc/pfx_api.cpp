@@ -470,11 +470,17 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
         ctx->wts_sigma_bits = sigma_bits;
         ctx->wts_valid = true;
     }
+    const float* wts = (const float*)ctx->d_wts.p + pad;
+    if (ctx->exact && radius >= 1 && radius <= pfxk_gauss_fused_exact_max_radius() && src_dev != dst_dev) {
+        // bit-exact mode at small radii (what sharpen / glow / drop shadow and the batch pipeline run): both passes in one kernel, no f32 intermediate in HBM
+        pfx_timer t(ctx, "gauss_fused");
+        PFX_HIP(ctx, pfxk_gauss_fused_exact(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, wts, radius, w, h));
+        return PFX_OK;
+    }
     if (!tmp_dev) {
         PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 16));
         tmp_dev = ctx->st_tmp.p;
     }
-    const float* wts = (const float*)ctx->d_wts.p + pad;
     {
         pfx_timer t(ctx, "gauss_h");
         PFX_HIP(ctx, pfxk_gauss_h(ctx->stream, (const uint8_t*)src_dev, (float*)tmp_dev, wts, radius, w, h, ctx->exact ? 1 : 0));
@@ -1306,6 +1312,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "box_py") == 0) { pfxk_box_set_force(-1, value); return PFX_OK; }
     if (std::strcmp(key, "box_px_switch") == 0) { pfxk_box_set_switch(value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_py_switch") == 0) { pfxk_box_set_switch(-1, value); return PFX_OK; }
+    if (std::strcmp(key, "gauss_fused_exact") == 0) { pfxk_gauss_set_fused_exact(value); return PFX_OK; }  // 0 = the bit-exact Gaussian always through the two kernels
     if (std::strcmp(key, "mesh_xcd") == 0) { pfxk_warp_set_mesh_xcd(value); return PFX_OK; }            // 0 = the fused mesh warp's plain 2-D tile order
     if (std::strcmp(key, "box_strip") == 0) { pfxk_box_set_strip(value, 0, -1); return PFX_OK; }          // 0 = radii >= 5 through the two-pass kernels
     if (std::strcmp(key, "box_strip_fill") == 0) { pfxk_box_set_strip(-1, value, -1); return PFX_OK; }

@@ -979,3 +979,27 @@ def test_hsl_with_non_finite_and_huge_parameters(gpu, oracle, params):
     assert_same(gpu.adjust(img, "hsl", params), oracle.adjust(img, "hsl", params), 0, f"hsl {params}")
     v = (params[2],) if np.isfinite(params[0]) else (params[0],)
     assert_same(gpu.adjust(img, "vibrance", v), oracle.adjust(img, "vibrance", v), 0, f"vibrance {v}")
+
+
+@pytest.mark.parametrize("sigma", [0.2, 0.34, 0.5, 1.0, 1.7, 2.5, 3.3, 4.0, 4.2, 5.0, 5.33, 5.5])
+@pytest.mark.parametrize("size", [(300, 300), (64, 32), (65, 33), (1, 50), (50, 1), (700, 45), (130, 1200), (1030, 70)])
+def test_exact_gaussian_fused_small_radii(gpu, oracle, sigma, size):
+    """bit-exact mode, radii 1 .. 16 (sigma <= 5.33): both passes in one kernel with the f32 intermediate in an LDS ring (k_gauss.hip: gauss_fused_exact_kernel) —
+    bit-identical to the oracle and to the two-kernel path (pfx_tune "gauss_fused_exact" = 0) on widths either side of one, two, eight and sixteen 64-column
+    strips, heights either side of a 32-row block and of a segment, images smaller than the window; radius 17 (sigma 5.5) takes the two kernels by itself.
+    This is the Gaussian inside sharpen / glow / drop shadow and the batch pipeline since round 5."""
+    w, h = size
+    img = I.random_rgba(w, h, 31 + w + int(sigma * 10)) if (w + h) % 3 else I.create_test_gradient(w, h)
+    ref = oracle.gaussian_blur(img, sigma)
+    gpu.r.set_exact(True)
+    try:
+        fused = gpu.r.blur_rgba(img, sigma)
+        gpu.r.tune("gauss_fused_exact", 0)
+        try:
+            two = gpu.r.blur_rgba(img, sigma)
+        finally:
+            gpu.r.tune("gauss_fused_exact", 1)
+    finally:
+        gpu.r.set_exact(False)
+    assert np.array_equal(fused, two), f"sigma {sigma} {size}: fused differs from the two kernels on {int((fused != two).any(-1).sum())} px"
+    assert_same(fused, ref, 0, f"exact gaussian sigma {sigma} {size}")

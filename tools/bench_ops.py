@@ -75,6 +75,8 @@ def main() -> int:
     timed("gaussian sigma=16 (matrix cores)", ["gauss_mfma"], lambda: r.gaussian_blur_dev(s, d, w, h, 16.0, t), px, 8, "fused H+V strip walk on v_mfma_f32_32x32x16_f16")
     r.set_exact(True)
     timed("gaussian sigma=16 (exact, no FMA)", ["gauss_h", "gauss_v"], lambda: r.gaussian_blur_dev(s, d, w, h, 16.0, t), px, 8, "bit-exact mode")
+    timed("gaussian sigma=1 (exact: fused)", ["gauss_fused"], lambda: r.gaussian_blur_dev(s, d, w, h, 1.0, t), px, 8, "bit-exact mode, both passes in one kernel (radii 1 .. 16): what sharpen / glow / drop shadow run")
+    timed("gaussian sigma=4 (exact: fused)", ["gauss_fused"], lambda: r.gaussian_blur_dev(s, d, w, h, 4.0, t), px, 8, "bit-exact mode, radius 12 (fused up to 16)")
     r.set_exact(False)
     timed("gaussian sigma=4", ["gauss_mfma"], lambda: r.gaussian_blur_dev(s, d, w, h, 4.0, t), px, 8)
     timed("hsl(30,-20,10)", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "hsl", [30.0, -20.0, 10.0]), px, 8)
