@@ -766,7 +766,8 @@ int g_box_px_force = 0, g_box_py_force = 0; // development sweep (pfx_tune "box_
 extern "C" void pfxk_box_set_force(int px, int py) { if (px >= 0) g_box_px_force = px; if (py >= 0) g_box_py_force = py; }
 int g_box_two_pass = 0; // pfxk_box_set_two_pass: keep the u8 intermediate in HBM (the pre-fusion path; A/B and parity tests)
 extern "C" void pfxk_box_set_two_pass(int on) { g_box_two_pass = on; }
-int g_box_strip = 1, g_box_strip_fill = 100, g_box_strip_nseg = 0; // pfxk_box_set_strip: the fused strip walk for radii 5 .. BS_MAXR (0 = two passes); chip fill in % of one wave of workgroups; forced segment count
+int g_box_strip = 2, g_box_strip_fill = 100, g_box_strip_nseg = 0; // pfxk_box_set_strip: 2 (default) = the fused strip walk for radii 1 .. BS_MAXR (8K r = 1 .. 4: 0.085-0.098 ms against the 64 x 64 tile kernel's 0.095-0.102),
+                                                                    // 1 = the tile kernel up to BF_MAXR and the strip walk above, 0 = tile kernel / two passes; chip fill in % of one round of workgroups; forced segment count
 extern "C" void pfxk_box_set_strip(int on, int fill, int nseg) { if (on >= 0) g_box_strip = on; if (fill > 0) g_box_strip_fill = fill; if (nseg >= 0) g_box_strip_nseg = nseg; }
 extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst,
                                     const uint8_t* d_mask, int radius, uint32_t w, uint32_t h, int force_two_pass)
@@ -775,7 +776,7 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
     const uint32_t d = (uint32_t)(2 * radius + 1);
     if (d >= 4096u) return hipErrorInvalidValue;
     const uint32_t magic = (uint32_t)((0x100000000ull / d) + 1ull), half = d / 2u;
-    if (radius <= BF_MAXR && g_box_two_pass == 0 && !force_two_pass && d_src != d_dst) { // small radii: both passes in one kernel (the halo recomputation stays below 1.6x)
+    if (radius <= BF_MAXR && g_box_strip != 2 && g_box_two_pass == 0 && !force_two_pass && d_src != d_dst) { // small radii: both passes in one kernel (the halo recomputation stays below 1.6x)
         const int side = BF_T + 2 * radius;
         const size_t lds = (size_t)(side * (side | 1) + side * (BF_T + 1)) * 4;
         auto go = [&](auto rc) -> hipError_t {
@@ -794,7 +795,7 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
         default: break;   // radius 0 never reaches the kernels (pfx_api.cpp copies); fall through to the two-pass path
         }
     }
-    if (radius > BF_MAXR && radius <= BS_MAXR && g_box_strip && g_box_two_pass == 0 && !force_two_pass && d_src != d_dst && (uint64_t)w * h < (1ull << 29)) { // fused strip walk, no intermediate in HBM
+    if ((radius > BF_MAXR || g_box_strip == 2) && radius >= 1 && radius <= BS_MAXR && g_box_strip && g_box_two_pass == 0 && !force_two_pass && d_src != d_dst && (uint64_t)w * h < (1ull << 29)) { // fused strip walk, no intermediate in HBM
         const int RR = 2 * radius + 1 + BS_RB;
         const size_t lds = (size_t)(((RR * BS_RP + 3) & ~3) + 4 * 2 * bs_pp(radius)) * 4;   // the ring, then two rows of prefix pairs per wave on a 16-byte boundary
         const int strips = (int)((w + BS_W - 1) / BS_W);

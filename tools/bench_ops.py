@@ -86,8 +86,8 @@ def main() -> int:
     lut = np.tile(np.arange(255, -1, -1, dtype=np.uint8), (4, 1))
     timed("levels/curves LUT apply", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "lut_rgba", lut=lut), px, 8)
     timed("vibrance", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "vibrance", [50.0]), px, 8)
-    timed("box blur r=3", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 3.0), px, 8, "both passes in one kernel on 64 x 64 tiles (r <= 4)")
-    timed("box blur r=9", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 9.0), px, 8, "fused column-strip walk, u8 intermediate in an LDS ring (radii 5 .. 60)")
+    timed("box blur r=3", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 3.0), px, 8, "fused column-strip walk (radii 1 .. 60)")
+    timed("box blur r=9", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 9.0), px, 8, "fused column-strip walk, u8 intermediate in an LDS ring")
     timed("box blur r=48", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 48.0), px, 8, "fused column-strip walk")
     timed("median r=1", ["median"], lambda: r.median_dev(s, d, w, h, 1), px, 8)
     timed("median r=2", ["median"], lambda: r.median_dev(s, d, w, h, 2), px, 8)
