@@ -37,9 +37,11 @@ PFX_DEV float4 gf_px(uint32_t px) { return make_float4(ubyte0(px), ubyte1(px), u
 __host__ __device__ constexpr int gf_src_pitch(int r) { const int n = GF_W + 2 * r + GF_XPAD; return n + ((5 - (n & 3)) & 3); }   // = 1 (mod 4): the four rows of a wave start in different banks
 // R is a template parameter: the tap loops are straight-line code over exactly the 2R + 1 taps of each of a lane's four outputs (the generic kernels' register
 // blocking pads every output to a multiple of four taps with zero weights: 40 % of the multiply-adds at R = 3), the weights sit in scalar registers.
-template <int R>
+// EPI: what leaves the vertical pass — 0 the blurred pixel; 1 / 2 the sharpen / glow combine of the SOURCE pixel with it (stylize.rs:135-137 / :60-64, k_effects.hip's
+// combine_kernel word for word: the blurred value enters rounded to u8, as it would from a buffer; alpha from the source; an unselected pixel keeps the source)
+template <int R, int EPI>
 __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const float* __restrict__ wts,
-                                                                int w, int h, int seg_rows, int nseg, int strips)
+                                                                int w, int h, int seg_rows, int nseg, int strips, const uint8_t* __restrict__ mask, float p0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t gf_lds[];
     const int tid = (int)threadIdx.x;
@@ -155,7 +157,28 @@ __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t*
                 }
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
-                    if (yo + o >= y0 && yo + o < y1) dst[(size_t)(yo + o) * w + x] = pack_round_rgba(acc[o].x, acc[o].y, acc[o].z, acc[o].w); // filters.rs:308-311
+                    if (yo + o >= y0 && yo + o < y1) {
+                        const size_t oi = (size_t)(yo + o) * w + x;
+                        const uint32_t b = pack_round_rgba(acc[o].x, acc[o].y, acc[o].z, acc[o].w); // filters.rs:308-311
+                        if constexpr (EPI == 0) dst[oi] = b;
+                        else {
+                            const uint32_t sp = src[oi];
+                            uint32_t px = sp;
+                            if (!(mask && mask[oi] == 0)) {
+                                float e[3];
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) {
+                                    const float sv = (float)((sp >> (8 * c)) & 0xffu), bv = (float)((b >> (8 * c)) & 0xffu);
+                                    if constexpr (EPI == 1) e[c] = sv + p0 * (sv - bv);
+                                    else { const float sn = div255(sv), bn = div255(bv); e[c] = (1.0f - (1.0f - sn) * (1.0f - bn * p0)) * 255.0f; }
+                                }
+                                px = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(e[0]), 0, sp);
+                                px = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(e[1]), 1, px);
+                                px = __builtin_amdgcn_cvt_pk_u8_f32(round_tie_prep(e[2]), 2, px);
+                            }
+                            dst[oi] = px;
+                        }
+                    }
             }
         }
         if (more) stage_store();   // s_src was last read before the barrier above; the next horizontal pass waits for the barrier at the loop's top
@@ -169,7 +192,8 @@ __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t*
 int g_fused_exact = 1; // pfxk_gauss_set_fused_exact (pfx_tune "gauss_fused_exact"): 0 = the bit-exact mode always through the two kernels (A/B, parity tests)
 extern "C" void pfxk_gauss_set_fused_exact(int on) { g_fused_exact = on; }
 extern "C" int pfxk_gauss_fused_exact_max_radius(void) { return g_fused_exact ? GF_MAXR : 0; }
-extern "C" hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h)
+extern "C" hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h,
+                                             int epilogue /* 0 blur, 1 sharpen, 2 glow */, float p0, const uint8_t* d_mask)
 {
     if (w == 0 || h == 0) return hipSuccess;
     if (radius < 1 || radius > GF_MAXR) return hipErrorInvalidValue;
@@ -183,13 +207,18 @@ extern "C" hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* 
     nseg = std::min(nseg, std::max(1, (int)h / (8 * radius + 64)));
     const int seg_rows = ((int)h + nseg - 1) / nseg;
     nseg = ((int)h + seg_rows - 1) / seg_rows;
-    auto go = [&](auto rc) -> hipError_t {
-        constexpr int R = decltype(rc)::value;
-        hipError_t e = hipFuncSetAttribute((const void*)gauss_fused_exact_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto go2 = [&](auto rc, auto ec) -> hipError_t {
+        constexpr int R = decltype(rc)::value, E = decltype(ec)::value;
+        hipError_t e = hipFuncSetAttribute((const void*)gauss_fused_exact_kernel<R, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e) return e;
-        gauss_fused_exact_kernel<R><<<dim3(8u * (uint32_t)(sg_max * nseg)), GF_T, lds, stream>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h,
-                                                                                                 seg_rows, nseg, strips);
+        gauss_fused_exact_kernel<R, E><<<dim3(8u * (uint32_t)(sg_max * nseg)), GF_T, lds, stream>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h,
+                                                                                                    seg_rows, nseg, strips, d_mask, p0);
         return hipGetLastError();
+    };
+    auto go = [&](auto rc) -> hipError_t {
+        if (epilogue == 1) return go2(rc, std::integral_constant<int, 1>{});
+        if (epilogue == 2) return go2(rc, std::integral_constant<int, 2>{});
+        return go2(rc, std::integral_constant<int, 0>{});
     };
     static_assert(GF_MAXR == 16, "gauss_fused_exact_kernel is instantiated for radii 1 .. 16");
     switch (radius) {

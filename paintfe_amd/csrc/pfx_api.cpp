@@ -427,6 +427,29 @@ int pfx_int_flatten_with_chunk_keys_dev(pfx_ctx* ctx, const void* const* layer_p
     return flatten_common(ctx, layer_ptrs_dev, nullptr, layers, n_layers, w, h, false, dst_dev, nullptr, nullptr, chunk_keys_host);
 }
 
+// sharpen / glow with the Gaussian and the combine in ONE kernel (k_gauss_exact.hip, epilogue 1 / 2) where the bit-exact fused Gaussian applies: radius 1 .. 16,
+// distinct buffers, exact mode.  Returns 1 when it ran, 0 when the caller has to take the two-step path, < 0 on error.
+int pfx_int_gauss_exact_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, int epilogue, float p0, const void* mask_dev)
+{
+    const int radius = pfx_host_gaussian_radius(sigma);
+    if (!ctx->exact || radius < 1 || radius > pfxk_gauss_fused_exact_max_radius() || src_dev == dst_dev || ranges_overlap(src_dev, dst_dev, img_bytes(w, h))) return 0;
+    uint32_t sigma_bits; std::memcpy(&sigma_bits, &sigma, 4);
+    const int pad = pfxk_gauss_weight_pad();
+    if (!ctx->wts_valid || ctx->wts_sigma_bits != sigma_bits) {
+        std::vector<float> k;
+        pfx_host_gaussian_kernel(sigma, k);
+        std::vector<float> padded(k.size() + 2 * (size_t)pad, 0.0f);
+        std::copy(k.begin(), k.end(), padded.begin() + pad);
+        PFX_TRY(pfx_reserve(ctx, ctx->d_wts, padded.size() * sizeof(float)));
+        PFX_TRY(pfx_h2d(ctx, ctx->d_wts.p, padded.data(), padded.size() * sizeof(float)));
+        ctx->wts_sigma_bits = sigma_bits;
+        ctx->wts_valid = true;
+    }
+    PFX_HIP(ctx, pfxk_gauss_fused_exact(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const float*)ctx->d_wts.p + pad, radius, w, h, epilogue, p0,
+                                        (const uint8_t*)mask_dev));
+    return 1;
+}
+
 int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, void* tmp_dev)
 {
     return pfx_gaussian_blur_band_dev(ctx, src_dev, dst_dev, w, h, sigma, tmp_dev, 0);
@@ -474,7 +497,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
     if (ctx->exact && radius >= 1 && radius <= pfxk_gauss_fused_exact_max_radius() && src_dev != dst_dev) {
         // bit-exact mode at small radii (what sharpen / glow / drop shadow and the batch pipeline run): both passes in one kernel, no f32 intermediate in HBM
         pfx_timer t(ctx, "gauss_fused");
-        PFX_HIP(ctx, pfxk_gauss_fused_exact(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, wts, radius, w, h));
+        PFX_HIP(ctx, pfxk_gauss_fused_exact(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, wts, radius, w, h, 0, 0.0f, nullptr));
         return PFX_OK;
     }
     if (!tmp_dev) {
