@@ -595,6 +595,14 @@ class GpuRenderer:
         self._check(self._lib.pfx_adjust_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
                                              C.c_int(opi), arr, n, _p(l), C.c_void_p(mask_ptr or None), C.c_int(sparse)))
 
+    def sharpen_dev(self, src_ptr, dst_ptr, w, h, amount, radius, mask_ptr=0):
+        self._check(self._lib.pfx_sharpen_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h), C.c_float(amount), C.c_float(radius),
+                                              C.c_void_p(mask_ptr or None)))
+
+    def glow_dev(self, src_ptr, dst_ptr, w, h, radius, intensity, mask_ptr=0):
+        self._check(self._lib.pfx_glow_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h), C.c_float(radius), C.c_float(intensity),
+                                           C.c_void_p(mask_ptr or None)))
+
     def box_blur_dev(self, src_ptr, dst_ptr, w, h, radius, mask_ptr=0, tmp_ptr=0):
         self._check(self._lib.pfx_box_blur_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
                                                C.c_float(radius), C.c_void_p(mask_ptr or None), C.c_void_p(tmp_ptr or None)))
