@@ -1068,6 +1068,38 @@ __global__ __launch_bounds__(64) PFX_SRT_ATTR void flatten_srt_kernel(const pfxk
     }
 }
 
+// Does dead-layer elimination pay on this stack?  (Stacks below the depth threshold: the class-sorting kernel wins where reset layers are spatially coherent — an
+// opaque photo layer covers whole units, which then start at that layer and read nothing below — and loses on per-pixel-random alpha, where every unit is split.)
+// One workgroup samples 256 units spread over the image against the topmost candidate and writes its verdict to pinned host memory, where a LATER composite of
+// the same stack reads it (pfx_api.cpp: flatten_common; the decision is a performance hint, every kernel is bit-exact).
+__global__ __launch_bounds__(1024) void dle_probe_kernel(const pfxk_layer_desc* __restrict__ layers, uint32_t cand_layer, uint32_t cand_kind, uint32_t n_px,
+                                                         uint32_t* __restrict__ verdict_pinned, uint32_t tag)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t units = (n_px + 191u) / 192u, bytes = n_px * 4u;
+    const pfx_v4i ra = make_rsrc(layers[cand_layer].pixels, bytes, PFX_RSRC_ALPHA8);
+    uint32_t good = 0u;
+#pragma unroll 4
+    for (uint32_t k = 0; k < 16u; ++k) {
+        const uint32_t u = (uint32_t)(((uint64_t)(wave * 16u + k) * units) / 256u);   // 256 sample units, evenly spaced
+        bool all_hit = true;
+#pragma unroll
+        for (uint32_t j = 0; j < 3u; ++j) {
+            const uint32_t px = u * 192u + 64u * j + lane;
+            const float a = pfx_buffer_load_format_f32(ra, (int)(px * 4u), 0, 0);       // past the image: 0 = "transparent"; the last unit may count as mixed
+            all_hit = all_hit && (px >= n_px || (cand_kind ? (a == 1.0f) : (a != 0.0f)));
+        }
+        good += __all(all_hit) ? 1u : 0u;
+    }
+    if (lane == 0) atomicAdd(&s_cnt, good);
+    __syncthreads();
+    // at least half of the units start at the candidate outright: the elimination kernel skips everything below it there and pays its classification elsewhere
+    if (threadIdx.x == 0) *verdict_pinned = tag | (s_cnt * 2u >= 256u ? 0x80000000u : 0u);
+}
+
 // float -> UNORM8 conversion of the typed store / UNORM8 -> float of the typed load against the arithmetic the kernels assume: for every byte
 // value k and channel, storing RN(k / 255) must write k and loading k must return RN(k / 255).  out[0] += mismatches
 __global__ __launch_bounds__(256) void unorm_store_check_kernel(uint8_t* __restrict__ scratch /* 1024 bytes */, unsigned long long* out)
@@ -1283,6 +1315,12 @@ extern "C" void pfxk_flatten_set_dle_plan(int kernel, int s1, int s2)
     if (kernel >= 0) g_dle_kernel = kernel;
     if (s1 >= -1) g_dle_s1 = s1;
     if (s2 >= -1) g_dle_s2 = s2;
+}
+extern "C" hipError_t pfxk_dle_probe(hipStream_t s, const pfxk_layer_desc* d_layers, uint32_t cand_layer, uint32_t cand_kind, uint32_t n_px, uint32_t* verdict_pinned,
+                                     uint32_t tag)
+{
+    dle_probe_kernel<<<1, 1024, 0, s>>>(d_layers, cand_layer, cand_kind, n_px, verdict_pinned, tag);
+    return hipGetLastError();
 }
 extern "C" hipError_t pfxk_unorm_store_check(hipStream_t s, uint8_t* d_scratch1k, unsigned long long* d_out)
 {

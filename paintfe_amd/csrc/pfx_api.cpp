@@ -157,7 +157,7 @@ struct preview_arg {
 int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* mask_ptrs, const pfx_layer_info* layers,
                 uint32_t n, uint32_t w, uint32_t h, bool from_store, uint32_t* n_desc, bool* general, bool* has_adj,
                 uint32_t track_info = 0xFFFFFFFFu, uint32_t* track_pos = nullptr, const uint8_t** track_pixels = nullptr,
-                pfxk_dle_cands* cands = nullptr, std::vector<uint8_t>* chunk_meta = nullptr)
+                pfxk_dle_cands* cands = nullptr, std::vector<uint8_t>* chunk_meta = nullptr, bool* shallow = nullptr)
 {
     std::vector<const uint8_t*> flag_ptrs; // per descriptor: the stored layer's chunk alpha summary (NULL: none)
     std::vector<pfxk_layer_desc> desc;
@@ -245,7 +245,8 @@ int build_stack(pfx_ctx* ctx, const void* const* layer_ptrs, const void* const* 
         // stream is less efficient than the plain streaming kernel's (4.7 against 5+ TB/s with the arithmetic taken out): it pays where the
         // blend arithmetic dominates — deep stacks — and loses up to 30 % on shallow, memory-bound ones (tools/ab_docs_dle.py: nine Normal
         // layers with S2's alpha 0.43 against 0.33 ms).  Stacks below 16 layers keep the plain kernel (pfx_tune "dle_min_layers").
-        if (desc.size() < (size_t)ctx->dle_min_layers) found.clear();
+        // ... unless the caller can decide per stack (flatten_common: a probe of the candidate's alpha, `shallow` tells it the threshold applied)
+        if (desc.size() < (size_t)ctx->dle_min_layers) { if (shallow && ctx->dle_adaptive) *shallow = true; else found.clear(); }
         const size_t kmax = std::min<size_t>(PFXK_DLE_MAX, std::max<size_t>(1, desc.size() / 6));
         const size_t first = found.size() > kmax ? found.size() - kmax : 0;
         for (size_t k = first; k < found.size(); ++k) {
@@ -298,8 +299,26 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
     bool general = false, has_adj = false;
     pfxk_dle_cands cands{};
     std::vector<uint8_t> chunk_meta;
+    bool shallow = false;
     PFX_TRY(build_stack(ctx, layer_ptrs, mask_ptrs, layers, n_layers, w, h, from_store, &n_desc, &general, &has_adj,
-                        pv ? pv->info.active_layer : 0xFFFFFFFFu, &active_pos, &active_pixels, &cands, from_store ? &chunk_meta : nullptr));
+                        pv ? pv->info.active_layer : 0xFFFFFFFFu, &active_pos, &active_pixels, &cands, from_store ? &chunk_meta : nullptr,
+                        from_store ? nullptr : &shallow));
+    bool probe_now = false;
+    uint32_t probe_layer = 0, probe_kind = 0;
+    if (shallow && cands.n > 0) {
+        // Below the depth threshold the elimination kernel runs only where a probe of THIS stack found its topmost reset layer coherent (an opaque photo layer,
+        // a filled background above old layers: most units start there and read nothing below; per-pixel-random alpha splits every unit and loses 30 %).  The
+        // probe runs once per stack, behind the composite that found none, and reports through pinned memory: later composites of the same stack use it.
+        const bool usable = !general && !region && !(pv && pv->d_pixels) && (uint64_t)w * h < (1ull << 30);
+        std::vector<uint8_t> key(ctx->desc_cache);
+        key.insert(key.end(), (const uint8_t*)&w, (const uint8_t*)&w + 4); key.insert(key.end(), (const uint8_t*)&h, (const uint8_t*)&h + 4);
+        const bool same = ctx->dle_probe_state != 0 && key == ctx->dle_probe_key;
+        if (same && ctx->dle_probe_state == 1 && hipEventQuery(ctx->ev_dle_probe) == hipSuccess)
+            ctx->dle_probe_state = *ctx->h_dle_verdict == (ctx->dle_probe_tag | 0x80000000u) ? 2 : 3;
+        if (usable && !same) { probe_now = true; ctx->dle_probe_key.swap(key); ctx->dle_probe_state = 0; }
+        probe_layer = cands.layer[cands.n - 1u]; probe_kind = cands.kind[cands.n - 1u];
+        if (!(usable && same && ctx->dle_probe_state == 2)) cands.n = 0;   // the plain streaming kernel
+    }
     const size_t nchunks = (size_t)((w + 63) / 64) * ((h + 63) / 64);
     uint8_t* d_chunks = nullptr;
     bool chunks_ready = false;
@@ -371,10 +390,23 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
         }
         parking_ok = ctx->unorm_store_ok == 1;
     }
-    pfx_timer t(ctx, "flatten");
-    PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
-                              general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region, &cands, d_chunk_start,
-                              parking_ok, ctx->stack_mode_class));
+    {
+        pfx_timer t(ctx, "flatten");
+        PFX_HIP(ctx, pfxk_flatten(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, n_desc, (const float*)ctx->d_adj.p,
+                                  general ? 1 : 0, fast_div ? 1 : 0, d_chunks, chunks_ready ? 1 : 0, w, h, (uint8_t*)dst_dev, PV.pixels ? &PV : nullptr, region, &cands, d_chunk_start,
+                                  parking_ok, ctx->stack_mode_class));
+    }
+    if (probe_now) {   // behind the composite (it may have been in place: the probe reads layers, and a layer that was the destination now holds the result — a hint all the same)
+        if (!ctx->h_dle_verdict) {
+            PFX_HIP(ctx, hipHostMalloc((void**)&ctx->h_dle_verdict, sizeof(uint32_t), hipHostMallocDefault));
+            *ctx->h_dle_verdict = 0;
+            PFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dle_probe, hipEventDisableTiming));
+        }
+        ctx->dle_probe_tag = (ctx->dle_probe_tag + 1u) & 0x7fffffffu;
+        PFX_HIP(ctx, pfxk_dle_probe(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, probe_layer, probe_kind, (uint32_t)((size_t)w * h), ctx->h_dle_verdict, ctx->dle_probe_tag));
+        PFX_HIP(ctx, hipEventRecord(ctx->ev_dle_probe, ctx->stream));
+        ctx->dle_probe_state = 1;
+    }
     return PFX_OK;
 }
 
@@ -1335,6 +1367,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "box_py") == 0) { pfxk_box_set_force(-1, value); return PFX_OK; }
     if (std::strcmp(key, "box_px_switch") == 0) { pfxk_box_set_switch(value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_py_switch") == 0) { pfxk_box_set_switch(-1, value); return PFX_OK; }
+    if (std::strcmp(key, "dle_adaptive") == 0) { ctx->dle_adaptive = value != 0; ctx->dle_probe_state = 0; return PFX_OK; }   // 0 = shallow stacks never take the elimination kernel
     if (std::strcmp(key, "gauss_fused_exact") == 0) { pfxk_gauss_set_fused_exact(value); return PFX_OK; }  // 0 = the bit-exact Gaussian always through the two kernels
     if (std::strcmp(key, "mesh_xcd") == 0) { pfxk_warp_set_mesh_xcd(value); return PFX_OK; }            // 0 = the fused mesh warp's plain 2-D tile order
     if (std::strcmp(key, "box_strip") == 0) { pfxk_box_set_strip(value, 0, -1); return PFX_OK; }          // 0 = radii >= 5 through the two-pass kernels

@@ -129,6 +129,8 @@ void pfx_ctx_destroy(pfx_ctx* ctx)
     for (auto* b : bufs) free_buf(*b);
     if (ctx->h_chunk_useful) (void)hipHostFree(ctx->h_chunk_useful);
     if (ctx->ev_chunk_useful) (void)hipEventDestroy(ctx->ev_chunk_useful);
+    if (ctx->h_dle_verdict) (void)hipHostFree(ctx->h_dle_verdict);
+    if (ctx->ev_dle_probe) (void)hipEventDestroy(ctx->ev_dle_probe);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -54,6 +54,15 @@ struct pfx_ctx {
     // composite of the same stack once `ev_chunk_useful` has fired — 0 = not built, 1 = pending, 2 = useful (table kept), 3 = useless (no table)
     uint32_t* h_chunk_useful = nullptr;
     hipEvent_t ev_chunk_useful = nullptr;
+    // shallow stacks (below dle_min_layers) with a reset layer: whether the elimination kernel pays depends on how coherent the reset layer's alpha is, which a
+    // probe kernel samples once per stack; its verdict arrives through pinned memory and is used from a later composite of the same stack on
+    // 0 = no probe, 1 = pending, 2 = elimination pays, 3 = it does not
+    int dle_probe_state = 0;
+    uint32_t* h_dle_verdict = nullptr;
+    uint32_t dle_probe_tag = 0;
+    hipEvent_t ev_dle_probe = nullptr;
+    std::vector<uint8_t> dle_probe_key;   // the probed stack's descriptors + size
+    bool dle_adaptive = true;             // pfx_tune "dle_adaptive"
     uint32_t chunk_tag = 0;
     int chunk_state = 0;
     uint64_t store_epoch = 0, chunk_epoch = 0;  // store_epoch moves whenever a stored layer's pixels or mask change

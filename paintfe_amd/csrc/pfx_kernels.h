@@ -66,6 +66,8 @@ hipError_t pfxk_chunk_alpha_flags(hipStream_t s, const uint8_t* d_px, uint32_t w
 hipError_t pfxk_chunk_start(hipStream_t s, const uint8_t* const* d_flag_ptrs, const uint8_t* d_want, uint32_t n_layers, uint32_t n_chunks,
                             uint8_t* d_start, uint32_t* useful_pinned /* may be NULL: receives `tag` if any chunk starts above layer 0 */, uint32_t tag);
 void       pfxk_flatten_set_dle(int units_per_wave /* 0 = default, < 0 = keep */, int ring_log2 /* 10 | 11, else keep */);
+/* samples 256 units against the topmost reset candidate; *verdict_pinned = tag | 0x80000000 when at least half start at it outright (k_flatten.hip: dle_probe_kernel) */
+hipError_t pfxk_dle_probe(hipStream_t s, const pfxk_layer_desc* d_layers, uint32_t cand_layer, uint32_t cand_kind, uint32_t n_px, uint32_t* verdict_pinned, uint32_t tag);
 hipError_t pfxk_flatten_dle_stats(unsigned long long* out16 /* may be NULL */, int reset); // synchronises the device
 void       pfxk_flatten_set_dle_dev(int stats_on /* < 0 keep */, int cfg /* < 0 keep */);
 void       pfxk_flatten_set_dle_sched(int sched /* 0 equal streams, 1 shrinking */, int fracA, int fracB); // < 0 keeps

@@ -432,3 +432,50 @@ def test_in_place_flatten_on_every_kernel_and_partial_overlap_refused(gpu, which
         r.dev_free(big)
         if which == "general":
             r.dev_free(mbuf)
+
+
+def test_shallow_stacks_take_the_elimination_kernel_only_where_a_probe_found_the_reset_layer_coherent():
+    """Below the depth threshold (16 layers) pfx_flatten_dev decides per stack: the first composite runs the streaming kernel and a probe of the topmost reset
+    layer's alpha behind it; from a later composite of the SAME stack on, the class-sorting kernel runs where at least half of the sampled units start at that layer
+    outright (an opaque photo layer) and never where its alpha is per-pixel random.  Whatever runs, the result is the oracle's."""
+    from paintfe_amd import GpuRenderer
+    r = GpuRenderer(0)                      # its own context: default threshold, no verdicts yet
+    rng = np.random.default_rng(99)
+    w, h, n = 640, 360, 9
+    stack = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    for k in range(1, n):
+        stack[k, ..., 3] = noise_alpha(rng, h, w, 0.3, 0.3)
+    stack[0, ..., 3] = 255
+    modes = [NORMAL, 1, 2, 8, 5, NORMAL, 1, 2, 8]
+    opac = [1.0] * n
+    bufs = [r.dev_alloc(w * h * 4) for _ in range(n + 1)]
+
+    def composite_and_count(calls):
+        ref = O.flatten_stack(stack, np.asarray(modes, np.uint8), np.asarray(opac, np.float32))
+        for k in range(n):
+            r.dev_upload(bufs[k], stack[k])
+        info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+        used = []
+        for _ in range(calls):
+            r.flatten_stats(reset=True)
+            r.flatten_dev(bufs[:n], info, w, h, bufs[n])
+            assert np.array_equal(r.dev_download(bufs[n], (h, w, 4)), ref)
+            used.append(r.flatten_stats(reset=True)["nat_units"] > 0)   # units the elimination kernel walked
+        return used
+
+    r.tune("dle_stats", 1)
+    try:
+        stack[5, ..., 3] = 255                                        # layer 5: an opaque photo (Normal at 100 %)
+        used = composite_and_count(4)
+        assert used[0] is False and used[-1] is True, used              # streaming first, elimination once the verdict is in
+        stack[5, ..., 3] = noise_alpha(rng, h, w, 0.3, 0.3)           # the same stack, new pixels: the verdict is a hint, the result still exact
+        assert composite_and_count(1) == [True]
+        opac[6] = 0.5                                                  # another stack (a descriptor differs): probed afresh, per-pixel-random alpha: never
+        assert composite_and_count(4) == [False, False, False, False]
+        r.tune("dle_adaptive", 0)
+        opac[6] = 1.0; stack[5, ..., 3] = 255
+        assert composite_and_count(3) == [False, False, False]
+    finally:
+        r.tune("dle_stats", 0)
+        for b in bufs:
+            r.dev_free(b)
