@@ -644,6 +644,17 @@ def main() -> int:
                 state["gathered_ok"] = True
             except Exception as e:  # noqa: BLE001
                 state["gather_error"] = f"{type(e).__name__}: {e}"[:500]
+        # per-rank phase clocks of one unpipelined step (flatten / halo exchange / filter / gather): where a rank's time goes on real links
+        if not state.get("band_error"):
+            try:
+                pipe.gather = not args.no_gather and not state.get("gather_error")
+                ph = pipe.phase_probe(ptrs, info)
+                mine = torch.tensor([ph["flatten"], ph["halo_exchange"], ph["filter"], ph["gather"]], dtype=torch.float64, device=None if backend == "gloo" else device)
+                every = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                state["phase_ms_per_rank"] = [dict(zip(("flatten", "halo_exchange", "filter", "gather"), [round(float(v), 4) for v in t.tolist()])) for t in every]
+            except Exception as e:  # noqa: BLE001 — diagnostics only
+                state["phase_probe_error"] = f"{type(e).__name__}: {e}"[:300]
         # the collective-free mode in the same run (one independent 8K document per rank), reported beside the headline
         del stack
         torch.cuda.empty_cache()
@@ -750,7 +761,9 @@ def main() -> int:
     if world > 1:
         out["ranks"] = {"world_size": dist.get_world_size(), "backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend,
                         "devices_visible": torch.cuda.device_count(),
-                        "per_rank_ms_per_step": state.get("headline_per_rank", state.get("per_rank_ms_per_step"))}
+                        "per_rank_ms_per_step": state.get("headline_per_rank", state.get("per_rank_ms_per_step")),
+                        **({"phase_ms_per_rank": state["phase_ms_per_rank"]} if state.get("phase_ms_per_rank") else {}),
+                        **({"phase_probe_error": state["phase_probe_error"]} if state.get("phase_probe_error") else {})}
     if doc_mode:
         out["doc_mode"] = doc_mode
     if band_mode and band_gathered:

@@ -317,6 +317,35 @@ class BandPipeline:
             self.pending[s] = dist.all_gather_into_tensor(self.slots[s], send, group=self.group, async_op=True)
         return self.slots[s]
 
+    def phase_probe(self, layer_ptrs, info):
+        """ONE unpipelined step with events around its phases (a collective: every rank calls it): ms of flatten, of the halo exchange as this rank's stream sees it
+        (send / receive + waiting for the neighbours' flattens), of the band filter and — over RCCL, when the pipeline gathers — of the all-gather.  What a first run
+        on a real multi-GPU node should print per rank beside the step time (bench.py: ranks.phase_ms_per_rank)."""
+        import torch
+        import torch.distributed as dist
+
+        self.finish()
+        pad, blurred = self.padded_sets[0], self.blurred[0]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        ev[0].record()
+        if self.rows:
+            self.r.flatten_dev(list(layer_ptrs), info, self.w, self.rows, pad[self.top:].data_ptr())
+        ev[1].record()
+        for req in self._start_exchange(pad):
+            req.wait()
+        ev[2].record()
+        if self.rows:
+            self._filter(pad, blurred)
+        ev[3].record()
+        if self.gather and dist.get_backend(self.group) != "gloo":
+            dist.all_gather_into_tensor(self.slots[0], blurred[self.top:self.top + self.max_rows], group=self.group, async_op=True).wait()
+        ev[4].record()
+        torch.cuda.synchronize()
+        names = ("flatten", "halo_exchange", "filter", "gather")
+        return {k: round(ev[i].elapsed_time(ev[i + 1]), 4) for i, k in enumerate(names)}
+
     def finish(self):
         """order the current stream behind every all-gather still in flight and flush a pipelined step (the host does not block)"""
         self._complete_inflight()

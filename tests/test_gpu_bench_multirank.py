@@ -41,6 +41,8 @@ def test_band_mode_is_the_default_and_matches_single_process(nproc):
     assert d["scaling"] == "strong" and d["n_gpus"] == nproc and "stays sharded" in d["config"]["sharding"]
     assert d["ranks"]["world_size"] == nproc and len(d["ranks"]["per_rank_ms_per_step"]) == nproc and all(t > 0 for t in d["ranks"]["per_rank_ms_per_step"])
     assert d["check"]["band_blur_max_diff_vs_oracle"] == 0  # exact Gaussian: bit-identical to the unsharded pipeline
+    ph = d["ranks"]["phase_ms_per_rank"]                     # one unpipelined step's phases per rank (BandPipeline.phase_probe)
+    assert len(ph) == nproc and all(p["flatten"] > 0 and p["filter"] > 0 and p["halo_exchange"] >= 0 for p in ph)
     assert abs(d["value"] - 640 * 400 / d["ms_per_step"] / 1e3) / d["value"] < 0.01  # ONE document per step for the whole job
     assert d["doc_mode"]["scaling"] == "weak" and d["doc_mode"]["value"] > 0
     # the headline leaves the blurred result sharded (halo exchange only); the same pipeline + an all-gather into every rank is timed beside it
