@@ -16,7 +16,7 @@ ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 r = GpuRenderer(0)
 t_end = time.time() + a.seconds
-counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0}
+counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0, "sharpen_glow": 0}
 case = a.seed * 1000003
 
 
@@ -41,7 +41,7 @@ def alpha_plane(rng, w, h):
 while time.time() < t_end:
     case += 1
     rng = np.random.default_rng(case)
-    what = rng.integers(0, 11)
+    what = rng.integers(0, 12)
     try:
         if what < 6:
             w, h = int(rng.integers(1, 700)), int(rng.integers(1, 120))
@@ -72,6 +72,18 @@ while time.time() < t_end:
             finally:
                 r.set_exact(False)
             counts["gauss"] += 1
+        elif what == 11:   # sharpen / glow in the DEFAULT context mode (the library runs the bit-exact Gaussian inside them; small radii: Gaussian + combine in one kernel)
+            w, h = int(rng.integers(1, 700)), int(rng.integers(1, 300))
+            img = I.random_rgba(w, h, case) if rng.random() < 0.7 else I.create_test_gradient(w, h)
+            mask = None if rng.random() < 0.6 else ((rng.random((h, w)) < 0.5).astype(np.uint8) * 255)
+            radius = float(rng.choice([0.2, 0.5, 1.0, 1.7, 3.0, 4.9, 5.4, 8.0]))
+            if rng.random() < 0.5:
+                amount = float(rng.choice([-0.5, 0.3, 1.0, 2.5]))
+                if not np.array_equal(r.sharpen_core(img, amount, radius, mask), O.sharpen(img, amount, radius, mask)): raise AssertionError(f"sharpen {w}x{h} amount {amount} radius {radius}")
+            else:
+                inten = float(rng.choice([0.2, 0.5, 1.0, 1.7]))
+                if not np.array_equal(r.glow_core(img, radius, inten, mask), O.glow(img, radius, inten, mask)): raise AssertionError(f"glow {w}x{h} radius {radius} intensity {inten}")
+            counts["sharpen_glow"] += 1
         elif what == 10:   # box blur: the fused tile (r <= 4), the fused strip walk (r <= 60) and the two-pass kernels, with and without a selection
             w, h = int(rng.integers(1, 900)), int(rng.integers(1, 400))
             radius = float(rng.choice([0.6, 1.0, 2.0, 4.0, 4.5, 5.0, 7.0, 9.0, 13.0, 24.0, 37.0, 48.0, 60.0, 61.0, 90.0])) - (0.3 if rng.random() < 0.3 else 0.0)
