@@ -18,6 +18,10 @@
 #include "pfx_kernels.h"
 #include <type_traits>
 
+typedef int mb_v4i __attribute__((ext_vector_type(4)));
+__device__ void mb_buffer_store_i8(uint8_t data, mb_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i8");
+__device__ uint8_t mb_buffer_load_i8(mb_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i8");
+
 namespace {
 using namespace pfxk;
 
@@ -206,7 +210,164 @@ __global__ __launch_bounds__(256) void median_bits_kernel(const uint8_t* __restr
     }
 }
 
+
+// ---- two adjacent columns per lane (radii 2..7) ----
+// The windows of columns x and x + 1 share 2r of their 2r + 1 columns.  A lane of this kernel owns one channel of a column PAIR: its plane registers
+// hold (2r + 2)-bit fields (the union of the two windows' columns) and both selects run on the same registers, each under its own candidate mask
+// (bits 0..2r of every field for x, bits 1..2r+1 for x + 1).  Fetching a row's fields from LDS and inserting them — as many instructions as before —
+// is paid once per two results, and so is the LDS traffic.  The field widths still pack as the single-column kernel's do (r = 3: four 8-bit fields
+// per register, r = 4: three of 10, r = 5..7: two of 16), so a select costs what it did; radius 8 (18-bit fields) stays on the kernel above.
+// The selects of the pair run one after the other in a two-trip loop (interleaving them buys nothing: tools/lab/select_chain.hip) so that the
+// code, unrolled over the 2r + 1 row slots, stays the size of the single-column kernel's.
+__device__ __forceinline__ mb_v4i mb_rsrc(const void* base, uint32_t bytes)
+{
+    const unsigned long long a = (unsigned long long)base;
+    mb_v4i r; r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = (int)(0xFACu | (7u << 12) | (4u << 15)); return r;
+}
+
+constexpr int MB2_COLS = 128; // columns per block: 4 waves x 16 pairs
+#ifndef PFX_MB2_ROWS
+#define PFX_MB2_ROWS 32
+#endif
+#ifndef PFX_MB2_KSEL
+#define PFX_MB2_KSEL 1       // the remaining rank by a bitop3 select (full rate) instead of v_min_u32
+#endif
+
+template <int R> struct mb2_geom {
+    static constexpr int S = 2 * R + 1;
+    static constexpr int FW = S + 1;                                          // field: the columns of both windows
+    static constexpr int RPR = FW <= 6 ? 5 : FW <= 8 ? 4 : FW <= 10 ? 3 : 2;  // rows per register (FW <= 16)
+    static constexpr int FO = 32 / RPR;
+    static constexpr int NR = (S + RPR - 1) / RPR;
+    static constexpr uint32_t FM = (1u << FW) - 1u;
+    static constexpr uint32_t cand_init(int reg)                              // window of column x; << 1 for x + 1
+    {
+        uint32_t m = 0;
+        for (int f = 0; f < RPR; ++f) if (reg * RPR + f < S) m |= ((1u << S) - 1u) << (f * FO);
+        return m;
+    }
+};
+
+template <int R, bool MASK>
+__global__ __launch_bounds__(256) void median_bits2_kernel(const uint8_t* __restrict__ src, const uint32_t* __restrict__ planes, uint8_t* __restrict__ dst,
+                                                          const uint8_t* __restrict__ mask, int w, int h, uint32_t nd)
+{
+    using G = mb2_geom<R>;
+    constexpr int S = G::S, NR = G::NR, ROWS = PFX_MB2_ROWS;
+    constexpr int NROW = ROWS + 2 * R;
+    // [row][channel][dword 0..4][plane]: 128 columns + 2r + 1 bits span five dwords of a plane row (160 bytes per row and channel)
+    __shared__ uint4 s_pl[NROW * 40];
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const int x0 = (int)blockIdx.x * MB2_COLS;
+    const int xa = x0 + (int)(wid * 32u + (lane >> 2) * 2u);
+    const uint32_t c = lane & 3u;
+    const int y0 = (int)blockIdx.y * ROWS, y1 = min(y0 + ROWS, h);
+    {
+        const uint32_t jq = (uint32_t)x0 >> 5;
+        const uint32_t row_q = nd * 8u;                              // uint4 per image row
+        const uint4* const pq = reinterpret_cast<const uint4*>(planes);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)NROW * 40u; i += 256u) {
+            const uint32_t row = i / 40u, rem = i - row * 40u, cc = rem / 10u, q = rem - cc * 10u; // q: 16-byte piece of the 160-byte run
+            const uint32_t yy = (uint32_t)min(max(y0 - R + (int)row, 0), h - 1);
+            const uint32_t dj = min(jq + (q >> 1), nd - 1u);          // past the row's last dword only for columns >= w
+            s_pl[i] = pq[(size_t)yy * row_q + ((size_t)cc * nd + dj) * 2u + (q & 1u)];
+        }
+    }
+    __syncthreads();
+    if ((int)(x0 + wid * 32u) >= w) return;
+    const uint32_t sh = (uint32_t)xa & 31u;
+    const uint4* const lcol = s_pl + c * 10u + (((uint32_t)(xa - x0) >> 5) * 2u); // + row * 40
+
+    uint32_t np[8][NR];
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) np[b][j] = 0u;
+
+    uint32_t f[8];
+    auto fetch = [&](int lrow) __attribute__((always_inline)) {
+        const uint4* p = lcol + lrow * 40;
+        const uint4 l0 = p[0], l1 = p[1], h0 = p[2], h1 = p[3];
+        f[0] = __builtin_amdgcn_alignbit(h0.x, l0.x, sh); f[1] = __builtin_amdgcn_alignbit(h0.y, l0.y, sh);
+        f[2] = __builtin_amdgcn_alignbit(h0.z, l0.z, sh); f[3] = __builtin_amdgcn_alignbit(h0.w, l0.w, sh);
+        f[4] = __builtin_amdgcn_alignbit(h1.x, l1.x, sh); f[5] = __builtin_amdgcn_alignbit(h1.y, l1.y, sh);
+        f[6] = __builtin_amdgcn_alignbit(h1.z, l1.z, sh); f[7] = __builtin_amdgcn_alignbit(h1.w, l1.w, sh);
+    };
+    auto insert = [&](auto slot_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(slot_c)::value, reg = s / G::RPR, off = (s % G::RPR) * G::FO;
+        constexpr uint32_t fm = G::FM << off;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) np[b][reg] = __builtin_amdgcn_bitop3_b32(np[b][reg], f[b] << off, fm, 0xd8);
+    };
+    auto select = [&](uint32_t win) __attribute__((always_inline)) -> uint32_t {
+        uint32_t cand[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) cand[j] = G::cand_init(j) << win;
+        uint32_t k = (uint32_t)(S * S) / 2u, res = 0u; // sorted[len / 2], noise.rs:401
+#pragma unroll
+        for (int b = 7; b >= 0; --b) {
+            uint32_t z[NR], cnt0 = 0u, cnt1 = 0u;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) asm("v_and_b32 %0, %1, %2" : "=v"(z[j]) : "v"(cand[j]), "v"(np[b][j]));
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {   // two accumulation chains from four registers on
+                if (NR >= 4 && (j & 1)) asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(cnt1) : "v"(z[j]), "v"(cnt1));
+                else asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(cnt0) : "v"(z[j]), "v"(cnt0));
+            }
+            const uint32_t c0 = NR >= 4 ? cnt0 + cnt1 : cnt0;   // candidates whose bit b is 0
+            const uint32_t d = k - c0;
+            uint32_t zm;                                        // k < c0: the rank-k candidate has bit b clear -> all ones
+            asm("v_ashrrev_i32 %0, 31, %1" : "=v"(zm) : "v"(d));
+            if (b > 0) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(cand[j]) : "v"(np[b][j]), "v"(zm)); // cand & ~(plane ^ zm)
+#if PFX_MB2_KSEL
+                k = __builtin_amdgcn_bitop3_b32(k, d, zm, 0xe4);   // zm ? k : d
+#else
+                k = min(k, d);
+#endif
+            }
+            res = __builtin_amdgcn_bitop3_b32(res, zm, 1u << b, 0xf2); // res | (~zm & bit)
+        }
+        return res;
+    };
+    const mb_v4i rs_dst = mb_rsrc(dst, (uint32_t)w * (uint32_t)h * 4u);
+    const mb_v4i rs_src = mb_rsrc(src, (uint32_t)w * (uint32_t)h * 4u);
+    const mb_v4i rs_msk = mb_rsrc(mask, MASK ? (uint32_t)w * (uint32_t)h : 0u);
+    // byte offsets inside the image row; a column past the right edge gets an offset no buffer holds (the store is dropped)
+    const int vo0 = xa < w ? xa * 4 + (int)c : (int)0x7fffffff, vo1 = xa + 1 < w ? (xa + 1) * 4 + (int)c : (int)0x7fffffff;
+    auto emit = [&](int y, uint32_t win, uint32_t res) __attribute__((always_inline)) {
+        const int vo = win ? vo1 : vo0;
+        uint8_t o = (uint8_t)res;
+        if constexpr (MASK) {
+            const uint8_t m = mb_buffer_load_i8(rs_msk, vo >> 2, y * w, 0), sv = mb_buffer_load_i8(rs_src, vo, y * w * 4, 0);
+            if (m == 0) o = sv;
+        }
+        mb_buffer_store_i8(o, rs_dst, vo, y * w * 4, 0);
+    };
+
+    static_for<0, S - 1>([&](auto sc) __attribute__((always_inline)) {
+        fetch((int)decltype(sc)::value);
+        insert(sc);
+    });
+    for (int y = y0; y < y1; y += S) {
+        bool done = false;
+        static_for<0, S>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            if (!done && y + u < y1) {
+                fetch(y - y0 + u + 2 * R);
+                insert(std::integral_constant<int, (S - 1 + u) % S>{});
+#pragma unroll 1
+                for (uint32_t win = 0; win < 2u; ++win) emit(y + u, win, select(win));
+            } else done = true;
+        });
+    }
+}
+
+int g_mb_pair = 1; // pfxk_median_bits_set_pair: radii 2..7 on the column-pair kernel
 } // namespace
+
+extern "C" void pfxk_median_bits_set_pair(int on) { g_mb_pair = on; }
 
 extern "C" size_t pfxk_median_bits_scratch(int radius, uint32_t w, uint32_t h)
 {
@@ -220,6 +381,14 @@ extern "C" hipError_t pfxk_median_bits(hipStream_t s, const uint8_t* d_src, uint
     if (radius < 2 || radius > 8) return hipErrorInvalidValue;
     const uint32_t nd = mb_dwords(w, radius);
     median_planes_kernel<<<dim3((nd + 7u) / 8u, (h + MP_ROWS - 1) / MP_ROWS), 256, 0, s>>>((const uint32_t*)d_src, d_planes, radius, (int)w, (int)h, nd);
+    if (g_mb_pair && radius <= 7) {
+        const dim3 g2((w + MB2_COLS - 1) / MB2_COLS, (h + PFX_MB2_ROWS - 1) / PFX_MB2_ROWS);
+#define PFX_MB2(R) case R: if (d_mask) median_bits2_kernel<R, true><<<g2, 256, 0, s>>>(d_src, d_planes, d_dst, d_mask, (int)w, (int)h, nd); \
+                           else median_bits2_kernel<R, false><<<g2, 256, 0, s>>>(d_src, d_planes, d_dst, d_mask, (int)w, (int)h, nd); break;
+        switch (radius) { PFX_MB2(2) PFX_MB2(3) PFX_MB2(4) PFX_MB2(5) PFX_MB2(6) PFX_MB2(7) }
+#undef PFX_MB2
+        return hipGetLastError();
+    }
     const dim3 g((w + 4 * MB_COLS - 1) / (4 * MB_COLS), (h + MB_ROWS - 1) / MB_ROWS);
 #define PFX_MB(R) case R: median_bits_kernel<R><<<g, 256, 0, s>>>(d_src, d_planes, d_dst, d_mask, (int)w, (int)h, nd); break;
     switch (radius) { PFX_MB(2) PFX_MB(3) PFX_MB(4) PFX_MB(5) PFX_MB(6) PFX_MB(7) PFX_MB(8) }

@@ -1360,6 +1360,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "dle_s2") == 0) { pfxk_flatten_set_dle_plan(-1, -2, value); return PFX_OK; }       // ... then every this many layers (-1: 3, 0: only the first)
     if (std::strcmp(key, "median_search1") == 0) { pfxk_median_set_search1(value); return PFX_OK; }
     if (std::strcmp(key, "outline_bits") == 0) { ctx->outline_bits = value != 0; return PFX_OK; }
+    if (std::strcmp(key, "median_pair") == 0) { pfxk_median_bits_set_pair(value); return PFX_OK; } // 0: the single-column bit-plane kernel for every radius
     if (std::strcmp(key, "median_bits_min") == 0) { ctx->median_bits_min = value; return PFX_OK; } // smallest radius on the bit-plane kernel (8: never)
     if (std::strcmp(key, "median_single") == 0) { pfxk_median_set_single(value); return PFX_OK; }
     if (std::strcmp(key, "box_prefix_from") == 0) { pfxk_box_set_prefix_from(value); return PFX_OK; }

@@ -135,6 +135,7 @@ hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, cons
                        uint32_t w, uint32_t h);
 // ---- k_median_bits.hip ---- radii 2..7 as a bit-sliced radix select over bit planes of the image (scratch: pfxk_median_bits_scratch bytes)
 size_t pfxk_median_bits_scratch(int radius, uint32_t w, uint32_t h);
+void pfxk_median_bits_set_pair(int on); // 1 (default): radii 2..7 on the column-pair kernel (two adjacent columns per lane on shared plane registers)
 hipError_t pfxk_median_bits(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, uint32_t* d_planes, int radius,
                             uint32_t w, uint32_t h);
 hipError_t pfxk_pixelate(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, uint32_t bs,

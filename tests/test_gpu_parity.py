@@ -363,23 +363,30 @@ def test_median_value_search_four_pixels_per_lane(gpu, oracle, radius, size):
 
 
 @pytest.mark.parametrize("radius", [2, 3, 4, 5, 6, 7, 8])
-@pytest.mark.parametrize("size", [(1, 1), (5, 3), (16, 40), (31, 33), (32, 32), (33, 31), (63, 70), (64, 16), (65, 97), (131, 23), (390, 41), (1031, 37)])
-def test_median_bit_plane_radix_select(gpu, oracle, radius, size):
+@pytest.mark.parametrize("size", [(1, 1), (5, 3), (16, 40), (31, 33), (32, 32), (33, 31), (63, 70), (64, 16), (65, 97), (127, 9), (128, 35), (129, 66), (131, 23), (390, 41), (1031, 37)])
+@pytest.mark.parametrize("pair", [1, 0])
+def test_median_bit_plane_radix_select(gpu, oracle, radius, size, pair):
     """k_median_bits.hip: the window as bit planes, rank select from the top plane down.  Sizes cross the 32-pixel dwords of a plane row,
-    the 16-column waves, the 32-row bands and the 2r+1-row ring (several turns), windows wider / taller than the image, masks, heavy ties
-    (the select must count equal elements exactly like the sort)"""
+    the 16-column waves (32 for the column-pair kernel) and the blocks of 64 / 128 columns, the 32-row bands and the 2r+1-row ring (several turns),
+    windows wider / taller than the image, odd widths (a pair whose second column is outside), masks, heavy ties (the select must count equal elements
+    exactly like the sort).  pair = 1: two adjacent columns per lane on shared plane registers (radii 2..7, shipped); 0: one column per lane (radius 8, and
+    every radius under pfx_tune "median_pair" = 0)"""
     w, h = size
+    if pair and radius == 8:
+        pytest.skip("radius 8 has no column-pair build (18-bit fields)")
     img = I.random_rgba(w, h, 2100 + 7 * w + radius)
     img[: h // 2] = (img[: h // 2] // 100) * 100
     img[:, : w // 3, 1] = 255
     img[:, w // 2:, 2] = 0
     mask = (np.random.default_rng(w + 5).random((h, w)) < 0.5).astype(np.uint8)
     gpu.r.tune("median_bits_min", 2)
+    gpu.r.tune("median_pair", pair)
     try:
         assert_same(gpu.median(img, radius), oracle.median(img, radius), 0, f"median bits r={radius} {w}x{h}")
         assert_same(gpu.median(img, radius, mask), oracle.median(img, radius, mask), 0, f"median bits r={radius} {w}x{h} masked")
     finally:
         gpu.r.tune("median_bits_min", MEDIAN_BITS_MIN)
+        gpu.r.tune("median_pair", 1)
 
 
 @pytest.mark.parametrize("seed", range(12))
