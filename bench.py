@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+PATTERN_CEILING_GBS = 5900.0   # measured: what 33 lock-step layer streams sustain without arithmetic (profiles/r05_nstream_read.txt)
 W8K, H8K, NLAYERS, SIGMA = 7680, 4320, 32, 16.0
 
 
@@ -711,6 +712,12 @@ def main() -> int:
                 **({"flatten_launches_per_step": per_step} if per_step > 1 else {}),
                 "pipeline_achieved_GBs": round(pipeline_bytes * args.steps * docs / elapsed / 1e9, 1),
                 "pipeline_frac": round(pipeline_bytes * args.steps * docs / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+    # what the memory system delivers to this access pattern with no arithmetic at all (33 separately allocated layers walked in lock step, raw loads, an XOR per
+    # register: tools/lab/nstream_read.hip, profiles/r05_nstream_read.txt): a measured constant of the chip, beside the data-sheet peak `frac` is quoted against
+    if dominant == "flatten" and achieved > 0:
+        roofline["pattern_ceiling"] = {"GBs": PATTERN_CEILING_GBS, "frac_of_it": round(achieved / PATTERN_CEILING_GBS, 4), "static": True,
+                                       "what": "N-stream lock-step read, >= 4 loads in flight per wave; 4.7-4.8 TB/s with the two a typed-load register budget allows",
+                                       "profile": "profiles/r05_nstream_read.txt"}
     # what actually limits each kernel: the contract's `frac` stays against HBM; the issue-slot view is beside it
     if pmc and d_ms > 0 and world == 1:
         fl = pmc.get("flatten", {})

@@ -114,6 +114,20 @@ __global__ __launch_bounds__(256) void k_cnd_mixed(uint32_t* out, uint32_t seed)
     for (int j = 0; j < 8; ++j) s ^= x[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+
+// packed FP32 (two f32 per lane and instruction, register pairs): does v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue at the scalar-f32 rate (= twice the flops)?
+#define PK_KERNEL(NAME, OPSTR) __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) { \
+    typedef float f2 __attribute__((ext_vector_type(2))); f2 x[8]; \
+    for (int j = 0; j < 8; ++j) { x[j].x = (float)(threadIdx.x + j + seed) * 1e-3f; x[j].y = x[j].x + 0.5f; } \
+    f2 y = {1.0001f, 0.9999f}, z = {1e-6f, -1e-6f}; \
+    for (int it = 0; it < 512; ++it) { \
+        asm volatile(OPSTR(0) OPSTR(1) OPSTR(2) OPSTR(3) OPSTR(4) OPSTR(5) OPSTR(6) OPSTR(7) \
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(y), "v"(z)); } \
+    float s = 0; for (int j = 0; j < 8; ++j) s += x[j].x + x[j].y; out[blockIdx.x * blockDim.x + threadIdx.x] = __builtin_bit_cast(uint32_t, s); }
+#define OP_PKFMA32(n) "v_pk_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define OP_PKMUL32(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n"
+#define OP_PKADD32(n) "v_pk_add_f32 %" #n ", %" #n ", %9\n"
+PK_KERNEL(k_pkfma32, OP_PKFMA32) PK_KERNEL(k_pkmul32, OP_PKMUL32) PK_KERNEL(k_pkadd32, OP_PKADD32)
 template <class K> double run(K k, uint32_t* out)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -142,6 +156,7 @@ int main()
     REPORT("v_med3_f32", k_med3f32) REPORT("v_min3_f32", k_min3f32) REPORT("v_pk_mul_f16", k_pkmulf16)
     REPORT("v_bcnt_u32_b32", k_bcnt) REPORT("v_bitop3_b32", k_bitop3) REPORT("v_alignbit_b32", k_alignbit) REPORT("v_lshl_or_b32", k_lshlor) REPORT("v_add3_u32", k_add3)
     REPORT("v_mul_hi_u32", k_mulhi) REPORT("v_mul_lo_u32", k_mullo) REPORT("v_mul_hi_u32_u24", k_mulhi24) REPORT("v_mul_u32_u24", k_mul24) REPORT("v_mad_u32_u24", k_mad24) REPORT("v_bfe_u32", k_bfe) REPORT("v_cvt_f32_u32", k_cvtu32) REPORT("v_lshl_add_u32", k_lshladd)
+    REPORT("v_pk_fma_f32 (2 f32 per lane)", k_pkfma32) REPORT("v_pk_mul_f32", k_pkmul32) REPORT("v_pk_add_f32", k_pkadd32)
     REPORT("v_bitop3 mixed regs (8 per iteration)", k_bitop3_mixed) REPORT("v_fma mixed regs", k_fma_mixed) REPORT("v_cmp + 8 v_cndmask mixed regs (9 insts counted as 8)", k_cnd_mixed)
     return 0;
 }
