@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/soak.py [--seconds S] [--seed N] — randomized parity soak on the GPU against the oracle (test infrastructure, like tests/): random layer stacks
 (sizes, depths, modes, opacities, alpha structure: noise, opaque / transparent runs and blocks, reset layers at random depths) through pfx_composite — which
-picks the class-sorting, streaming or general compositor by itself —, random-sigma Gaussians in the default (<= 1 LSB) and exact (bit-exact) modes, random-radius box blurs (bit-exact), random
+picks the class-sorting, streaming or general compositor by itself —, random-sigma Gaussians in the default (<= 1 LSB) and exact (bit-exact) modes, random-radius box blurs and medians (bit-exact), random
 displacement and mesh warps (bit-exact).  Prints one JSON line; exits 1 on the first mismatch with the case's seed."""
 import argparse, json, os, sys, time
 import numpy as np
@@ -16,7 +16,7 @@ ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 r = GpuRenderer(0)
 t_end = time.time() + a.seconds
-counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0, "sharpen_glow": 0}
+counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0, "sharpen_glow": 0, "median": 0}
 case = a.seed * 1000003
 
 
@@ -41,7 +41,7 @@ def alpha_plane(rng, w, h):
 while time.time() < t_end:
     case += 1
     rng = np.random.default_rng(case)
-    what = rng.integers(0, 12)
+    what = rng.integers(0, 13)
     try:
         if what < 6:
             w, h = int(rng.integers(1, 700)), int(rng.integers(1, 120))
@@ -84,6 +84,15 @@ while time.time() < t_end:
                 inten = float(rng.choice([0.2, 0.5, 1.0, 1.7]))
                 if not np.array_equal(r.glow_core(img, radius, inten, mask), O.glow(img, radius, inten, mask)): raise AssertionError(f"glow {w}x{h} radius {radius} intensity {inten}")
             counts["sharpen_glow"] += 1
+        elif what == 12:   # median: sorted-column networks (r <= 2), the bit-plane select on column pairs (3 .. 7) and single columns (8), the value search beyond; ties, masks
+            w, h = int(rng.integers(1, 420)), int(rng.integers(1, 140))
+            radius = int(rng.choice([1, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 12]))
+            img = I.random_rgba(w, h, case)
+            if rng.random() < 0.5: img = (img // int(rng.choice([16, 64, 100]))) * int(rng.choice([16, 64, 100]))   # heavy ties
+            if rng.random() < 0.3: img[:, : max(1, w // 3), int(rng.integers(0, 4))] = int(rng.choice([0, 255]))
+            mask = None if rng.random() < 0.6 else ((rng.random((h, w)) < 0.5).astype(np.uint8) * 255)
+            if not np.array_equal(r.median_core(img, radius, mask), O.median(img, radius, mask)): raise AssertionError(f"median {w}x{h} radius {radius} mask {mask is not None}")
+            counts["median"] += 1
         elif what == 10:   # box blur: the fused tile (r <= 4), the fused strip walk (r <= 60) and the two-pass kernels, with and without a selection
             w, h = int(rng.integers(1, 900)), int(rng.integers(1, 400))
             radius = float(rng.choice([0.6, 1.0, 2.0, 4.0, 4.5, 5.0, 7.0, 9.0, 13.0, 24.0, 37.0, 48.0, 60.0, 61.0, 90.0])) - (0.3 if rng.random() < 0.3 else 0.0)
