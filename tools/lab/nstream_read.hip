@@ -4,6 +4,7 @@
 //   VEC   dwords per lane and load (1 = buffer_load_dword, the compositor's 4 bytes per lane; 4 = buffer_load_dwordx4)
 //   DEPTH loads in flight per wave
 //   shape 0: a wave walks units; per unit it reads piece u of layer 0, 1, … N−1 (N streams interleaved at 256·VEC-byte grain)
+//   shape 2: as shape 0 with the wave's units a whole launch apart (unit = wave + i * waves): long streams, compact window of addresses in flight
 //   shape 1: the same bytes as ONE stream (layer-major: the wave reads N consecutive pieces of one buffer) — the contiguous ceiling
 // Prints one JSON line per configuration.  Build: hipcc -O3 --offload-arch=gfx950 -o tools/lab/_bin/nstream_read tools/lab/nstream_read.hip
 #include <hip/hip_runtime.h>
@@ -38,8 +39,12 @@ __global__ __launch_bounds__(64 * WPB) void k(Layers L, int n_layers, uint32_t l
     const uint32_t u0 = wave * upw, u1 = min(u0 + upw, n_units);
     const v4i rd = rsrc(dst, layer_bytes);
     const int vo = (int)(lane * 4u * VEC);
-    if (SHAPE == 0) {
-        for (uint32_t u = u0; u < u1; ++u) {
+    if (SHAPE == 0 || SHAPE == 2) {
+        // SHAPE 2: the wave's units are n_waves apart (unit = wave + i * n_waves): all resident waves advance through one compact window of the buffers
+        const uint32_t n_waves = (n_units + upw - 1) / upw;
+        for (uint32_t uu = u0; uu < u0 + upw; ++uu) {
+            const uint32_t u = SHAPE == 2 ? wave + (uu - u0) * n_waves : uu;
+            if (u >= n_units || (SHAPE == 2 && wave >= n_waves)) break;
             const int so = (int)(u * unit_bytes);
             Reg<VEC> acc; acc.zero();
             for (int l = 0; l < n_layers; l += DEPTH) {
@@ -101,7 +106,7 @@ static void run(const Layers& L, int n_layers, uint32_t layer_bytes, uint8_t* ds
     hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)k<VEC, DEPTH, SHAPE, WPB>);
     const double bytes = (double)layer_bytes * (n_layers + 1);
     printf("{\"shape\": \"%s\", \"layers\": %d, \"bytes_per_lane\": %d, \"depth\": %d, \"waves_per_wg\": %d, \"units_per_wave\": %u, \"vgprs\": %d, \"ms_min\": %.4f, \"ms_med\": %.4f, \"TBs_min\": %.3f, \"TBs_med\": %.3f}\n",
-           SHAPE ? "one stream" : "N streams", n_layers, 4 * VEC, DEPTH, WPB, upw, fa.numRegs, ms.front(), ms[ms.size() / 2], bytes / ms.front() * 1e-9, bytes / ms[ms.size() / 2] * 1e-9);
+           SHAPE == 1 ? "one stream" : SHAPE == 2 ? "N strided" : "N streams", n_layers, 4 * VEC, DEPTH, WPB, upw, fa.numRegs, ms.front(), ms[ms.size() / 2], bytes / ms.front() * 1e-9, bytes / ms[ms.size() / 2] * 1e-9);
     fflush(stdout);
     hipEventDestroy(e0); hipEventDestroy(e1);
 }
@@ -120,6 +125,13 @@ int main(int argc, char** argv)
     uint8_t* dst; hipMalloc(&dst, layer_bytes);
     hipDeviceSynchronize();
     printf("# skew %zu bytes per layer\n", skew);
+    if (argc > 2) {   // units-per-wave sweep at the compositor's depth (2) and at 4, contiguous against strided streams
+        for (uint32_t upw : {1u, 2u, 4u, 8u, 16u, 32u, 64u}) {
+            run<1, 2, 0, 1>(L, 33, layer_bytes, dst, upw); run<1, 2, 2, 1>(L, 33, layer_bytes, dst, upw);
+            run<1, 4, 0, 1>(L, 33, layer_bytes, dst, upw); run<1, 4, 2, 1>(L, 33, layer_bytes, dst, upw);
+        }
+        return 0;
+    }
     for (int n : {1, 9, 33}) {
         for (uint32_t upw : {4u, 16u}) {
             run<1, 2, 0, 1>(L, n, layer_bytes, dst, upw);
