@@ -400,8 +400,8 @@ int flatten_common(pfx_ctx* ctx, const void* const* layer_ptrs, const void* cons
         if (!ctx->h_dle_verdict) {
             PFX_HIP(ctx, hipHostMalloc((void**)&ctx->h_dle_verdict, sizeof(uint32_t), hipHostMallocDefault));
             *ctx->h_dle_verdict = 0;
-            PFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dle_probe, hipEventDisableTiming));
         }
+        if (!ctx->ev_dle_probe) PFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_dle_probe, hipEventDisableTiming));
         ctx->dle_probe_tag = (ctx->dle_probe_tag + 1u) & 0x7fffffffu;
         PFX_HIP(ctx, pfxk_dle_probe(ctx->stream, (const pfxk_layer_desc*)ctx->d_desc.p, probe_layer, probe_kind, (uint32_t)((size_t)w * h), ctx->h_dle_verdict, ctx->dle_probe_tag));
         PFX_HIP(ctx, hipEventRecord(ctx->ev_dle_probe, ctx->stream));
