@@ -81,14 +81,27 @@ PFX_DEV bool tip_coverage(const pfxk_brush& B, const pfxk_stamp& S, const uint8_
     return true;
 }
 
+// BINNED: the host has dealt the stamps to the 64 x 64 chunks their bounding boxes touch (pfx_api.cpp: brush_bin_stamps — TiledImage's chunk grid); a workgroup
+// takes four rows of one ACTIVE chunk (`chunks[blockIdx.x]` = chunk x, chunk y, first entry, entries) and walks that chunk's stamp list `bins` (indices into
+// `stamps`, in stroke order).  The work is then proportional to the painted area, not to the stroke's bounding box times its length: a diagonal stroke of 6 501
+// stamps across an 8K preview layer 2.07 -> see profiles/r05_tuning.md.  Every per-pixel test is the unbinned kernel's, so the result is bit-identical.
+template <bool BINNED>
 __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ target, uint32_t w, uint32_t h, pfxk_brush B,
-                                                    const pfxk_stamp* __restrict__ stamps, uint32_t n_pts,
+                                                    const pfxk_stamp* __restrict__ stamps, uint32_t n_pts_all,
                                                     const uint8_t* __restrict__ lut, const uint8_t* __restrict__ tip_mask,
-                                                    const uint8_t* __restrict__ selection, int bx0, int by0, int bx1, int by1)
+                                                    const uint8_t* __restrict__ selection, int bx0, int by0, int bx1, int by1,
+                                                    const uint4* __restrict__ chunks, const uint32_t* __restrict__ bins)
 {
     // a wave covers one 64-pixel row segment: gy and the segment's x range are wave-uniform
     const uint32_t lane = threadIdx.x & 63u;
-    const int gx0 = bx0 + (int)(blockIdx.x * 64u), gx = gx0 + (int)lane;
+    uint32_t n_pts = n_pts_all;
+    if constexpr (BINNED) {
+        const uint4 ch = chunks[blockIdx.x];
+        bx0 = (int)(ch.x * 64u); by0 = (int)(ch.y * 64u);
+        bx1 = min(bx0 + 63, (int)w - 1); by1 = min(by0 + 63, (int)h - 1);
+        bins += ch.z; n_pts = ch.w;
+    }
+    const int gx0 = BINNED ? bx0 : bx0 + (int)(blockIdx.x * 64u), gx = gx0 + (int)lane;
     const int gy = by0 + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (gy > by1 || gx0 > bx1) return; // whole wave
     const size_t i = (size_t)gy * w + (size_t)min(gx, bx1);
@@ -170,11 +183,13 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
     for (uint32_t k0 = 0; k0 < n_pts; k0 += 64u) {
         const uint32_t kk = k0 + lane;
         bool seen = false;
+        uint32_t sidx = kk;                                   // BINNED: entry kk of the chunk's list names stamp bins[kk]
+        if constexpr (BINNED) sidx = kk < n_pts ? bins[kk] : 0u;
         if (kk < n_pts) {
-            const float cx = stamps[kk].cx, cy = stamps[kk].cy;
+            const float cx = stamps[sidx].cx, cy = stamps[sidx].cy;
             uint32_t min_x, max_x, min_y, max_y;
             if (B.tip_size) { // tip_coverage's box
-                const float half = (float)B.tip_size / 2.0f, eh = stamps[kk].rotated ? half * 1.41421356237309504880f : half;
+                const float half = (float)B.tip_size / 2.0f, eh = stamps[sidx].rotated ? half * 1.41421356237309504880f : half;
                 min_x = rs_f32_as_u32(__builtin_fmaxf(cx - eh, 0.0f)); min_y = rs_f32_as_u32(__builtin_fmaxf(cy - eh, 0.0f));
                 max_x = min(rs_f32_as_u32(cx + eh), wm1); max_y = min(rs_f32_as_u32(cy + eh), hm1);
             } else {          // :209-215
@@ -187,8 +202,9 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
         }
         unsigned long long m = __ballot(seen);
         while (m) {
-            const uint32_t k = k0 + (uint32_t)__builtin_ctzll(m);
+            const uint32_t j = (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
+            const uint32_t k = BINNED ? (uint32_t)__builtin_amdgcn_readlane((int)sidx, (int)j) : k0 + j;
             if (active) stamp_px(k);
         }
     }
@@ -203,6 +219,17 @@ extern "C" hipError_t pfxk_brush_stamps(hipStream_t s, uint8_t* d_target, uint32
 {
     if (n_points == 0 || bx1 < bx0 || by1 < by0) return hipSuccess;
     dim3 g((uint32_t)(bx1 - bx0 + 64) / 64u, (uint32_t)(by1 - by0 + 4) / 4u);
-    brush_kernel<<<g, 256, 0, s>>>((uint32_t*)d_target, w, h, *B, d_stamps, n_points, d_lut256, d_tip_mask, d_selection, bx0, by0, bx1, by1);
+    brush_kernel<false><<<g, 256, 0, s>>>((uint32_t*)d_target, w, h, *B, d_stamps, n_points, d_lut256, d_tip_mask, d_selection, bx0, by0, bx1, by1, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+// the same stamps dealt to chunks: d_chunks = n_chunks x {chunk x, chunk y, first entry of d_bins, entries}, d_bins = stamp indices in stroke order per chunk
+extern "C" hipError_t pfxk_brush_stamps_binned(hipStream_t s, uint8_t* d_target, uint32_t w, uint32_t h, const pfxk_brush* B,
+                                               const pfxk_stamp* d_stamps, uint32_t n_points, const uint8_t* d_lut256, const uint8_t* d_tip_mask,
+                                               const uint8_t* d_selection, const uint32_t* d_chunks, uint32_t n_chunks, const uint32_t* d_bins)
+{
+    if (n_points == 0 || n_chunks == 0) return hipSuccess;
+    brush_kernel<true><<<dim3(n_chunks, 16), 256, 0, s>>>((uint32_t*)d_target, w, h, *B, d_stamps, n_points, d_lut256, d_tip_mask, d_selection, 0, 0, 0, 0,
+                                                         (const uint4*)d_chunks, d_bins);
     return hipGetLastError();
 }

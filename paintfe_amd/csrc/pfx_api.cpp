@@ -880,12 +880,64 @@ int pfx_brush_stamps_ex_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t
     const int bx1 = (int)std::min((float)(w - 1), ceilf(std::min(maxx + pad, 1.0e9f))), by1 = (int)std::min((float)(h - 1), ceilf(std::min(maxy + pad, 1.0e9f)));
     if (bx1 < bx0 || by1 < by0) return PFX_OK;
     const size_t stamp_bytes = st.size() * sizeof(pfxk_stamp), tip_bytes = image_tip ? (size_t)dyn->tip_mask_size * dyn->tip_mask_size : 0;
-    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, stamp_bytes + tip_bytes + 512));
+    // Strokes of more than one cull group: deal the stamps to the 64 x 64 chunks (TiledImage's grid) their boxes touch, so that the kernel's work follows the painted
+    // area instead of the stroke's bounding box times its length.  The box is the kernel's own (k_brush.hip: the stamp test of brush_kernel / tip_coverage), computed
+    // with the same float operations, so a chunk's list holds every stamp one of its pixels can see, in stroke order.
+    std::vector<uint32_t> chunk_tab, bins;
+    if (n_points > 64u && ctx->brush_binning) {
+        auto f2u = [](float v) -> uint32_t { return (v > 0.0f) ? ((v >= 4294967296.0f) ? 0xffffffffu : (uint32_t)v) : 0u; };
+        const uint32_t wm1 = w - 1u, hm1 = h - 1u, ncx = (w + 63u) / 64u, ncy = (h + 63u) / 64u;
+        std::vector<uint32_t> box(4 * (size_t)n_points), count((size_t)ncx * ncy, 0u);
+        uint64_t entries = 0;
+        for (uint32_t i = 0; i < n_points; ++i) {
+            const pfxk_stamp& S = st[i];
+            uint32_t x0, x1, y0, y1;
+            if (image_tip) {
+                const float hf = (float)dyn->tip_mask_size / 2.0f, eh = S.rotated ? hf * 1.41421356237309504880f : hf;
+                x0 = f2u(fmaxf(S.cx - eh, 0.0f)); y0 = f2u(fmaxf(S.cy - eh, 0.0f));
+                x1 = std::min(f2u(S.cx + eh), wm1); y1 = std::min(f2u(S.cy + eh), hm1);
+            } else {
+                x0 = f2u(fmaxf(floorf(S.cx - B.draw_radius), 0.0f)); x1 = std::min(f2u(ceilf(S.cx + B.draw_radius)), wm1);
+                y0 = f2u(fmaxf(floorf(S.cy - B.draw_radius), 0.0f)); y1 = std::min(f2u(ceilf(S.cy + B.draw_radius)), hm1);
+            }
+            uint32_t* b = &box[4 * (size_t)i];
+            if (x0 > x1 || y0 > y1) { b[0] = 1; b[1] = 0; b[2] = 1; b[3] = 0; continue; }   // the stamp touches no pixel
+            b[0] = x0 >> 6; b[1] = x1 >> 6; b[2] = y0 >> 6; b[3] = y1 >> 6;
+            entries += (uint64_t)(b[1] - b[0] + 1u) * (b[3] - b[2] + 1u);
+            if (entries > (8ull << 20)) break;
+        }
+        if (entries > 0 && entries <= (8ull << 20)) {   // beyond 8 M entries (huge tips on long strokes) the unbinned kernel runs
+            for (uint32_t i = 0; i < n_points; ++i) {
+                const uint32_t* b = &box[4 * (size_t)i];
+                for (uint32_t cy = b[2]; cy <= b[3] && b[0] <= b[1]; ++cy)
+                    for (uint32_t cx = b[0]; cx <= b[1]; ++cx) ++count[(size_t)cy * ncx + cx];
+            }
+            std::vector<uint32_t> first(count.size());
+            uint32_t off = 0;
+            for (size_t c = 0; c < count.size(); ++c) {
+                first[c] = off;
+                if (count[c]) { chunk_tab.push_back((uint32_t)(c % ncx)); chunk_tab.push_back((uint32_t)(c / ncx)); chunk_tab.push_back(off); chunk_tab.push_back(count[c]); }
+                off += count[c];
+            }
+            bins.resize(off);
+            for (uint32_t i = 0; i < n_points; ++i) {   // stamps in order: every chunk's list comes out in stroke order
+                const uint32_t* b = &box[4 * (size_t)i];
+                for (uint32_t cy = b[2]; cy <= b[3] && b[0] <= b[1]; ++cy)
+                    for (uint32_t cx = b[0]; cx <= b[1]; ++cx) bins[first[(size_t)cy * ncx + cx]++] = i;
+            }
+        }
+    }
+    const size_t tab_off = (stamp_bytes + tip_bytes + 15u) & ~(size_t)15u, tab_bytes = chunk_tab.size() * 4u, bins_bytes = bins.size() * 4u;
+    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, tab_off + tab_bytes + bins_bytes + 512));
     PFX_TRY(pfx_h2d(ctx, ctx->d_pts.p, st.data(), stamp_bytes));
     const uint8_t* d_tip = nullptr;
     if (image_tip) {
         PFX_TRY(pfx_h2d(ctx, (uint8_t*)ctx->d_pts.p + stamp_bytes, dyn->tip_mask, tip_bytes));
         d_tip = (const uint8_t*)ctx->d_pts.p + stamp_bytes;
+    }
+    if (!chunk_tab.empty()) {
+        PFX_TRY(pfx_h2d(ctx, (uint8_t*)ctx->d_pts.p + tab_off, chunk_tab.data(), tab_bytes));
+        PFX_TRY(pfx_h2d(ctx, (uint8_t*)ctx->d_pts.p + tab_off + tab_bytes, bins.data(), bins_bytes));
     }
     PFX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `st` is pageable host memory about to go out of scope
     const uint8_t* d_lut = nullptr;
@@ -896,8 +948,13 @@ int pfx_brush_stamps_ex_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t
         d_lut = (const uint8_t*)ctx->d_lut.p;
     }
     pfx_timer t(ctx, "brush_stamps");
-    PFX_HIP(ctx, pfxk_brush_stamps(ctx->stream, (uint8_t*)target_dev, w, h, &B, (const pfxk_stamp*)ctx->d_pts.p, n_points, d_lut, d_tip,
-                                   (const uint8_t*)selection_dev, bx0, by0, bx1, by1));
+    if (!chunk_tab.empty())
+        PFX_HIP(ctx, pfxk_brush_stamps_binned(ctx->stream, (uint8_t*)target_dev, w, h, &B, (const pfxk_stamp*)ctx->d_pts.p, n_points, d_lut, d_tip,
+                                              (const uint8_t*)selection_dev, (const uint32_t*)((const uint8_t*)ctx->d_pts.p + tab_off), (uint32_t)(chunk_tab.size() / 4u),
+                                              (const uint32_t*)((const uint8_t*)ctx->d_pts.p + tab_off + tab_bytes)));
+    else
+        PFX_HIP(ctx, pfxk_brush_stamps(ctx->stream, (uint8_t*)target_dev, w, h, &B, (const pfxk_stamp*)ctx->d_pts.p, n_points, d_lut, d_tip,
+                                       (const uint8_t*)selection_dev, bx0, by0, bx1, by1));
     return PFX_OK;
 }
 
@@ -1360,6 +1417,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "dle_s2") == 0) { pfxk_flatten_set_dle_plan(-1, -2, value); return PFX_OK; }       // ... then every this many layers (-1: 3, 0: only the first)
     if (std::strcmp(key, "median_search1") == 0) { pfxk_median_set_search1(value); return PFX_OK; }
     if (std::strcmp(key, "outline_bits") == 0) { ctx->outline_bits = value != 0; return PFX_OK; }
+    if (std::strcmp(key, "brush_binning") == 0) { ctx->brush_binning = value != 0; return PFX_OK; }   // 0: long strokes on the bounding-box kernel too
     if (std::strcmp(key, "median_pair") == 0) { pfxk_median_bits_set_pair(value); return PFX_OK; } // 0: the single-column bit-plane kernel for every radius
     if (std::strcmp(key, "median_bits_min") == 0) { ctx->median_bits_min = value; return PFX_OK; } // smallest radius on the bit-plane kernel (8: never)
     if (std::strcmp(key, "median_single") == 0) { pfxk_median_set_single(value); return PFX_OK; }

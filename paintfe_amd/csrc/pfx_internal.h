@@ -44,6 +44,7 @@ struct pfx_ctx {
     // ref: src/gpu/renderer.rs:232-236)
     pfx_devbuf st_in, st_out, st_mask, st_tmp, st_aux, st_aux2;
     bool outline_bits = true;  // pfx_tune "outline_bits": the outline's window search on a bit plane of alpha != 0 (0: the per-element scan)
+    bool brush_binning = true; // pfx_tune "brush_binning": strokes of more than 64 stamps are dealt to 64 x 64 chunks on the host (pfx_brush_stamps_ex_dev)
     int median_bits_min = 3;   // pfx_tune "median_bits_min": radii >= this (and <= 8) take k_median_bits.hip (r = 2: 0.35 ms against the networks' 0.22)
     pfx_devbuf fx_a, fx_b; // effect-bank scratch (crystallize cell table, drop-shadow planes)
     // small parameter buffers

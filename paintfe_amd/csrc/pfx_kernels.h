@@ -235,6 +235,10 @@ typedef struct pfxk_stamp { float cx, cy; uint32_t rgb8; float cos_a, sin_a; uin
 hipError_t pfxk_brush_stamps(hipStream_t s, uint8_t* d_target, uint32_t w, uint32_t h, const pfxk_brush* B,
                              const pfxk_stamp* d_stamps, uint32_t n_stamps, const uint8_t* d_lut256, const uint8_t* d_tip_mask,
                              const uint8_t* d_selection, int bx0, int by0, int bx1, int by1);
+/* the same with the stamps dealt to the 64 x 64 chunks their boxes touch: d_chunks = n_chunks x {chunk x, chunk y, first entry, entries}, d_bins = stamp indices (stroke order per chunk) */
+hipError_t pfxk_brush_stamps_binned(hipStream_t s, uint8_t* d_target, uint32_t w, uint32_t h, const pfxk_brush* B, const pfxk_stamp* d_stamps, uint32_t n_points,
+                                    const uint8_t* d_lut256, const uint8_t* d_tip_mask, const uint8_t* d_selection, const uint32_t* d_chunks, uint32_t n_chunks,
+                                    const uint32_t* d_bins);
 hipError_t pfxk_brush_commit(hipStream_t s, uint8_t* d_layer, const uint8_t* d_preview, const uint8_t* d_selection,
                              uint32_t w, uint32_t h, uint32_t mode, int is_eraser);
 // element-wise blend_pixel_static over two pixel arrays (spot checks / stroke commit)

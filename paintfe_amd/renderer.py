@@ -518,6 +518,13 @@ class GpuRenderer:
         arr = (_lib.DispDab * max(len(dabs), 1))(*[_lib.DispDab(int(d[0]), *[float(v) for v in d[1:]]) for d in dabs])
         self._check(self._lib.pfx_displacement_brushes_dev(self._h, C.c_void_p(disp_ptr), C.c_uint32(w), C.c_uint32(h), arr, C.c_uint32(len(dabs))))
 
+    def brush_stamps_dev(self, target_ptr: int, w: int, h: int, brush: Brush, points, selection_ptr: int = 0, dyn=None):
+        """pfx_brush_stamps_ex_dev: the stamp loop into a device-resident w*h RGBA8 target (the interactive path: the preview layer stays on the GPU)"""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        d, keep = self.make_dynamics(**dyn) if dyn is not None else (None, None)
+        self._check(self._lib.pfx_brush_stamps_ex_dev(self._h, C.c_void_p(target_ptr), C.c_uint32(w), C.c_uint32(h), C.byref(brush),
+                                                      C.byref(d) if d is not None else None, _p(pts), C.c_uint32(len(pts)), C.c_void_p(selection_ptr or None)))
+
     def resize_image_dev(self, src_ptr, w, h, dst_ptr, new_w, new_h, filter="bilinear"):
         self._check(self._lib.pfx_resize_image_dev(self._h, C.c_void_p(src_ptr), C.c_uint32(w), C.c_uint32(h), C.c_void_p(dst_ptr), C.c_uint32(new_w),
                                                    C.c_uint32(new_h), _enum(RESIZE_FILTERS, filter)))

@@ -734,6 +734,46 @@ def test_brush_dynamics(gpu, oracle, case):
         assert not np.array_equal(ref, oracle.brush_stamps(target, brush, pts, sel))
 
 
+
+@pytest.mark.parametrize("case", ["paint", "paint_noaa", "eraser", "dodge", "sponge_selection", "scatter_jitter", "tip_random_rotation", "tip_eraser"])
+@pytest.mark.parametrize("size", [(333, 190), (64, 64), (130, 65)])
+def test_brush_long_strokes_binned_by_chunk(gpu, oracle, case, size):
+    """Strokes of more than 64 stamps are dealt to the 64 x 64 chunks their boxes touch on the host (pfx_brush_stamps_ex_dev) and the kernel walks per-chunk
+    lists: the result must be the serial stamp loop's (oracle) and the bounding-box kernel's (pfx_tune "brush_binning" = 0) bit for bit — order-dependent modes
+    (max-alpha ties, eraser, Dodge / Sponge read-modify-write), stamps off the canvas and across chunk borders, canvases that are not whole chunks, image tips
+    whose rotated boxes are larger, scatter that moves stamps into other chunks."""
+    w, h = size
+    rng = np.random.default_rng(sum(map(ord, case)) + w)
+    n = 420
+    t = np.linspace(0, 9 * np.pi, n)
+    pts = np.stack([w * (0.5 + 0.62 * np.cos(t * 0.7) * np.sin(t * 0.13 + 0.4)), h * (0.5 + 0.62 * np.sin(t * 0.9))], axis=1).astype(np.float32)
+    pts[::37] += rng.uniform(-40, 40, size=pts[::37].shape).astype(np.float32)   # jumps: lists are not contiguous runs
+    target = I.random_rgba(w, h, 9) if ("dodge" in case or "sponge" in case) else np.zeros((h, w, 4), np.uint8)
+    if "eraser" in case:
+        target[:, : w // 2, 3] = 60
+    brush = dict(size=23.0, hardness=0.6, anti_aliased=case != "paint_noaa", color=(0.85, 0.3, 0.1, 0.9), flow=0.8, is_eraser="eraser" in case,
+                 mode=1 if "dodge" in case else (3 if "sponge" in case else 0))
+    dyn, sel = None, None
+    if "selection" in case:
+        sel = (rng.random((h, w)) < 0.8).astype(np.uint8) * 255
+    if case == "scatter_jitter":
+        dyn = dict(stamp_counter=77, scatter=0.9, hue_jitter=0.6, brightness_jitter=0.4)
+    if case.startswith("tip"):
+        tip = gpu.r.brush_tip_rescale(_tip_source(96), 31.0, 0.6)
+        brush["size"] = 31.0
+        dyn = dict(stamp_counter=5, tip_mask=tip)
+        if "rotation" in case:
+            dyn["tip_random_rotation"], dyn["tip_rotation_range"] = True, (-90.0, 250.0)
+    ref = oracle.brush_stamps(target, brush, pts, sel, dyn)
+    assert not np.array_equal(ref, target)
+    for binning in (1, 0):
+        gpu.r.tune("brush_binning", binning)
+        try:
+            assert_same(gpu.brush_stamps(target, brush, pts, sel, dyn), ref, 0, f"long stroke {case} {w}x{h} binning={binning}")
+        finally:
+            gpu.r.tune("brush_binning", 1)
+
+
 def test_brush_commit(gpu):
     w, h = 100, 80
     layer = I.random_rgba(w, h, 70)

@@ -162,6 +162,24 @@ def main() -> int:
         print("   ", name, round(r.timing_read(name)[0] / args.reps, 4), "ms", flush=True)
     del img, overlays, a, b, tmp4
 
+    # ---------------- brush stamp loop on a device-resident 8K preview layer (A13): px = stamped pixel visits (stamps x pi r^2)
+    w, h = 7680, 4320
+    tgt = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+
+    def line(p0, p1):   # draw_line_no_dirty's dense 1-px stepping (brush_render.rs:762-835)
+        n = int(max(abs(p1[0] - p0[0]), abs(p1[1] - p0[1]))) + 1
+        t = np.linspace(0.0, 1.0, n, dtype=np.float32)
+        return np.stack([p0[0] + (p1[0] - p0[0]) * t, p0[1] + (p1[1] - p0[1]) * t], axis=1)
+    tt = np.linspace(0, 40 * np.pi, 4000, dtype=np.float32)
+    scribble = np.stack([3800 + 1200 * np.cos(tt * 0.37) * np.sin(tt * 0.11 + 1.0), 2100 + 1200 * np.sin(tt * 0.53) * np.cos(tt * 0.07)], axis=1).astype(np.float32)
+    for name, b, pts in (("brush: mouse segment, 60 stamps, size 50", r.make_brush(50.0, 0.75, True, (0.8, 0.2, 0.1, 1.0)), line((3000, 2000), (3059, 2010))),
+                         ("brush: diagonal stroke, 6501 stamps, size 100", r.make_brush(100.0, 0.75, True, (0.1, 0.2, 0.9, 1.0)), line((500, 500), (7000, 3800))),
+                         ("brush: scribble, 4000 stamps, size 120", r.make_brush(120.0, 0.5, True, (0.1, 0.7, 0.2, 0.8)), scribble),
+                         ("brush: dodge, diagonal stroke, size 100", r.make_brush(100.0, 0.75, True, (1, 1, 1, 1.0), mode=1), line((500, 500), (7000, 3800)))):
+        timed(name, ["brush_stamps"], lambda: r.brush_stamps_dev(tgt.data_ptr(), w, h, b, pts), int(len(pts) * np.pi * (b.size / 2) ** 2), 0,
+              "kernel only (the call adds the host prologue and the stamp upload, ~0.03-0.06 ms); Mpx_s = stamped pixel visits (a pixel stays in its lane's register across the stamps: no HBM figure); strokes of > 64 stamps are dealt to 64 x 64 chunks")
+    del tgt
+
     # ---------------- 16K (config 4: mesh warp 6x6 Catmull-Rom + liquify displacement)
     w, h = 15360, 8640
     px = w * h
