@@ -51,17 +51,12 @@ PFX_DEV int32_t rs_f32_as_i32(float v)
     return (int32_t)v;
 }
 
-// geometry of one image-tip stamp at pixel (gx, gy): draw_image_tip_no_dirty :584-727.  Returns false when the stamp does not
-// touch the pixel; otherwise geom_u8 = the tip mask's coverage there (nearest texel, or bilinear under inverse rotation).
-PFX_DEV bool tip_coverage(const pfxk_brush& B, const pfxk_stamp& S, const uint8_t* __restrict__ mask, int gx, int gy, uint32_t wm1, uint32_t hm1,
-                          uint32_t& geom_u8)
+// geometry of one image-tip stamp at pixel (gx, gy): draw_image_tip_no_dirty :584-727 — the caller has already tested the stamp's box (S.x0 .. S.y1, :584-587).
+// Returns false when the stamp does not touch the pixel; otherwise geom_u8 = the tip mask's coverage there (nearest texel, or bilinear under inverse rotation).
+PFX_DEV bool tip_coverage(const pfxk_brush& B, const pfxk_stamp& S, const uint8_t* __restrict__ mask, int gx, int gy, uint32_t& geom_u8)
 {
     const uint32_t ms = B.tip_size;
     const float half = (float)ms / 2.0f;
-    const float eh = S.rotated ? half * 1.41421356237309504880f : half;
-    const uint32_t min_x = rs_f32_as_u32(__builtin_fmaxf(S.cx - eh, 0.0f)), min_y = rs_f32_as_u32(__builtin_fmaxf(S.cy - eh, 0.0f));
-    const uint32_t max_x = min(rs_f32_as_u32(S.cx + eh), wm1), max_y = min(rs_f32_as_u32(S.cy + eh), hm1);
-    if ((uint32_t)gx < min_x || (uint32_t)gx > max_x || (uint32_t)gy < min_y || (uint32_t)gy > max_y) return false;
     const float rel_x = (float)gx - S.cx, rel_y = (float)gy - S.cy;
     if (S.rotated) {
         const float rot_x = rel_x * S.cos_a - rel_y * S.sin_a + half, rot_y = rel_x * S.sin_a + rel_y * S.cos_a + half;
@@ -81,11 +76,41 @@ PFX_DEV bool tip_coverage(const pfxk_brush& B, const pfxk_stamp& S, const uint8_
     return true;
 }
 
-// BINNED: the host has dealt the stamps to the 64 x 64 chunks their bounding boxes touch (pfx_api.cpp: brush_bin_stamps — TiledImage's chunk grid); a workgroup
-// takes four rows of one ACTIVE chunk (`chunks[blockIdx.x]` = chunk x, chunk y, first entry, entries) and walks that chunk's stamp list `bins` (indices into
-// `stamps`, in stroke order).  The work is then proportional to the painted area, not to the stroke's bounding box times its length: a diagonal stroke of 6 501
-// stamps across an 8K preview layer 2.07 -> see profiles/r05_tuning.md.  Every per-pixel test is the unbinned kernel's, so the result is bit-identical.
-template <bool BINNED>
+// compute_brush_alpha (brush_render.rs:54-82; k_brush_math.h is the host's form) with its two divisions by wave-uniform denominators — the radius and
+// edge1 - edge0 — as prepared reciprocals (k_common.h: rdiv, correctly rounded, identical to `/`; numerators here are 0 or >= 2^-24 in magnitude, below 2^20).
+// The caller guarantees radius > 0 (brush_prepare skips radius^2 < 0.001).
+struct brush_alpha_k { rdiv radius, edge; float hard_m1, edge0, edge1; };
+PFX_DEV brush_alpha_k brush_alpha_prepare(float radius, float hardness)
+{
+    const float edge0 = radius + 0.5f, edge1 = radius - 0.5f;
+    return {rdiv_prepare(radius), rdiv_prepare(edge1 - edge0), rs_clamp(hardness, 0.0f, 1.0f) - 1.0f, edge0, edge1};
+}
+template <bool AA> PFX_DEV float brush_alpha_dev(const brush_alpha_k& K, float dist, float radius)
+{
+    const float t = rs_clamp(rdiv_apply(K.radius, dist), 0.0f, 1.0f);
+    const float falloff = t * t * (3.0f - 2.0f * t);
+    const float material_alpha = 1.0f + K.hard_m1 * falloff;
+    float coverage;
+    if constexpr (AA) {
+        if (dist <= K.edge1) coverage = 1.0f;
+        else if (dist >= K.edge0) coverage = 0.0f;
+        else {
+            const float x = rs_clamp(rdiv_apply(K.edge, dist - K.edge0), 0.0f, 1.0f);
+            coverage = x * x * (3.0f - 2.0f * x);
+        }
+    } else coverage = (dist <= radius) ? 1.0f : 0.0f;
+    return material_alpha * coverage;
+}
+
+// KIND: what a stamp does to a pixel — wave-uniform for the whole launch, so each kind is its own straight-line kernel body
+enum : int { BK_PAINT = 0, BK_ERASER = 1, BK_TONE = 2 /* Dodge / Burn / Sponge */, BK_TIP = 3 /* image tip: paint or eraser */ };
+
+// BINNED: the host has dealt the stamps to the 64 x 64 chunks their bounding boxes touch (pfx_api.cpp: pfx_brush_stamps_ex_dev — TiledImage's chunk grid); a
+// workgroup takes four rows of one ACTIVE chunk (`chunks[blockIdx.x]` = chunk x, chunk y, first entry, entries) and walks that chunk's stamp list `bins`
+// (indices into `stamps`, in stroke order).  The work is then proportional to the painted area, not to the stroke's bounding box times its length.  Every
+// per-pixel test is the unbinned kernel's, so the result is bit-identical.  A stamp's pixel box (S.x0 .. S.y1: :209-215 for the round tip, :584-587 for an image
+// tip) is computed once by the host prologue with the reference's float operations.
+template <bool BINNED, int KIND, bool DIRECT>
 __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ target, uint32_t w, uint32_t h, pfxk_brush B,
                                                     const pfxk_stamp* __restrict__ stamps, uint32_t n_pts_all,
                                                     const uint8_t* __restrict__ lut, const uint8_t* __restrict__ tip_mask,
@@ -109,13 +134,15 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
     if (active && selection && selection[i] == 0) active = false; // :312-320
     uint32_t px = active ? target[i] : 0u;
     const uint32_t px_in = px;
-    const uint32_t wm1 = w ? w - 1u : 0u, hm1 = h ? h - 1u : 0u;
     const uint32_t seg_lo = (uint32_t)gx0, seg_hi = (uint32_t)min(gx0 + 63, bx1);
-    auto stamp_px = [&](uint32_t k) {
-        const pfxk_stamp S = stamps[k]; // uniform -> scalar loads
-        if (B.tip_size) { // image tip (:533-760): max-alpha stamping or eraser only, no brush modes, no 0.01 cut-off for paint
+    const brush_alpha_k AK = brush_alpha_prepare(B.radius, B.hardness);
+    const float gain = B.src_a * B.flow;
+    (void)AK; (void)gain;
+    auto stamp_px = [&](const pfxk_stamp& S) {   // S is wave-uniform (broadcast from the lane that culled it)
+        if ((uint32_t)gx < S.x0 || (uint32_t)gx > S.x1 || (uint32_t)gy < S.y0 || (uint32_t)gy > S.y1) return;   // the stamp's box (host prologue)
+        if constexpr (KIND == BK_TIP) { // image tip (:533-760): max-alpha stamping or eraser only, no brush modes, no 0.01 cut-off for paint
             uint32_t g8;
-            if (!tip_coverage(B, S, tip_mask, gx, gy, wm1, hm1, g8) || g8 == 0u) return;
+            if (!tip_coverage(B, S, tip_mask, gx, gy, g8) || g8 == 0u) return;
             const float geom_alpha = div255((float)g8);
             if (B.is_eraser) {
                 const float erase_strength = geom_alpha * B.src_a * B.flow;
@@ -126,89 +153,109 @@ __global__ __launch_bounds__(256) void brush_kernel(uint32_t* __restrict__ targe
                 if (a8 >= (px >> 24)) px = S.rgb8 | (a8 << 24);
             }
             return;
-        }
-        const float2 c = make_float2(S.cx, S.cy);
-        // stamp bounding box exactly as the reference computes it (:209-215)
-        const uint32_t min_x = rs_f32_as_u32(__builtin_fmaxf(__builtin_floorf(c.x - B.draw_radius), 0.0f));
-        const uint32_t max_x = min(rs_f32_as_u32(__builtin_ceilf(c.x + B.draw_radius)), wm1);
-        const uint32_t min_y = rs_f32_as_u32(__builtin_fmaxf(__builtin_floorf(c.y - B.draw_radius), 0.0f));
-        const uint32_t max_y = min(rs_f32_as_u32(__builtin_ceilf(c.y + B.draw_radius)), hm1);
-        if ((uint32_t)gx < min_x || (uint32_t)gx > max_x || (uint32_t)gy < min_y || (uint32_t)gy > max_y) return;
-        const float dy = (float)gy - c.y, dx = (float)gx - c.x;
-        const float dist_sq = dx * dx + dy * dy;
-        if (dist_sq > B.draw_radius_sq) return;
-        uint32_t geom_u8;
-        if (B.use_direct_alpha) {
-            const float a = pfx_brush_alpha(__builtin_sqrtf(dist_sq), B.radius, B.hardness, B.anti_aliased != 0);
-            geom_u8 = (uint32_t)__builtin_fminf(__builtin_roundf(a * 255.0f), 255.0f); // :330-333
         } else {
-            geom_u8 = lut[rs_f32_as_u32(__builtin_fminf(dist_sq * B.inv_radius_sq * 255.0f, 255.0f))]; // :335-336
-        }
-        if (geom_u8 == 0u) return;
-        const float geom_alpha = div255((float)geom_u8);
-        if (B.is_eraser) { // :345-356
-            const float erase_strength = geom_alpha * B.src_a * B.flow;
-            if (erase_strength < 0.01f) return;
-            const float old_mask = div255((float)(px >> 24));
-            if (erase_strength > old_mask) px = (uint32_t)trunc_u8f(erase_strength * 255.0f) << 24;
-        } else {
-            const float brush_alpha = geom_alpha * B.src_a * B.flow;
-            if (brush_alpha < 0.01f) return;
-            if (B.mode == 0) { // Normal: max-alpha stamping, ties overwrite (:363-373)
-                const uint32_t a8 = (uint32_t)trunc_u8f(brush_alpha * 255.0f);
-                if (a8 >= (px >> 24)) px = S.rgb8 | (a8 << 24);
-            } else { // Dodge / Burn / Sponge (:374-393)
-                hsl3 c3 = rgb_to_hsl(div255(ubyte0(px)), div255(ubyte1(px)), div255(ubyte2(px)));
-                const float strength = brush_alpha * 0.5f;
-                if (B.mode == 1) c3.l = rs_clamp(c3.l + strength, 0.0f, 1.0f);
-                else if (B.mode == 2) c3.l = rs_clamp(c3.l - strength, 0.0f, 1.0f);
-                else if (B.mode == 3) c3.s = rs_clamp(c3.s - strength, 0.0f, 1.0f);
-                float nr, ng, nb;
-                if (__builtin_fabsf(c3.s) < 1e-6f) { nr = ng = nb = c3.l; }
-                else {
-                    const float q = (c3.l < 0.5f) ? c3.l * (1.0f + c3.s) : c3.l + c3.s - c3.l * c3.s;
-                    const float p = 2.0f * c3.l - q;
-                    nr = hue_to_rgb(p, q, c3.h + 1.0f / 3.0f);
-                    ng = hue_to_rgb(p, q, c3.h);
-                    nb = hue_to_rgb(p, q, c3.h - 1.0f / 3.0f);
+            const float dy = (float)gy - S.cy, dx = (float)gx - S.cx;
+            const float dist_sq = dx * dx + dy * dy;
+            if (dist_sq > B.draw_radius_sq) return;
+            uint32_t geom_u8;
+            if constexpr (DIRECT) {   // anti-aliased: the alpha straight from the distance (:330-333); DIRECT <=> draw_radius > radius <=> anti_aliased
+                const float a = brush_alpha_dev<true>(AK, __builtin_sqrtf(dist_sq), B.radius);
+                geom_u8 = (uint32_t)__builtin_fminf(__builtin_roundf(a * 255.0f), 255.0f);
+            } else {
+                geom_u8 = lut[rs_f32_as_u32(__builtin_fminf(dist_sq * B.inv_radius_sq * 255.0f, 255.0f))]; // :335-336
+            }
+            if (geom_u8 == 0u) return;
+            const float geom_alpha = div255((float)geom_u8);
+            if constexpr (KIND == BK_ERASER) { // :345-356
+                const float erase_strength = geom_alpha * B.src_a * B.flow;
+                if (erase_strength < 0.01f) return;
+                const float old_mask = div255((float)(px >> 24));
+                if (erase_strength > old_mask) px = (uint32_t)trunc_u8f(erase_strength * 255.0f) << 24;
+            } else {
+                const float brush_alpha = geom_alpha * B.src_a * B.flow;
+                if (brush_alpha < 0.01f) return;
+                if constexpr (KIND == BK_PAINT) { // Normal: max-alpha stamping, ties overwrite (:363-373)
+                    const uint32_t a8 = (uint32_t)trunc_u8f(brush_alpha * 255.0f);
+                    if (a8 >= (px >> 24)) px = S.rgb8 | (a8 << 24);
+                } else { // Dodge / Burn / Sponge (:374-393)
+                    hsl3 c3 = rgb_to_hsl(div255(ubyte0(px)), div255(ubyte1(px)), div255(ubyte2(px)));
+                    const float strength = brush_alpha * 0.5f;
+                    if (B.mode == 1) c3.l = rs_clamp(c3.l + strength, 0.0f, 1.0f);
+                    else if (B.mode == 2) c3.l = rs_clamp(c3.l - strength, 0.0f, 1.0f);
+                    else if (B.mode == 3) c3.s = rs_clamp(c3.s - strength, 0.0f, 1.0f);
+                    float nr, ng, nb;
+                    if (__builtin_fabsf(c3.s) < 1e-6f) { nr = ng = nb = c3.l; }
+                    else {
+                        const float q = (c3.l < 0.5f) ? c3.l * (1.0f + c3.s) : c3.l + c3.s - c3.l * c3.s;
+                        const float p = 2.0f * c3.l - q;
+                        nr = hue_to_rgb(p, q, c3.h + 1.0f / 3.0f);
+                        ng = hue_to_rgb(p, q, c3.h);
+                        nb = hue_to_rgb(p, q, c3.h - 1.0f / 3.0f);
+                    }
+                    px = (px & 0xff000000u) | (uint32_t)trunc_u8f(nr * 255.0f) | ((uint32_t)trunc_u8f(ng * 255.0f) << 8) |
+                         ((uint32_t)trunc_u8f(nb * 255.0f) << 16);
                 }
-                px = (px & 0xff000000u) | (uint32_t)trunc_u8f(nr * 255.0f) | ((uint32_t)trunc_u8f(ng * 255.0f) << 8) |
-                     ((uint32_t)trunc_u8f(nb * 255.0f) << 16);
             }
         }
     };
-    // Stamp culling, 64 stamps at a time: lane j tests stamp k0 + j's bounding box — the very box the per-pixel test uses — against the
-    // wave's row segment; only the stamps some lane of the wave can see are walked, in order.  (A long diagonal stroke's bounding box is
-    // mostly empty and a row segment sees a few per cent of the stamps: without this every lane walked all of them.)
+    // Stamp culling, 64 stamps at a time: lane j tests stamp k0 + j's box — the very box the per-pixel test uses — against the wave's row segment; only the
+    // stamps some lane of the wave can see are walked, in order.  (A long diagonal stroke's bounding box is mostly empty and a row segment sees a few per cent
+    // of the stamps: without this every lane walked all of them.)
     for (uint32_t k0 = 0; k0 < n_pts; k0 += 64u) {
         const uint32_t kk = k0 + lane;
         bool seen = false;
         uint32_t sidx = kk;                                   // BINNED: entry kk of the chunk's list names stamp bins[kk]
         if constexpr (BINNED) sidx = kk < n_pts ? bins[kk] : 0u;
+        // Short strokes (the bounding-box launch: a mouse segment's few dozen stamps, where a wave has nothing else to hide latency behind): the lane keeps the
+        // stamp it tested and the walk broadcasts a visible stamp's fields from that lane (v_readlane) instead of fetching the stamp again through the scalar
+        // cache — 0.035 -> 0.028 ms for a 60-stamp segment.  Long (binned) strokes keep the scalar loads: their waves overlap each other's latency and the eight
+        // broadcasts per stamp cost more than they save (6 501-stamp stroke 0.214 against 0.250 ms, same box).
+        constexpr bool BCAST = !BINNED;
+        uint4 q0 = make_uint4(0u, 0u, 0u, 0u), bx = make_uint4(1u, 0u, 1u, 0u);
+        float2 rot = make_float2(1.0f, 0.0f);
         if (kk < n_pts) {
-            const float cx = stamps[sidx].cx, cy = stamps[sidx].cy;
-            uint32_t min_x, max_x, min_y, max_y;
-            if (B.tip_size) { // tip_coverage's box
-                const float half = (float)B.tip_size / 2.0f, eh = stamps[sidx].rotated ? half * 1.41421356237309504880f : half;
-                min_x = rs_f32_as_u32(__builtin_fmaxf(cx - eh, 0.0f)); min_y = rs_f32_as_u32(__builtin_fmaxf(cy - eh, 0.0f));
-                max_x = min(rs_f32_as_u32(cx + eh), wm1); max_y = min(rs_f32_as_u32(cy + eh), hm1);
-            } else {          // :209-215
-                min_x = rs_f32_as_u32(__builtin_fmaxf(__builtin_floorf(cx - B.draw_radius), 0.0f));
-                max_x = min(rs_f32_as_u32(__builtin_ceilf(cx + B.draw_radius)), wm1);
-                min_y = rs_f32_as_u32(__builtin_fmaxf(__builtin_floorf(cy - B.draw_radius), 0.0f));
-                max_y = min(rs_f32_as_u32(__builtin_ceilf(cy + B.draw_radius)), hm1);
-            }
-            seen = !(seg_hi < min_x || seg_lo > max_x || (uint32_t)gy < min_y || (uint32_t)gy > max_y);
+            const uint4* sp = reinterpret_cast<const uint4*>(&stamps[sidx]);
+            bx = sp[1];
+            if constexpr (BCAST) { q0 = sp[0]; if constexpr (KIND == BK_TIP) rot = *reinterpret_cast<const float2*>(sp + 2); }
+            seen = !(seg_hi < bx.x || seg_lo > bx.y || (uint32_t)gy < bx.z || (uint32_t)gy > bx.w);
         }
         unsigned long long m = __ballot(seen);
         while (m) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(m);
+            const int j = (int)__builtin_ctzll(m);
             m &= m - 1ull;
-            const uint32_t k = BINNED ? (uint32_t)__builtin_amdgcn_readlane((int)sidx, (int)j) : k0 + j;
-            if (active) stamp_px(k);
+            if constexpr (BCAST) {
+                auto bc = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); };
+                pfxk_stamp S;
+                S.cx = __builtin_bit_cast(float, bc(q0.x)); S.cy = __builtin_bit_cast(float, bc(q0.y)); S.rgb8 = bc(q0.z);
+                S.x0 = bc(bx.x); S.x1 = bc(bx.y); S.y0 = bc(bx.z); S.y1 = bc(bx.w);
+                if constexpr (KIND == BK_TIP) {
+                    S.rotated = bc(q0.w);
+                    S.cos_a = __builtin_bit_cast(float, bc(__builtin_bit_cast(uint32_t, rot.x))); S.sin_a = __builtin_bit_cast(float, bc(__builtin_bit_cast(uint32_t, rot.y)));
+                } else { S.rotated = 0u; S.cos_a = 1.0f; S.sin_a = 0.0f; }
+                if (active) stamp_px(S);
+            } else {
+                if (active) stamp_px(stamps[(uint32_t)__builtin_amdgcn_readlane((int)sidx, j)]);   // uniform index -> scalar loads
+            }
         }
     }
     if (px != px_in) target[i] = px;
+}
+
+template <bool BINNED>
+hipError_t launch_brush(hipStream_t s, dim3 g, uint8_t* d_target, uint32_t w, uint32_t h, const pfxk_brush* B, const pfxk_stamp* d_stamps, uint32_t n_points,
+                        const uint8_t* d_lut256, const uint8_t* d_tip_mask, const uint8_t* d_selection, int bx0, int by0, int bx1, int by1, const uint32_t* d_chunks,
+                        const uint32_t* d_bins)
+{
+#define PFX_BRUSH_GO(KIND, DIRECT) brush_kernel<BINNED, KIND, DIRECT><<<g, 256, 0, s>>>((uint32_t*)d_target, w, h, *B, d_stamps, n_points, d_lut256, d_tip_mask, \
+                                                                                   d_selection, bx0, by0, bx1, by1, (const uint4*)d_chunks, d_bins)
+    if (B->tip_size) PFX_BRUSH_GO(BK_TIP, false);
+    else if (B->use_direct_alpha) {
+        if (B->is_eraser) PFX_BRUSH_GO(BK_ERASER, true); else if (B->mode == 0) PFX_BRUSH_GO(BK_PAINT, true); else PFX_BRUSH_GO(BK_TONE, true);
+    } else {
+        if (B->is_eraser) PFX_BRUSH_GO(BK_ERASER, false); else if (B->mode == 0) PFX_BRUSH_GO(BK_PAINT, false); else PFX_BRUSH_GO(BK_TONE, false);
+    }
+#undef PFX_BRUSH_GO
+    return hipGetLastError();
 }
 
 } // namespace
@@ -218,9 +265,8 @@ extern "C" hipError_t pfxk_brush_stamps(hipStream_t s, uint8_t* d_target, uint32
                                         const uint8_t* d_selection, int bx0, int by0, int bx1, int by1)
 {
     if (n_points == 0 || bx1 < bx0 || by1 < by0) return hipSuccess;
-    dim3 g((uint32_t)(bx1 - bx0 + 64) / 64u, (uint32_t)(by1 - by0 + 4) / 4u);
-    brush_kernel<false><<<g, 256, 0, s>>>((uint32_t*)d_target, w, h, *B, d_stamps, n_points, d_lut256, d_tip_mask, d_selection, bx0, by0, bx1, by1, nullptr, nullptr);
-    return hipGetLastError();
+    const dim3 g((uint32_t)(bx1 - bx0 + 64) / 64u, (uint32_t)(by1 - by0 + 4) / 4u);
+    return launch_brush<false>(s, g, d_target, w, h, B, d_stamps, n_points, d_lut256, d_tip_mask, d_selection, bx0, by0, bx1, by1, nullptr, nullptr);
 }
 
 // the same stamps dealt to chunks: d_chunks = n_chunks x {chunk x, chunk y, first entry of d_bins, entries}, d_bins = stamp indices in stroke order per chunk
@@ -229,7 +275,5 @@ extern "C" hipError_t pfxk_brush_stamps_binned(hipStream_t s, uint8_t* d_target,
                                                const uint8_t* d_selection, const uint32_t* d_chunks, uint32_t n_chunks, const uint32_t* d_bins)
 {
     if (n_points == 0 || n_chunks == 0) return hipSuccess;
-    brush_kernel<true><<<dim3(n_chunks, 16), 256, 0, s>>>((uint32_t*)d_target, w, h, *B, d_stamps, n_points, d_lut256, d_tip_mask, d_selection, 0, 0, 0, 0,
-                                                         (const uint4*)d_chunks, d_bins);
-    return hipGetLastError();
+    return launch_brush<true>(s, dim3(n_chunks, 16), d_target, w, h, B, d_stamps, n_points, d_lut256, d_tip_mask, d_selection, 0, 0, 0, 0, d_chunks, d_bins);
 }

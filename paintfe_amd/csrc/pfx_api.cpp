@@ -872,6 +872,22 @@ int pfx_brush_stamps_ex_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t
         }
         if (i == 0) { minx = maxx = S.cx; miny = maxy = S.cy; }
         else { minx = std::min(minx, S.cx); maxx = std::max(maxx, S.cx); miny = std::min(miny, S.cy); maxy = std::max(maxy, S.cy); }
+        // the stamp's pixel box, with the reference's float operations (:209-215 round tip, :584-587 image tip; `as u32` saturates, NaN -> 0): the kernel tests
+        // pixels against it and the binning below deals the stamp to the chunks it touches
+        {
+            auto f2u = [](float v) -> uint32_t { return (v > 0.0f) ? ((v >= 4294967296.0f) ? 0xffffffffu : (uint32_t)v) : 0u; };
+            const uint32_t wm1 = w - 1u, hm1 = h - 1u;
+            if (image_tip) {
+                const float eh = S.rotated ? half * 1.41421356237309504880f : half;
+                S.x0 = f2u(fmaxf(S.cx - eh, 0.0f)); S.y0 = f2u(fmaxf(S.cy - eh, 0.0f));
+                S.x1 = std::min(f2u(S.cx + eh), wm1); S.y1 = std::min(f2u(S.cy + eh), hm1);
+            } else {
+                S.x0 = f2u(fmaxf(floorf(S.cx - B.draw_radius), 0.0f)); S.x1 = std::min(f2u(ceilf(S.cx + B.draw_radius)), wm1);
+                S.y0 = f2u(fmaxf(floorf(S.cy - B.draw_radius), 0.0f)); S.y1 = std::min(f2u(ceilf(S.cy + B.draw_radius)), hm1);
+            }
+            if (S.x0 > S.x1 || S.y0 > S.y1) { S.x0 = 1u; S.x1 = 0u; S.y0 = 1u; S.y1 = 0u; }   // touches no pixel
+            S.pad[0] = S.pad[1] = 0u;
+        }
     }
     // bounding box of the whole stroke: union of the per-stamp boxes (brush_render.rs:209-215, 584-587) plus slack
     const float pad = reach + 2.0f;
@@ -881,30 +897,18 @@ int pfx_brush_stamps_ex_dev(pfx_ctx* ctx, void* target_dev, uint32_t w, uint32_t
     if (bx1 < bx0 || by1 < by0) return PFX_OK;
     const size_t stamp_bytes = st.size() * sizeof(pfxk_stamp), tip_bytes = image_tip ? (size_t)dyn->tip_mask_size * dyn->tip_mask_size : 0;
     // Strokes of more than one cull group: deal the stamps to the 64 x 64 chunks (TiledImage's grid) their boxes touch, so that the kernel's work follows the painted
-    // area instead of the stroke's bounding box times its length.  The box is the kernel's own (k_brush.hip: the stamp test of brush_kernel / tip_coverage), computed
-    // with the same float operations, so a chunk's list holds every stamp one of its pixels can see, in stroke order.
+    // area instead of the stroke's bounding box times its length.  A chunk's list holds every stamp whose pixel box (above) touches it, in stroke order.
     std::vector<uint32_t> chunk_tab, bins;
     if (n_points > 64u && ctx->brush_binning) {
-        auto f2u = [](float v) -> uint32_t { return (v > 0.0f) ? ((v >= 4294967296.0f) ? 0xffffffffu : (uint32_t)v) : 0u; };
-        const uint32_t wm1 = w - 1u, hm1 = h - 1u, ncx = (w + 63u) / 64u, ncy = (h + 63u) / 64u;
+        const uint32_t ncx = (w + 63u) / 64u, ncy = (h + 63u) / 64u;
         std::vector<uint32_t> box(4 * (size_t)n_points), count((size_t)ncx * ncy, 0u);
         uint64_t entries = 0;
-        for (uint32_t i = 0; i < n_points; ++i) {
+        for (uint32_t i = 0; i < n_points && entries <= (8ull << 20); ++i) {
             const pfxk_stamp& S = st[i];
-            uint32_t x0, x1, y0, y1;
-            if (image_tip) {
-                const float hf = (float)dyn->tip_mask_size / 2.0f, eh = S.rotated ? hf * 1.41421356237309504880f : hf;
-                x0 = f2u(fmaxf(S.cx - eh, 0.0f)); y0 = f2u(fmaxf(S.cy - eh, 0.0f));
-                x1 = std::min(f2u(S.cx + eh), wm1); y1 = std::min(f2u(S.cy + eh), hm1);
-            } else {
-                x0 = f2u(fmaxf(floorf(S.cx - B.draw_radius), 0.0f)); x1 = std::min(f2u(ceilf(S.cx + B.draw_radius)), wm1);
-                y0 = f2u(fmaxf(floorf(S.cy - B.draw_radius), 0.0f)); y1 = std::min(f2u(ceilf(S.cy + B.draw_radius)), hm1);
-            }
             uint32_t* b = &box[4 * (size_t)i];
-            if (x0 > x1 || y0 > y1) { b[0] = 1; b[1] = 0; b[2] = 1; b[3] = 0; continue; }   // the stamp touches no pixel
-            b[0] = x0 >> 6; b[1] = x1 >> 6; b[2] = y0 >> 6; b[3] = y1 >> 6;
+            if (S.x0 > S.x1) { b[0] = 1; b[1] = 0; b[2] = 1; b[3] = 0; continue; }
+            b[0] = S.x0 >> 6; b[1] = S.x1 >> 6; b[2] = S.y0 >> 6; b[3] = S.y1 >> 6;
             entries += (uint64_t)(b[1] - b[0] + 1u) * (b[3] - b[2] + 1u);
-            if (entries > (8ull << 20)) break;
         }
         if (entries > 0 && entries <= (8ull << 20)) {   // beyond 8 M entries (huge tips on long strokes) the unbinned kernel runs
             for (uint32_t i = 0; i < n_points; ++i) {

@@ -231,7 +231,8 @@ typedef struct pfxk_brush {
 } pfxk_brush;
 // one stamp after the host prologue of draw_circle_no_dirty / draw_image_tip_no_dirty: scattered centre, jittered colour bytes,
 // inverse-rotation cosine / sine of an image tip
-typedef struct pfxk_stamp { float cx, cy; uint32_t rgb8; float cos_a, sin_a; uint32_t rotated; } pfxk_stamp;
+// … and the stamp's pixel box [x0, x1] x [y0, y1] (brush_render.rs:209-215 / :584-587), 16-byte aligned: x0 > x1 = the stamp touches no pixel
+typedef struct pfxk_stamp { float cx, cy; uint32_t rgb8; uint32_t rotated; uint32_t x0, x1, y0, y1; float cos_a, sin_a; uint32_t pad[2]; } pfxk_stamp;
 hipError_t pfxk_brush_stamps(hipStream_t s, uint8_t* d_target, uint32_t w, uint32_t h, const pfxk_brush* B,
                              const pfxk_stamp* d_stamps, uint32_t n_stamps, const uint8_t* d_lut256, const uint8_t* d_tip_mask,
                              const uint8_t* d_selection, int bx0, int by0, int bx1, int by1);

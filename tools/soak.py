@@ -2,7 +2,7 @@
 """tools/soak.py [--seconds S] [--seed N] — randomized parity soak on the GPU against the oracle (test infrastructure, like tests/): random layer stacks
 (sizes, depths, modes, opacities, alpha structure: noise, opaque / transparent runs and blocks, reset layers at random depths) through pfx_composite — which
 picks the class-sorting, streaming or general compositor by itself —, random-sigma Gaussians in the default (<= 1 LSB) and exact (bit-exact) modes, random-radius box blurs and medians (bit-exact), random
-displacement and mesh warps (bit-exact).  Prints one JSON line; exits 1 on the first mismatch with the case's seed."""
+displacement and mesh warps (bit-exact), random brush strokes of every stamp kind (bit-exact).  Prints one JSON line; exits 1 on the first mismatch with the case's seed."""
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,7 @@ ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 r = GpuRenderer(0)
 t_end = time.time() + a.seconds
-counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0, "sharpen_glow": 0, "median": 0}
+counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0, "sharpen_glow": 0, "median": 0, "brush": 0}
 case = a.seed * 1000003
 
 
@@ -41,7 +41,7 @@ def alpha_plane(rng, w, h):
 while time.time() < t_end:
     case += 1
     rng = np.random.default_rng(case)
-    what = rng.integers(0, 13)
+    what = rng.integers(0, 14)
     try:
         if what < 6:
             w, h = int(rng.integers(1, 700)), int(rng.integers(1, 120))
@@ -84,6 +84,26 @@ while time.time() < t_end:
                 inten = float(rng.choice([0.2, 0.5, 1.0, 1.7]))
                 if not np.array_equal(r.glow_core(img, radius, inten, mask), O.glow(img, radius, inten, mask)): raise AssertionError(f"glow {w}x{h} radius {radius} intensity {inten}")
             counts["sharpen_glow"] += 1
+        elif what == 13:   # brush strokes: short (bounding-box launch) and long (dealt to 64 x 64 chunks), every stamp kind, off-canvas stamps, selections
+            w, h = int(rng.integers(1, 500)), int(rng.integers(1, 300))
+            n = int(rng.choice([1, 7, 40, 64, 65, 150, 500]))
+            t = np.linspace(0, float(rng.uniform(2, 30)), n)
+            pts = np.stack([w * (0.5 + 0.7 * np.cos(t * 0.7) * np.sin(t * 0.13 + 0.4)), h * (0.5 + 0.7 * np.sin(t * 0.9))], axis=1).astype(np.float32)
+            if rng.random() < 0.5: pts += rng.uniform(-25, 25, size=pts.shape).astype(np.float32)
+            kind = int(rng.integers(0, 5))
+            brush = dict(size=float(rng.choice([0.8, 3.0, 9.5, 23.0, 60.0, 131.0])), hardness=float(rng.random()), anti_aliased=bool(rng.random() < 0.7),
+                         color=(float(rng.random()), float(rng.random()), float(rng.random()), float(rng.uniform(0.05, 1.0))), flow=float(rng.uniform(0.05, 1.0)),
+                         is_eraser=kind == 1, mode=[0, 0, 1, 2, 3][kind])
+            target = I.random_rgba(w, h, case) if kind >= 2 else np.zeros((h, w, 4), np.uint8)
+            if kind == 1: target[:, : w // 2, 3] = int(rng.integers(0, 256))
+            sel = None if rng.random() < 0.6 else ((rng.random((h, w)) < 0.7).astype(np.uint8) * 255)
+            dyn = None if rng.random() < 0.6 else dict(stamp_counter=int(rng.integers(0, 1 << 30)), scatter=float(rng.choice([0.0, 0.5])), hue_jitter=float(rng.choice([0.0, 0.6])),
+                                                        brightness_jitter=float(rng.choice([0.0, 0.4])))
+            got = r.brush_stamps(target, r.make_brush(**brush), pts, sel, dyn)
+            ref = target.copy(); ob = O.make_brush(**brush)
+            for (x, y) in pts: O.brush_stamp(ref, ob, float(x), float(y), sel, dyn)
+            if not np.array_equal(got, ref): raise AssertionError(f"brush {w}x{h} n {n} kind {kind} size {brush['size']} aa {brush['anti_aliased']} sel {sel is not None} dyn {dyn}")
+            counts["brush"] += 1
         elif what == 12:   # median: sorted-column networks (r <= 2), the bit-plane select on column pairs (3 .. 7) and single columns (8), the value search beyond; ties, masks
             w, h = int(rng.integers(1, 420)), int(rng.integers(1, 140))
             radius = int(rng.choice([1, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 12]))
