@@ -81,6 +81,8 @@ def main() -> int:
     timed("gaussian sigma=4", ["gauss_mfma"], lambda: r.gaussian_blur_dev(s, d, w, h, 4.0, t), px, 8)
     timed("hsl(30,-20,10)", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "hsl", [30.0, -20.0, 10.0]), px, 8)
     timed("hsl masked + FROM_FLAT", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "hsl", [30.0, -20.0, 10.0], mask_ptr=m, sparse=1), px, 9)
+    timed("TiledImage round trip (from_rgba_image -> to_rgba_image)", ["tiled_roundtrip"], lambda: r.tiled_roundtrip_dev(s, d, w, h), px, 8,
+          "A0: chunks of 64 x 64 whose alpha is all zero are dropped; one pass")
     timed("invert", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "invert"), px, 8)
     timed("brightness_contrast", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "brightness_contrast", [30.0, 20.0]), px, 8)
     lut = np.tile(np.arange(255, -1, -1, dtype=np.uint8), (4, 1))
