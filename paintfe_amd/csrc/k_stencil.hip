@@ -747,6 +747,24 @@ __global__ __launch_bounds__(256) void pixelate_kernel(const uint32_t* __restric
     dst[i] = src[(size_t)sy * w + sx];
 }
 
+// Four pixels per lane, one 16-byte store (no selection, rows 16-byte aligned): the block row is wave-uniform, the block column is divided out once per
+// lane and carried over the four pixels — 8K block 8: 0.051 -> 0.038 ms.  The op writes every pixel and reads 1 / bs^2 of them.
+__global__ __launch_bounds__(256) void pixelate4_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t bs, uint32_t w, uint32_t h)
+{
+    const uint32_t x = (blockIdx.x * 64u + (threadIdx.x & 63u)) * 4u;
+    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (x >= w || y >= h) return;
+    const uint32_t sy = min((y / bs) * bs + bs / 2u, h - 1u);
+    const uint32_t* row = src + (size_t)sy * w;
+    uint32_t q = x / bs, r = x - q * bs, v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = row[min(q * bs + bs / 2u, w - 1u)];
+        if (++r == bs) { r = 0u; ++q; }
+    }
+    *reinterpret_cast<uint4*>(dst + (size_t)y * w + x) = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 } // namespace
 
 int g_median_search1 = 0; // pfxk_median_set_search1: the value search with one pixel per lane (the pre-sharing kernel)
@@ -957,6 +975,10 @@ extern "C" hipError_t pfxk_pixelate(hipStream_t s, const uint8_t* d_src, uint8_t
                                     uint32_t w, uint32_t h)
 {
     if (w == 0 || h == 0) return hipSuccess;
+    if (!d_mask && (w & 3u) == 0u && ((uintptr_t)d_dst & 15u) == 0u) {
+        pixelate4_kernel<<<dim3((w / 4u + 63u) / 64u, (h + 3) / 4), 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, bs, w, h);
+        return hipGetLastError();
+    }
     dim3 g((w + 63) / 64, (h + 3) / 4);
     pixelate_kernel<<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, bs, w, h);
     return hipGetLastError();

@@ -595,6 +595,10 @@ class GpuRenderer:
         self._check(self._lib.pfx_gaussian_blur_band_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w),
                                                          C.c_uint32(h), C.c_float(sigma), C.c_void_p(tmp_ptr or None), C.c_uint32(first_row)))
 
+    def pixelate_dev(self, src_ptr, dst_ptr, w, h, block_size, mask_ptr=0):
+        self._check(self._lib.pfx_pixelate_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h), C.c_uint32(block_size),
+                                               C.c_void_p(mask_ptr or None)))
+
     def tiled_roundtrip_dev(self, src_ptr, dst_ptr, w, h):
         """TiledImage::from_rgba_image -> to_rgba_image on device buffers (tiled_image.rs:50-104, 271-293): chunks whose alpha is all zero are dropped"""
         self._check(self._lib.pfx_tiled_roundtrip_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h)))

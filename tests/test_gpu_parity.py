@@ -434,12 +434,15 @@ def test_median_large_radius_sliding_histogram_bitexact(gpu, oracle, radius, siz
     assert np.array_equal(gpu.r.median_core(img, radius, mask), oracle.median(img, radius, mask))
 
 
-@pytest.mark.parametrize("block", [0, 1, 2, 5, 8, 64, 1000])
-def test_pixelate_bitexact(gpu, oracle, block):
-    img = I.random_rgba(203, 99, block)
-    mask = (np.random.default_rng(3).random((99, 203)) < 0.5).astype(np.uint8)
-    assert_same(gpu.pixelate(img, block), oracle.pixelate(img, block), 0, f"pixelate {block}")
-    assert_same(gpu.pixelate(img, block, mask), oracle.pixelate(img, block, mask), 0, f"pixelate {block} masked")
+@pytest.mark.parametrize("block", [0, 1, 2, 3, 5, 8, 64, 1000])
+@pytest.mark.parametrize("size", [(203, 99), (204, 99), (256, 64), (4, 1), (1028, 7)])
+def test_pixelate_bitexact(gpu, oracle, block, size):
+    """widths that are multiples of four take the four-pixels-per-lane kernel (no selection), the others and every masked call the one-pixel kernel"""
+    w, h = size
+    img = I.random_rgba(w, h, block)
+    mask = (np.random.default_rng(3).random((h, w)) < 0.5).astype(np.uint8)
+    assert_same(gpu.pixelate(img, block), oracle.pixelate(img, block), 0, f"pixelate {block} {w}x{h}")
+    assert_same(gpu.pixelate(img, block, mask), oracle.pixelate(img, block, mask), 0, f"pixelate {block} {w}x{h} masked")
 
 
 # ------------------------------------------------------------------ pointwise bank

@@ -98,6 +98,7 @@ def main() -> int:
     timed("median r=5", ["median"], lambda: r.median_dev(s, d, w, h, 5), px, 8, "bit-plane radix select")
     timed("median r=7", ["median"], lambda: r.median_dev(s, d, w, h, 7), px, 8, "225-element windows, bit-plane radix select")
     # ---------------- the rest of the effect bank (k_effects2.hip), script VM, resamplers
+    timed("pixelate block=8", ["pixelate"], lambda: r.pixelate_dev(s, d, w, h, 8), px, 8, "A6: nearest sample at the block centre (reads 1 / 64 of the pixels)")
     timed("vignette", ["vignette"], lambda: r.vignette_dev(s, d, w, h, 0.8, 0.5), px, 8)
     timed("add_noise gaussian mono", ["add_noise"], lambda: r.add_noise_dev(s, d, w, h, 30.0, "gaussian", True, 42, 1.0, 1), px, 8, "f64 ln + cos per pixel")
     timed("add_noise perlin 3 octaves", ["add_noise"], lambda: r.add_noise_dev(s, d, w, h, 50.0, "perlin", False, 42, 5.0, 3), px, 8)
