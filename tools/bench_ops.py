@@ -205,6 +205,8 @@ def main() -> int:
         wgt = torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * (400.0 / 3) ** 2)) * 0.8
         fx += ddx * wgt
         fy += ddy * wgt
+    timed("mesh displacement field 6x6 (16K, B3: generate_displacement_from_mesh)", ["mesh_displacement"],
+          lambda: r.mesh_displacement_dev(orig, deformed, 6, 6, w, h, disp.data_ptr()), px, 8, "writes the 8 B/px f32 field the fused warp never materialises")
     disp[..., 0] = fx
     disp[..., 1] = fy
     del fx, fy, yy, xx
