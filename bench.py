@@ -474,6 +474,50 @@ def c_abi_group_leg(args, torch, devices, w, h, n, info, steps, warmup):
     return out
 
 
+def live_traffic(args, kernel_hint="flatten"):
+    """HBM bytes per launch of the dominant kernel from rocprofv3's FETCH_SIZE / WRITE_SIZE counters, collected NOW on this box: two short child runs of this
+    script (`--pmc-child`: a few launches of the compositor on the headline stack) under `rocprofv3 --kernel-trace --pmc <one counter>` — separate passes,
+    FETCH_SIZE doubled, as guides/MI355X_MICROARCH.md prescribes for gfx950.  PMC collection needs rocprofv3 around the process, which is why it cannot be
+    this process; the children run after every timed leg.  Returns (dict, None) or (None, reason); never raises, never outlives its timeout."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="pfx_pmc_", dir="/tmp")
+    res = {}
+    try:
+        for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):   # KB; FETCH_SIZE x 2 (gfx950 correction)
+            cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "4", "--width", str(args.width), "--height", str(args.height),
+                   "--layers", str(args.layers)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)   # the exact process group this call started
+                except Exception:
+                    pass
+                return None, f"{counter} pass timed out"
+            vals = []
+            for f in glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_hint in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"{counter} pass returned no rows for a {kernel_hint} kernel (exit code {p.returncode})"
+            res[counter] = (sum(vals) / len(vals) * scale, len(vals))
+        return {"hbm_bytes": int(round(res["FETCH_SIZE"][0] + res["WRITE_SIZE"][0], -5)), "fetch_bytes": int(res["FETCH_SIZE"][0]),
+                "write_bytes": int(res["WRITE_SIZE"][0]), "launches_counted": res["FETCH_SIZE"][1],
+                "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE around two child runs of this script on this box (separate passes; FETCH_SIZE x 2: gfx950)"}, None
+    except Exception as e:  # noqa: BLE001 — diagnostics only
+        return None, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -497,6 +541,10 @@ def main() -> int:
     ap.add_argument("--images", type=int, default=1024, help="batch4k: images in the batch (whole job)")
     ap.add_argument("--slots", type=int, default=3, help="batch4k: buffer sets in the per-GPU upload / kernels / download pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the live HBM-traffic pass (two short rocprofv3 child runs, FETCH_SIZE and WRITE_SIZE, after everything else); roofline.traffic then "
+                         "comes from the committed counter pass (profiles/rNN_pmc.json) and is marked static")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: N launches of the dominant kernel on the headline stack, nothing printed
     ap.add_argument("--headline-only", action="store_true", help="skip the other BASELINE configurations (development runs)")
     ap.add_argument("--tune", action="append", default=[], help="key=value kernel tuning knob (development)")
     ap.add_argument("--exact", action="store_true", help="Gaussian without FMA contraction (bit-exact with the CPU path)")
@@ -557,6 +605,15 @@ def main() -> int:
     radius = int(np.ceil(np.float32(args.sigma) * np.float32(3.0)))
     modes, opac = synth_params(n, 0x5EED0002)
     info = [(k, float(opac[k]), True, int(modes[k])) for k in range(n)]
+    if args.pmc_child:
+        # the counted launches of live_traffic(): the headline stack, the dominant kernel, nothing else on the device
+        stack, _, _ = synth_stack(torch, device, w, h, n, seed=0x5EED0002)
+        out_c = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
+        ptrs_c = [stack[k].data_ptr() for k in range(n)]
+        for _ in range(args.pmc_child):
+            r.flatten_dev(ptrs_c, info, w, h, out_c.data_ptr())
+        torch.cuda.synchronize()
+        return 0
 
     state = {}
 
@@ -893,6 +950,19 @@ def main() -> int:
             cfgs, cfg_failed = other_configs(args, torch, r, device, O, flat, blurred)
             out["configs"] = cfgs
             failed += cfg_failed
+        # LAST, with nothing else on the device: the dominant kernel's HBM traffic from this box's counters (the other counter fields stay static: they need
+        # SQ passes whose collection slows the kernels down)
+        if world == 1 and not band_mode and not args.no_live_pmc and dominant == "flatten" and not args.tune:
+            torch.cuda.synchronize()
+            live, why = live_traffic(args)
+            rf = out.get("roofline") or {}
+            if live:
+                rf["traffic"] = live["hbm_bytes"]
+                rf["traffic_live"] = live
+                if isinstance(rf.get("static"), dict):
+                    rf["static"]["fields"] = [f for f in rf["static"]["fields"] if f != "traffic"]
+            else:
+                rf["traffic_live"] = {"error": why}
         if failed:  # a wrong-but-fast kernel must not be scored
             out["value"] = None
             out["failed_checks"] = failed

@@ -236,3 +236,24 @@ def test_pipelined_band_steps_return_the_previous_document(nproc, tmp_path):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                         "--master-port", str(29690 + nproc), str(script)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert "PIPELINED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_single_rank_line_carries_live_hbm_traffic():
+    """N = 1: roofline.traffic comes from a FETCH_SIZE and a WRITE_SIZE pass collected by the run itself (two rocprofv3 child runs after the timed legs), not
+    from a committed profile; the compositor reads every layer once and writes the frame once, so the figure sits just above the algorithmic bytes"""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not installed")
+    w, h, n = 2048, 1024, 20
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--width", str(w), "--height", str(h), "--layers", str(n),
+           "--sigma", "3.0", "--no-cpu-baseline", "--no-group", "--headline-only"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
+    rf = json.loads(lines[0])["roofline"]
+    live = rf["traffic_live"]
+    assert "error" not in live, live
+    alg = (4 * n + 4) * w * h
+    assert rf["traffic"] == live["hbm_bytes"] and live["launches_counted"] >= 4
+    assert 0.95 * alg <= live["hbm_bytes"] <= 1.35 * alg, (live, alg)
+    assert abs(live["write_bytes"] - 4 * w * h) <= 0.2 * 4 * w * h
