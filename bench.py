@@ -485,8 +485,8 @@ def live_traffic(args, kernel_hint="flatten"):
     tmp = tempfile.mkdtemp(prefix="pfx_pmc_", dir="/tmp")
     res = {}
     try:
-        for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):   # KB; FETCH_SIZE x 2 (gfx950 correction)
-            cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--",
+        for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0), ("SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32", 1.0)):   # KB; FETCH_SIZE x 2 (gfx950 correction)
+            cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", *counter.split(), "-d", os.path.join(tmp, counter.split()[0]), "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "4", "--width", str(args.width), "--height", str(args.height),
                    "--layers", str(args.layers)]
             env = dict(os.environ, TMPDIR="/tmp")
@@ -501,17 +501,26 @@ def live_traffic(args, kernel_hint="flatten"):
                 except Exception:
                     pass
                 return None, f"{counter} pass timed out"
-            vals = []
-            for f in glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if kernel_hint in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
-                return None, f"{counter} pass returned no rows for a {kernel_hint} kernel (exit code {p.returncode})"
-            res[counter] = (sum(vals) / len(vals) * scale, len(vals))
-        return {"hbm_bytes": int(round(res["FETCH_SIZE"][0] + res["WRITE_SIZE"][0], -5)), "fetch_bytes": int(res["FETCH_SIZE"][0]),
-                "write_bytes": int(res["WRITE_SIZE"][0]), "launches_counted": res["FETCH_SIZE"][1],
-                "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE around two child runs of this script on this box (separate passes; FETCH_SIZE x 2: gfx950)"}, None
+            for c in counter.split():
+                vals = []
+                for f in glob.glob(os.path.join(tmp, counter.split()[0], "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if kernel_hint in row.get("Kernel_Name", "") and row.get("Counter_Name") == c:
+                            vals.append(float(row["Counter_Value"]))
+                if not vals:
+                    if c.startswith("SQ_"):   # the instruction counts are an extra: the traffic stands without them
+                        continue
+                    return None, f"{c} pass returned no rows for a {kernel_hint} kernel (exit code {p.returncode})"
+                res[c] = (sum(vals) / len(vals) * scale, len(vals))
+        d = {"hbm_bytes": int(round(res["FETCH_SIZE"][0] + res["WRITE_SIZE"][0], -5)), "fetch_bytes": int(res["FETCH_SIZE"][0]),
+             "write_bytes": int(res["WRITE_SIZE"][0]), "launches_counted": res["FETCH_SIZE"][1],
+             "how": "rocprofv3 --kernel-trace --pmc <counters> around short child runs of this script on this box (FETCH_SIZE, WRITE_SIZE and the SQ instruction counts "
+                    "in separate passes; FETCH_SIZE x 2: gfx950)"}
+        if "SQ_INSTS_VALU" in res:
+            d["valu_wave_insts"] = int(res["SQ_INSTS_VALU"][0])
+            if "SQ_INSTS_VALU_TRANS_F32" in res:
+                d["valu_trans_wave_insts"] = int(res["SQ_INSTS_VALU_TRANS_F32"][0])
+        return d, None
     except Exception as e:  # noqa: BLE001 — diagnostics only
         return None, f"{type(e).__name__}: {e}"[:200]
     finally:
@@ -959,8 +968,21 @@ def main() -> int:
             if live:
                 rf["traffic"] = live["hbm_bytes"]
                 rf["traffic_live"] = live
+                now_live = ["traffic"]
+                d_ms_l = (rf.get("kernel_ms") or {}).get("flatten", 0.0)
+                if live.get("valu_wave_insts") and d_ms_l > 0:
+                    # the instruction count is a property of the launch (the same stack, the same kernel): this box's count against this run's duration, at the
+                    # clock this run sampled while the workload ran (the committed pass's clock otherwise)
+                    clk = rf.get("clock_ghz_sustained") or 2.0
+                    rf["valu_frac"] = round(live["valu_wave_insts"] * 2 / (1024 * clk * 1e9 * d_ms_l * 1e-3), 3)
+                    rf["valu_insts_per_layer_px"] = round(live["valu_wave_insts"] * 64 / (args.layers * args.width * args.height), 1)
+                    now_live += ["valu_frac", "valu_insts_per_layer_px"]
+                    if rf.get("fma_sustained_T_lane_ops_s"):
+                        slots = live["valu_wave_insts"] + 3 * live.get("valu_trans_wave_insts", 0)
+                        rf["valu_frac_of_sustained_fma_rate"] = round(slots * 64 / (d_ms_l * 1e-3) / (rf["fma_sustained_T_lane_ops_s"] * 1e12), 3)
+                        now_live.append("valu_frac_of_sustained_fma_rate")
                 if isinstance(rf.get("static"), dict):
-                    rf["static"]["fields"] = [f for f in rf["static"]["fields"] if f != "traffic"]
+                    rf["static"]["fields"] = [f for f in rf["static"]["fields"] if f not in now_live]
             else:
                 rf["traffic_live"] = {"error": why}
         if failed:  # a wrong-but-fast kernel must not be scored
