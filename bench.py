@@ -482,6 +482,8 @@ def live_traffic(args, kernel_hint="flatten"):
     import csv, glob, shutil, signal, subprocess, tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler (no nested rocprofv3)"
     tmp = tempfile.mkdtemp(prefix="pfx_pmc_", dir="/tmp")
     res = {}
     try:

@@ -7,9 +7,9 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --headline-only --no-group"
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --headline-only --no-group --no-live-pmc"
 # the trace pass runs bench.py's default step / warm-up counts (the clocks ramp over the first launches: a 7-launch run reads 10 % slow)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $ROOT/bench.py --no-cpu-baseline --headline-only --no-group > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $ROOT/bench.py --no-cpu-baseline --headline-only --no-group --no-live-pmc > $OUT/trace.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o bench -- $BENCH > $OUT/pmc_sq.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/pmc_sq2 -o bench -- $BENCH > $OUT/pmc_sq2.log 2>&1
 # instruction classes: FMA / MUL / ADD f32 issue in 2 cycles per wave64, everything else in 4 (min / max / trunc / cvt / compare / select), transcendentals
