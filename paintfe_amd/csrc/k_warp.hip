@@ -446,7 +446,10 @@ __global__ __launch_bounds__(256) void disp_brush_kernel(float2* __restrict__ di
     if (py >= by1 || px0 >= bx1) return; // whole wave
     const bool active = px < bx1;
     float2* p = disp + (size_t)py * w + (size_t)min(px, bx1 - 1);
-    float2 d = active ? *p : make_float2(0.0f, 0.0f);
+    // the field is read when the wave meets its first dab and written back only by the lanes a dab reached: the dabs' common bounding box is mostly
+    // untouched field (32 dabs of radius 400 spread over a 16K field: 0.36 -> 0.20 ms), and `x += 0` would not even be a no-op for -0.0
+    float2 d = make_float2(0.0f, 0.0f);
+    bool loaded = false, touched = false;
     const int seg_hi = min(px0 + 64, bx1); // exclusive
     auto dab_px = [&](uint32_t k) {
         const pfxk_disp_dab D = dabs[k]; // uniform -> scalar loads
@@ -454,6 +457,7 @@ __global__ __launch_bounds__(256) void disp_brush_kernel(float2* __restrict__ di
         const float dx = (float)px - D.cx, dy = (float)py - D.cy;
         const float dist_sq = dx * dx + dy * dy;
         if (dist_sq > D.r * D.r) return;
+        touched = true;
         if (D.mode == 0) {        // push :1051-1085
             const float weight = (float)exp((double)(-dist_sq / D.sigma_sq_2)) * D.strength;
             d.x += D.delta_x * weight;
@@ -480,13 +484,14 @@ __global__ __launch_bounds__(256) void disp_brush_kernel(float2* __restrict__ di
         bool seen = false;
         if (kk < n) seen = !(seg_hi <= dabs[kk].x0 || px0 >= dabs[kk].x1 || py < dabs[kk].y0 || py >= dabs[kk].y1);
         unsigned long long m = __ballot(seen);
+        if (m && !loaded) { loaded = true; if (active) d = *p; }   // wave-uniform
         while (m) {
             const uint32_t k = k0 + (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
             if (active) dab_px(k);
         }
     }
-    if (active) *p = d;
+    if (active && touched) *p = d;
 }
 
 extern "C" hipError_t pfxk_disp_brushes(hipStream_t s, float* d_disp, uint32_t w, uint32_t h, const pfxk_disp_dab* d_dabs, uint32_t n, int bx0, int by0,

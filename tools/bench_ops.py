@@ -210,6 +210,13 @@ def main() -> int:
     disp[..., 0] = fx
     disp[..., 1] = fy
     del fx, fy, yy, xx
+    rngd = np.random.default_rng(7)
+    dabs = [(int(m), float(rngd.uniform(2000, w - 2000)), float(rngd.uniform(1500, h - 1500)), float(rngd.uniform(-20, 20)), float(rngd.uniform(-20, 20)), 400.0, 0.6)
+            for m in (0, 1, 2, 3, 4, 0, 0, 0) * 4]
+    fld = torch.zeros((h, w, 2), dtype=torch.float32, device=dev)
+    timed("liquify dabs into the field: 32 dabs, radius 400 (16K)", ["displacement_brush"], lambda: r.displacement_brushes_dev(fld.data_ptr(), w, h, dabs),
+          int(32 * np.pi * 400 * 400), 0, "DisplacementField::apply_* on the device-resident field (N4): Mpx_s = dab pixel visits")
+    del fld
     timed("liquify displacement warp (16K)", ["warp_displacement"], lambda: r.warp_displacement_dev(s, w, h, disp.data_ptr(), w, h, d), px, 16,
           "4 + 8 (field) + 4 B/px")
 
