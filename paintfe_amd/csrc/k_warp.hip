@@ -436,13 +436,21 @@ extern "C" hipError_t pfxk_warp_displacement(hipStream_t s, const uint8_t* d_src
 // order, accumulating in registers (same per-pixel order of the `+=`), one read and one write of the field per launch.
 // exp() is evaluated in f64 and rounded once (see k_effects2.hip's header): the field may differ from the CPU path in the last
 // ulp of a weight, which stays far below the warp's +-1 LSB.
+// CHUNKED: the launch runs over the 64 x 64 chunks some dab's box touches (`chunks[blockIdx.x]` = chunk x | chunk y << 16, built by the host) instead of the
+// dabs' common bounding box, which for dabs spread over a large field is mostly untouched
+template <bool CHUNKED>
 __global__ __launch_bounds__(256) void disp_brush_kernel(float2* __restrict__ disp, uint32_t w, const pfxk_disp_dab* __restrict__ dabs, uint32_t n,
-                                                         int bx0, int by0, int bx1, int by1)
+                                                         int bx0, int by0, int bx1, int by1, const uint32_t* __restrict__ chunks)
 {
+    if constexpr (CHUNKED) {   // the chunk, clipped to the dabs' bounding box (exclusive upper bounds)
+        const uint32_t ch = chunks[blockIdx.x];
+        const int cx0 = (int)((ch & 0xffffu) * 64u), cy0 = (int)((ch >> 16) * 64u);
+        bx1 = min(bx1, cx0 + 64); by1 = min(by1, cy0 + 64); bx0 = max(bx0, cx0); by0 = max(by0, cy0);
+    }
     // a wave covers one 64-pixel row segment (py and the segment's x range are wave-uniform); dabs are culled against it 64 at a time
     // with the reference's own loop bounds, so a lane only walks the dabs its wave can see — in order, like the reference's `+=`
     const uint32_t lane = threadIdx.x & 63u;
-    const int px0 = bx0 + (int)(blockIdx.x * 64u), px = px0 + (int)lane, py = by0 + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int px0 = bx0 + (CHUNKED ? 0 : (int)(blockIdx.x * 64u)), px = px0 + (int)lane, py = by0 + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (py >= by1 || px0 >= bx1) return; // whole wave
     const bool active = px < bx1;
     float2* p = disp + (size_t)py * w + (size_t)min(px, bx1 - 1);
@@ -500,7 +508,17 @@ extern "C" hipError_t pfxk_disp_brushes(hipStream_t s, float* d_disp, uint32_t w
     (void)h;
     if (n == 0 || bx1 <= bx0 || by1 <= by0) return hipSuccess;
     dim3 g((uint32_t)(bx1 - bx0 + 63) / 64, (uint32_t)(by1 - by0 + 3) / 4);
-    disp_brush_kernel<<<g, 256, 0, s>>>((float2*)d_disp, w, d_dabs, n, bx0, by0, bx1, by1);
+    disp_brush_kernel<false><<<g, 256, 0, s>>>((float2*)d_disp, w, d_dabs, n, bx0, by0, bx1, by1, nullptr);
+    return hipGetLastError();
+}
+
+// the same over a list of 64 x 64 chunks (chunk x | chunk y << 16) instead of the whole bounding box
+extern "C" hipError_t pfxk_disp_brushes_chunked(hipStream_t s, float* d_disp, uint32_t w, uint32_t h, const pfxk_disp_dab* d_dabs, uint32_t n, int bx0, int by0,
+                                                int bx1, int by1, const uint32_t* d_chunks, uint32_t n_chunks)
+{
+    (void)h;
+    if (n == 0 || n_chunks == 0 || bx1 <= bx0 || by1 <= by0) return hipSuccess;
+    disp_brush_kernel<true><<<dim3(n_chunks, 16), 256, 0, s>>>((float2*)d_disp, w, d_dabs, n, bx0, by0, bx1, by1, d_chunks);
     return hipGetLastError();
 }
 

@@ -711,11 +711,34 @@ int pfx_displacement_brushes_dev(pfx_ctx* ctx, void* disp_dev, uint32_t w, uint3
         if (K.x1 > K.x0 && K.y1 > K.y0) { bx0 = std::min(bx0, K.x0); by0 = std::min(by0, K.y0); bx1 = std::max(bx1, K.x1); by1 = std::max(by1, K.y1); }
     }
     if (bx1 <= bx0 || by1 <= by0) return PFX_OK; // every dab is off-canvas
-    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, k.size() * sizeof(pfxk_disp_dab)));
+    // Dabs spread over a large field: launch over the 64 x 64 chunks their boxes touch instead of the common bounding box when that is less than half of it
+    std::vector<uint32_t> chunks;
+    {
+        const uint32_t cx0 = (uint32_t)bx0 >> 6, cy0 = (uint32_t)by0 >> 6, ncx = (((uint32_t)bx1 + 63u) >> 6) - cx0, ncy = (((uint32_t)by1 + 63u) >> 6) - cy0;
+        if ((uint64_t)ncx * ncy >= 256u && ncx < 65536u && ncy < 65536u) {
+            std::vector<uint8_t> hit((size_t)ncx * ncy, 0);
+            for (const pfxk_disp_dab& K : k) {
+                if (!(K.x1 > K.x0 && K.y1 > K.y0)) continue;
+                for (uint32_t cy = (uint32_t)K.y0 >> 6; cy <= ((uint32_t)K.y1 - 1u) >> 6; ++cy)
+                    for (uint32_t cx = (uint32_t)K.x0 >> 6; cx <= ((uint32_t)K.x1 - 1u) >> 6; ++cx) hit[(size_t)(cy - cy0) * ncx + (cx - cx0)] = 1;
+            }
+            for (uint32_t cy = 0; cy < ncy; ++cy)
+                for (uint32_t cx = 0; cx < ncx; ++cx)
+                    if (hit[(size_t)cy * ncx + cx]) chunks.push_back((cx0 + cx) | ((cy0 + cy) << 16));
+            if (chunks.size() * 2u > (size_t)ncx * ncy) chunks.clear();   // mostly covered: the plain launch
+        }
+    }
+    const size_t dab_bytes = (k.size() * sizeof(pfxk_disp_dab) + 15u) & ~(size_t)15u;
+    PFX_TRY(pfx_reserve(ctx, ctx->d_pts, dab_bytes + chunks.size() * 4u + 16u));
     PFX_TRY(pfx_h2d(ctx, ctx->d_pts.p, k.data(), k.size() * sizeof(pfxk_disp_dab)));
-    PFX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `k` is pageable host memory about to go out of scope
+    if (!chunks.empty()) PFX_TRY(pfx_h2d(ctx, (uint8_t*)ctx->d_pts.p + dab_bytes, chunks.data(), chunks.size() * 4u));
+    PFX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `k` / `chunks` are pageable host memory about to go out of scope
     pfx_timer t(ctx, "displacement_brush");
-    PFX_HIP(ctx, pfxk_disp_brushes(ctx->stream, (float*)disp_dev, w, h, (const pfxk_disp_dab*)ctx->d_pts.p, n_dabs, bx0, by0, bx1, by1));
+    if (!chunks.empty())
+        PFX_HIP(ctx, pfxk_disp_brushes_chunked(ctx->stream, (float*)disp_dev, w, h, (const pfxk_disp_dab*)ctx->d_pts.p, n_dabs, bx0, by0, bx1, by1,
+                                               (const uint32_t*)((const uint8_t*)ctx->d_pts.p + dab_bytes), (uint32_t)chunks.size()));
+    else
+        PFX_HIP(ctx, pfxk_disp_brushes(ctx->stream, (float*)disp_dev, w, h, (const pfxk_disp_dab*)ctx->d_pts.p, n_dabs, bx0, by0, bx1, by1));
     return PFX_OK;
 }
 

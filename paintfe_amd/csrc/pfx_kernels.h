@@ -220,6 +220,9 @@ hipError_t pfxk_warp_mesh(hipStream_t s, const uint8_t* d_src, const float* d_or
 typedef struct pfxk_disp_dab { int32_t mode, x0, y0, x1, y1; float cx, cy, delta_x, delta_y, r, sigma_sq_2, strength; } pfxk_disp_dab;
 hipError_t pfxk_disp_brushes(hipStream_t s, float* d_disp, uint32_t w, uint32_t h, const pfxk_disp_dab* d_dabs, uint32_t n, int bx0, int by0, int bx1,
                              int by1);
+/* … over the 64 x 64 chunks a dab's box touches (d_chunks: chunk x | chunk y << 16) instead of the whole bounding box */
+hipError_t pfxk_disp_brushes_chunked(hipStream_t s, float* d_disp, uint32_t w, uint32_t h, const pfxk_disp_dab* d_dabs, uint32_t n, int bx0, int by0, int bx1, int by1,
+                                     const uint32_t* d_chunks, uint32_t n_chunks);
 
 // ---- k_brush.hip ----
 typedef struct pfxk_brush {

@@ -638,6 +638,42 @@ def test_displacement_brushes_host(gpu):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
 
 
+def test_displacement_brushes_spread_over_a_large_field(gpu):
+    """dabs far apart on a large field take the launch over the chunks their boxes touch (pfx_displacement_brushes_dev: less than half of the common bounding
+    box) — the result must be the plain launch's (a compact batch of the same dabs, one call each) and the oracle's; untouched field keeps its bits (-0.0 included)"""
+    w, h = 1700, 1300
+    rng = np.random.default_rng(21)
+    centres = [(90.0, 80.0), (1600.0, 1210.0), (850.0, 640.0), (1650.0, 70.0), (63.5, 1240.0)]
+    dabs = []
+    for k in range(30):
+        cx, cy = centres[k % len(centres)]
+        dabs.append((int(rng.integers(0, 5)), cx + float(rng.uniform(-30, 30)), cy + float(rng.uniform(-30, 30)), float(rng.uniform(-8, 8)), float(rng.uniform(-8, 8)),
+                     float(rng.uniform(5, 70)), float(rng.uniform(0.1, 1.0))))
+    start = np.zeros((h, w, 2), np.float32)
+    start[::7, ::5] = -0.0
+    start[300:310, 400:420] = 3.25
+    ref = start.copy()
+    for d in dabs:
+        O.displacement_brush(ref, *d)
+    dev = gpu.r.dev_alloc(w * h * 8)
+    dev2 = gpu.r.dev_alloc(w * h * 8)
+    try:
+        gpu.r.dev_upload(dev, start)
+        gpu.r.displacement_brushes_dev(dev, w, h, dabs)            # one batch: spread -> chunk launch
+        got = gpu.r.dev_download(dev, (h, w, 2), np.float32)
+        gpu.r.dev_upload(dev2, start)
+        for d in dabs:                                             # one dab per call: compact boxes -> plain launch
+            gpu.r.displacement_brushes_dev(dev2, w, h, [d])
+        one_by_one = gpu.r.dev_download(dev2, (h, w, 2), np.float32)
+        assert np.array_equal(got.view(np.uint32), one_by_one.view(np.uint32))
+        assert np.allclose(got, ref, rtol=2e-6, atol=2e-6), float(np.abs(got - ref).max())
+        untouched = ref.view(np.uint32) == start.view(np.uint32)
+        assert np.array_equal(got.view(np.uint32)[untouched], start.view(np.uint32)[untouched])
+    finally:
+        gpu.r.dev_free(dev)
+        gpu.r.dev_free(dev2)
+
+
 def test_displacement_brushes_on_a_device_field(gpu):
     """a Liquify stroke (mixed dabs, overlapping, partly off-canvas, integer-radius edge) accumulated on the device, then warped"""
     w, h = 300, 200
