@@ -208,3 +208,19 @@ def test_design_md_measured_blocks_are_generated_from_the_committed_profiles():
     a newer profile without a regenerated DESIGN.md, fails here."""
     r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_bench_live_counter_pass_fails_soft():
+    """bench.py's live HBM-traffic pass (rocprofv3 child runs) must never take the headline line down with it: without a device (this suite), without rocprofv3,
+    or under an outer profiler it returns (None, reason) and the line keeps the committed figure"""
+    import argparse
+    import importlib
+    bench = importlib.import_module("bench")
+    os.environ["ROCPROF_TEST_MARK"] = "1"          # looks like an outer profiler: refused before anything is started
+    try:
+        d, why = bench.live_traffic(argparse.Namespace(width=64, height=64, layers=4))
+        assert d is None and "profiler" in why
+    finally:
+        del os.environ["ROCPROF_TEST_MARK"]
+    d, why = bench.live_traffic(argparse.Namespace(width=64, height=64, layers=4))   # no GPU here: the child fails, the parent reports it
+    assert d is None and isinstance(why, str) and why
