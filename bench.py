@@ -658,7 +658,7 @@ def main() -> int:
             state["per_rank_ms_per_step"] = [round(float(t.item()), 4) for t in every]
             el = max_over_ranks(el, device=device)  # the step time of the job is the slowest rank's
         kern = {}
-        for name in ("flatten", "gauss_mfma", "gauss_h", "gauss_v"):
+        for name in ("flatten", "gauss_mfma", "gauss_h", "gauss_v", "gauss_fused"):
             ms, cnt = r.timing_read(name)
             if cnt:
                 kern[name] = (ms / cnt, cnt)
@@ -756,6 +756,23 @@ def main() -> int:
         flat_view = flat
         if world == 1:
             state["clock_power"] = clock_power_sample(torch, step, dev_index)
+        if world == 1 and not args.exact:
+            # the strict-f32 pipeline beside the default one: the same step with the Gaussian in the bit-exact mode (f32 taps, one rounding per
+            # operation, no matrix cores), timed the same way into its own result buffer and checked whole-frame at tolerance 0 where the default leg is checked
+            blurred_x = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
+
+            def step_exact():
+                r.flatten_dev(ptrs, info, w, h, flat.data_ptr())
+                r.gaussian_blur_dev(flat.data_ptr(), blurred_x.data_ptr(), w, h, args.sigma)
+
+            keep = state.get("step_ms")
+            r.set_exact(True)
+            try:
+                x_el, x_kern = timed(step_exact)
+            finally:
+                r.set_exact(False)
+            state["exact_leg"] = {"elapsed": x_el, "kern": x_kern, "step_ms": state.get("step_ms"), "image": blurred_x}
+            state["step_ms"] = keep
 
     px_per_step = w * h
     docs = 1 if (band_mode or world == 1) else world         # band mode: the whole job is one document per step
@@ -832,7 +849,17 @@ def main() -> int:
                                                 "" if args.no_gather else " (the all-gathered variant of the same run: band_gathered_result)")) if band_mode else
                                   ("one independent document per GPU, no collective" if world > 1 else "single GPU")},
            "step_ms_hip_events": state.get("headline_step_ms", state.get("step_ms")),   # the headline's, not a secondary mode's
+           "prewarm": PREWARM,   # untimed steps in front of the --warmup steps of every timed leg (the clock needs ~30 ms of load to settle)
            "roofline": roofline}
+    if state.get("exact_leg"):
+        xl = state["exact_leg"]
+        x_bytes = pipeline_bytes * args.steps / xl["elapsed"] / 1e9
+        out["value_exact_f32"] = round(px_per_step * args.steps / xl["elapsed"] / 1e6, 1)
+        out["ms_per_step_exact"] = round(xl["elapsed"] / args.steps * 1e3, 4)
+        out["pipeline_frac_exact"] = round(x_bytes / HBM_PEAK_GBS, 4)
+        out["exact_f32_leg"] = {"what": "the same step with the Gaussian in the bit-exact mode (f32 taps and sums, one rounding per operation; dtype f32 throughout)",
+                                "kernel_ms": {k: round(v[0], 4) for k, v in xl["kern"].items()}, "step_ms_hip_events": xl["step_ms"],
+                                "pipeline_achieved_GBs": round(x_bytes, 1)}
     if world > 1:
         out["ranks"] = {"world_size": dist.get_world_size(), "backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend,
                         "devices_visible": torch.cuda.device_count(),
@@ -915,6 +942,12 @@ def main() -> int:
                 out["check"]["gaussian_channels_off_by_one"] = round(float((gb != blurred.cpu().numpy()).mean()), 6)
                 if dmax > (0 if args.exact else 1):
                     failed.append("gaussian_whole_frame_max_diff")
+                if state.get("exact_leg"):
+                    x_ok = bool(np.array_equal(gb, state["exact_leg"]["image"].cpu().numpy()))
+                    out["exact_f32_leg"]["gaussian_whole_frame_bitexact"] = x_ok
+                    if not x_ok:
+                        out["value_exact_f32"] = None
+                        failed.append("exact_f32_leg_gaussian_whole_frame_bitexact")
             # the reference-faithful variant beside the fair one: rayon collects the chunks and ONE thread writes them back
             # (canvas_state.rs:686-695)
             O.set_serial_writeback(True)
@@ -930,6 +963,18 @@ def main() -> int:
                                    "faithful": {"value": round(sw * sh / ((t5 - t4) + (t3 - t2)) / 1e6, 2), "unit": "Mpixels/s", "cores": cores,
                                                 "what": f"same sample with the reference's collect + single-threaded put_pixel write-back "
                                                         f"(canvas_state.rs:686-695): flatten {t5 - t4:.2f}s + gaussian {t3 - t2:.2f}s"}}
+        if state.get("exact_leg") and "gaussian_whole_frame_bitexact" not in out.get("exact_f32_leg", {}):
+            # no whole-frame baseline in this run: a full-width window of the strict-f32 result against the oracle's Gaussian of the same flatten rows
+            lo_w, hi_w = max(0, 1000 - radius), min(h, 1256 + radius)
+            ref_w = O.gaussian_blur(flat_view[lo_w:hi_w].contiguous().cpu().numpy(), args.sigma)
+            a0 = 0 if lo_w == 0 else radius
+            a1 = (hi_w - lo_w) if hi_w == h else (hi_w - lo_w) - radius
+            x_ok = bool(np.array_equal(ref_w[a0:a1], state["exact_leg"]["image"][lo_w + a0:lo_w + a1].contiguous().cpu().numpy()))
+            out["exact_f32_leg"]["gaussian_window_bitexact"] = x_ok
+            if not x_ok:
+                out["value_exact_f32"] = None
+                failed.append("exact_f32_leg_gaussian_window_bitexact")
+        state.pop("exact_leg", None)
         if not args.no_group and (world == 1 or band_mode):
             # the C-ABI multi-GPU path (one process, every device), beside the torch.distributed headline; the other ranks wait on the host (host_pg)
             devices = list(range(world)) if (world > 1 and backend == "nccl") else [dev_index] * world

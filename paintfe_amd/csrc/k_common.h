@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define PFX_DEV __device__ __forceinline__
 
@@ -138,6 +139,23 @@ PFX_DEV uint32_t xcd_swizzle(uint32_t bid, uint32_t nblocks)
     uint32_t main = per * NXCD;
     if (bid >= main) return bid; // ragged tail keeps its position
     return (bid % NXCD) * per + (bid / NXCD);
+}
+
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (kernel, device) pair: a launcher keeps one `lds_grant` per kernel instantiation (a function-local
+// static of the templated launch lambda) and asks the runtime only when the pair needs more than it was granted before — not on every launch.
+struct lds_grant { std::atomic<uint32_t> bytes[32]; };
+inline hipError_t grant_lds(lds_grant& g, const void* kernel, size_t lds)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e) return e;
+    const bool slot = dev >= 0 && dev < 32;
+    if (slot && g.bytes[dev].load(std::memory_order_relaxed) >= lds) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e) return e;
+    if (slot) g.bytes[dev].store((uint32_t)lds, std::memory_order_relaxed);
+    return hipSuccess;
 }
 
 } // namespace pfxk

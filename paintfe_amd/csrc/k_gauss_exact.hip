@@ -209,7 +209,8 @@ extern "C" hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* 
     nseg = ((int)h + seg_rows - 1) / seg_rows;
     auto go2 = [&](auto rc, auto ec) -> hipError_t {
         constexpr int R = decltype(rc)::value, E = decltype(ec)::value;
-        hipError_t e = hipFuncSetAttribute((const void*)gauss_fused_exact_kernel<R, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static lds_grant grant;   // one per (R, E) instantiation
+        hipError_t e = grant_lds(grant, (const void*)gauss_fused_exact_kernel<R, E>, lds);
         if (e) return e;
         gauss_fused_exact_kernel<R, E><<<dim3(8u * (uint32_t)(sg_max * nseg)), GF_T, lds, stream>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h,
                                                                                                     seg_rows, nseg, strips, d_mask, p0);

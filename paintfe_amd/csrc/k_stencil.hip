@@ -799,7 +799,8 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
         const size_t lds = (size_t)(side * (side | 1) + side * (BF_T + 1)) * 4;
         auto go = [&](auto rc) -> hipError_t {
             constexpr int R = decltype(rc)::value;
-            hipError_t e = hipFuncSetAttribute((const void*)box_fused_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            static lds_grant grant;
+            hipError_t e = grant_lds(grant, (const void*)box_fused_kernel<R>, lds);
             if (e) return e;
             box_fused_kernel<R><<<dim3((w + BF_T - 1) / BF_T, (h + BF_T - 1) / BF_T), 256, lds, s>>>((const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, half, magic, (int)w, (int)h);
             return hipGetLastError();
@@ -829,7 +830,8 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
         const float inv_d = 1.0f / (float)d;
         auto go = [&](auto mk) -> hipError_t {
             constexpr bool MK = decltype(mk)::value;
-            hipError_t e = hipFuncSetAttribute((const void*)box_strip_kernel<MK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            static lds_grant grant;
+            hipError_t e = grant_lds(grant, (const void*)box_strip_kernel<MK>, lds);
             if (e) return e;
             box_strip_kernel<MK><<<dim3(8u * (uint32_t)(sg_max * nseg)), 256, lds, s>>>((const uint32_t*)d_src, d_mask, (uint32_t*)d_dst, radius, inv_d, (int)w, (int)h,
                                                                                       seg_rows, nseg, strips);

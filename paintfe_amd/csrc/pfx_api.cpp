@@ -461,10 +461,15 @@ int pfx_int_flatten_with_chunk_keys_dev(pfx_ctx* ctx, const void* const* layer_p
 
 // sharpen / glow with the Gaussian and the combine in ONE kernel (k_gauss_exact.hip, epilogue 1 / 2) where the bit-exact fused Gaussian applies: radius 1 .. 16,
 // distinct buffers, exact mode.  Returns 1 when it ran, 0 when the caller has to take the two-step path, < 0 on error.
+int pfx_int_gauss_exact_combine_applies(pfx_ctx* ctx, const void* src_dev, const void* dst_dev, uint32_t w, uint32_t h, float sigma)
+{
+    const int radius = pfx_host_gaussian_radius(sigma);
+    return ctx->exact && radius >= 1 && radius <= pfxk_gauss_fused_exact_max_radius() && src_dev != dst_dev && !ranges_overlap(src_dev, dst_dev, img_bytes(w, h));
+}
 int pfx_int_gauss_exact_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, int epilogue, float p0, const void* mask_dev)
 {
     const int radius = pfx_host_gaussian_radius(sigma);
-    if (!ctx->exact || radius < 1 || radius > pfxk_gauss_fused_exact_max_radius() || src_dev == dst_dev || ranges_overlap(src_dev, dst_dev, img_bytes(w, h))) return 0;
+    if (!pfx_int_gauss_exact_combine_applies(ctx, src_dev, dst_dev, w, h, sigma)) return 0;
     uint32_t sigma_bits; std::memcpy(&sigma_bits, &sigma, 4);
     const int pad = pfxk_gauss_weight_pad();
     if (!ctx->wts_valid || ctx->wts_sigma_bits != sigma_bits) {

@@ -42,10 +42,12 @@ int blur_then_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t
     const size_t bytes = (size_t)w * h * 4;
     {   // small radii: the bit-exact Gaussian and the combine in one kernel — the blurred image never exists in memory
         exact_gauss_scope g(ctx);
-        pfx_timer t(ctx, timer);
-        const int ran = pfx_int_gauss_exact_combine(ctx, src_dev, dst_dev, w, h, radius, op == PFXK_FX_SHARPEN ? 1 : 2, p0, mask_dev);
-        if (ran < 0) return ran;
-        if (ran == 1) return PFX_OK;
+        if (pfx_int_gauss_exact_combine_applies(ctx, src_dev, dst_dev, w, h, radius)) {   // the timer only around a launch that happens
+            pfx_timer t(ctx, timer);
+            const int ran = pfx_int_gauss_exact_combine(ctx, src_dev, dst_dev, w, h, radius, op == PFXK_FX_SHARPEN ? 1 : 2, p0, mask_dev);
+            if (ran < 0) return ran;
+            if (ran == 1) return PFX_OK;
+        }
     }
     PFX_TRY(pfx_reserve(ctx, ctx->st_aux2, bytes));
     PFX_TRY(effect_gaussian(ctx, src_dev, ctx->st_aux2.p, w, h, radius));

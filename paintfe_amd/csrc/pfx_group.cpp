@@ -739,7 +739,7 @@ static int flatten_filter_impl(pfx_group* g, const pfx_layer_info* layers, uint3
     for (auto& mem : g->m) {
         PFXG_HIP(g, hipSetDevice(mem.device));
         PFXG_HIP(g, hipEventRecord(mem.ev_done, stream_of(mem)));
-        if (!blur) PFXG_HIP(g, mark(mem, 2, stream_of(mem)));
+        if (!blur || mem.y1 == mem.y0) PFXG_HIP(g, mark(mem, 2, stream_of(mem)));   // a member with an empty band skipped the filter loop: its phase 2 is empty, not stale
         PFXG_HIP(g, mark(mem, 3, stream_of(mem)));
         mem.tm_valid = g->phase_timing;
     }

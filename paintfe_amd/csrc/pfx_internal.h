@@ -133,6 +133,7 @@ extern "C" int pfx_int_flatten_with_chunk_keys_dev(pfx_ctx* ctx, const void* con
                                                    uint32_t w, uint32_t h, void* dst_dev, const uint8_t* chunk_keys_host);
 
 // blur_with_selection on device-resident images (pfx_api.cpp); mask_host may be NULL (= no selection)
+extern "C" int pfx_int_gauss_exact_combine_applies(pfx_ctx* ctx, const void* src_dev, const void* dst_dev, uint32_t w, uint32_t h, float sigma);
 extern "C" int pfx_int_gauss_exact_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, int epilogue, float p0, const void* mask_dev); // 1 ran, 0 not applicable
 int pfx_int_blur_with_selection_dev(pfx_ctx* ctx, const void* d_src, void* d_dst, uint32_t w, uint32_t h, float sigma,
                                     const uint8_t* mask_host, const void* d_mask);

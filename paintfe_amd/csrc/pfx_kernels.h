@@ -49,7 +49,7 @@ typedef struct pfxk_region { uint32_t x0, y0, rw, rh; } pfxk_region;
 // below them wherever their alpha qualifies — kind 0: Overwrite, alpha != 0 (canvas_state.rs:1275-1281); kind 1: Normal at
 // opacity >= 1, alpha == 255 (:1258).  The compositor skips the layers below a pixel's topmost reset (k_flatten.hip, flatten_dle_kernel).
 #define PFXK_DLE_MAX 4
-#define PFXK_DESC_PAD 16 /* copies of the last layer descriptor the host appends: srt_layers (k_flatten.hip) reads up to descriptor n + 2, srt_early<NB> up to n + 2 NB - 3 */
+#define PFXK_DESC_PAD 16 /* copies of the last layer descriptor the host appends: srt_layers (k_flatten.hip) reads up to descriptor n + 2, srt_early<NB> up to n + 2 NB - 2 (valid indices end at n + PFXK_DESC_PAD - 1) */
 typedef struct pfxk_dle_cands { uint32_t n; uint32_t layer[PFXK_DLE_MAX]; uint32_t kind[PFXK_DLE_MAX]; uint32_t stats; /* set by the launcher */ } pfxk_dle_cands;
 hipError_t pfxk_flatten(hipStream_t stream, const pfxk_layer_desc* d_layers, uint32_t n_layers,
                         const float* d_adj_table, int general, int fast_div, uint8_t* d_chunk_active, int chunk_active_ready, uint32_t w,
