@@ -569,6 +569,11 @@ void        pfx_script_output_free(pfx_script_output* out);
 int pfx_script_check(const char* source, uint32_t w, uint32_t h, pfx_script_result* result);
 /* the `pfx` batch CLI main (same flags as src/cli.rs:43-89); returns the process exit code */
 int pfx_cli_main(int argc, char** argv);
+/* the CLI's PNG reader on a buffer (ref: load_image_sync -> image::open(..) -> to_rgba8, src/io.rs:693-723, called from src/cli.rs:234): every colour type and bit depth, Adam7, tRNS.
+ * *rgba_out is malloc'd w*h*4 bytes, released with pfx_png_free.  Malformed input -> PFX_ERR_INVALID + message; never reads or allocates beyond what
+ * the IDAT data can inflate to.  No device needed. */
+int  pfx_png_decode_mem(const uint8_t* bytes, size_t n_bytes, uint8_t** rgba_out, uint32_t* w_out, uint32_t* h_out, char* err, size_t err_cap);
+void pfx_png_free(uint8_t* rgba);
 
 /* ================= N2: PFE project files and TiledImage import / export on the device =====================================
  * A .pfe file is the bincode 1.x (little-endian, fixed-width integers, u64 lengths) image of ProjectFileV0..V3

@@ -30,7 +30,6 @@ typedef float pfx_v4f __attribute__((ext_vector_type(4)));
 typedef int pfx_v4i __attribute__((ext_vector_type(4)));
 __device__ pfx_v4f pfx_buffer_load_format_v4f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
 __device__ float pfx_buffer_load_format_f32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.f32");
-__device__ int pfx_buffer_load_i32(pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
 __device__ void pfx_buffer_store_i32(int data, pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
 __device__ void pfx_buffer_store_format_v4f32(pfx_v4f data, pfx_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.format.v4f32");
 
@@ -844,63 +843,9 @@ PFX_DEV void srt_early(float (&acc)[1][4], const pfxk_layer_desc* __restrict__ l
     pre(pre, std::integral_constant<int, 0>{});
     for (uint32_t li = lb; li < le; li += (uint32_t)NB) seq(seq, std::integral_constant<int, 0>{}, li);
 }
-// Round 6: the same pass on RAW dword loads — a layer pixel in flight costs one register instead of four and a quarter of the texture path's
-// return traffic, so NB - 1 = 3 ... 7 layers can be in flight inside the 64 registers the eight waves leave; the wave converts a pixel when it consumes it
-// (v_cvt_f32_ubyteN + the proved two-operation div255 per channel = RN(byte / 255), the value the typed load delivers: pfx_ctx.cpp:selfcheck_div255 and
-// pfxk_unorm_store_check).  The blend's mode / opacity are re-read from the descriptor table one layer ahead (two scalar registers, not 2 NB).
-template <int NB, bool NOBLEND = false>
-PFX_DEV void srt_early_raw(float (&acc)[1][4], const pfxk_layer_desc* __restrict__ layers, uint32_t lb, uint32_t le, uint32_t bytes, int voff)
-{
-    static_assert(NB >= 2 && 2 * NB - 2 < PFXK_DESC_PAD, "descriptor padding");
-    uint32_t raw[NB];
-    const pfxk_layer_desc* nptr = layers + lb;
-    const pfxk_layer_desc* bptr = layers + lb;
-    const uint8_t* npx = nptr->pixels;
-    uint32_t bm = bptr->mode, bo = bptr->adj_off;
-    uint32_t lead = 0u;
-    bool recount = true;
-    uint32_t fi = lb;              // layer the next request is for: requests beyond the pass go through an EMPTY resource (range-checked out: no memory access)
-    auto fetch = [&](auto SET) {
-        constexpr int S = decltype(SET)::value;
-        const pfx_v4i rs = make_rsrc_canonical(npx, fi < le ? bytes : 0u, PFX_RSRC_RAW32);
-        raw[S] = (uint32_t)pfx_buffer_load_i32(rs, voff, 0, 0);
-        fi += 1u;
-        nptr += 1;
-        npx = nptr->pixels;
-    };
-    auto blend = [&](auto SET, uint32_t K) {
-        constexpr int S = decltype(SET)::value;
-        if (K < le) {
-            const uint32_t p = raw[S];
-            const float t[1][4] = {{div255(ubyte0(p)), div255(ubyte1(p)), div255(ubyte2(p)), div255(ubyte3(p))}};
-            if constexpr (NOBLEND) { acc[0][0] += t[0][0]; acc[0][1] += t[0][1]; acc[0][2] += t[0][2]; acc[0][3] = t[0][3]; }
-            else {
-                if (recount) { lead = count_lead<1>(acc); recount = false; }
-                stream_layer_groups<1>(acc, t, bm, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(bo)), lead);
-                recount = true;
-            }
-            bptr += 1;
-            bm = bptr->mode; bo = bptr->adj_off;
-        }
-    };
-    auto seq = [&](auto self, auto I, uint32_t li) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (i < NB) {
-            fetch(std::integral_constant<int, (i + NB - 1) % NB>{});
-            blend(std::integral_constant<int, i>{}, li + (uint32_t)i);
-            self(self, std::integral_constant<int, i + 1>{}, li);
-        }
-    };
-    auto pre = [&](auto self, auto I) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (i < NB - 1) { fetch(std::integral_constant<int, i>{}); self(self, std::integral_constant<int, i + 1>{}); }
-    };
-    pre(pre, std::integral_constant<int, 0>{});
-    for (uint32_t li = lb; li < le; li += (uint32_t)NB) seq(seq, std::integral_constant<int, 0>{}, li);
-}
-#ifndef PFX_EARLY_RAW
-#define PFX_EARLY_RAW 0  // 0 = typed loads (srt_early<PFX_EARLY_NB>); N >= 2 = raw dword loads with N register sets (srt_early_raw<N>)
-#endif
+// Round 6: the same pass on RAW dword loads (one register per layer in flight, 2 / 3 / 5 / 7 layers in flight, converted on consumption) was built
+// bit-exact and measured 2 ... 10 % SLOWER (profiles/r06_early_raw_ab.txt, profiles/r06_tuning.md): the waves wait less, the launch takes longer — the 12 conversion
+// instructions per early pixel cost more than the deeper queue buys.  Code removed; typed loads stay.
 #ifndef PFX_EARLY_NB
 #define PFX_EARLY_NB 2   // 8K x 32 layers (S2), one box: 2 sets 0.990-1.010 ms, 4 sets 1.013-1.018, 6 / 8 sets 1.04-1.05, srt_layers<1> 1.044-1.048 (profiles/r05_tuning.md)
 #endif
@@ -1057,10 +1002,7 @@ __global__ __launch_bounds__(64) PFX_SRT_ATTR void flatten_srt_kernel(const pfxk
 #if PFX_SRT_PRIO
                 __builtin_amdgcn_s_setprio(PFX_SRT_PRIO & 3);
 #endif
-#if PFX_EARLY_RAW > 0
-                (void)none;
-                srt_early_raw<PFX_EARLY_RAW, NOBLEND>(a1, layers, s_u, r, bytes, v1[0]);
-#elif PFX_EARLY_NB > 0
+#if PFX_EARLY_NB > 0
                 (void)none;
                 srt_early<PFX_EARLY_NB, NOBLEND, TR>(a1, layers, s_u, r, bytes, v1[0], tph + 4);
 #else

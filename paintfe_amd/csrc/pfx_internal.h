@@ -143,6 +143,8 @@ int pfx_int_blur_with_selection_dev(pfx_ctx* ctx, const void* d_src, void* d_dst
 int pfx_int_script_run_dev(pfx_ctx* ctx, const char* source, uint32_t* w, uint32_t* h, const uint8_t* mask, pfx_script_result* result,
                            std::vector<std::string>* console, std::vector<pfx_canvas_op>* ops);
 
+extern "C" int pfx_int_script_check_limited(const char* source, uint32_t w, uint32_t h, pfx_script_result* result, uint64_t max_ops);
+
 // run_one's script step on a document (pfx_project.cpp): pfx_project_run_script plus the console lines for --verbose
 int pfx_int_project_run_script(pfx_ctx* ctx, pfx_project* p, const char* source, pfx_script_result* result, std::vector<std::string>* console);
 

@@ -22,7 +22,6 @@ namespace rhai {
 
 namespace {
 constexpr int ST_SCRIPT = -6, ST_UNSUPPORTED = -5; // PFX_ERR_SCRIPT / PFX_ERR_UNSUPPORTED (include/pfx.h)
-constexpr uint64_t MAX_OPS = 50000000ull;          // scripting.rs:288
 constexpr int MAX_CALL_LEVELS = 64;                // scripting.rs:289
 constexpr size_t MAX_STRING = 10000, MAX_ARRAY = 10000; // scripting.rs:291-292
 
@@ -901,7 +900,7 @@ struct Eval {
 
     void tick(const Node& n)
     {
-        if (++in.ops_ > MAX_OPS) fail("Too many operations", n);
+        if (++in.ops_ > in.max_ops) fail("Too many operations", n);
     }
     Var* find(const std::string& name)
     {

@@ -128,6 +128,7 @@ public:
     explicit Interp(Host* host) : host_(host) {}
     bool run(const char* source, Error& err);      // parse + execute
     uint64_t ops() const { return ops_; }
+    uint64_t max_ops = 50000000ull;               // Engine::set_max_operations, scripting.rs:288 (lowered by the hardening harness only)
     std::vector<std::string> console;
     // compile a closure to device bytecode (n_params 4 or 6; img_w / img_h resolve width() / height())
     bool compile_closure(const Closure& c, int n_params, int64_t img_w, int64_t img_h, BcProgram& out, Error& err);

@@ -83,6 +83,9 @@ bool png_decode(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgba, ui
         const size_t pw = (w - P.x0 + P.dx - 1) / P.dx, ph = (h - P.y0 + P.dy - 1) / P.dy;
         total += ph * (1 + (pw * bpp_bits + 7) / 8);
     }
+    // deflate cannot expand by more than 1032 : 1 (RFC 1951: a 258-byte match per 2 bits): a header that promises more scanline bytes than the IDAT data can
+    // inflate to is refused BEFORE the buffers for it are allocated (a 60-byte file must not cost a gigabyte)
+    if (total / 1032u > idat.size()) { why = "image data too short for the declared dimensions"; return false; }
     std::vector<uint8_t> raw(total);
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) { why = "zlib inflate failed"; return false; }
@@ -137,6 +140,36 @@ bool png_decode(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgba, ui
     }
     return true;
 }
+
+} // namespace
+
+extern "C" int pfx_png_decode_mem(const uint8_t* bytes, size_t n_bytes, uint8_t** rgba_out, uint32_t* w_out, uint32_t* h_out, char* err, size_t err_cap)
+{
+    if (err && err_cap) err[0] = 0;
+    if (!bytes || !rgba_out || !w_out || !h_out) return PFX_ERR_INVALID;
+    *rgba_out = nullptr; *w_out = *h_out = 0;
+    std::string why;
+    try {
+        const std::vector<uint8_t> file(bytes, bytes + n_bytes);
+        std::vector<uint8_t> px;
+        uint32_t w = 0, h = 0;
+        if (!png_decode(file, px, w, h, why)) {
+            if (err && err_cap) std::snprintf(err, err_cap, "%s", why.c_str());
+            return PFX_ERR_INVALID;
+        }
+        uint8_t* out = (uint8_t*)std::malloc(px.size());
+        if (!out) return PFX_ERR_OOM;
+        std::memcpy(out, px.data(), px.size());
+        *rgba_out = out; *w_out = w; *h_out = h;
+        return PFX_OK;
+    } catch (const std::bad_alloc&) {
+        if (err && err_cap) std::snprintf(err, err_cap, "out of memory");
+        return PFX_ERR_OOM;
+    }
+}
+extern "C" void pfx_png_free(uint8_t* rgba) { std::free(rgba); }
+
+namespace {
 
 void put_chunk(std::vector<uint8_t>& out, const char* type, const uint8_t* data, size_t len)
 {

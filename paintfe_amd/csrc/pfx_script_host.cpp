@@ -638,6 +638,12 @@ int pfx_script_run(pfx_ctx* ctx, const char* source, uint8_t* pixels_inout, uint
 
 int pfx_script_check(const char* source, uint32_t w, uint32_t h, pfx_script_result* result)
 {
+    return pfx_int_script_check_limited(source, w, h, result, 0);
+}
+
+// pfx_script_check with a lower operation budget (0 = the reference's 50 M): the hardening harness runs 10^5 mutated scripts, most of which loop
+int pfx_int_script_check_limited(const char* source, uint32_t w, uint32_t h, pfx_script_result* result, uint64_t max_ops)
+{
     if (result) std::memset(result, 0, sizeof *result);
     if (!source) return PFX_ERR_INVALID;
     ScriptHost host;
@@ -645,6 +651,7 @@ int pfx_script_check(const char* source, uint32_t w, uint32_t h, pfx_script_resu
     host.h = h;
     host.rng = time_seed();
     rhai::Interp in(&host);
+    if (max_ops) in.max_ops = max_ops;
     rhai::Error err;
     const bool ok = in.run(source, err);
     fill_result(result, ok ? nullptr : &err, in.console, in.ops());
