@@ -6,7 +6,9 @@ Importing it does not load the library; constructing a ``GpuRenderer`` does, and
 or the GPU is missing.  There is no CPU fallback anywhere in this package.
 """
 from ._lib import LIB_PATH, PfxError, load  # noqa: F401
-from .renderer import (ADJUST_OPS, BLEND_MODES, DENSE, FROM_FLAT, IN_PLACE, RHAI_OPS, GpuRenderer, script_check)  # noqa: F401
+from .renderer import (ADJUST_OPS, BLEND_MODES, DENSE, FROM_FLAT, IN_PLACE, RHAI_OPS, GpuRenderer, png_decode, script_check)  # noqa: F401
+
+from .project import PfeError, Project  # noqa: F401,E402
 
 __all__ = ["GpuRenderer", "PfxError", "load", "LIB_PATH", "BLEND_MODES", "ADJUST_OPS", "RHAI_OPS", "DENSE", "FROM_FLAT",
-           "IN_PLACE", "script_check"]
+           "IN_PLACE", "script_check", "png_decode", "Project"]

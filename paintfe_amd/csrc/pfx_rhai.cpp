@@ -300,7 +300,7 @@ NodeP mk(NK k, const Tok& t) { auto n = std::make_shared<Node>(); n->k = k; n->l
 
 class Parser {
 public:
-    explicit Parser(const char* src, int line0 = 1, int col0 = 1) : lx_(src, line0, col0) { cur_ = lx_.next(); }
+    explicit Parser(const char* src, int line0 = 1, int col0 = 1, int depth0 = 0) : lx_(src, line0, col0), depth_(depth0) { cur_ = lx_.next(); }
     NodeP program()
     {
         auto b = mk(NK::Block, cur_);
@@ -346,6 +346,7 @@ private:
     }
     NodeP block()
     {
+        DepthGuard g(*this, cur_);   // nested blocks count against the same limit as nested expressions (Engine::set_max_expr_depths, scripting.rs:290)
         auto b = mk(NK::Block, cur_);
         expect_p("{", "to start a statement block");
         while (!is_p("}")) {
@@ -578,7 +579,8 @@ private:
             if (is_p("[")) {
                 auto n = mk(NK::Index, cur_);
                 eat();
-                n->kids = {e, expr(0)};
+                n->kids.push_back(e);          // not `= {e, expr(0)}`: g++ 11 leaks the constructed elements of a braced list when a later one throws (GCC PR 66139)
+                n->kids.push_back(expr(0));
                 expect_p("]", "to close this index expression");
                 e = n;
             } else if (is_p(".")) {
@@ -684,7 +686,11 @@ private:
             auto n = mk(NK::Interp, t);
             for (const auto& part : t.parts) {
                 if (!part.first) { auto s = mk(NK::StrLit, t); s->text = part.second; n->kids.push_back(s); }
-                else { Parser sub(part.second.c_str(), t.line, t.col); n->kids.push_back(sub.single_expr()); }
+                else {   // an interpolated expression nests like a parenthesised one: the sub-parser inherits the depth (and pays one level)
+                    DepthGuard g(*this, t);
+                    Parser sub(part.second.c_str(), t.line, t.col, depth_);
+                    n->kids.push_back(sub.single_expr());
+                }
             }
             return n;
         }

@@ -108,6 +108,23 @@ def script_check(source: str, w: int = 64, h: int = 64):
     return [s for s in res.console.decode(errors="replace").split("\n") if s]
 
 
+def png_decode(raw: bytes) -> np.ndarray:
+    """The CLI's PNG reader on a buffer (pfx_png_decode_mem; ref: load_image_sync, src/io.rs:693-723): (h, w, 4) uint8.  No device needed."""
+    lib = _lib.load()
+    lib.pfx_png_decode_mem.restype = C.c_int
+    lib.pfx_png_free.restype = None
+    out, w, h = C.POINTER(C.c_uint8)(), C.c_uint32(), C.c_uint32()
+    err = C.create_string_buffer(256)
+    buf = (C.c_uint8 * max(len(raw), 1)).from_buffer_copy(raw if raw else b"\0")
+    st = lib.pfx_png_decode_mem(buf, C.c_size_t(len(raw)), C.byref(out), C.byref(w), C.byref(h), err, C.c_size_t(256))
+    if st != _lib.OK:
+        raise PfxError(st, err.value.decode(errors="replace"))
+    try:
+        return np.ctypeslib.as_array(out, shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib.pfx_png_free(out)
+
+
 def _install_effects(cls):
     def make(name, marshal):
         def core(self, img, *a, mask=None, **kw):
