@@ -398,6 +398,22 @@ int pfx_adjust_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w,
                    const float* params, uint32_t n_params, const uint8_t* lut_host, const void* mask_dev, int sparse_mode);
 int pfx_rhai_adjust_dev(pfx_ctx* ctx, void* pixels_dev, uint32_t w, uint32_t h, int op, const float* params,
                         uint32_t n_params);
+/* Chains (round 6): several ops on a device-resident image in as few passes over memory as the kernels allow.  The result equals calling the single-op entry
+ * points one after the other — pfx_gaussian_blur_dev / pfx_box_blur_dev (no selection) / pfx_adjust_dev (PFX_DENSE, no selection) / pfx_rhai_adjust_dev — bit for
+ * bit, in the context's current Gaussian mode: every op still rounds to u8, only the trips through memory go.  A run of pointwise ops is one launch; a bit-exact
+ * Gaussian of radius <= 16 followed by pointwise ops is one launch (the blurred image never exists in memory).  This is what a script's
+ * `apply_gaussian_blur(4.0); apply_hsl(..); apply_invert();` (ref: src/ops/scripting.rs:869-1075 and :1095-1140, each call a full pass over the image on the CPU) and the batch
+ * pipeline run through.  src_dev == dst_dev is allowed for chains without a blur. */
+typedef enum pfx_chain_kind { PFX_CHAIN_ADJUST = 0 /* op = pfx_adjust_op */, PFX_CHAIN_RHAI = 1 /* op = pfx_rhai_op */, PFX_CHAIN_GAUSSIAN = 2 /* params[0] = sigma */,
+                              PFX_CHAIN_BOX = 3 /* params[0] = radius */ } pfx_chain_kind;
+typedef struct pfx_chain_op {
+    int32_t  kind;          /* pfx_chain_kind */
+    int32_t  op;            /* PFX_CHAIN_ADJUST / PFX_CHAIN_RHAI: the op id; otherwise ignored */
+    uint32_t n_params;
+    float    params[12];    /* as for the op's own entry point */
+    const uint8_t* lut;     /* host, 1024 bytes: PFX_OP_GRADIENT_MAP / PFX_OP_LUT_RGBA; NULL otherwise */
+} pfx_chain_op;
+int pfx_chain_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, const pfx_chain_op* ops, uint32_t n_ops);
 int pfx_warp_displacement_dev(pfx_ctx* ctx, const void* src_dev, uint32_t sw, uint32_t sh, const void* disp_dev,
                               uint32_t w, uint32_t h, void* dst_dev);
 int pfx_mesh_displacement_dev(pfx_ctx* ctx, const float* orig_pts_xy, const float* deformed_pts_xy, uint32_t cols,
@@ -727,8 +743,9 @@ typedef struct pfx_batch_params {
     uint32_t n_keep;
     const uint32_t* keep_indices;
     uint8_t* const* keep_out;
-    uint32_t fast_gaussian;               /* 0 (default) = the bit-exact f32 Gaussian: every result equals the CPU path exactly (the blur feeds HSL, which amplifies
-                                             a +-1 LSB input, and the stream is PCIe-bound either way); 1 = the default-mode Gaussian (f16 taps, +-1 LSB before HSL) */
+    uint32_t out_of_contract_fast_gaussian; /* 0 (default) = the bit-exact f32 Gaussian: every result equals the CPU path exactly.  1 leaves the +-1 LSB contract: the
+                                             default-mode Gaussian (f16 taps, +-1 LSB) feeds HSL, which amplifies it — up to 4 LSB in the result (measured); a
+                                             development / comparison switch, never a production setting (the stream is PCIe-bound either way) */
 } pfx_batch_params;
 typedef struct pfx_batch_stats {
     double   seconds;              /* first enqueue .. last result back on the host, slowest device */

@@ -54,6 +54,10 @@ class Preview(C.Structure):
     _fields_ = [("active_layer", C.c_uint32), ("blend_mode", C.c_uint8), ("is_eraser", C.c_uint8), ("replaces_layer", C.c_uint8), ("_pad", C.c_uint8)]
 
 
+class ChainOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("op", C.c_int32), ("n_params", C.c_uint32), ("params", C.c_float * 12), ("lut", C.c_void_p)]
+
+
 class CanvasOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("w", C.c_uint32), ("h", C.c_uint32), ("anchor_x", C.c_uint32), ("anchor_y", C.c_uint32)]
 

@@ -14,7 +14,7 @@ class BatchParams(C.Structure):
     _fields_ = [("w", C.c_uint32), ("h", C.c_uint32), ("sigma", C.c_float), ("hue", C.c_float), ("saturation", C.c_float),
                 ("lightness", C.c_float), ("n_overlays", C.c_uint32), ("overlays_host", C.POINTER(C.c_void_p)),
                 ("overlay_modes", C.c_void_p), ("overlay_opacity", C.c_void_p), ("slots", C.c_uint32), ("n_keep", C.c_uint32),
-                ("keep_indices", C.c_void_p), ("keep_out", C.POINTER(C.c_void_p)), ("fast_gaussian", C.c_uint32)]
+                ("keep_indices", C.c_void_p), ("keep_out", C.POINTER(C.c_void_p)), ("out_of_contract_fast_gaussian", C.c_uint32)]
 
 
 class BatchStats(C.Structure):
@@ -41,7 +41,7 @@ def run_batch(devices: Sequence[int], n_images: int, pool: List[np.ndarray], ove
     P.overlay_modes = modes.ctypes.data
     P.overlay_opacity = None
     P.slots = slots
-    P.fast_gaussian = 1 if fast else 0
+    P.out_of_contract_fast_gaussian = 1 if fast else 0
     keep_idx = np.asarray(list(keep), np.uint32)
     outs = [np.zeros((h, w, 4), np.uint8) for _ in keep_idx]
     out_ptrs = (C.c_void_p * max(len(outs), 1))(*[o.ctypes.data for o in outs])

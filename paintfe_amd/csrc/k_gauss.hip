@@ -24,6 +24,7 @@
 #include <atomic>
 #include <algorithm>
 #include "pfx_kernels.h"
+#include "k_pointwise.h"
 
 using namespace pfxk;
 
@@ -282,11 +283,14 @@ inline size_t gauss_strip_lds_bytes(int nkb, int hp)
 
 // DBG: the development instantiation (switchable parts, s_memtime stamps); the shipped one has none of those branches — a dozen
 // skipped-over stamps per iteration were 10 % of the kernel
-template <bool FAST, int NKB, bool DBG, int WP = 2, int HP = 2>
+// CHAIN (round 6, pfx_chain_dev): pfxk_chain = the consumers put every blurred pixel through a chain of table-free pointwise ops between rounding and staging
+// (k_pointwise.h: chain_apply on the u8 pixel — what the ops would read from a buffer): `Gaussian -> HSL` is one launch, the blurred image never reaches memory.
+struct gs_no_chain {};
+template <bool FAST, int NKB, bool DBG, int WP = 2, int HP = 2, class CHAIN = gs_no_chain>
 __global__ __launch_bounds__(512, ((NKB <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && WP == 1) ? 4 : 2)) void gauss_strip_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8, float inv_scale2,
                                                              float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg, int dbg_arg,
-                                                             unsigned long long* __restrict__ dbg_buf)
+                                                             unsigned long long* __restrict__ dbg_buf, const CHAIN chain = CHAIN{})
 {
     constexpr int GS_XROW = gs_xrow(NKB);
     // ring = two steps of 32 rows: the one the consumers load this iteration (finished before the last barrier) and the one the producers are storing
@@ -593,6 +597,7 @@ __global__ __launch_bounds__(512, ((NKB <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && WP == 
                 // D[m][n]: n = output row i of the block; reg q -> m = (q & 3) + 8 (q >> 2) + 4 hh = xl' * 4 + c' with c' = q & 3,
                 // xl' = 2 (q >> 2) + hh: regs 4g .. 4g+3 are the RGBA of pixel (8 xb + 2 g + hh, row i)
                 uint32_t* orow = OUT + (v & 1) * 32 * GM_OUT_PITCH + i * GM_OUT_PITCH + 8 * xb + hh;
+                uint32_t px4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     // `.round().clamp(0, 255) as u8` (filters.rs:308-311) with the final scale fused in: v_cvt_pk_u8_f32 rounds to nearest
@@ -601,8 +606,11 @@ __global__ __launch_bounds__(512, ((NKB <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && WP == 
                     uint32_t px = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) px = __builtin_amdgcn_cvt_pk_u8_f32(((WP == 2 || HP == 2) ? accA[4 * g + e] + accX[4 * g + e] : accA[4 * g + e]) * inv_scale2, e, px);
-                    orow[2 * g] = px;
+                    px4[g] = px;
                 }
+                if constexpr (!std::is_same<CHAIN, gs_no_chain>::value) pw::chain_apply<4>(chain, nullptr, px4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) orow[2 * g] = px4[g];
             }
             stamp(it, 6);
             __syncthreads();
@@ -657,8 +665,8 @@ extern "C" hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8
 extern "C" int pfxk_gauss_mfma_max_radius(void) { return GM_MAXR; }
 extern "C" int pfxk_gauss_mfma_wlen(void) { return GM_WLEN; }
 extern "C" int pfxk_gauss_mfma_woff(void) { return GM_WOFF; }
-extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit,
-                                      int radius, float inv_scale2, float bias_c, float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus)
+static hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit,
+                                    int radius, float inv_scale2, float bias_c, float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus, const pfxk_chain* chain)
 {
     if (w == 0 || h == 0) return hipSuccess;
     if (radius < 1 || radius > GM_MAXR) return hipErrorInvalidValue;
@@ -694,8 +702,17 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
         auto go = [&](auto kern) {
             errs = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (errs) return;
-            kern<<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, dbg, g_dbg_buf);
+            kern<<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, dbg, g_dbg_buf, gs_no_chain{});
         };
+        if (chain) {   // the chained form exists for the shipped configuration only (aligned buffers, one-piece weights, two-piece horizontal result)
+            if (!(fast && wp == 1 && hp == 2)) { errs = hipErrorNotSupported; return; }
+            static lds_grant grant;
+            errs = grant_lds(grant, (const void*)gauss_strip_kernel<true, NK, false, 1, 2, pfxk_chain>, lds);
+            if (errs) return;
+            gauss_strip_kernel<true, NK, false, 1, 2, pfxk_chain><<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph,
+                                                                                             n_steps, per, 0, nullptr, *chain);
+            return;
+        }
         if (fast && dbg && wp == 1 && hp == 2) go(gauss_strip_kernel<true, NK, true, 1, 2>); // development (tools/gauss_dbg.py, tools/gauss_timeline.py)
         else if (fast && dbg) go(gauss_strip_kernel<true, NK, true>);
         else if (fast && wp == 1 && hp == 2) go(gauss_strip_kernel<true, NK, false, 1, 2>);
@@ -713,4 +730,18 @@ extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, 
     }
     if (errs) return errs;
     return hipGetLastError();
+}
+
+extern "C" hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit,
+                                      int radius, float inv_scale2, float bias_c, float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus)
+{
+    return launch_gauss_mfma(stream, d_src, d_dst, d_wsplit, radius, inv_scale2, bias_c, bias_single, w, h, first_row, n_cus, nullptr);
+}
+// the same with a chain of table-free pointwise ops applied to every blurred pixel before it is stored; hipErrorNotSupported when the buffers / width are not
+// 16-byte aligned or a development piece count is selected (the caller then runs the two launches)
+extern "C" hipError_t pfxk_gauss_mfma_chain(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit, int radius, float inv_scale2, float bias_c,
+                                            float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus, const pfxk_chain* chain)
+{
+    if (!chain || chain->n == 0 || chain->n > PFXK_CHAIN_MAX || chain->n_luts != 0) return hipErrorInvalidValue;
+    return launch_gauss_mfma(stream, d_src, d_dst, d_wsplit, radius, inv_scale2, bias_c, bias_single, w, h, first_row, n_cus, chain);
 }

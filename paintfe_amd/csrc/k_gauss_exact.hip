@@ -7,6 +7,7 @@
 #include <algorithm>
 #include "k_common.h"
 #include "pfx_kernels.h"
+#include "k_pointwise.h"
 
 using namespace pfxk;
 
@@ -39,9 +40,14 @@ __host__ __device__ constexpr int gf_src_pitch(int r) { const int n = GF_W + 2 *
 // blocking pads every output to a multiple of four taps with zero weights: 40 % of the multiply-adds at R = 3), the weights sit in scalar registers.
 // EPI: what leaves the vertical pass — 0 the blurred pixel; 1 / 2 the sharpen / glow combine of the SOURCE pixel with it (stylize.rs:135-137 / :60-64, k_effects.hip's
 // combine_kernel word for word: the blurred value enters rounded to u8, as it would from a buffer; alpha from the source; an unselected pixel keeps the source)
-template <int R, int EPI>
+// EPI 3 (round 6, pfx_chain_dev): the blurred pixel goes through a chain of pointwise ops before it is stored (k_pointwise.h: chain_apply on the rounded u8 pixel —
+// what the ops would read from a buffer), so `Gaussian -> HSL -> ...` is one launch and the blurred image never exists in memory; the chain's tables sit behind the
+// staged source rows in LDS.
+struct gf_no_chain {};
+template <int R, int EPI, class CHAIN = gf_no_chain>
 __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const float* __restrict__ wts,
-                                                                int w, int h, int seg_rows, int nseg, int strips, const uint8_t* __restrict__ mask, float p0)
+                                                                int w, int h, int seg_rows, int nseg, int strips, const uint8_t* __restrict__ mask, float p0,
+                                                                const CHAIN chain = CHAIN{}, const uint8_t* __restrict__ luts_g = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t gf_lds[];
     const int tid = (int)threadIdx.x;
@@ -55,6 +61,12 @@ __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t*
     float4* const ring = reinterpret_cast<float4*>(gf_lds);                              // [RR][GF_W]: intermediate row v lives in slot (v - v_begin) mod RR
     uint32_t* const s_src = reinterpret_cast<uint32_t*>(gf_lds + (size_t)RR * GF_W * 16);  // [GF_RB][sp]
     const int v_begin = y0 - r, v_end = y1 + r;
+    const uint8_t* const s_luts = gf_lds + (size_t)RR * GF_W * 16 + (size_t)GF_RB * sp * 4;   // EPI 3: the chain's tables (n_luts x 1024 bytes)
+    if constexpr (EPI == 3) {
+        for (uint32_t i = (uint32_t)tid; i < chain.n_luts * 256u; i += (uint32_t)GF_T)
+            reinterpret_cast<uint32_t*>(gf_lds + (size_t)RR * GF_W * 16 + (size_t)GF_RB * sp * 4)[i] = reinterpret_cast<const uint32_t*>(luts_g)[i];
+        // the first barrier of the block loop below orders these stores before any vertical pass reads them
+    }
     float wt[KLEN];
 #pragma unroll
     for (int k = 0; k < KLEN; ++k) wt[k] = wts[k];                                        // uniform: scalar registers
@@ -155,6 +167,15 @@ __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t*
 #pragma unroll
                     for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
                 }
+                if constexpr (EPI == 3) {
+                    uint32_t b4[4];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) b4[o] = pack_round_rgba(acc[o].x, acc[o].y, acc[o].z, acc[o].w); // filters.rs:308-311
+                    pw::chain_apply<4>(chain, s_luts, b4);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        if (yo + o >= y0 && yo + o < y1) dst[(size_t)(yo + o) * w + x] = b4[o];
+                } else
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
                     if (yo + o >= y0 && yo + o < y1) {
@@ -192,13 +213,14 @@ __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t*
 int g_fused_exact = 1; // pfxk_gauss_set_fused_exact (pfx_tune "gauss_fused_exact"): 0 = the bit-exact mode always through the two kernels (A/B, parity tests)
 extern "C" void pfxk_gauss_set_fused_exact(int on) { g_fused_exact = on; }
 extern "C" int pfxk_gauss_fused_exact_max_radius(void) { return g_fused_exact ? GF_MAXR : 0; }
-extern "C" hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h,
-                                             int epilogue /* 0 blur, 1 sharpen, 2 glow */, float p0, const uint8_t* d_mask)
+static hipError_t launch_fused_exact(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h,
+                                     int epilogue /* 0 blur, 1 sharpen, 2 glow, 3 chain */, float p0, const uint8_t* d_mask, const pfxk_chain* chain, const uint8_t* d_luts)
 {
     if (w == 0 || h == 0) return hipSuccess;
     if (radius < 1 || radius > GF_MAXR) return hipErrorInvalidValue;
+    if (epilogue == 3 && (!chain || chain->n > PFXK_CHAIN_MAX || chain->n_luts > PFXK_CHAIN_LUTS || (chain->n_luts && !d_luts))) return hipErrorInvalidValue;
     const int RR = 2 * radius + 1 + GF_RB;
-    const size_t lds = (size_t)RR * GF_W * 16 + (size_t)GF_RB * gf_src_pitch(radius) * 4;
+    const size_t lds = (size_t)RR * GF_W * 16 + (size_t)GF_RB * gf_src_pitch(radius) * 4 + (epilogue == 3 ? (size_t)chain->n_luts * 1024 : 0);
     const int strips = (int)((w + GF_W - 1) / GF_W);
     // one round of workgroups per XCD (32 CUs x what the LDS footprint allows), segments of at least 8r + 64 rows (the 2r rows of run-in stay small)
     const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / lds));
@@ -207,18 +229,26 @@ extern "C" hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* 
     nseg = std::min(nseg, std::max(1, (int)h / (8 * radius + 64)));
     const int seg_rows = ((int)h + nseg - 1) / nseg;
     nseg = ((int)h + seg_rows - 1) / seg_rows;
+    const dim3 grid(8u * (uint32_t)(sg_max * nseg));
     auto go2 = [&](auto rc, auto ec) -> hipError_t {
         constexpr int R = decltype(rc)::value, E = decltype(ec)::value;
         static lds_grant grant;   // one per (R, E) instantiation
-        hipError_t e = grant_lds(grant, (const void*)gauss_fused_exact_kernel<R, E>, lds);
-        if (e) return e;
-        gauss_fused_exact_kernel<R, E><<<dim3(8u * (uint32_t)(sg_max * nseg)), GF_T, lds, stream>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h,
-                                                                                                    seg_rows, nseg, strips, d_mask, p0);
+        if constexpr (E == 3) {
+            hipError_t e = grant_lds(grant, (const void*)gauss_fused_exact_kernel<R, 3, pfxk_chain>, lds);
+            if (e) return e;
+            gauss_fused_exact_kernel<R, 3, pfxk_chain><<<grid, GF_T, lds, stream>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h, seg_rows, nseg, strips,
+                                                                                    nullptr, 0.0f, *chain, d_luts);
+        } else {
+            hipError_t e = grant_lds(grant, (const void*)gauss_fused_exact_kernel<R, E>, lds);
+            if (e) return e;
+            gauss_fused_exact_kernel<R, E><<<grid, GF_T, lds, stream>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h, seg_rows, nseg, strips, d_mask, p0);
+        }
         return hipGetLastError();
     };
     auto go = [&](auto rc) -> hipError_t {
         if (epilogue == 1) return go2(rc, std::integral_constant<int, 1>{});
         if (epilogue == 2) return go2(rc, std::integral_constant<int, 2>{});
+        if (epilogue == 3) return go2(rc, std::integral_constant<int, 3>{});
         return go2(rc, std::integral_constant<int, 0>{});
     };
     static_assert(GF_MAXR == 16, "gauss_fused_exact_kernel is instantiated for radii 1 .. 16");
@@ -228,4 +258,15 @@ extern "C" hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* 
 #undef PFX_GF
     default: return hipErrorInvalidValue;
     }
+}
+extern "C" hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h,
+                                             int epilogue /* 0 blur, 1 sharpen, 2 glow */, float p0, const uint8_t* d_mask)
+{
+    if (epilogue < 0 || epilogue > 2) return hipErrorInvalidValue;
+    return launch_fused_exact(stream, d_src, d_dst, d_wts_tap0, radius, w, h, epilogue, p0, d_mask, nullptr, nullptr);
+}
+extern "C" hipError_t pfxk_gauss_fused_exact_chain(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h,
+                                                   const pfxk_chain* C, const uint8_t* d_luts)
+{
+    return launch_fused_exact(stream, d_src, d_dst, d_wts_tap0, radius, w, h, 3, 0.0f, nullptr, C, d_luts);
 }

@@ -461,15 +461,9 @@ int pfx_int_flatten_with_chunk_keys_dev(pfx_ctx* ctx, const void* const* layer_p
 
 // sharpen / glow with the Gaussian and the combine in ONE kernel (k_gauss_exact.hip, epilogue 1 / 2) where the bit-exact fused Gaussian applies: radius 1 .. 16,
 // distinct buffers, exact mode.  Returns 1 when it ran, 0 when the caller has to take the two-step path, < 0 on error.
-int pfx_int_gauss_exact_combine_applies(pfx_ctx* ctx, const void* src_dev, const void* dst_dev, uint32_t w, uint32_t h, float sigma)
+// the f32 taps of sigma on the device (cached per context): *wts points at tap 0, pfxk_gauss_weight_pad() zero taps on both sides
+int pfx_int_gauss_exact_weights(pfx_ctx* ctx, float sigma, const float** wts)
 {
-    const int radius = pfx_host_gaussian_radius(sigma);
-    return ctx->exact && radius >= 1 && radius <= pfxk_gauss_fused_exact_max_radius() && src_dev != dst_dev && !ranges_overlap(src_dev, dst_dev, img_bytes(w, h));
-}
-int pfx_int_gauss_exact_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, int epilogue, float p0, const void* mask_dev)
-{
-    const int radius = pfx_host_gaussian_radius(sigma);
-    if (!pfx_int_gauss_exact_combine_applies(ctx, src_dev, dst_dev, w, h, sigma)) return 0;
     uint32_t sigma_bits; std::memcpy(&sigma_bits, &sigma, 4);
     const int pad = pfxk_gauss_weight_pad();
     if (!ctx->wts_valid || ctx->wts_sigma_bits != sigma_bits) {
@@ -482,9 +476,39 @@ int pfx_int_gauss_exact_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev
         ctx->wts_sigma_bits = sigma_bits;
         ctx->wts_valid = true;
     }
-    PFX_HIP(ctx, pfxk_gauss_fused_exact(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const float*)ctx->d_wts.p + pad, radius, w, h, epilogue, p0,
-                                        (const uint8_t*)mask_dev));
+    *wts = (const float*)ctx->d_wts.p + pad;
+    return PFX_OK;
+}
+int pfx_int_gauss_exact_combine_applies(pfx_ctx* ctx, const void* src_dev, const void* dst_dev, uint32_t w, uint32_t h, float sigma)
+{
+    const int radius = pfx_host_gaussian_radius(sigma);
+    return ctx->exact && radius >= 1 && radius <= pfxk_gauss_fused_exact_max_radius() && src_dev != dst_dev && !ranges_overlap(src_dev, dst_dev, img_bytes(w, h));
+}
+int pfx_int_gauss_exact_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, int epilogue, float p0, const void* mask_dev)
+{
+    const int radius = pfx_host_gaussian_radius(sigma);
+    if (!pfx_int_gauss_exact_combine_applies(ctx, src_dev, dst_dev, w, h, sigma)) return 0;
+    const float* wts = nullptr;
+    PFX_TRY(pfx_int_gauss_exact_weights(ctx, sigma, &wts));
+    PFX_HIP(ctx, pfxk_gauss_fused_exact(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, wts, radius, w, h, epilogue, p0, (const uint8_t*)mask_dev));
     return 1;
+}
+
+// the matrix-core Gaussian's f16 tap tables for sigma on the device (cached per context)
+static int gauss_mfma_tables(pfx_ctx* ctx, float sigma)
+{
+    uint32_t sigma_bits; std::memcpy(&sigma_bits, &sigma, 4);
+    if (!ctx->wsplit_valid || ctx->wsplit_sigma_bits != sigma_bits) {
+        std::vector<float> k;
+        pfx_host_gaussian_kernel(sigma, k);
+        std::vector<uint16_t> ws;
+        ctx->wsplit_inv_scale = pfx_host_gaussian_split_f16(k, pfxk_gauss_mfma_wlen(), pfxk_gauss_mfma_woff(), ws, &ctx->wsplit_bias, &ctx->wsplit_bias_single);
+        PFX_TRY(pfx_reserve(ctx, ctx->d_wsplit, ws.size() * sizeof(uint16_t)));
+        PFX_TRY(pfx_h2d(ctx, ctx->d_wsplit.p, ws.data(), ws.size() * sizeof(uint16_t)));
+        ctx->wsplit_sigma_bits = sigma_bits;
+        ctx->wsplit_valid = true;
+    }
+    return PFX_OK;
 }
 
 int pfx_gaussian_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, void* tmp_dev)
@@ -504,16 +528,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
     uint32_t sigma_bits; std::memcpy(&sigma_bits, &sigma, 4);
     if (!ctx->exact && radius >= 1 && radius <= pfxk_gauss_mfma_max_radius() && src_dev != dst_dev) {
         // default mode: fused H+V on the matrix cores, no intermediate in HBM, no scratch (k_gauss.hip:gauss_strip_kernel)
-        if (!ctx->wsplit_valid || ctx->wsplit_sigma_bits != sigma_bits) {
-            std::vector<float> k;
-            pfx_host_gaussian_kernel(sigma, k);
-            std::vector<uint16_t> ws;
-            ctx->wsplit_inv_scale = pfx_host_gaussian_split_f16(k, pfxk_gauss_mfma_wlen(), pfxk_gauss_mfma_woff(), ws, &ctx->wsplit_bias, &ctx->wsplit_bias_single);
-            PFX_TRY(pfx_reserve(ctx, ctx->d_wsplit, ws.size() * sizeof(uint16_t)));
-            PFX_TRY(pfx_h2d(ctx, ctx->d_wsplit.p, ws.data(), ws.size() * sizeof(uint16_t)));
-            ctx->wsplit_sigma_bits = sigma_bits;
-            ctx->wsplit_valid = true;
-        }
+        PFX_TRY(gauss_mfma_tables(ctx, sigma));
         pfx_timer t(ctx, "gauss_mfma");
         PFX_HIP(ctx, pfxk_gauss_mfma(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint16_t*)ctx->d_wsplit.p,
                                      radius, ctx->wsplit_inv_scale, ctx->wsplit_bias, ctx->wsplit_bias_single, w, h, first_row, ctx->n_cus > 0 ? ctx->n_cus : 256));
@@ -635,11 +650,11 @@ int pfx_adjust_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w,
     return PFX_OK;
 }
 
-int pfx_rhai_adjust_dev(pfx_ctx* ctx, void* pixels_dev, uint32_t w, uint32_t h, int op, const float* p, uint32_t n)
+// parameter block of a Rhai-flavour op (scripting.rs:869-1075); `lut` (256 bytes) is filled when the op reads a table
+static int prepare_rhai(pfx_ctx* ctx, int op, const float* p, uint32_t n, pfxk_params& P, uint8_t (&lut)[256], bool& needs_lut)
 {
-    PFX_TRY(check_img(ctx, pixels_dev, pixels_dev, w, h, "pfx_rhai_adjust_dev"));
-    pfxk_params P;
     std::memset(&P, 0, sizeof P);
+    needs_lut = false;
     auto need = [&](uint32_t k) { return n >= k && p != nullptr; };
     bool ok = true;
     switch (op) {
@@ -657,17 +672,149 @@ int pfx_rhai_adjust_dev(pfx_ctx* ctx, void* pixels_dev, uint32_t w, uint32_t h, 
         if ((ok = need(1))) P.p[0] = pfx_host_exposure_gain(p[0]);
         break;
     case PFX_RHAI_LEVELS:
-        if ((ok = need(3))) {
-            uint8_t lut[256];
-            pfx_host_rhai_levels_lut(p[0], p[1], p[2], lut);
-            PFX_TRY(upload_lut(ctx, lut, 256));
-        }
+        if ((ok = need(3))) { pfx_host_rhai_levels_lut(p[0], p[1], p[2], lut); needs_lut = true; }
         break;
     default: return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_rhai_adjust: unknown op %d", op);
     }
     if (!ok) return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_rhai_adjust: op %d needs more parameters", op);
+    return PFX_OK;
+}
+
+int pfx_rhai_adjust_dev(pfx_ctx* ctx, void* pixels_dev, uint32_t w, uint32_t h, int op, const float* p, uint32_t n)
+{
+    PFX_TRY(check_img(ctx, pixels_dev, pixels_dev, w, h, "pfx_rhai_adjust_dev"));
+    pfxk_params P;
+    uint8_t lut[256];
+    bool needs_lut = false;
+    PFX_TRY(prepare_rhai(ctx, op, p, n, P, lut, needs_lut));
+    if (needs_lut) PFX_TRY(upload_lut(ctx, lut, 256));
     pfx_timer t(ctx, "rhai_adjust");
     PFX_HIP(ctx, pfxk_rhai_adjust(ctx->stream, (uint8_t*)pixels_dev, (const uint8_t*)ctx->d_lut.p, op, &P, w, h));
+    return PFX_OK;
+}
+
+// ---- chains (round 6): several ops, as few passes over memory as the kernels allow; results equal the single-op entry points applied one after the other ----
+// A run of pointwise ops is ONE launch (k_pointwise.hip: pointwise_chain_kernel, each op re-quantises to u8 in registers); a bit-exact Gaussian of radius <= 16
+// followed by pointwise ops is ONE launch too (k_gauss_exact.hip, epilogue 3: the blurred image never exists in memory).  Every other stencil op runs as its own
+// launch and hands its result to the next stage through at most one scratch image.  References: the ops' own (src/ops/filters.rs:214-316, src/ops/adjustments.rs,
+// src/ops/scripting.rs:869-1075); the chain itself is how a script `apply_gaussian_blur(..); apply_hsl(..);` or the batch pipeline strings them together.
+namespace {
+struct chain_stage { int stencil = -1; uint32_t first = 0, count = 0; };   // stencil: index of the stage's Gaussian / box op or -1; [first, first + count): its pointwise ops
+bool chain_pointwise(const pfx_chain_op& o) { return o.kind == PFX_CHAIN_ADJUST || o.kind == PFX_CHAIN_RHAI; }
+}
+
+static int chain_prepare(pfx_ctx* ctx, const pfx_chain_op* ops, uint32_t first, uint32_t count, pfxk_chain& C)
+{
+    std::memset(&C, 0, sizeof C);
+    uint8_t luts[PFXK_CHAIN_LUTS][1024];
+    for (uint32_t k = 0; k < count; ++k) {
+        const pfx_chain_op& o = ops[first + k];
+        bool needs_lut = false;
+        if (o.kind == PFX_CHAIN_ADJUST) {
+            PFX_TRY(prepare_adjust(ctx, o.op, o.params, o.n_params, C.P[k], needs_lut));
+            C.op[k] = (uint32_t)o.op;
+            if (needs_lut) {
+                PFX_REQUIRE(ctx, o.lut != nullptr, "pfx_chain_dev: this op needs a LUT");
+                std::memcpy(luts[C.n_luts], o.lut, 1024);
+            }
+        } else {
+            uint8_t l256[256];
+            PFX_TRY(prepare_rhai(ctx, o.op, o.params, o.n_params, C.P[k], l256, needs_lut));
+            C.op[k] = PFXK_CHAIN_RHAI | (uint32_t)o.op;
+            if (needs_lut) { std::memset(luts[C.n_luts], 0, 1024); std::memcpy(luts[C.n_luts], l256, 256); }
+        }
+        if (needs_lut) C.lut_slot[k] = C.n_luts++;
+    }
+    C.n = count;
+    if (C.n_luts) {
+        PFX_TRY(pfx_reserve(ctx, ctx->d_chain_luts, (size_t)PFXK_CHAIN_LUTS * 1024));
+        PFX_TRY(pfx_h2d(ctx, ctx->d_chain_luts.p, luts, (size_t)C.n_luts * 1024));
+    }
+    return PFX_OK;
+}
+
+int pfx_chain_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, const pfx_chain_op* ops, uint32_t n_ops)
+{
+    PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_chain_dev"));
+    PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_chain_dev", true));
+    PFX_REQUIRE(ctx, ops != nullptr || n_ops == 0, "pfx_chain_dev: null op list");
+    const size_t bytes = img_bytes(w, h);
+    // stages: [stencil op +] a run of pointwise ops that one launch can carry (PFXK_CHAIN_MAX ops, PFXK_CHAIN_LUTS tables)
+    std::vector<chain_stage> stages;
+    uint32_t n_stencil = 0;
+    for (uint32_t i = 0; i < n_ops;) {
+        chain_stage st;
+        if (!chain_pointwise(ops[i])) {
+            if (ops[i].kind != PFX_CHAIN_GAUSSIAN && ops[i].kind != PFX_CHAIN_BOX) return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_chain_dev: unknown op kind %d", ops[i].kind);
+            PFX_REQUIRE(ctx, ops[i].n_params >= 1, "pfx_chain_dev: a blur needs its sigma / radius in params[0]");
+            st.stencil = (int)i++;
+            ++n_stencil;
+        }
+        st.first = i;
+        uint32_t luts = 0;
+        while (i < n_ops && chain_pointwise(ops[i]) && st.count < PFXK_CHAIN_MAX) {
+            const bool lut_op = ops[i].kind == PFX_CHAIN_ADJUST ? (ops[i].op == PFX_OP_GRADIENT_MAP || ops[i].op == PFX_OP_LUT_RGBA) : ops[i].op == PFX_RHAI_LEVELS;
+            if (lut_op && luts == PFXK_CHAIN_LUTS) break;
+            luts += lut_op ? 1u : 0u;
+            ++st.count; ++i;
+        }
+        stages.push_back(st);
+    }
+    if (src_dev == dst_dev) PFX_REQUIRE(ctx, n_stencil == 0, "pfx_chain_dev: a chain with a blur cannot run in place");
+    if (stages.empty()) {
+        if (src_dev != dst_dev) PFX_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return PFX_OK;
+    }
+    if (n_stencil > 1 || (n_stencil == 1 && stages.front().stencil < 0)) PFX_TRY(pfx_reserve(ctx, ctx->st_chain, bytes));
+    // a stencil stage writes dst or the scratch image, alternating so that the LAST one writes dst (pointwise stages behind a stencil run in place)
+    uint32_t seen = 0;
+    auto stencil_out = [&](uint32_t j) -> void* { return ((n_stencil - 1u - j) % 2u == 0u) ? dst_dev : ctx->st_chain.p; };
+    const void* cur = src_dev;
+    for (const chain_stage& st : stages) {
+        pfxk_chain C;
+        if (st.count) PFX_TRY(chain_prepare(ctx, ops, st.first, st.count, C));
+        if (st.stencil < 0) {
+            // pointwise only: in place behind a stencil; in front of the first one into the buffer that stencil does not write
+            void* out = cur == src_dev ? (n_stencil == 0 ? dst_dev : (stencil_out(0) == dst_dev ? ctx->st_chain.p : dst_dev)) : const_cast<void*>(cur);
+            pfx_timer t(ctx, "chain");
+            PFX_HIP(ctx, pfxk_pointwise_chain(ctx->stream, (const uint8_t*)cur, (uint8_t*)out, (const uint8_t*)ctx->d_chain_luts.p, &C, w, h));
+            cur = out;
+            continue;
+        }
+        const pfx_chain_op& so = ops[st.stencil];
+        void* out = stencil_out(seen++);
+        bool fused = false;
+        if (so.kind == PFX_CHAIN_GAUSSIAN && st.count) {
+            const float sigma = so.params[0];
+            const int radius = pfx_host_gaussian_radius(sigma);
+            if (ctx->exact && radius >= 1 && radius <= pfxk_gauss_fused_exact_max_radius()) {
+                const float* wts = nullptr;
+                PFX_TRY(pfx_int_gauss_exact_weights(ctx, sigma, &wts));
+                pfx_timer t(ctx, "gauss_fused_chain");
+                PFX_HIP(ctx, pfxk_gauss_fused_exact_chain(ctx->stream, (const uint8_t*)cur, (uint8_t*)out, wts, radius, w, h, &C, (const uint8_t*)ctx->d_chain_luts.p));
+                fused = true;
+            } else if (!ctx->exact && radius >= 1 && radius <= pfxk_gauss_mfma_max_radius() && C.n_luts == 0 && ctx->chain_mfma_epilogue) {
+                // default mode: the chain rides in the matrix-core Gaussian's store (table-free ops, aligned buffers; otherwise the two launches below)
+                PFX_TRY(gauss_mfma_tables(ctx, sigma));
+                pfx_timer t(ctx, "gauss_mfma_chain");
+                const hipError_t e = pfxk_gauss_mfma_chain(ctx->stream, (const uint8_t*)cur, (uint8_t*)out, (const uint16_t*)ctx->d_wsplit.p, radius, ctx->wsplit_inv_scale,
+                                                           ctx->wsplit_bias, ctx->wsplit_bias_single, w, h, 0u, ctx->n_cus > 0 ? ctx->n_cus : 256, &C);
+                if (e == hipSuccess) fused = true;
+                else if (e != hipErrorNotSupported) PFX_HIP(ctx, e);
+                else (void)hipGetLastError();
+            }
+        }
+        if (!fused) {
+            if (so.kind == PFX_CHAIN_GAUSSIAN) PFX_TRY(pfx_gaussian_blur_dev(ctx, cur, out, w, h, so.params[0], nullptr));
+            else PFX_TRY(pfx_box_blur_dev(ctx, cur, out, w, h, so.params[0], nullptr, nullptr));
+            if (st.count) {
+                pfx_timer t(ctx, "chain");
+                PFX_HIP(ctx, pfxk_pointwise_chain(ctx->stream, (const uint8_t*)out, (uint8_t*)out, (const uint8_t*)ctx->d_chain_luts.p, &C, w, h));
+            }
+        }
+        cur = out;
+    }
+    if (cur != dst_dev) PFX_HIP(ctx, hipMemcpyAsync(dst_dev, cur, bytes, hipMemcpyDeviceToDevice, ctx->stream));   // unreachable by construction; kept as a guard
     return PFX_OK;
 }
 
@@ -1465,6 +1612,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "box_strip_fill") == 0) { pfxk_box_set_strip(-1, value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_strip_nseg") == 0) { pfxk_box_set_strip(-1, 0, value); return PFX_OK; }
     if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
+    if (std::strcmp(key, "chain_mfma") == 0) { ctx->chain_mfma_epilogue = value != 0; return PFX_OK; } // pfx_chain_dev: the chain in the matrix-core Gaussian's store (1) or as its own launch (0)
     if (std::strcmp(key, "gauss_fast_effects") == 0) { ctx->gauss_fast_effects = value != 0; return PFX_OK; } // sharpen / glow / shadow on the default-mode Gaussian (+-amount LSB)
     if (std::strcmp(key, "resize_two_pass") == 0) { ctx->resize_two_pass = value != 0; return PFX_OK; } // A/B and the parity test of the fused kernel
     return pfx_fail(ctx, PFX_ERR_INVALID, "pfx_tune: unknown key %s", key);

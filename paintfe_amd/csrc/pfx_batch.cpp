@@ -60,17 +60,17 @@ void run_device_body(int device, uint32_t rank, uint32_t world, uint32_t n_image
     std::vector<slot> S(n_slots);
     std::vector<void*> d_ov(P.n_overlays, nullptr);
     pfx_ctx* ctx = nullptr;            // kernels of all slots run in order on this context's stream: one scratch set serves them
-    void *d_a = nullptr, *d_b = nullptr;
+    void* d_b = nullptr;   // blur -> HSL result, layer 0 of the flatten (the blurred image itself needs no buffer: pfx_chain_dev)
     hipStream_t s_up = nullptr, s_down = nullptr;
     auto fail = [&](int st, const std::string& m) { if (R.status == PFX_OK) { R.status = st; R.err = m; } };
     auto hip = [&](hipError_t e, const char* what) { if (e != hipSuccess) fail(e == hipErrorOutOfMemory ? PFX_ERR_OOM : PFX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
 
     if (!hip(hipSetDevice(device), "hipSetDevice")) return;
     if (pfx_ctx_create(device, &ctx) != PFX_OK) fail(PFX_ERR_HIP, "pfx_ctx_create failed");
-    else if (!P.fast_gaussian) (void)pfx_ctx_set_exact(ctx, 1);
+    else if (!P.out_of_contract_fast_gaussian) (void)pfx_ctx_set_exact(ctx, 1);
     if (R.status == PFX_OK) {
         (void)(hip(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking), "hipStreamCreate") && hip(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking), "hipStreamCreate") &&
-               hip(hipMalloc(&d_a, bytes), "hipMalloc") && hip(hipMalloc(&d_b, bytes), "hipMalloc"));
+               hip(hipMalloc(&d_b, bytes), "hipMalloc"));
     }
     if (R.status == PFX_OK)
         for (auto& s : S) {
@@ -128,8 +128,13 @@ void run_device_body(int device, uint32_t rank, uint32_t world, uint32_t n_image
         const void* ptrs[1 + 8];
         ptrs[0] = d_b;
         for (uint32_t o = 0; o < P.n_overlays; ++o) ptrs[1 + o] = d_ov[o];
-        int rc = pfx_gaussian_blur_dev(ctx, s.d_in, d_a, P.w, P.h, P.sigma, nullptr);
-        if (rc == PFX_OK) rc = pfx_adjust_dev(ctx, d_a, d_b, P.w, P.h, PFX_OP_HSL, hsl, 3, nullptr, nullptr, PFX_DENSE);
+        // Gaussian -> HSL as a chain: ONE launch in the bit-exact mode at sigma <= 5.33 (the blurred image never exists in memory), blur + in-place HSL otherwise
+        pfx_chain_op ch[2];
+        std::memset(ch, 0, sizeof ch);
+        ch[0].kind = PFX_CHAIN_GAUSSIAN; ch[0].n_params = 1; ch[0].params[0] = P.sigma;
+        ch[1].kind = PFX_CHAIN_ADJUST; ch[1].op = PFX_OP_HSL; ch[1].n_params = 3;
+        ch[1].params[0] = hsl[0]; ch[1].params[1] = hsl[1]; ch[1].params[2] = hsl[2];
+        int rc = pfx_chain_dev(ctx, s.d_in, d_b, P.w, P.h, ch, 2);
         if (rc == PFX_OK) rc = pfx_flatten_dev(ctx, ptrs, nullptr, li.data(), 1 + P.n_overlays, P.w, P.h, s.d_out);
         if (rc != PFX_OK) { fail(rc, pfx_last_error(ctx)); break; }
         if (s.timed) (void)hipEventRecord(s.k1, s_comp);
@@ -152,7 +157,6 @@ void run_device_body(int device, uint32_t rank, uint32_t world, uint32_t n_image
         for (hipEvent_t e : {s.uploaded, s.computed, s.done, s.k0, s.k1})
             if (e) (void)hipEventDestroy(e);
     }
-    if (d_a) (void)hipFree(d_a);
     if (d_b) (void)hipFree(d_b);
     for (void* p : d_ov) if (p) (void)hipFree(p);
     if (ctx) pfx_ctx_destroy(ctx);

@@ -125,7 +125,7 @@ void pfx_ctx_destroy(pfx_ctx* ctx)
     for (auto& t : ctx->timings) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto& kv : ctx->layers) { free_buf(kv.second.pixels); free_buf(kv.second.mask); free_buf(kv.second.chunk_flags); }
     pfx_devbuf* bufs[] = {&ctx->st_in, &ctx->st_out, &ctx->st_mask, &ctx->st_tmp, &ctx->st_aux, &ctx->st_aux2, &ctx->fx_a, &ctx->fx_b, &ctx->d_desc,
-                          &ctx->d_adj, &ctx->d_chunks, &ctx->d_chunk_meta, &ctx->d_chunk_start, &ctx->d_wts, &ctx->d_wsplit, &ctx->warp_src, &ctx->d_lut, &ctx->d_pts, &ctx->d_misc};
+                          &ctx->d_adj, &ctx->d_chunks, &ctx->d_chunk_meta, &ctx->d_chunk_start, &ctx->d_wts, &ctx->d_wsplit, &ctx->warp_src, &ctx->d_lut, &ctx->d_pts, &ctx->d_misc, &ctx->st_chain, &ctx->d_chain_luts};
     for (auto* b : bufs) free_buf(*b);
     if (ctx->h_chunk_useful) (void)hipHostFree(ctx->h_chunk_useful);
     if (ctx->ev_chunk_useful) (void)hipEventDestroy(ctx->ev_chunk_useful);

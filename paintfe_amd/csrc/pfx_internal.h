@@ -49,6 +49,8 @@ struct pfx_ctx {
     pfx_devbuf fx_a, fx_b; // effect-bank scratch (crystallize cell table, drop-shadow planes)
     // small parameter buffers
     pfx_devbuf d_desc, d_adj, d_chunks, d_wts, d_lut, d_pts, d_misc;
+    bool chain_mfma_epilogue = true;     // pfx_tune "chain_mfma": 0 = a default-mode Gaussian in a chain runs as its own launch (A/B of the fused store)
+    pfx_devbuf st_chain, d_chain_luts;   // pfx_chain_dev: ping-pong image between two stencil stages; the tables of a chain's LUT ops (PFXK_CHAIN_LUTS x 1024)
     pfx_devbuf d_chunk_meta, d_chunk_start;     // per-layer summary pointers + wanted bits, and the per-chunk start table built from them
     std::vector<uint8_t> chunk_meta_cache;
     // whether the table of the stack in chunk_meta_cache skips anything: written by the table kernel into pinned memory (tag), read on a later
@@ -133,6 +135,7 @@ extern "C" int pfx_int_flatten_with_chunk_keys_dev(pfx_ctx* ctx, const void* con
                                                    uint32_t w, uint32_t h, void* dst_dev, const uint8_t* chunk_keys_host);
 
 // blur_with_selection on device-resident images (pfx_api.cpp); mask_host may be NULL (= no selection)
+extern "C" int pfx_int_gauss_exact_weights(pfx_ctx* ctx, float sigma, const float** wts);
 extern "C" int pfx_int_gauss_exact_combine_applies(pfx_ctx* ctx, const void* src_dev, const void* dst_dev, uint32_t w, uint32_t h, float sigma);
 extern "C" int pfx_int_gauss_exact_combine(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, uint32_t h, float sigma, int epilogue, float p0, const void* mask_dev); // 1 ran, 0 not applicable
 int pfx_int_blur_with_selection_dev(pfx_ctx* ctx, const void* d_src, void* d_dst, uint32_t w, uint32_t h, float sigma,

@@ -97,9 +97,29 @@ int        pfxk_gauss_mfma_wlen(void);
 int        pfxk_gauss_mfma_woff(void);
 hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit,
                            int radius, float inv_scale2, float bias_c, float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus);
+hipError_t pfxk_gauss_mfma_chain(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit, int radius, float inv_scale2, float bias_c,
+                                 float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus, const struct pfxk_chain* chain);
 void       pfxk_gauss_set_mfma_parts(int weight_parts, int h_parts); // f16 pieces per weight (2 or 1) / per horizontal result (2, or 1 with single weights)
 hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8_t* d_dst, const float* d_wts_tap0, int radius,
                         uint32_t w, uint32_t h, int exact);
+
+// ---- chains of pointwise ops (round 6: pfx_chain_dev) ----
+// op[i] = a PFXK_OP_* id (ops::adjustments flavour) or PFXK_CHAIN_RHAI | a PFXK_RHAI_* id (Rhai-inline flavour); P[i] = its prepared parameter block;
+// lut_slot[i] = which 1024-byte table of the chain's LUT buffer the op reads (ops without a table: 0).
+#define PFXK_CHAIN_MAX 8
+#define PFXK_CHAIN_LUTS 4
+#define PFXK_CHAIN_RHAI 0x100u
+typedef struct pfxk_chain {
+    uint32_t n, n_luts;
+    uint32_t op[PFXK_CHAIN_MAX];
+    uint32_t lut_slot[PFXK_CHAIN_MAX];
+    pfxk_params P[PFXK_CHAIN_MAX];
+} pfxk_chain;
+// every op of the chain on every pixel, one pass over memory (d_src == d_dst allowed); d_luts: n_luts x 1024 bytes
+hipError_t pfxk_pointwise_chain(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_luts, const pfxk_chain* C, uint32_t w, uint32_t h);
+// the bit-exact fused Gaussian with the chain applied to every blurred pixel in its store (epilogue 3 of pfxk_gauss_fused_exact)
+hipError_t pfxk_gauss_fused_exact_chain(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h,
+                                        const pfxk_chain* C, const uint8_t* d_luts);
 
 // ---- k_pointwise.hip ---- (d_lut: 1024 readable bytes when the op uses a LUT)
 hipError_t pfxk_adjust(hipStream_t s, const uint8_t* d_src, uint8_t* d_dst, const uint8_t* d_mask, const uint8_t* d_lut,

@@ -52,6 +52,10 @@ struct ScriptHost : rhai::Host {
     size_t bytes() const { return (size_t)w * h * 4; }
     const void* d_mask() const { return has_mask ? ctx->st_mask.p : nullptr; }
 
+    // Consecutive Rhai-inline effects (apply_exposure(); apply_sepia(); apply_invert(); ...) are QUEUED and run as one pass over the image when something
+    // needs it — another kind of effect, a pixel read, the end of the script (pfx_chain_dev: each op still re-quantises to u8 in registers, so the result is
+    // what the one-launch-per-call form gives).  On the CPU every such call is a full pass over the image (scripting.rs:869-1075).
+    std::vector<pfx_chain_op> pending;
     int dev_ready()
     {
         if (dev_stale) {
@@ -60,10 +64,17 @@ struct ScriptHost : rhai::Host {
             PFX_TRY(pfx_sync(ctx)); // host_px may be modified again right away
             dev_stale = false;
         }
+        if (!pending.empty()) {
+            const std::vector<pfx_chain_op> run(std::move(pending));
+            pending.clear();
+            PFX_TRY(pfx_chain_dev(ctx, cur->p, cur->p, w, h, run.data(), (uint32_t)run.size()));
+            image_changed_on_device();
+        }
         return PFX_OK;
     }
     int host_ready()
     {
+        if (!pending.empty()) PFX_TRY(dev_ready());   // queued effects first: the mirror must show their result
         if (!host_valid) {
             host_px.resize(bytes());
             PFX_TRY(pfx_d2h(ctx, host_px.data(), cur->p, bytes()));
@@ -375,7 +386,11 @@ int ScriptHost::call(rhai::Interp& in, const std::string& name, std::vector<Valu
     // ---------------------------------------------------------------- effects: Rhai-inline flavour (truncating, mask ignored; :869-1075)
     auto inline_fx = [&](int op, const float* p, uint32_t np) {
         if (need_image()) return 2;
-        return dev(inplace([&](void* img) { return pfx_rhai_adjust_dev(ctx, img, w, h, op, p, np); }));
+        pfx_chain_op o{};
+        o.kind = PFX_CHAIN_RHAI; o.op = op; o.n_params = np;
+        for (uint32_t k = 0; k < np; ++k) o.params[k] = p[k];
+        pending.push_back(o);   // runs with its neighbours in one pass (dev_ready)
+        return 2;
     };
     FN("apply_invert") if (sig({})) return inline_fx(PFX_RHAI_INVERT, nullptr, 0);
     FN("apply_desaturate") if (sig({})) return inline_fx(PFX_RHAI_DESATURATE, nullptr, 0);

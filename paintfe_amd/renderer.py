@@ -13,7 +13,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import Brush, LayerInfo, PfxError, ScriptResult
+from ._lib import Brush, ChainOp, LayerInfo, PfxError, ScriptResult
 
 DENSE, FROM_FLAT, IN_PLACE = 0, 1, 2
 
@@ -626,6 +626,30 @@ class GpuRenderer:
         l = None if lut is None else _u8(lut)
         self._check(self._lib.pfx_adjust_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h),
                                              C.c_int(opi), arr, n, _p(l), C.c_void_p(mask_ptr or None), C.c_int(sparse)))
+
+    def chain_dev(self, src_ptr, dst_ptr, w, h, ops):
+        """pfx_chain_dev: ops = [("gaussian", sigma) | ("box", radius) | ("adjust", name, params[, lut]) | ("rhai", name, params)], applied in order with as few
+        passes over memory as the kernels allow; equals the single-op calls one after the other, bit for bit"""
+        arr = (ChainOp * max(len(ops), 1))()
+        keep = []
+        for k, o in enumerate(ops):
+            kind = o[0]
+            if kind in ("gaussian", "box"):
+                arr[k].kind = 2 if kind == "gaussian" else 3
+                arr[k].n_params = 1
+                arr[k].params[0] = float(o[1])
+            else:
+                names = ADJUST_OPS if kind == "adjust" else RHAI_OPS
+                arr[k].kind = 0 if kind == "adjust" else 1
+                arr[k].op = names.index(o[1]) if isinstance(o[1], str) else int(o[1])
+                ps = list(o[2]) if len(o) > 2 and o[2] is not None else []
+                arr[k].n_params = len(ps)
+                for i, v in enumerate(ps):
+                    arr[k].params[i] = float(v)
+                if len(o) > 3 and o[3] is not None:
+                    l = _u8(o[3]); keep.append(l)
+                    arr[k].lut = l.ctypes.data
+        self._check(self._lib.pfx_chain_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h), arr, C.c_uint32(len(ops))))
 
     def sharpen_dev(self, src_ptr, dst_ptr, w, h, amount, radius, mask_ptr=0):
         self._check(self._lib.pfx_sharpen_dev(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_uint32(w), C.c_uint32(h), C.c_float(amount), C.c_float(radius),

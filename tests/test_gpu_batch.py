@@ -1,6 +1,6 @@
 """pfx_batch_pipeline (BASELINE config 5's driver): a 16-image batch streamed through the pipeline slots must give, for every
 sampled image, exactly what the single calls give.  Against the oracle it is BIT-EXACT by default (the pipeline runs the bit-exact
-Gaussian unless the caller sets pfx_batch_params.fast_gaussian: the blur feeds HSL, which amplifies a +-1 LSB input, and the stream is
+Gaussian unless the caller sets pfx_batch_params.out_of_contract_fast_gaussian: the blur feeds HSL, which amplifies a +-1 LSB input, and the stream is
 PCIe-bound either way); with fast_gaussian (MFMA, +-1 LSB class) the few channels the Gaussian rounds differently stay within a small
 bound after HSL and three blends.
 

@@ -83,6 +83,25 @@ def main() -> int:
     timed("hsl masked + FROM_FLAT", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "hsl", [30.0, -20.0, 10.0], mask_ptr=m, sparse=1), px, 9)
     timed("TiledImage round trip (from_rgba_image -> to_rgba_image)", ["tiled_roundtrip"], lambda: r.tiled_roundtrip_dev(s, d, w, h), px, 8,
           "A0: chunks of 64 x 64 whose alpha is all zero are dropped; one pass")
+    # chains (round 6, pfx_chain_dev): several ops, one pass where the kernels allow; every row's result equals the single-op calls one after the other
+    three = [("rhai", "exposure", (0.5,)), ("rhai", "sepia"), ("rhai", "invert")]
+    timed("chain: exposure -> sepia -> invert (a script's three calls, ONE pass)", ["chain"], lambda: r.chain_dev(s, d, w, h, three), px, 8,
+          "pfx_chain_dev; as three launches the same ops cost 3 x a streaming pass")
+
+    def three_launches():
+        r.chain_dev(s, d, w, h, three[:1]); r.chain_dev(d, d, w, h, three[1:2]); r.chain_dev(d, d, w, h, three[2:])
+    timed("the same three ops as three launches", ["chain"], three_launches, px, 24, "8 B/px each")
+    g_hsl = [("gaussian", 16.0), ("adjust", "hsl", (30.0, -20.0, 10.0))]
+    timed("chain: gaussian sigma=16 -> hsl (config 2, ONE launch)", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_hsl), px, 16,
+          "HSL in the matrix-core Gaussian's store; 16 B/px = the two-launch form's algorithmic bytes")
+    r.tune("chain_mfma", 0)
+    timed("the same as two launches (gaussian, then hsl in place)", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_hsl), px, 16)
+    r.tune("chain_mfma", 1)
+    g4_hsl = [("gaussian", 4.0), ("adjust", "hsl", (30.0, -20.0, 10.0))]
+    r.set_exact(True)
+    timed("chain: exact gaussian sigma=4 -> hsl (config 5's first two ops, ONE launch)", ["gauss_fused_chain", "gauss_fused", "chain"], lambda: r.chain_dev(s, d, w, h, g4_hsl), px, 16,
+          "bit-exact fused Gaussian with the chain in its store")
+    r.set_exact(False)
     timed("invert", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "invert"), px, 8)
     timed("brightness_contrast", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "brightness_contrast", [30.0, 20.0]), px, 8)
     lut = np.tile(np.arange(255, -1, -1, dtype=np.uint8), (4, 1))
