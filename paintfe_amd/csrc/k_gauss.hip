@@ -286,12 +286,16 @@ inline size_t gauss_strip_lds_bytes(int nkb, int hp)
 // CHAIN (round 6, pfx_chain_dev): pfxk_chain = the consumers put every blurred pixel through a chain of table-free pointwise ops between rounding and staging
 // (k_pointwise.h: chain_apply on the u8 pixel — what the ops would read from a buffer): `Gaussian -> HSL` is one launch, the blurred image never reaches memory.
 struct gs_no_chain {};
+// workgroups per CU the build is compiled for (x 2 = waves per SIMD): two up to 8 K blocks with one-piece weights
+template <class CHAIN> constexpr int gs_wg_per_cu(int nkb, int wp) { return (nkb <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && wp == 1) ? 2 : 1; }
 template <bool FAST, int NKB, bool DBG, int WP = 2, int HP = 2, class CHAIN = gs_no_chain>
-__global__ __launch_bounds__(512, ((NKB <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && WP == 1) ? 4 : 2)) void gauss_strip_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(512, 2 * gs_wg_per_cu<CHAIN>(NKB, WP)) void gauss_strip_kernel(const CHAIN chain_arg /* first: read through the kernarg segment (k_pointwise.h) */,
+                                                             const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              const uint16_t* __restrict__ wsplit, int w, int h, int r, int R8, float inv_scale2,
                                                              float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg, int dbg_arg,
-                                                             unsigned long long* __restrict__ dbg_buf, const CHAIN chain = CHAIN{})
+                                                             unsigned long long* __restrict__ dbg_buf)
 {
+    const pw::chain_kptr chain = pw::chain_in_kernarg();   // meaningful in the CHAIN builds only
     constexpr int GS_XROW = gs_xrow(NKB);
     // ring = two steps of 32 rows: the one the consumers load this iteration (finished before the last barrier) and the one the producers are storing
     constexpr int RING = 64, YP = RING + 8, PLANE = GM_COLS * YP + 32, HALF = NKB / 2, PPL = 2 * NKB; // PPL: pixels per producer lane
@@ -379,6 +383,10 @@ __global__ __launch_bounds__(512, ((NKB <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && WP == 
         }
     };
 
+    // CHAIN builds: the consumers put their four pixels of a block through the chain between rounding and staging.  (Spreading the pointwise arithmetic over all
+    // eight waves at store time was built too: the 24-way op dispatch then has ten inline sites — hipcc leaves it out of line, and a call inside this loop costs a
+    // closure in scratch whose reloads share vmcnt with the source prefetch: 0.78 ms against 0.22, profiles/r06_tuning.md.)
+    constexpr bool CH = !std::is_same<CHAIN, gs_no_chain>::value;
     if (producer) {
         // BORDER: the strip's source window leaves the image; chosen once per workgroup so that the loop has no data-dependent
         // branch around its loads.  A 4-pixel piece is wholly inside or wholly outside the row (w % 4 == 0 in the FAST
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(512, ((NKB <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && WP == 
                     for (int e = 0; e < 4; ++e) px = __builtin_amdgcn_cvt_pk_u8_f32(((WP == 2 || HP == 2) ? accA[4 * g + e] + accX[4 * g + e] : accA[4 * g + e]) * inv_scale2, e, px);
                     px4[g] = px;
                 }
-                if constexpr (!std::is_same<CHAIN, gs_no_chain>::value) pw::chain_apply<4>(chain, nullptr, px4);
+                if constexpr (CH) pw::chain_apply<4>(chain, nullptr, px4);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) orow[2 * g] = px4[g];
             }
@@ -690,7 +698,8 @@ static hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_src, ui
         // (tools/lab/gauss_seg.py, sigma 16): 8K 1 / 2 / 3 segments = 0.166 / 0.175 / 0.184 ms, 4K 0.080 / 0.053 / 0.070, 1080p 4 segments 0.023
         // against 0.033 for the 7 the previous rule ("just under two workgroups per CU") chose
         // workgroups per CU: LDS (one ring + patches: two fit) and registers (the kernel is built for 4 waves per SIMD up to 8 K blocks, 2 beyond)
-        const int resident = n_cus * (int)std::min<size_t>((NK <= (PFX_GAUSS_TWO_WG8 ? 8 : 6) && wp == 1) ? 2 : 1, std::max<size_t>(1, (size_t)160 * 1024 / lds));
+        const int by_regs = chain ? gs_wg_per_cu<pfxk_chain>(NK, wp) : gs_wg_per_cu<gs_no_chain>(NK, wp);
+        const int resident = n_cus * (int)std::min<size_t>((size_t)by_regs, std::max<size_t>(1, (size_t)160 * 1024 / lds));
         int n_seg = resident / tiles_x;
         if (g_mfma_seg > 0) n_seg = g_mfma_seg; // tuning override (its own key: "gauss_v_cfg" only configures the VALU vertical pass)
         if (n_seg < 1) n_seg = 1;
@@ -702,15 +711,15 @@ static hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_src, ui
         auto go = [&](auto kern) {
             errs = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (errs) return;
-            kern<<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, dbg, g_dbg_buf, gs_no_chain{});
+            kern<<<grid, 512, lds, stream>>>(gs_no_chain{}, d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, dbg, g_dbg_buf);
         };
         if (chain) {   // the chained form exists for the shipped configuration only (aligned buffers, one-piece weights, two-piece horizontal result)
             if (!(fast && wp == 1 && hp == 2)) { errs = hipErrorNotSupported; return; }
             static lds_grant grant;
             errs = grant_lds(grant, (const void*)gauss_strip_kernel<true, NK, false, 1, 2, pfxk_chain>, lds);
             if (errs) return;
-            gauss_strip_kernel<true, NK, false, 1, 2, pfxk_chain><<<grid, 512, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph,
-                                                                                             n_steps, per, 0, nullptr, *chain);
+            gauss_strip_kernel<true, NK, false, 1, 2, pfxk_chain><<<grid, 512, lds, stream>>>(*chain, d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph,
+                                                                                             n_steps, per, 0, nullptr);
             return;
         }
         if (fast && dbg && wp == 1 && hp == 2) go(gauss_strip_kernel<true, NK, true, 1, 2>); // development (tools/gauss_dbg.py, tools/gauss_timeline.py)

@@ -45,10 +45,12 @@ __host__ __device__ constexpr int gf_src_pitch(int r) { const int n = GF_W + 2 *
 // staged source rows in LDS.
 struct gf_no_chain {};
 template <int R, int EPI, class CHAIN = gf_no_chain>
-__global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const float* __restrict__ wts,
+__global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const CHAIN chain_arg /* first: the chain is read through the kernarg segment (k_pointwise.h) */,
+                                                                const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const float* __restrict__ wts,
                                                                 int w, int h, int seg_rows, int nseg, int strips, const uint8_t* __restrict__ mask, float p0,
-                                                                const CHAIN chain = CHAIN{}, const uint8_t* __restrict__ luts_g = nullptr)
+                                                                const uint8_t* __restrict__ luts_g)
 {
+    const pw::chain_kptr chain = pw::chain_in_kernarg();   // meaningful for EPI 3 only
     extern __shared__ __attribute__((aligned(16))) uint8_t gf_lds[];
     const int tid = (int)threadIdx.x;
     const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);   // XCD k owns a contiguous group of strips (block b runs on XCD b % 8)
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const uint32_t*
     const int v_begin = y0 - r, v_end = y1 + r;
     const uint8_t* const s_luts = gf_lds + (size_t)RR * GF_W * 16 + (size_t)GF_RB * sp * 4;   // EPI 3: the chain's tables (n_luts x 1024 bytes)
     if constexpr (EPI == 3) {
-        for (uint32_t i = (uint32_t)tid; i < chain.n_luts * 256u; i += (uint32_t)GF_T)
+        for (uint32_t i = (uint32_t)tid; i < chain->n_luts * 256u; i += (uint32_t)GF_T)
             reinterpret_cast<uint32_t*>(gf_lds + (size_t)RR * GF_W * 16 + (size_t)GF_RB * sp * 4)[i] = reinterpret_cast<const uint32_t*>(luts_g)[i];
         // the first barrier of the block loop below orders these stores before any vertical pass reads them
     }
@@ -236,12 +238,13 @@ static hipError_t launch_fused_exact(hipStream_t stream, const uint8_t* d_src, u
         if constexpr (E == 3) {
             hipError_t e = grant_lds(grant, (const void*)gauss_fused_exact_kernel<R, 3, pfxk_chain>, lds);
             if (e) return e;
-            gauss_fused_exact_kernel<R, 3, pfxk_chain><<<grid, GF_T, lds, stream>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h, seg_rows, nseg, strips,
-                                                                                    nullptr, 0.0f, *chain, d_luts);
+            gauss_fused_exact_kernel<R, 3, pfxk_chain><<<grid, GF_T, lds, stream>>>(*chain, (const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h, seg_rows, nseg, strips,
+                                                                                    nullptr, 0.0f, d_luts);
         } else {
             hipError_t e = grant_lds(grant, (const void*)gauss_fused_exact_kernel<R, E>, lds);
             if (e) return e;
-            gauss_fused_exact_kernel<R, E><<<grid, GF_T, lds, stream>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h, seg_rows, nseg, strips, d_mask, p0);
+            gauss_fused_exact_kernel<R, E><<<grid, GF_T, lds, stream>>>(gf_no_chain{}, (const uint32_t*)d_src, (uint32_t*)d_dst, d_wts_tap0, (int)w, (int)h, seg_rows, nseg, strips, d_mask, p0,
+                                                                        nullptr);
         }
         return hipGetLastError();
     };

@@ -233,16 +233,26 @@ PFX_DEV void chain_step(const pfxk_params& P, const uint8_t* __restrict__ lut, u
 #pragma unroll
     for (int k = 0; k < N; ++k) px[k] = apply_px<OP, RHAI>(P, lut, px[k]);
 }
+// The chain is always the kernel's FIRST parameter and is read through the kernarg segment (constant address space, wave-uniform addresses: scalar loads into
+// SGPRs).  Indexing the by-value parameter itself with the run-time op index makes hipcc copy the whole struct to scratch and read the parameters back per lane
+// through the vector memory path — in the matrix-core Gaussian those reads share vmcnt with the source prefetch and serialise it (measured: 0.78 ms against 0.22).
+typedef const pfxk_chain __attribute__((address_space(4)))* chain_kptr;
+PFX_DEV chain_kptr chain_in_kernarg() { return (chain_kptr)__builtin_amdgcn_kernarg_segment_ptr(); }
 template <int N>
-PFX_DEV void chain_apply(const pfxk_chain& C, const uint8_t* __restrict__ luts, uint32_t (&px)[N])
+PFX_DEV void chain_apply(chain_kptr C, const uint8_t* __restrict__ luts, uint32_t (&px)[N])
 {
-    for (uint32_t i = 0; i < C.n; ++i) {
-        const uint32_t code = C.op[i];
-        const pfxk_params& P = C.P[i];
-        const uint8_t* lut = luts + 1024u * C.lut_slot[i];
+    const uint32_t n = C->n;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t code = C->op[i];
+        // the parameter block is fetched INSIDE each case: only the fields that op reads are loaded (dead loads go), so a chain costs a handful of scalar
+        // registers in the kernels that host it instead of twelve
+        auto params = [&]() { pfxk_params P;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) P.p[k] = C->P[i].p[k];
+            return P; };
         switch (code) {
-#define PFX_CA(OP) case OP: chain_step<N, OP, false>(P, lut, px); break;
-#define PFX_CR(OP) case PFXK_CHAIN_RHAI | OP: chain_step<N, OP, true>(P, lut, px); break;
+#define PFX_CA(OP) case OP: chain_step<N, OP, false>(params(), luts + 1024u * C->lut_slot[i], px); break;
+#define PFX_CR(OP) case PFXK_CHAIN_RHAI | OP: chain_step<N, OP, true>(params(), luts + 1024u * C->lut_slot[i], px); break;
             PFX_CA(PFXK_OP_INVERT) PFX_CA(PFXK_OP_INVERT_ALPHA) PFX_CA(PFXK_OP_SEPIA) PFX_CA(PFXK_OP_BRIGHTNESS_CONTRAST) PFX_CA(PFXK_OP_HSL)
             PFX_CA(PFXK_OP_EXPOSURE) PFX_CA(PFXK_OP_HIGHLIGHTS_SHADOWS) PFX_CA(PFXK_OP_TEMPERATURE_TINT) PFX_CA(PFXK_OP_THRESHOLD)
             PFX_CA(PFXK_OP_POSTERIZE) PFX_CA(PFXK_OP_COLOR_BALANCE) PFX_CA(PFXK_OP_GRADIENT_MAP) PFX_CA(PFXK_OP_BLACK_AND_WHITE)

@@ -133,12 +133,13 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t* __restric
 
 // A chain of pointwise ops in ONE pass (pfx_chain_dev): the same chunk tiling, dense mode, no selection.  A lane's 16 pixels go through the ops one op at a time
 // (k_pointwise.h: chain_apply); tables of the chain's LUT ops are staged in LDS once per workgroup.
-__global__ __launch_bounds__(256) void pointwise_chain_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint8_t* __restrict__ luts_g,
-                                                              const pfxk_chain C, uint32_t w, uint32_t h)
+__global__ __launch_bounds__(256) void pointwise_chain_kernel(const pfxk_chain C_arg /* first: read through the kernarg segment (k_pointwise.h) */, const uint8_t* __restrict__ src,
+                                                              uint8_t* __restrict__ dst, const uint8_t* __restrict__ luts_g, uint32_t w, uint32_t h)
 {
+    const chain_kptr C = chain_in_kernarg();
     __shared__ uint8_t luts[PFXK_CHAIN_LUTS * 1024];
-    if (C.n_luts) {
-        for (uint32_t i = threadIdx.x; i < C.n_luts * 256u; i += 256u) reinterpret_cast<uint32_t*>(luts)[i] = reinterpret_cast<const uint32_t*>(luts_g)[i];
+    if (C->n_luts) {
+        for (uint32_t i = threadIdx.x; i < C->n_luts * 256u; i += 256u) reinterpret_cast<uint32_t*>(luts)[i] = reinterpret_cast<const uint32_t*>(luts_g)[i];
         __syncthreads();
     }
     const uint32_t cxn = (w + 63u) / 64u;
@@ -155,7 +156,12 @@ __global__ __launch_bounds__(256) void pointwise_chain_kernel(const uint8_t* __r
             const uint4 v = *reinterpret_cast<const uint4*>(s32 + (size_t)(by + r0 + 16u * k) * w + x);
             px[4 * k] = v.x; px[4 * k + 1] = v.y; px[4 * k + 2] = v.z; px[4 * k + 3] = v.w;
         }
-        chain_apply<16>(C, luts, px);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // a row's four pixels at a time: 16 at once cost 206 registers (two waves per SIMD on an HBM-bound kernel)
+            uint32_t q[4] = {px[4 * k], px[4 * k + 1], px[4 * k + 2], px[4 * k + 3]};
+            chain_apply<4>(C, luts, q);
+            px[4 * k] = q[0]; px[4 * k + 1] = q[1]; px[4 * k + 2] = q[2]; px[4 * k + 3] = q[3];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             *reinterpret_cast<uint4*>(d32 + (size_t)(by + r0 + 16u * k) * w + x) = make_uint4(px[4 * k], px[4 * k + 1], px[4 * k + 2], px[4 * k + 3]);
@@ -168,7 +174,12 @@ __global__ __launch_bounds__(256) void pointwise_chain_kernel(const uint8_t* __r
             const uint32_t y = by + r0 + 16u * k;
             px[4 * k + p] = (y < h && x + p < w) ? s32[(size_t)y * w + x + p] : 0u;
         }
-    chain_apply<16>(C, luts, px);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t q[4] = {px[4 * k], px[4 * k + 1], px[4 * k + 2], px[4 * k + 3]};
+        chain_apply<4>(C, luts, q);
+        px[4 * k] = q[0]; px[4 * k + 1] = q[1]; px[4 * k + 2] = q[2]; px[4 * k + 3] = q[3];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -226,6 +237,6 @@ extern "C" hipError_t pfxk_pointwise_chain(hipStream_t s, const uint8_t* d_src, 
     if (w == 0 || h == 0 || C->n == 0) return hipSuccess;
     if (C->n > PFXK_CHAIN_MAX || C->n_luts > PFXK_CHAIN_LUTS) return hipErrorInvalidValue;
     const uint32_t nchunks = ((w + 63u) / 64u) * ((h + 63u) / 64u);
-    pointwise_chain_kernel<<<nchunks, 256, 0, s>>>(d_src, d_dst, d_luts, *C, w, h);
+    pointwise_chain_kernel<<<nchunks, 256, 0, s>>>(*C, d_src, d_dst, d_luts, w, h);
     return hipGetLastError();
 }

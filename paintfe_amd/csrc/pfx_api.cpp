@@ -784,7 +784,16 @@ int pfx_chain_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w, 
         const pfx_chain_op& so = ops[st.stencil];
         void* out = stencil_out(seen++);
         bool fused = false;
-        if (so.kind == PFX_CHAIN_GAUSSIAN && st.count) {
+        // The pointwise run rides in the Gaussian's store only when it is light: a Gaussian kernel is bound by its own arithmetic and dependency chains, not by HBM,
+        // so an op of ~140 instructions per pixel (HSL, vibrance) costs there what it costs as a streaming pass of its own and the fused launch saves nothing
+        // (8K sigma 16 -> HSL: 0.210 ms fused against 0.206 as two launches; bit-exact sigma 4 -> HSL 0.381 against 0.371: profiles/r06_tuning.md); light ops
+        // (invert, exposure, brightness / contrast, tables ...) cost a few instructions and save the 8 B/px round trip.  pfx_tune "chain_fuse_heavy" = 1 fuses anyway.
+        bool heavy = false;
+        for (uint32_t k = 0; k < st.count; ++k) {
+            const pfx_chain_op& o = ops[st.first + k];
+            heavy = heavy || (o.kind == PFX_CHAIN_ADJUST && (o.op == PFX_OP_HSL || o.op == PFX_OP_VIBRANCE)) || (o.kind == PFX_CHAIN_RHAI && o.op == PFX_RHAI_HSL);
+        }
+        if (so.kind == PFX_CHAIN_GAUSSIAN && st.count && (!heavy || ctx->chain_fuse_heavy)) {
             const float sigma = so.params[0];
             const int radius = pfx_host_gaussian_radius(sigma);
             if (ctx->exact && radius >= 1 && radius <= pfxk_gauss_fused_exact_max_radius()) {
@@ -1612,6 +1621,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "box_strip_fill") == 0) { pfxk_box_set_strip(-1, value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_strip_nseg") == 0) { pfxk_box_set_strip(-1, 0, value); return PFX_OK; }
     if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
+    if (std::strcmp(key, "chain_fuse_heavy") == 0) { ctx->chain_fuse_heavy = value != 0; return PFX_OK; } // pfx_chain_dev: HSL / vibrance in a Gaussian's store too (measured: no gain)
     if (std::strcmp(key, "chain_mfma") == 0) { ctx->chain_mfma_epilogue = value != 0; return PFX_OK; } // pfx_chain_dev: the chain in the matrix-core Gaussian's store (1) or as its own launch (0)
     if (std::strcmp(key, "gauss_fast_effects") == 0) { ctx->gauss_fast_effects = value != 0; return PFX_OK; } // sharpen / glow / shadow on the default-mode Gaussian (+-amount LSB)
     if (std::strcmp(key, "resize_two_pass") == 0) { ctx->resize_two_pass = value != 0; return PFX_OK; } // A/B and the parity test of the fused kernel

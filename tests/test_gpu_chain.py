@@ -93,6 +93,29 @@ def test_exact_gaussian_with_the_chain_in_its_store(r, sigma):
         r.set_exact(False)
 
 
+def test_heavy_ops_fused_into_the_gaussians_on_request(r):
+    """HSL / vibrance run as their own in-place pass behind a Gaussian by default (no gain from fusing, profiles/r06_tuning.md); pfx_tune chain_fuse_heavy = 1 puts
+    them in the Gaussian's store — both kernels' chained forms must give the same bits"""
+    img = I.random_rgba(256, 160, seed=9)
+    ops = [("gaussian", 3.0), ("adjust", "hsl", (30.0, -20.0, 10.0)), ("adjust", "vibrance", (35.0,)), ("rhai", "hsl", (5.0, 5.0, 5.0))]
+    try:
+        r.set_exact(True)
+        want = run_oracle(img, ops)
+        assert np.array_equal(run_chain(r, img, ops), want)
+        r.tune("chain_fuse_heavy", 1)
+        assert np.array_equal(run_chain(r, img, ops), want)
+        r.set_exact(False)                      # default mode: matrix-core Gaussian, fused against unfused
+        fused = run_chain(r, img, ops)
+        r.tune("chain_fuse_heavy", 0)
+        assert np.array_equal(run_chain(r, img, ops), fused)
+        light = [("gaussian", 3.0), ("adjust", "exposure", (0.4,)), ("adjust", "invert")]
+        a = run_chain(r, img, light)            # light ops: in the matrix-core Gaussian's store by default
+        r.tune("chain_mfma", 0)
+        assert np.array_equal(run_chain(r, img, light), a)
+    finally:
+        r.tune("chain_mfma", 1); r.tune("chain_fuse_heavy", 0); r.set_exact(False)
+
+
 def test_stencils_between_pointwise_runs_ping_pong_through_the_scratch_image(r):
     r.set_exact(True)
     try:

@@ -92,15 +92,26 @@ def main() -> int:
         r.chain_dev(s, d, w, h, three[:1]); r.chain_dev(d, d, w, h, three[1:2]); r.chain_dev(d, d, w, h, three[2:])
     timed("the same three ops as three launches", ["chain"], three_launches, px, 24, "8 B/px each")
     g_hsl = [("gaussian", 16.0), ("adjust", "hsl", (30.0, -20.0, 10.0))]
-    timed("chain: gaussian sigma=16 -> hsl (config 2, ONE launch)", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_hsl), px, 16,
-          "HSL in the matrix-core Gaussian's store; 16 B/px = the two-launch form's algorithmic bytes")
+    timed("chain: gaussian sigma=16 -> hsl (config 2)", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_hsl), px, 16,
+          "pfx_chain_dev: the Gaussian, then HSL in place (HSL is heavy: not fused by default)")
+    r.tune("chain_fuse_heavy", 1)
+    timed("gaussian sigma=16 -> hsl with HSL in the matrix-core Gaussian's store (chain_fuse_heavy, not the default)", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_hsl), px, 16,
+          "the default runs this pair as two launches: HSL is 143 instructions per pixel and costs in the store what it costs as its own pass")
+    r.tune("chain_fuse_heavy", 0)
+    g_light = [("gaussian", 16.0), ("adjust", "brightness_contrast", (20.0, 10.0)), ("adjust", "invert")]
+    timed("chain: gaussian sigma=16 -> brightness/contrast -> invert (ONE launch)", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_light), px, 24,
+          "light ops in the Gaussian's store; 24 B/px = the three-launch form's algorithmic bytes")
     r.tune("chain_mfma", 0)
-    timed("the same as two launches (gaussian, then hsl in place)", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_hsl), px, 16)
+    timed("the same, gaussian sigma=16 then brightness/contrast -> invert, as two launches", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_light), px, 24)
+    timed("the same, gaussian sigma=16 then hsl, as two launches", ["gauss_mfma_chain", "gauss_mfma", "chain"], lambda: r.chain_dev(s, d, w, h, g_hsl), px, 16)
     r.tune("chain_mfma", 1)
     g4_hsl = [("gaussian", 4.0), ("adjust", "hsl", (30.0, -20.0, 10.0))]
     r.set_exact(True)
-    timed("chain: exact gaussian sigma=4 -> hsl (config 5's first two ops, ONE launch)", ["gauss_fused_chain", "gauss_fused", "chain"], lambda: r.chain_dev(s, d, w, h, g4_hsl), px, 16,
-          "bit-exact fused Gaussian with the chain in its store")
+    timed("chain: exact gaussian sigma=4 -> hsl (config 5's first two ops)", ["gauss_fused_chain", "gauss_fused", "chain"], lambda: r.chain_dev(s, d, w, h, g4_hsl), px, 16,
+          "bit-exact fused Gaussian, then HSL in place")
+    g4_light = [("gaussian", 4.0), ("adjust", "exposure", (0.5,)), ("adjust", "invert")]
+    timed("chain: exact gaussian sigma=4 -> exposure -> invert (ONE launch)", ["gauss_fused_chain", "gauss_fused", "chain"], lambda: r.chain_dev(s, d, w, h, g4_light), px, 24,
+          "light ops in the bit-exact fused Gaussian's store")
     r.set_exact(False)
     timed("invert", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "invert"), px, 8)
     timed("brightness_contrast", ["adjust"], lambda: r.adjust_dev(s, d, w, h, "brightness_contrast", [30.0, 20.0]), px, 8)

@@ -5,7 +5,8 @@
     profiles/rNN_bench_n1.json  bench.py                the headline line with every BASELINE configuration
     profiles/rNN_pmc.json       tools/prof.sh + tools/pmc_json.py   rocprofv3 averages and PMC figures of the two headline kernels
 
-The newest rNN of each is used.  The blocks between `<!-- BEGIN GENERATED:name -->` and `<!-- END GENERATED:name -->` in DESIGN.md are replaced;
+The newest rNN of each is used.  The blocks between `<!-- BEGIN GENERATED:name -->` and `<!-- END GENERATED:name -->` in DESIGN.md (headline) and
+profiles/ops_table.md (operation table) are replaced;
 `--check` exits 1 if DESIGN.md is not what the profiles produce (tests/test_host_logic.py runs it, so a stale table fails the CPU gate).
 Prose outside the blocks carries no measured figure that a profile holds; history lives in profiles/rNN_tuning.md."""
 import ast, glob, json, os, re, sys
@@ -97,20 +98,24 @@ def main():
     names = {"bench": os.path.relpath(fb, ROOT), "pmc": os.path.relpath(fp, ROOT), "ops": os.path.relpath(fo, ROOT)}
     b = json.loads(open(fb).read().strip().splitlines()[-1])
     p = json.load(open(fp))
-    blocks = {"headline": block_headline(b, p, names), "ops": block_ops(ops_rows(fo), names)}
-    path = os.path.join(ROOT, "DESIGN.md")
-    text = open(path).read()
-    new = text
-    for name, body in blocks.items():
+    # the headline block lives in DESIGN.md; the per-operation table (70 rows) in profiles/ops_table.md, which DESIGN.md links to (round 6: DESIGN.md describes the
+    # shipped design in <= 25 KB)
+    blocks = {"headline": ("DESIGN.md", block_headline(b, p, names)), "ops": (os.path.join("profiles", "ops_table.md"), block_ops(ops_rows(fo), names))}
+    stale = []
+    for name, (rel, body) in blocks.items():
+        path = os.path.join(ROOT, rel)
+        text = open(path).read()
         pat = re.compile(rf"(<!-- BEGIN GENERATED:{name} -->\n).*?(<!-- END GENERATED:{name} -->)", re.S)
-        if not pat.search(new): raise SystemExit(f"DESIGN.md has no GENERATED:{name} block")
-        new = pat.sub(lambda m: m.group(1) + body + "\n" + m.group(2), new)
-    if check:
+        if not pat.search(text): raise SystemExit(f"{rel} has no GENERATED:{name} block")
+        new = pat.sub(lambda m: m.group(1) + body + "\n" + m.group(2), text)
         if new != text:
-            print("DESIGN.md is stale: run python tools/design_tables.py"); return 1
-        print("DESIGN.md generated blocks are current"); return 0
-    open(path, "w").write(new)
-    print("DESIGN.md updated from", names)
+            stale.append(rel)
+            if not check: open(path, "w").write(new)
+    if check:
+        if stale:
+            print("stale generated blocks in", stale, ": run python tools/design_tables.py"); return 1
+        print("generated blocks are current"); return 0
+    print("updated", stale or "nothing", "from", names)
     return 0
 
 
