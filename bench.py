@@ -249,8 +249,8 @@ def other_configs(args, torch, r, device, O, flat, blurred):
     dmax = int(np.abs(ref_blur.astype(np.int16) - got_blur.astype(np.int16)).max())
     hsl_ok = bool(np.array_equal(O.adjust(got_blur, "hsl", hp), got_hsl))
     ms2 = k.get("gauss_mfma", 0.0) + k.get("adjust", 0.0)
-    # the same two ops as ONE launch (pfx_chain_dev: HSL applied to the blurred pixel in the Gaussian's store, the blurred image never reaches memory): 4 + 4
-    # algorithmic bytes per pixel of traffic, quoted against the same 16 B/px as the two-launch form so that the two lines compare as times
+    # the same two ops through pfx_chain_dev (what a script's `apply_gaussian_blur(16.0); apply_hsl(..);` or the batch pipeline runs): light pointwise ops ride in the
+    # Gaussian's store (one launch), HSL — 143 instructions per pixel — runs as a chain launch in place behind it; quoted against the same 16 B/px either way
     fused = torch.empty_like(flat)
     chain = [("gaussian", SIGMA), ("adjust", "hsl", hp)]
     kc = kernel_ms(("gauss_mfma_chain", "gauss_mfma", "chain"), lambda: r.chain_dev(flat.data_ptr(), fused.data_ptr(), w, h, chain), 20)
@@ -258,7 +258,9 @@ def other_configs(args, torch, r, device, O, flat, blurred):
     ms2c = sum(kc.values())
     out["config2_gaussian16_hsl_8k"] = entry(ms2c, 16 * px, kernel_ms={n: round(v, 4) for n, v in kc.items()}, launches=len(kc),
                                              gaussian_mode="matrix cores: one f16 per tap, horizontal result as two f16, f32 accumulate (+-1 LSB class)",
-                                             what="pfx_chain_dev(Gaussian sigma=16 -> HSL): one launch, HSL in the Gaussian's store",
+                                             what="pfx_chain_dev(Gaussian sigma=16 -> HSL): " + ("one launch, HSL in the Gaussian's store" if len(kc) == 1 else
+                                                  "the Gaussian, then HSL in place as a chain launch (HSL is 143 instructions per pixel: in the Gaussian's store it costs what "
+                                                  "it costs as its own pass, so pfx_chain_dev does not fuse it; profiles/r06_tuning.md)"),
                                              check={"gaussian_window_max_diff_vs_oracle": dmax, "hsl_window_bitexact_on_the_gpu_blur": hsl_ok,
                                                     "whole_frame_identical_to_the_two_launch_form": same})
     out["config2_two_launches"] = entry(ms2, 16 * px, kernel_ms={n: round(v, 4) for n, v in k.items()}, what="pfx_gaussian_blur_dev then pfx_adjust_dev (round 5's config-2 line)")

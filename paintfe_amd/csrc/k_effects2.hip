@@ -48,33 +48,27 @@ PFX_DEV float hash_f32(uint32_t x, uint32_t y, uint32_t seed)
     return (float)(h & 0x00FFFFFFu) / 16777216.0f; // power of two: exact
 }
 
-// noise.rs:53-71
+// Value noise on the integer lattice (hashed corner values, quintic fade, bilinear blend), and its octave sum.  References: perlin_noise_2d
+// src/ops/effects/noise.rs:53-71, turbulence src/ops/effects/distort.rs:229-246 — their operation order, which is the parity contract.
+PFX_DEV float fade5(float t) { return t * t * t * (t * (t * 6.0f - 15.0f) + 10.0f); }
+PFX_DEV float blend_to(float from, float to, float t) { return from + t * (to - from); }
 PFX_DEV float perlin_noise_2d(float x, float y, uint32_t seed)
 {
-    const int xi = rs_i32(__builtin_floorf(x)), yi = rs_i32(__builtin_floorf(y));
-    const float xf = x - (float)xi, yf = y - (float)yi;
-    const float u = xf * xf * xf * (xf * (xf * 6.0f - 15.0f) + 10.0f);
-    const float v = yf * yf * yf * (yf * (yf * 6.0f - 15.0f) + 10.0f);
-    const float n00 = hash_f32((uint32_t)xi, (uint32_t)yi, seed);
-    const float n10 = hash_f32((uint32_t)xi + 1u, (uint32_t)yi, seed);
-    const float n01 = hash_f32((uint32_t)xi, (uint32_t)yi + 1u, seed);
-    const float n11 = hash_f32((uint32_t)xi + 1u, (uint32_t)yi + 1u, seed);
-    const float nx0 = n00 + u * (n10 - n00);
-    const float nx1 = n01 + u * (n11 - n01);
-    return nx0 + v * (nx1 - nx0);
+    const int cx = rs_i32(__builtin_floorf(x)), cy = rs_i32(__builtin_floorf(y));   // lattice cell
+    const float wx = fade5(x - (float)cx), wy = fade5(y - (float)cy);
+    const uint32_t ux = (uint32_t)cx, uy = (uint32_t)cy;
+    const float lower = blend_to(hash_f32(ux, uy, seed), hash_f32(ux + 1u, uy, seed), wx);
+    const float upper = blend_to(hash_f32(ux, uy + 1u, seed), hash_f32(ux + 1u, uy + 1u, seed), wx);
+    return blend_to(lower, upper, wy);
 }
-
-// distort.rs:229-246
 PFX_DEV float turbulence_2d(float x, float y, uint32_t seed, uint32_t octaves, float roughness)
 {
-    float total = 0.0f, amplitude = 1.0f, frequency = 1.0f, max_amplitude = 0.0f;
-    for (uint32_t i = 0; i < octaves; ++i) {
-        total += perlin_noise_2d(x * frequency, y * frequency, seed + i * 1000u) * amplitude;
-        max_amplitude += amplitude;
-        amplitude *= roughness;
-        frequency *= 2.0f;
+    float sum = 0.0f, weight = 1.0f, scale = 1.0f, weights = 0.0f;
+    for (uint32_t o = 0; o < octaves; ++o, weight *= roughness, scale *= 2.0f) {
+        sum += perlin_noise_2d(x * scale, y * scale, seed + o * 1000u) * weight;
+        weights += weight;
     }
-    return max_amplitude > 0.0f ? total / max_amplitude : 0.0f;
+    return weights > 0.0f ? sum / weights : 0.0f;
 }
 
 // effects.rs:108-140 (clamp-to-edge, weight form p00(1-dx)(1-dy)+...; NOT the warp's bilinear)

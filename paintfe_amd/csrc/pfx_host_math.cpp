@@ -205,48 +205,71 @@ void pfx_build_stretch_lut(uint8_t mn, uint8_t mx, uint8_t lut[256])
     }
 }
 
-// ref: build_curves_lut (Fritsch–Carlson monotone cubic), src/ops/adjustments.rs:640-729
+// Curves LUT: a monotone piecewise-cubic Hermite interpolant through the control points (Fritsch–Carlson limiter on the tangents), sampled at the 256 byte
+// values.  Reference: build_curves_lut, src/ops/adjustments.rs:640-729 — the operation ORDER below is that function's (it is the rounding contract, pinned by
+// tests/golden/curves_kat.json's 60-digit known answers); the organisation is ours: secant slopes, limited tangents, then one Hermite evaluation per byte.
+namespace {
+struct curve_knots {
+    const float* p; uint32_t n;
+    float x(uint32_t i) const { return p[2 * i]; }
+    float y(uint32_t i) const { return p[2 * i + 1]; }
+};
+constexpr float CURVE_EPS = 1e-6f;
+// slope of the chord between knots i and i + 1 (0 for a vertical chord)
+float chord_slope(const curve_knots& K, uint32_t i)
+{
+    const float run = K.x(i + 1) - K.x(i), rise = K.y(i + 1) - K.y(i);
+    return (fabsf(run) < CURVE_EPS) ? 0.0f : rise / run;
+}
+// cubic Hermite on [xa, xb] with end values ya, yb and end tangents ta, tb
+float hermite_at(float x, float xa, float xb, float ya, float yb, float ta, float tb)
+{
+    const float span = xb - xa;
+    if (fabsf(span) < CURVE_EPS) return ya;
+    const float u = (x - xa) / span, u2 = u * u, u3 = u2 * u;
+    const float w_ya = 2.0f * u3 - 3.0f * u2 + 1.0f, w_ta = u3 - 2.0f * u2 + u;
+    const float w_yb = -2.0f * u3 + 3.0f * u2, w_tb = u3 - u2;
+    return w_ya * ya + w_ta * span * ta + w_yb * yb + w_tb * span * tb;
+}
+}  // namespace
+
 void pfx_build_curves_lut(const float* pts, uint32_t n, uint8_t lut[256])
 {
     if (!pts || n < 2) { for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i; return; }
-    auto X = [&](uint32_t i) { return pts[i * 2]; };
-    auto Y = [&](uint32_t i) { return pts[i * 2 + 1]; };
-    std::vector<float> delta(n - 1), m(n, 0.0f);
-    for (uint32_t i = 0; i + 1 < n; ++i) {
-        const float dx = X(i + 1) - X(i), dy = Y(i + 1) - Y(i);
-        delta[i] = (fabsf(dx) < 1e-6f) ? 0.0f : dy / dx;
+    const curve_knots K{pts, n};
+    const uint32_t last = n - 1;
+    std::vector<float> chord(last), tangent(n, 0.0f);
+    for (uint32_t i = 0; i < last; ++i) chord[i] = chord_slope(K, i);
+    // interior tangents: mean of the neighbouring chords, zero at a local extremum; ends take their one chord
+    tangent[0] = chord[0];
+    tangent[last] = chord[last - 1];
+    for (uint32_t i = 1; i < last; ++i) {
+        const float left = chord[i - 1], right = chord[i];
+        tangent[i] = (left * right <= 0.0f) ? 0.0f : (left + right) / 2.0f;
     }
-    m[0] = delta[0];
-    m[n - 1] = delta[n - 2];
-    for (uint32_t i = 1; i + 1 < n; ++i) m[i] = (delta[i - 1] * delta[i] <= 0.0f) ? 0.0f : (delta[i - 1] + delta[i]) / 2.0f;
-    for (uint32_t i = 0; i + 1 < n; ++i) {
-        if (fabsf(delta[i]) < 1e-6f) { m[i] = 0.0f; m[i + 1] = 0.0f; continue; }
-        const float alpha = m[i] / delta[i], beta = m[i + 1] / delta[i];
-        const float s = alpha * alpha + beta * beta;
-        if (s > 9.0f) {
-            const float tau = 3.0f / sqrtf(s);
-            m[i] = tau * alpha * delta[i];
-            m[i + 1] = tau * beta * delta[i];
+    // limiter: keep (tangent / chord) of both ends of a segment inside the circle of radius 3
+    for (uint32_t i = 0; i < last; ++i) {
+        const float c = chord[i];
+        if (fabsf(c) < CURVE_EPS) { tangent[i] = 0.0f; tangent[i + 1] = 0.0f; continue; }
+        const float ra = tangent[i] / c, rb = tangent[i + 1] / c;
+        const float r2 = ra * ra + rb * rb;
+        if (r2 > 9.0f) {
+            const float shrink = 3.0f / sqrtf(r2);
+            tangent[i] = shrink * ra * c;
+            tangent[i + 1] = shrink * rb * c;
         }
     }
     for (int i = 0; i < 256; ++i) {
         const float x = (float)i;
-        uint32_t seg = 0;
-        for (uint32_t j = 0; j + 1 < n; ++j) if (x >= X(j)) seg = j;
-        float val;
-        if (x <= X(0)) val = Y(0);
-        else if (x >= X(n - 1)) val = Y(n - 1);
+        float v;
+        if (x <= K.x(0)) v = K.y(0);
+        else if (x >= K.x(last)) v = K.y(last);
         else {
-            const float x0 = X(seg), x1 = X(seg + 1), y0 = Y(seg), y1 = Y(seg + 1), hh = x1 - x0;
-            if (fabsf(hh) < 1e-6f) val = y0;
-            else {
-                const float t = (x - x0) / hh, t2 = t * t, t3 = t2 * t;
-                const float h00 = 2.0f * t3 - 3.0f * t2 + 1.0f, h10 = t3 - 2.0f * t2 + t;
-                const float h01 = -2.0f * t3 + 3.0f * t2, h11 = t3 - t2;
-                val = h00 * y0 + h10 * hh * m[seg] + h01 * y1 + h11 * hh * m[seg + 1];
-            }
+            uint32_t seg = 0;   // the last segment whose left knot is not right of x
+            for (uint32_t j = last; j-- > 0;) if (x >= K.x(j)) { seg = j; break; }
+            v = hermite_at(x, K.x(seg), K.x(seg + 1), K.y(seg), K.y(seg + 1), tangent[seg], tangent[seg + 1]);
         }
-        lut[i] = round_u8(val);
+        lut[i] = round_u8(v);
     }
 }
 
