@@ -190,6 +190,7 @@ int g_mfma_seg = 0; // tuning knob (pfxk_gauss_set_mfma_segments): row segments 
 // 0.243 -> 0.190; channels that differ (all by 1): uniform noise 4.9e-5 -> 3.6e-4, photograph-like ramps + noise 5.0e-5 -> 4.8e-5, smooth ramps
 // 1e-7 -> 8e-9.  One piece for both (pfx_tune "gauss_parts" = 11) runs sigma 16 in 0.114 ms but rounds the horizontal result to 11 bits — 0.125 LSB
 // steps at the bright end: 2 % of a smooth ramp's channels come out one off; kept as a measured variant, not shipped.
+int g_mfma_cols64 = 1;   // pfxk_gauss_set_mfma_cols64 (pfx_tune "gauss_cols64"): 8-K-block launches on the 64-column kernel (1) or the 32-column one (0); identical results
 std::atomic<int> g_mfma_wp{1}, g_mfma_hp{2};   // process-wide development knobs read by batch workers' threads
 
 template <bool EXACT>
@@ -641,6 +642,250 @@ __global__ __launch_bounds__(512, 2 * gs_wg_per_cu<CHAIN>(NKB, WP)) void gauss_s
     }
 }
 
+
+// ---- 64-column strips (round 6) -----------------------------------------------------------------------------------------------------------
+// The same walk with a workgroup owning 64 columns: four producer waves + EIGHT consumer waves (768 threads, one workgroup per CU).  A producer row's window is
+// 16 (NKB + 2) samples for 64 outputs instead of 2 x 16 NKB for two 32-column strips: the fetch, de-interleave and fragment work per output column drops by
+// (NKB + 2) / (2 NKB) (10 / 16 at sigma 16) while the MFMA count per column stays what it was — the second 32-column block of the strip multiplies the SAME A fragments,
+// two K blocks further on, with the SAME Toeplitz fragments (B for block 1 at K block kb is block 0's at kb - 2: 32 columns are two K blocks).  Every output column
+// therefore sees the grouping of its taps into K blocks and their accumulation order that the 32-column kernel gives it: results are bit-identical to
+// gauss_strip_kernel<true, NKB, false, 1, 2> (tests/test_gpu_parity.py compares the two), band identity included.  Consumers are the 32-column kernel's, eight of them.
+#ifndef PFX_G6_BREG
+#define PFX_G6_BREG 1  // the consumers keep their Toeplitz fragments in registers (0: read from LDS in front of every MFMA, like the producers): -1.5 .. -3 % (profiles/r06_tuning.md)
+#endif
+#ifndef PFX_G6_GSD
+#define PFX_G6_GSD 2   // source steps in flight per producer lane (development A/B: 3)
+#endif
+constexpr int G6_COLS = 64, G6_OUT_PITCH = 68, G6_T = 768;
+constexpr int g6_xrow(int nkp) { return 16 * nkp + 16; }
+inline size_t gauss_strip64_lds_bytes(int nkb)
+{
+    return (size_t)4 * 2 * (G6_COLS * 72 + 32) * 2 + (size_t)2 * 32 * G6_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * g6_xrow(nkb + 2) + (size_t)nkb * 64 * 16;
+}
+template <int NKB>
+__global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint16_t* __restrict__ wsplit, int w, int h,
+                                                             int r, int R8, float inv_scale2, float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg)
+{
+    static_assert(NKB == 8, "a producer lane fetches 16 + 4 pixels of a 160-pixel window row");
+    constexpr int NKP = NKB + 2, GS_XROW = g6_xrow(NKP);
+    constexpr int RING = 64, YP = RING + 8, PLANE = G6_COLS * YP + 32, HALF = NKB / 2, GSD = PFX_G6_GSD;
+    extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
+    constexpr size_t RING_BYTES = (size_t)4 * 2 * PLANE * 2;
+    _Float16* HR = reinterpret_cast<_Float16*>(gm_lds);                                          // [part][c][x][YP]
+    uint32_t* OUT = reinterpret_cast<uint32_t*>(gm_lds + RING_BYTES);                             // [2][32][G6_OUT_PITCH]
+    uint8_t* XP = gm_lds + RING_BYTES + (size_t)2 * 32 * G6_OUT_PITCH * 4;                        // [producer wave][c][row][GS_XROW]
+    pfx_f16x8* const BL = reinterpret_cast<pfx_f16x8*>(XP + (size_t)4 * 4 * 8 * GS_XROW);         // Toeplitz fragments, one per K block and lane
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hh = lane >> 5;
+    const bool producer = wave < 4;
+    if (wave == 0) {
+        const _Float16* w1 = reinterpret_cast<const _Float16*>(wsplit) + GM_WOFF + 2 * GM_WLEN;   // the one-piece table
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int t0 = 16 * kb + 8 * hh - i - (R8 - r);
+            pfx_f16x8 b1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b1[j] = w1[t0 + j];
+            BL[kb * 64 + lane] = b1;
+        }
+    }
+    __syncthreads();
+    auto B1 = [&](int kb) -> pfx_f16x8 { return BL[kb * 64 + lane]; };
+    const int bid = (int)xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ci = bid % n_cols, seg = bid / n_cols;
+    const int x0 = ci * G6_COLS;
+    const int t_first = seg * steps_per_seg, t_last = min(t_first + steps_per_seg, n_steps);
+    if (t_first >= t_last) return;
+    const int nst = t_last - t_first;
+    const int a0 = 32 * t_first - y_phase - R8;
+    const int n_hsteps = nst + HALF - 1;
+    const int last = nst + HALF + 1, n_iter = ((last + GSD) / GSD) * GSD;
+
+    if (producer) {
+        auto walk = [&](auto borderc) {
+            constexpr bool BORDER = decltype(borderc)::value;
+            // fetch role of a lane: row lane >> 3 of the wave's 8; pixels [16 fs, 16 fs + 16) of the 160-pixel window and the quad [128 + 4 fs, +4)
+            const int frow = lane >> 3, fs = lane & 7;
+            const int fx = x0 - R8;
+            auto piece_x = [&](int q) { return q < 4 ? fx + 16 * fs + 4 * q : fx + 128 + 4 * fs; };
+            uint32_t raw[GSD][20];
+            auto fetch = [&](auto bufc, int hs_req) {
+                constexpr int BUF = decltype(bufc)::value;
+                const int hs = min(hs_req, n_hsteps - 1);
+                const int ysrc = min(max(a0 + 32 * hs + 8 * wave + frow, 0), h - 1);
+                const uint32_t* line = reinterpret_cast<const uint32_t*>(src) + (size_t)ysrc * w;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const int xp = piece_x(q), xc = BORDER ? min(max(xp, 0), w - 4) : xp;
+                    const uint4 v = *reinterpret_cast<const uint4*>(line + xc);
+                    raw[BUF][4 * q] = v.x; raw[BUF][4 * q + 1] = v.y; raw[BUF][4 * q + 2] = v.z; raw[BUF][4 * q + 3] = v.w;
+                }
+            };
+            uint8_t* xp_w = XP + (size_t)wave * 4 * 8 * GS_XROW;
+            pfx_f32x16 acc[2], neg_bias;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { neg_bias[q] = -bias_c; acc[0][q] = 0.0f; acc[1][q] = 0.0f; }
+            auto produce = [&](auto bufc, int it) {
+                constexpr int BUF = decltype(bufc)::value;
+                if (it >= 1 && it - 1 < n_hsteps) {   // (0) split and store the 32 rows x 64 columns whose MFMAs were issued before the last barrier
+                    const int ro = (32 * (it - 1)) % RING + 8 * wave + 4 * hh;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            pfx_f16x4 h1, h2;
+#pragma unroll
+                            for (int e = 0; e < 4; e += 2) {
+                                const float va = acc[nb][4 * g + e], vb = acc[nb][4 * g + e + 1];
+                                const pfx_f16x2 hi = pkrtz(va, vb);
+                                const pfx_f16x2 lo = pkrtz(va - (float)hi[0], vb - (float)hi[1]);
+                                h1[e] = hi[0]; h1[e + 1] = hi[1]; h2[e] = lo[0]; h2[e + 1] = lo[1];
+                            }
+                            *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(0 * 4 + g) * PLANE + (32 * nb + i) * YP + ro) = h1;
+                            *reinterpret_cast<pfx_f16x4*>(HR + (size_t)(1 * 4 + g) * PLANE + (32 * nb + i) * YP + ro) = h2;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // (1) de-interleave: a lane's 16 + 4 samples of a channel leave as one 16-byte and one 4-byte store
+                    uint32_t pl[4][5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        uint32_t p0 = raw[BUF][4 * q], p1 = raw[BUF][4 * q + 1], p2 = raw[BUF][4 * q + 2], p3 = raw[BUF][4 * q + 3];
+                        if constexpr (BORDER) {
+                            const int xp = piece_x(q);
+                            const uint32_t e = xp < 0 ? p0 : p3;
+                            const bool out = xp < 0 || xp >= w;
+                            p0 = out ? e : p0; p1 = out ? e : p1; p2 = out ? e : p2; p3 = out ? e : p3;
+                        }
+                        const uint32_t lo01 = __builtin_amdgcn_perm(p1, p0, 0x05010400u), hi01 = __builtin_amdgcn_perm(p1, p0, 0x07030602u);
+                        const uint32_t lo23 = __builtin_amdgcn_perm(p3, p2, 0x05010400u), hi23 = __builtin_amdgcn_perm(p3, p2, 0x07030602u);
+                        pl[0][q] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+                        pl[1][q] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+                        pl[2][q] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+                        pl[3][q] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint8_t* d = xp_w + c * 8 * GS_XROW + frow * GS_XROW;
+                        *reinterpret_cast<uint4*>(d + 16 * fs) = make_uint4(pl[c][0], pl[c][1], pl[c][2], pl[c][3]);
+                        *reinterpret_cast<uint32_t*>(d + 128 + 4 * fs) = pl[c][4];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(std::integral_constant<int, BUF>{}, it + GSD);
+                __builtin_amdgcn_sched_barrier(0);
+                pfx_f16x8 fr[NKP];   // (2) A fragments of the 160-sample window: row m = channel * 8 + row, K slot (hh, kb) = samples [16 kb + 8 hh, +8)
+                {
+                    const uint8_t* mine = xp_w + (size_t)(i >> 3) * 8 * GS_XROW + (i & 7) * GS_XROW + 8 * hh;
+#pragma unroll
+                    for (int kb = 0; kb < NKP; ++kb) {
+                        const uint2 d = *reinterpret_cast<const uint2*>(mine + 16 * kb);
+                        uint32_t qa[4];
+                        qa[0] = __builtin_amdgcn_perm(d.x, 0x64646464u, 0x00050004u); qa[1] = __builtin_amdgcn_perm(d.x, 0x64646464u, 0x00070006u);
+                        qa[2] = __builtin_amdgcn_perm(d.y, 0x64646464u, 0x00050004u); qa[3] = __builtin_amdgcn_perm(d.y, 0x64646464u, 0x00070006u);
+                        fr[kb] = __builtin_bit_cast(pfx_f16x8, qa);
+                    }
+                }
+                if (it < n_hsteps) {   // (3) column block nb multiplies window K blocks 2 nb .. 2 nb + NKB - 1 with Toeplitz fragments 0 .. NKB - 1: two independent chains
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        const pfx_f16x8 b = B1(kb);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb], b, kb ? acc[0] : neg_bias, 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[kb + 2], b, kb ? acc[1] : neg_bias, 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            };
+            fetch(std::integral_constant<int, 0>{}, 0);
+            fetch(std::integral_constant<int, 1>{}, 1);
+            if constexpr (GSD > 2) fetch(std::integral_constant<int, 2 % GSD>{}, 2);
+            for (int it = 0; it < n_iter; it += GSD) {
+                produce(std::integral_constant<int, 0>{}, it);
+                produce(std::integral_constant<int, 1>{}, it + 1);
+                if constexpr (GSD > 2) produce(std::integral_constant<int, 2 % GSD>{}, it + 2);
+            }
+        };
+        const bool interior = __builtin_amdgcn_readfirstlane((x0 - R8 >= 0 && x0 - R8 + 16 * NKP <= w) ? 1 : 0) != 0;
+        if (interior) walk(std::false_type{}); else walk(std::true_type{});
+    } else {
+        // the 32-column kernel's consumer, eight waves of it: wave 4 + xb owns columns [8 xb, 8 xb + 8) of the strip
+        constexpr int EARLY = NKB - 2;
+        const int xb = wave - 4, xl = i >> 2, c = i & 3;
+        const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
+        const _Float16* a2p = HR + (size_t)(1 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
+        const int st_t = tid - 256, st_rr = st_t >> 4, st_cg = 4 * (st_t & 15);
+        pfx_f16x8 f1[NKB], f2[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) { f1[kb] = pfx_f16x8{}; f2[kb] = pfx_f16x8{}; }
+#if PFX_G6_BREG
+        pfx_f16x8 Bc[NKB];   // the consumers' Toeplitz fragments in registers (three waves per SIMD leave 168): 16 LDS reads fewer per iteration and wave
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) { Bc[kb] = BL[kb * 64 + lane]; asm volatile("" : "+v"(Bc[kb])); }
+        auto BC = [&](int kb) -> pfx_f16x8 { return Bc[kb]; };
+#else
+        auto BC = [&](int kb) -> pfx_f16x8 { return B1(kb); };
+#endif
+        auto consume = [&](auto phasec, int it) {
+            constexpr int PH = decltype(phasec)::value;
+            const int v = it - HALF - 1, vp = v - 1;
+            const bool active = v >= 0 && v < nst;
+            const int st_y = 32 * (t_first + vp) - y_phase + st_rr;
+            const bool do_store = vp >= 0 && vp < nst && st_y >= 0 && st_y < h && x0 + st_cg < w;
+            const uint4 ov = *reinterpret_cast<const uint4*>(OUT + (vp & 1) * 32 * G6_OUT_PITCH + st_rr * G6_OUT_PITCH + st_cg);
+#pragma unroll
+            for (int kb = EARLY; kb < NKB; ++kb) {
+                const int ro = 32 * (it & 1) + 16 * (kb - EARLY);
+                const int slot = (2 * PH + kb) % NKB;
+                f1[slot] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
+                f2[slot] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pfx_f32x16 accA, accX;
+            if (active) {
+#pragma unroll
+                for (int kb = 0; kb < EARLY; ++kb) {
+                    const int slot = (2 * PH + kb) % NKB;
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], BC(kb), kb ? accA : pfx_f32x16{}, 0, 0, 0);
+                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[slot], BC(kb), kb ? accX : pfx_f32x16{}, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (do_store) *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(dst) + (size_t)st_y * w + x0 + st_cg) = ov;
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) {
+#pragma unroll
+                for (int kb = EARLY; kb < NKB; ++kb) {
+                    const int slot = (2 * PH + kb) % NKB;
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[slot], BC(kb), accA, 0, 0, 0);
+                    accX = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[slot], BC(kb), accX, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                uint32_t* orow = OUT + (v & 1) * 32 * G6_OUT_PITCH + i * G6_OUT_PITCH + 8 * xb + hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t px = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) px = __builtin_amdgcn_cvt_pk_u8_f32((accA[4 * g + e] + accX[4 * g + e]) * inv_scale2, e, px);
+                    orow[2 * g] = px;
+                }
+            }
+            __syncthreads();
+        };
+        auto phase_call = [&](auto qc, int it) {
+            constexpr int Q = decltype(qc)::value;
+            if (it < n_iter) consume(std::integral_constant<int, (Q + HALF - 1) % HALF>{}, it);
+        };
+        for (int it = 0; it < n_iter; it += HALF) {
+            phase_call(std::integral_constant<int, 0>{}, it);
+            phase_call(std::integral_constant<int, 1>{}, it + 1);
+            phase_call(std::integral_constant<int, 2>{}, it + 2);
+            phase_call(std::integral_constant<int, 3>{}, it + 3);
+        }
+    }
+}
+
 } // namespace
 
 // LDS bounds: H tile (1024 + 2r + 12) x 20 B and the narrowest V tile (256 + 2r + 4) rows x 5 x 16 B <= 160 KiB
@@ -648,6 +893,7 @@ extern "C" int pfxk_gauss_max_radius(void) { return 850; }
 extern "C" void pfxk_gauss_set_v_config(int cfg) { g_v_cfg = cfg; }
 extern "C" void pfxk_gauss_set_mfma_segments(int n) { g_mfma_seg = n > 0 && n < 256 ? n : 0; }
 extern "C" void pfxk_gauss_set_mfma_parts(int wp, int hp) { g_mfma_wp = wp == 1 ? 1 : 2; g_mfma_hp = (hp == 1 && wp == 1) ? 1 : 2; }
+extern "C" void pfxk_gauss_set_mfma_cols64(int on) { g_mfma_cols64 = on != 0; }
 extern "C" void pfxk_gauss_set_dbg_buf(unsigned long long* p) { g_dbg_buf = p; }
 extern "C" int pfxk_gauss_weight_pad(void) { return W_PAD; }
 
@@ -730,6 +976,21 @@ static hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_src, ui
         else if (wp == 1) go(gauss_strip_kernel<false, NK, false, 1, 2>); // unaligned buffers / widths: the same tables and bias as the fast instantiation
         else go(gauss_strip_kernel<false, NK, false>);
     };
+    if (g_mfma_cols64 && nkb == 8 && fast && wp == 1 && hp == 2 && !chain && !(g_v_cfg >> 9)) {
+        // 64-column strips (sigma 10.7 .. 16): one workgroup of twelve waves per CU; bit-identical to the 32-column kernel
+        const int tiles64 = ((int)w + G6_COLS - 1) / G6_COLS;
+        const size_t lds = gauss_strip64_lds_bytes(8);
+        int n_seg = std::max(1, n_cus / tiles64);
+        if (g_mfma_seg > 0) n_seg = g_mfma_seg;
+        int per = (n_steps + n_seg - 1) / n_seg;
+        if (per < 4) per = n_steps < 4 ? n_steps : 4;
+        n_seg = (n_steps + per - 1) / per;
+        static lds_grant grant;
+        hipError_t e = grant_lds(grant, (const void*)gauss_strip64_kernel<8>, lds);
+        if (e) return e;
+        gauss_strip64_kernel<8><<<tiles64 * n_seg, G6_T, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles64, y_ph, n_steps, per);
+        return hipGetLastError();
+    }
     switch (nkb) {
     case 4: launch_s(std::integral_constant<int, 4>{}); break;
     case 6: launch_s(std::integral_constant<int, 6>{}); break;

@@ -1095,3 +1095,27 @@ def test_exact_gaussian_fused_small_radii(gpu, oracle, sigma, size):
         gpu.r.set_exact(False)
     assert np.array_equal(fused, two), f"sigma {sigma} {size}: fused differs from the two kernels on {int((fused != two).any(-1).sum())} px"
     assert_same(fused, ref, 0, f"exact gaussian sigma {sigma} {size}")
+
+
+def test_mfma_gaussian_64_column_strips_are_bit_identical_to_32_column_strips(gpu):
+    """round 6: sigma 10.7 .. 16 (8 K blocks) run a workgroup of twelve waves on 64-column strips; every output column keeps the K-block grouping and accumulation
+    order of the 32-column kernel, so the two must agree bit for bit — whole images, ragged widths (strips that leave the image), bands (first_row)"""
+    r = gpu.r
+    for (w, h) in [(256, 96), (1024, 300), (196, 70), (64, 33), (2052, 180), (388, 515)]:
+        img = I.random_rgba(w, h, seed=w + 3 * h)
+        a, b, c = (r.dev_alloc(img.nbytes) for _ in range(3))
+        try:
+            r.dev_upload(a, img)
+            for sigma in (11.0, 13.7, 16.0):
+                for first_row in (0, 17, 64):
+                    r.tune("gauss_cols64", 1)
+                    r.gaussian_blur_dev(a, b, w, h, sigma, first_row=first_row)
+                    r.tune("gauss_cols64", 0)
+                    r.gaussian_blur_dev(a, c, w, h, sigma, first_row=first_row)
+                    r.synchronize()
+                    x, y = r.dev_download(b, img.shape), r.dev_download(c, img.shape)
+                    assert np.array_equal(x, y), (w, h, sigma, first_row, int((x != y).sum()))
+        finally:
+            r.tune("gauss_cols64", 1)
+            for p in (a, b, c):
+                r.dev_free(p)

@@ -16,7 +16,7 @@ ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 r = GpuRenderer(0)
 t_end = time.time() + a.seconds
-counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0, "sharpen_glow": 0, "median": 0, "brush": 0}
+counts = {"stacks": 0, "gauss": 0, "warps": 0, "mesh": 0, "box": 0, "sharpen_glow": 0, "median": 0, "brush": 0, "chains": 0}
 case = a.seed * 1000003
 
 
@@ -41,7 +41,7 @@ def alpha_plane(rng, w, h):
 while time.time() < t_end:
     case += 1
     rng = np.random.default_rng(case)
-    what = rng.integers(0, 14)
+    what = rng.integers(0, 15)
     try:
         if what < 6:
             w, h = int(rng.integers(1, 700)), int(rng.integers(1, 120))
@@ -120,6 +120,35 @@ while time.time() < t_end:
             mask = None if rng.random() < 0.6 else ((rng.random((h, w)) < 0.5).astype(np.uint8) * 255)
             if not np.array_equal(r.box_blur_core(img, radius, mask), O.box_blur(img, radius, mask)): raise AssertionError(f"box blur {w}x{h} radius {radius} mask {mask is not None}")
             counts["box"] += 1
+        elif what == 14:   # chains (round 6): random runs of pointwise ops of both flavours, optionally behind a Gaussian / box blur, in the bit-exact Gaussian mode, as one
+            # pfx_chain_dev call against the oracle op by op (fused stores of both Gaussians with light and — on request — heavy ops, long runs cut into launches, tables)
+            w, h = int(rng.integers(1, 500)), int(rng.integers(1, 260))
+            img = I.random_rgba(w, h, case)
+            PW = [("adjust", "hsl", (float(rng.uniform(-180, 180)), float(rng.uniform(-100, 100)), float(rng.uniform(-50, 50)))), ("adjust", "invert"),
+                  ("adjust", "brightness_contrast", (float(rng.uniform(-60, 60)), float(rng.uniform(-60, 60)))), ("adjust", "exposure", (float(rng.uniform(-2, 2)),)),
+                  ("adjust", "vibrance", (float(rng.uniform(-100, 100)),)), ("adjust", "sepia"), ("adjust", "posterize", (float(rng.integers(2, 9)),)),
+                  ("adjust", "threshold", (float(rng.uniform(0, 255)),)), ("adjust", "desaturate"), ("adjust", "invert_alpha"),
+                  ("adjust", "lut_rgba", (), rng.integers(0, 256, 1024, dtype=np.uint8)), ("adjust", "gradient_map", (), rng.integers(0, 256, 1024, dtype=np.uint8)),
+                  ("rhai", "invert"), ("rhai", "sepia_strength", (float(rng.random()),)), ("rhai", "brightness_contrast", (float(rng.uniform(-40, 40)), float(rng.uniform(-40, 40)))),
+                  ("rhai", "hsl", (float(rng.uniform(-90, 90)), float(rng.uniform(-50, 50)), float(rng.uniform(-20, 20)))), ("rhai", "exposure", (float(rng.uniform(-1, 1)),)),
+                  ("rhai", "levels", (float(rng.uniform(0, 60)), float(rng.uniform(180, 255)), float(rng.uniform(0.5, 2.0))))]
+            ops = []
+            if rng.random() < 0.6: ops.append(("gaussian", float(rng.choice([0.4, 1.0, 2.5, 4.0, 5.33, 7.0, 12.0, 16.0]))) if rng.random() < 0.75 else ("box", float(rng.choice([0.3, 1.0, 3.0, 9.0]))))
+            for _ in range(int(rng.integers(0, 11))): ops.append(PW[int(rng.integers(0, len(PW)))])
+            if rng.random() < 0.2 and ops: ops.insert(int(rng.integers(0, len(ops) + 1)), ("box", 2.0))
+            ref = img
+            for o in ops:
+                ref = O.gaussian_blur(ref, o[1]) if o[0] == "gaussian" else O.box_blur(ref, o[1]) if o[0] == "box" else \
+                    O.adjust(ref, o[1], o[2] if len(o) > 2 else (), lut=o[3] if len(o) > 3 else None) if o[0] == "adjust" else O.rhai_adjust(ref, o[1], o[2] if len(o) > 2 else ())
+            da, db = r.dev_alloc(img.nbytes), r.dev_alloc(img.nbytes)
+            r.set_exact(True); r.tune("chain_fuse_heavy", int(rng.random() < 0.5))
+            try:
+                r.dev_upload(da, img); r.chain_dev(da, db, w, h, ops); r.synchronize()
+                got = r.dev_download(db, img.shape)
+            finally:
+                r.set_exact(False); r.tune("chain_fuse_heavy", 0); r.dev_free(da); r.dev_free(db)
+            if not np.array_equal(got, ref): raise AssertionError(f"chain {w}x{h}: {[o[:2] for o in ops]}")
+            counts["chains"] += 1
         elif what == 8:
             w, h = int(rng.integers(1, 600)), int(rng.integers(1, 200))
             sw, sh = (w, h) if rng.random() < 0.6 else (int(rng.integers(1, 600)), int(rng.integers(1, 200)))
