@@ -190,7 +190,7 @@ int g_mfma_seg = 0; // tuning knob (pfxk_gauss_set_mfma_segments): row segments 
 // 0.243 -> 0.190; channels that differ (all by 1): uniform noise 4.9e-5 -> 3.6e-4, photograph-like ramps + noise 5.0e-5 -> 4.8e-5, smooth ramps
 // 1e-7 -> 8e-9.  One piece for both (pfx_tune "gauss_parts" = 11) runs sigma 16 in 0.114 ms but rounds the horizontal result to 11 bits — 0.125 LSB
 // steps at the bright end: 2 % of a smooth ramp's channels come out one off; kept as a measured variant, not shipped.
-int g_mfma_cols64 = 1;   // pfxk_gauss_set_mfma_cols64 (pfx_tune "gauss_cols64"): 8-K-block launches on the 64-column kernel (1) or the 32-column one (0); identical results
+int g_mfma_cols64 = 6;   // 6 and 8 K blocks (sigma 5.4 .. 16) ship on it: 8K sigma 8 0.094 -> 0.090, sigma 16 0.122 -> 0.111; 4 K blocks measure equal (0.075) and stay on two 32-column workgroups per CU.  pfxk_gauss_set_mfma_cols64 (pfx_tune "gauss_cols64"): bit 0 / 1 / 2 = launches with 4 / 6 / 8 K blocks on the 64-column kernel (else the 32-column one); identical results
 std::atomic<int> g_mfma_wp{1}, g_mfma_hp{2};   // process-wide development knobs read by batch workers' threads
 
 template <bool EXACT>
@@ -666,8 +666,9 @@ template <int NKB>
 __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint16_t* __restrict__ wsplit, int w, int h,
                                                              int r, int R8, float inv_scale2, float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg)
 {
-    static_assert(NKB == 8, "a producer lane fetches 16 + 4 pixels of a 160-pixel window row");
+    static_assert(NKB == 4 || NKB == 6 || NKB == 8, "a producer lane fetches 16 pixels of the window row (+ 4 of the last 32 when the window has 160)");
     constexpr int NKP = NKB + 2, GS_XROW = g6_xrow(NKP);
+    constexpr int QN = NKP == 10 ? 5 : 4;   // 16-byte pieces a producer lane fetches per row: 8 lanes x 16 pixels cover 128; a 160-pixel window adds one quad per lane, a 96-pixel one idles two lanes
     constexpr int RING = 64, YP = RING + 8, PLANE = G6_COLS * YP + 32, HALF = NKB / 2, GSD = PFX_G6_GSD;
     extern __shared__ __attribute__((aligned(16))) uint8_t gm_lds[];
     constexpr size_t RING_BYTES = (size_t)4 * 2 * PLANE * 2;
@@ -709,15 +710,16 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const uint8_t* __re
             const int frow = lane >> 3, fs = lane & 7;
             const int fx = x0 - R8;
             auto piece_x = [&](int q) { return q < 4 ? fx + 16 * fs + 4 * q : fx + 128 + 4 * fs; };
-            uint32_t raw[GSD][20];
+            uint32_t raw[GSD][4 * QN];
+            const bool in_window = 16 * fs < 16 * NKP;   // NKB = 4: lanes 6 and 7 of a row fetch pixels beyond the 96-pixel window (loaded from clamped addresses, never stored)
             auto fetch = [&](auto bufc, int hs_req) {
                 constexpr int BUF = decltype(bufc)::value;
                 const int hs = min(hs_req, n_hsteps - 1);
                 const int ysrc = min(max(a0 + 32 * hs + 8 * wave + frow, 0), h - 1);
                 const uint32_t* line = reinterpret_cast<const uint32_t*>(src) + (size_t)ysrc * w;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    const int xp = piece_x(q), xc = BORDER ? min(max(xp, 0), w - 4) : xp;
+                for (int q = 0; q < QN; ++q) {
+                    const int xp = piece_x(q), xc = (BORDER || NKP < 8) ? min(max(xp, 0), w - 4) : xp;
                     const uint4 v = *reinterpret_cast<const uint4*>(line + xc);
                     raw[BUF][4 * q] = v.x; raw[BUF][4 * q + 1] = v.y; raw[BUF][4 * q + 2] = v.z; raw[BUF][4 * q + 3] = v.w;
                 }
@@ -749,9 +751,9 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const uint8_t* __re
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 {   // (1) de-interleave: a lane's 16 + 4 samples of a channel leave as one 16-byte and one 4-byte store
-                    uint32_t pl[4][5];
+                    uint32_t pl[4][QN];
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) {
+                    for (int q = 0; q < QN; ++q) {
                         uint32_t p0 = raw[BUF][4 * q], p1 = raw[BUF][4 * q + 1], p2 = raw[BUF][4 * q + 2], p3 = raw[BUF][4 * q + 3];
                         if constexpr (BORDER) {
                             const int xp = piece_x(q);
@@ -769,8 +771,8 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const uint8_t* __re
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         uint8_t* d = xp_w + c * 8 * GS_XROW + frow * GS_XROW;
-                        *reinterpret_cast<uint4*>(d + 16 * fs) = make_uint4(pl[c][0], pl[c][1], pl[c][2], pl[c][3]);
-                        *reinterpret_cast<uint32_t*>(d + 128 + 4 * fs) = pl[c][4];
+                        if (NKP >= 8 || in_window) *reinterpret_cast<uint4*>(d + 16 * fs) = make_uint4(pl[c][0], pl[c][1], pl[c][2], pl[c][3]);
+                        if constexpr (QN == 5) *reinterpret_cast<uint32_t*>(d + 128 + 4 * fs) = pl[c][4];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -880,8 +882,8 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const uint8_t* __re
         for (int it = 0; it < n_iter; it += HALF) {
             phase_call(std::integral_constant<int, 0>{}, it);
             phase_call(std::integral_constant<int, 1>{}, it + 1);
-            phase_call(std::integral_constant<int, 2>{}, it + 2);
-            phase_call(std::integral_constant<int, 3>{}, it + 3);
+            if constexpr (HALF > 2) phase_call(std::integral_constant<int, 2 % HALF>{}, it + 2);
+            if constexpr (HALF > 3) phase_call(std::integral_constant<int, 3 % HALF>{}, it + 3);
         }
     }
 }
@@ -893,7 +895,7 @@ extern "C" int pfxk_gauss_max_radius(void) { return 850; }
 extern "C" void pfxk_gauss_set_v_config(int cfg) { g_v_cfg = cfg; }
 extern "C" void pfxk_gauss_set_mfma_segments(int n) { g_mfma_seg = n > 0 && n < 256 ? n : 0; }
 extern "C" void pfxk_gauss_set_mfma_parts(int wp, int hp) { g_mfma_wp = wp == 1 ? 1 : 2; g_mfma_hp = (hp == 1 && wp == 1) ? 1 : 2; }
-extern "C" void pfxk_gauss_set_mfma_cols64(int on) { g_mfma_cols64 = on != 0; }
+extern "C" void pfxk_gauss_set_mfma_cols64(int mask) { g_mfma_cols64 = mask & 7; }
 extern "C" void pfxk_gauss_set_dbg_buf(unsigned long long* p) { g_dbg_buf = p; }
 extern "C" int pfxk_gauss_weight_pad(void) { return W_PAD; }
 
@@ -976,20 +978,24 @@ static hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_src, ui
         else if (wp == 1) go(gauss_strip_kernel<false, NK, false, 1, 2>); // unaligned buffers / widths: the same tables and bias as the fast instantiation
         else go(gauss_strip_kernel<false, NK, false>);
     };
-    if (g_mfma_cols64 && nkb == 8 && fast && wp == 1 && hp == 2 && !chain && !(g_v_cfg >> 9)) {
-        // 64-column strips (sigma 10.7 .. 16): one workgroup of twelve waves per CU; bit-identical to the 32-column kernel
+    if (nkb <= 8 && fast && wp == 1 && hp == 2 && !chain && !(g_v_cfg >> 9) && ((g_mfma_cols64 >> (nkb / 2 - 2)) & 1)) {
+        // 64-column strips (up to 8 K blocks, sigma <= 16): one workgroup of twelve waves per CU; bit-identical to the 32-column kernel
         const int tiles64 = ((int)w + G6_COLS - 1) / G6_COLS;
-        const size_t lds = gauss_strip64_lds_bytes(8);
+        const size_t lds = gauss_strip64_lds_bytes(nkb);
         int n_seg = std::max(1, n_cus / tiles64);
         if (g_mfma_seg > 0) n_seg = g_mfma_seg;
         int per = (n_steps + n_seg - 1) / n_seg;
         if (per < 4) per = n_steps < 4 ? n_steps : 4;
         n_seg = (n_steps + per - 1) / per;
-        static lds_grant grant;
-        hipError_t e = grant_lds(grant, (const void*)gauss_strip64_kernel<8>, lds);
-        if (e) return e;
-        gauss_strip64_kernel<8><<<tiles64 * n_seg, G6_T, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles64, y_ph, n_steps, per);
-        return hipGetLastError();
+        auto go64 = [&](auto nkc) -> hipError_t {
+            constexpr int NK = decltype(nkc)::value;
+            static lds_grant grant;
+            hipError_t e = grant_lds(grant, (const void*)gauss_strip64_kernel<NK>, lds);
+            if (e) return e;
+            gauss_strip64_kernel<NK><<<tiles64 * n_seg, G6_T, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles64, y_ph, n_steps, per);
+            return hipGetLastError();
+        };
+        return nkb == 8 ? go64(std::integral_constant<int, 8>{}) : nkb == 6 ? go64(std::integral_constant<int, 6>{}) : go64(std::integral_constant<int, 4>{});
     }
     switch (nkb) {
     case 4: launch_s(std::integral_constant<int, 4>{}); break;

@@ -99,7 +99,7 @@ hipError_t pfxk_gauss_mfma(hipStream_t stream, const uint8_t* d_src, uint8_t* d_
                            int radius, float inv_scale2, float bias_c, float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus);
 hipError_t pfxk_gauss_mfma_chain(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const uint16_t* d_wsplit, int radius, float inv_scale2, float bias_c,
                                  float bias_single, uint32_t w, uint32_t h, uint32_t first_row, int n_cus, const struct pfxk_chain* chain);
-void       pfxk_gauss_set_mfma_cols64(int on); // 1 (default): 8-K-block launches (sigma 10.7 .. 16) on 64-column strips; 0: 32-column strips (bit-identical results)
+void       pfxk_gauss_set_mfma_cols64(int mask); // bit 0 / 1 / 2: launches with 4 / 6 / 8 K blocks (sigma <= 5.3 / 10.6 / 16) on 64-column strips instead of 32-column ones (bit-identical results)
 void       pfxk_gauss_set_mfma_parts(int weight_parts, int h_parts); // f16 pieces per weight (2 or 1) / per horizontal result (2, or 1 with single weights)
 hipError_t pfxk_gauss_v(hipStream_t stream, const float* d_tmp, uint8_t* d_dst, const float* d_wts_tap0, int radius,
                         uint32_t w, uint32_t h, int exact);

@@ -1098,17 +1098,18 @@ def test_exact_gaussian_fused_small_radii(gpu, oracle, sigma, size):
 
 
 def test_mfma_gaussian_64_column_strips_are_bit_identical_to_32_column_strips(gpu):
-    """round 6: sigma 10.7 .. 16 (8 K blocks) run a workgroup of twelve waves on 64-column strips; every output column keeps the K-block grouping and accumulation
-    order of the 32-column kernel, so the two must agree bit for bit — whole images, ragged widths (strips that leave the image), bands (first_row)"""
+    """round 6: up to 8 K blocks (sigma <= 16) the matrix-core Gaussian can run a workgroup of twelve waves on 64-column strips; every output column keeps the K-block
+    grouping and accumulation order of the 32-column kernel, so the two must agree bit for bit — whole images, ragged widths (strips that leave the image), bands
+    (first_row), all three K-block counts (pfx_tune "gauss_cols64": bit 0 / 1 / 2 = 4 / 6 / 8 K blocks on the 64-column kernel; 6 and 8 K blocks ship on it)"""
     r = gpu.r
     for (w, h) in [(256, 96), (1024, 300), (196, 70), (64, 33), (2052, 180), (388, 515)]:
         img = I.random_rgba(w, h, seed=w + 3 * h)
         a, b, c = (r.dev_alloc(img.nbytes) for _ in range(3))
         try:
             r.dev_upload(a, img)
-            for sigma in (11.0, 13.7, 16.0):
+            for sigma in (1.5, 4.0, 5.3, 6.0, 9.0, 10.5, 11.0, 13.7, 16.0):
                 for first_row in (0, 17, 64):
-                    r.tune("gauss_cols64", 1)
+                    r.tune("gauss_cols64", 7)
                     r.gaussian_blur_dev(a, b, w, h, sigma, first_row=first_row)
                     r.tune("gauss_cols64", 0)
                     r.gaussian_blur_dev(a, c, w, h, sigma, first_row=first_row)
@@ -1116,6 +1117,6 @@ def test_mfma_gaussian_64_column_strips_are_bit_identical_to_32_column_strips(gp
                     x, y = r.dev_download(b, img.shape), r.dev_download(c, img.shape)
                     assert np.array_equal(x, y), (w, h, sigma, first_row, int((x != y).sum()))
         finally:
-            r.tune("gauss_cols64", 1)
+            r.tune("gauss_cols64", 6)
             for p in (a, b, c):
                 r.dev_free(p)

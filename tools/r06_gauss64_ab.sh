@@ -20,8 +20,8 @@ src = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda"); dst = 
 for _ in range(300): r.gaussian_blur_dev(src.data_ptr(), dst.data_ptr(), w, h, 16.0)
 torch.cuda.synchronize()
 lib = os.path.basename(os.environ.get("PFX_LIB_PATH", "libpfx.so"))
-for sigma in (11.0, 13.7, 16.0):
-    for cols in (0, 1):
+for sigma in (2.0, 4.0, 5.3, 6.0, 8.0, 10.0, 16.0):
+    for cols in (0, 7):
         r.tune("gauss_cols64", cols)
         for _ in range(50): r.gaussian_blur_dev(src.data_ptr(), dst.data_ptr(), w, h, sigma)
         torch.cuda.synchronize(); r.timing_reset(); r.timing_enable(True)
