@@ -32,7 +32,7 @@ def name(kernel):
 
 px = W * H
 fl = next((k for k in ("flatten_srt_kernel", "flatten_dle_kernel", "flatten_stream_kernel") if k in txt), "flatten_stream_kernel")
-gs = "gauss_strip_kernel"
+gs = "gauss_strip64_kernel" if "gauss_strip64_kernel" in txt else "gauss_strip_kernel"   # round 6: sigma 5.4 .. 16 run the 64-column kernel
 cyc_f, cyc_g = val(fl, "GRBM_GUI_ACTIVE") / 8, val(gs, "GRBM_GUI_ACTIVE") / 8
 d = {
     "source": "tools/prof.sh -> tools/prof_summary.py -> tools/pmc_json.py (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group; "

@@ -8,7 +8,7 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("flatten_srt_kernel", "flatten_dle_kernel", "flatten_stream_kernel", "flatten_kernel", "gauss_strip_kernel", "gauss_planarize_kernel", "gauss_mfma_kernel", "gauss_h_kernel", "gauss_v_kernel", "pointwise_kernel", "box_", "median_kernel", "warp_", "mesh_kernel",
+OURS = ("flatten_srt_kernel", "flatten_dle_kernel", "flatten_stream_kernel", "flatten_kernel", "gauss_strip64_kernel", "gauss_strip_kernel", "gauss_fused_exact_kernel", "pointwise_chain_kernel", "gauss_planarize_kernel", "gauss_mfma_kernel", "gauss_h_kernel", "gauss_v_kernel", "pointwise_kernel", "box_", "median_kernel", "warp_", "mesh_kernel",
         "brush_kernel", "chunk_kernel")
 
 
