@@ -662,10 +662,13 @@ inline size_t gauss_strip64_lds_bytes(int nkb)
 {
     return (size_t)4 * 2 * (G6_COLS * 72 + 32) * 2 + (size_t)2 * 32 * G6_OUT_PITCH * 4 + (size_t)4 * 4 * 8 * g6_xrow(nkb + 2) + (size_t)nkb * 64 * 16;
 }
-template <int NKB>
-__global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint16_t* __restrict__ wsplit, int w, int h,
+template <int NKB, class CHAIN = gs_no_chain>
+__global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const CHAIN chain_arg /* first: read through the kernarg segment (k_pointwise.h) */, const uint8_t* __restrict__ src,
+                                                             uint8_t* __restrict__ dst, const uint16_t* __restrict__ wsplit, int w, int h,
                                                              int r, int R8, float inv_scale2, float bias_c, int n_cols, int y_phase, int n_steps, int steps_per_seg)
 {
+    const pw::chain_kptr chain = pw::chain_in_kernarg();   // meaningful in the CHAIN builds only
+    constexpr bool CH64 = !std::is_same<CHAIN, gs_no_chain>::value;
     static_assert(NKB == 4 || NKB == 6 || NKB == 8, "a producer lane fetches 16 pixels of the window row (+ 4 of the last 32 when the window has 160)");
     constexpr int NKP = NKB + 2, GS_XROW = g6_xrow(NKP);
     constexpr int QN = NKP == 10 ? 5 : 4;   // 16-byte pieces a producer lane fetches per row: 8 lanes x 16 pixels cover 128; a 160-pixel window adds one quad per lane, a 96-pixel one idles two lanes
@@ -865,13 +868,17 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const uint8_t* __re
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 uint32_t* orow = OUT + (v & 1) * 32 * G6_OUT_PITCH + i * G6_OUT_PITCH + 8 * xb + hh;
+                uint32_t px4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint32_t px = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) px = __builtin_amdgcn_cvt_pk_u8_f32((accA[4 * g + e] + accX[4 * g + e]) * inv_scale2, e, px);
-                    orow[2 * g] = px;
+                    px4[g] = px;
                 }
+                if constexpr (CH64) pw::chain_apply<4>(chain, nullptr, px4);   // a chain's light pointwise ops, between rounding and staging (pfx_chain_dev)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) orow[2 * g] = px4[g];
             }
             __syncthreads();
         };
@@ -978,7 +985,7 @@ static hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_src, ui
         else if (wp == 1) go(gauss_strip_kernel<false, NK, false, 1, 2>); // unaligned buffers / widths: the same tables and bias as the fast instantiation
         else go(gauss_strip_kernel<false, NK, false>);
     };
-    if (nkb <= 8 && fast && wp == 1 && hp == 2 && !chain && !(g_v_cfg >> 9) && ((g_mfma_cols64 >> (nkb / 2 - 2)) & 1)) {
+    if (nkb <= 8 && fast && wp == 1 && hp == 2 && !(g_v_cfg >> 9) && ((g_mfma_cols64 >> (nkb / 2 - 2)) & 1)) {
         // 64-column strips (up to 8 K blocks, sigma <= 16): one workgroup of twelve waves per CU; bit-identical to the 32-column kernel
         const int tiles64 = ((int)w + G6_COLS - 1) / G6_COLS;
         const size_t lds = gauss_strip64_lds_bytes(nkb);
@@ -989,10 +996,17 @@ static hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_src, ui
         n_seg = (n_steps + per - 1) / per;
         auto go64 = [&](auto nkc) -> hipError_t {
             constexpr int NK = decltype(nkc)::value;
-            static lds_grant grant;
+            static lds_grant grant, grant_c;
+            if (chain) {
+                hipError_t e = grant_lds(grant_c, (const void*)gauss_strip64_kernel<NK, pfxk_chain>, lds);
+                if (e) return e;
+                gauss_strip64_kernel<NK, pfxk_chain><<<tiles64 * n_seg, G6_T, lds, stream>>>(*chain, d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles64, y_ph,
+                                                                                            n_steps, per);
+                return hipGetLastError();
+            }
             hipError_t e = grant_lds(grant, (const void*)gauss_strip64_kernel<NK>, lds);
             if (e) return e;
-            gauss_strip64_kernel<NK><<<tiles64 * n_seg, G6_T, lds, stream>>>(d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles64, y_ph, n_steps, per);
+            gauss_strip64_kernel<NK><<<tiles64 * n_seg, G6_T, lds, stream>>>(gs_no_chain{}, d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles64, y_ph, n_steps, per);
             return hipGetLastError();
         };
         return nkb == 8 ? go64(std::integral_constant<int, 8>{}) : nkb == 6 ? go64(std::integral_constant<int, 6>{}) : go64(std::integral_constant<int, 4>{});

@@ -108,10 +108,12 @@ def test_heavy_ops_fused_into_the_gaussians_on_request(r):
         fused = run_chain(r, img, ops)
         r.tune("chain_fuse_heavy", 0)
         assert np.array_equal(run_chain(r, img, ops), fused)
-        light = [("gaussian", 3.0), ("adjust", "exposure", (0.4,)), ("adjust", "invert")]
-        a = run_chain(r, img, light)            # light ops: in the matrix-core Gaussian's store by default
-        r.tune("chain_mfma", 0)
-        assert np.array_equal(run_chain(r, img, light), a)
+        for sigma in (3.0, 8.0, 14.0):          # 4 K blocks (32-column strips), 6 and 8 (64-column strips): every chained build of the matrix-core Gaussian
+            light = [("gaussian", sigma), ("adjust", "exposure", (0.4,)), ("adjust", "invert")]
+            r.tune("chain_mfma", 1)
+            a = run_chain(r, img, light)        # light ops: in the matrix-core Gaussian's store by default
+            r.tune("chain_mfma", 0)
+            assert np.array_equal(run_chain(r, img, light), a), sigma
     finally:
         r.tune("chain_mfma", 1); r.tune("chain_fuse_heavy", 0); r.set_exact(False)
 
