@@ -46,6 +46,10 @@ def block_headline(b, p, names):
     L.append(f"| `value` | **{b['value']:,.0f} Mpixels/s** = {b['ms_per_step']:.4f} ms per step ({b['steps']} timed steps; HIP-event step times min / median / max "
              f"{b['step_ms_hip_events']['min']:.3f} / {b['step_ms_hip_events']['median']:.3f} / {b['step_ms_hip_events']['max']:.3f} ms) |")
     L.append(f"| kernels per step (HIP events) | flatten {km['flatten']:.4f} ms, Gaussian {km.get('gauss_mfma', 0):.4f} ms |")
+    if b.get("value_exact_f32"):
+        xk = (b.get("exact_f32_leg") or {}).get("kernel_ms", {})
+        L.append(f"| `value_exact_f32` (same step, bit-exact f32 Gaussian) | {b['value_exact_f32']:,.0f} Mpixels/s = {b['ms_per_step_exact']:.4f} ms per step, pipeline {b['pipeline_frac_exact']:.3f} of 8 TB/s; "
+                 f"Gaussian {sum(v for k, v in xk.items() if k.startswith('gauss')):.3f} ms; whole frame bit-exact: {(b.get('exact_f32_leg') or {}).get('gaussian_whole_frame_bitexact')} |")
     L.append(f"| `roofline` (compositor, 132 B/px) | {r['achieved']:,.0f} GB/s = **{r['frac']:.3f} of 8 TB/s**; pipeline (140 B/px) {r['pipeline_achieved_GBs']:,.0f} GB/s = {r['pipeline_frac']:.3f} |")
     L.append(f"| rocprofv3 averages (under the profiler) | `{f['kernel']}` {f['avg_ns_profiled'] / 1e6:.4f} ms, `{g['kernel']}` {g['avg_ns_profiled'] / 1e6:.4f} ms |")
     L.append(f"| compositor HBM traffic (FETCH_SIZE × 2 + WRITE_SIZE) | {f['hbm_bytes'] / 1e9:.3f} GB per launch = {f['hbm_bytes'] / f['algorithmic_bytes']:.3f} × the algorithmic {f['algorithmic_bytes'] / 1e9:.3f} GB |")
@@ -54,11 +58,11 @@ def block_headline(b, p, names):
     L.append(f"| compositor unit occupancy (profiled, {f['clock_ghz']:.2f} GHz) | VALU issue {f.get('valu_issue_frac_inmix', 0):.2f} (in-mix costs; {f['valu_issue_frac_profiled']:.2f} with every instruction at 2 cycles), "
              f"scalar unit {f['salu_unit_frac_profiled']:.2f}, texture path ~{f.get('texture_path_frac_profiled', 0):.2f} |")
     L.append(f"| Gaussian (profiled) | MFMA pipe {g['mfma_pipe_frac_profiled']:.2f} busy, LDS {g['lds_busy_frac_profiled']:.2f}, HBM traffic {g['hbm_bytes'] / g['algorithmic_bytes']:.2f} × algorithmic |")
-    if cp: L.append(f"| clock and power during the timed workload | {cp.get('clock_ghz_sustained')} GHz sustained (spec {cp.get('clock_ghz_max_spec')}), {cp.get('socket_power_w')} W of a {cp.get('power_cap_w')} W cap ({cp.get('how')}) |")
+    if cp: L.append(f"| clock and power during the timed workload | {cp.get('clock_ghz_sustained')} GHz sustained (spec {cp.get('clock_ghz_max_spec')}), {cp.get('socket_power_w')} W of a {cp.get('power_cap_w')} W cap |")
     ck = b.get("check", {})
     L.append(f"| parity checks of the timed results | flatten whole frame bit-exact: {ck.get('flatten_whole_frame_bitexact')}; Gaussian whole frame max abs diff {ck.get('gaussian_whole_frame_max_diff')}, "
              f"{ck.get('gaussian_channels_off_by_one')} of the channels off by one |")
-    if cb: L.append(f"| `cpu_baseline` | {cb.get('value')} {cb.get('unit')} on {cb.get('cores')} cores ({cb.get('kind')}; faithful variant {cb.get('faithful', {}).get('value')}): {cb.get('sample')} |")
+    if cb: L.append(f"| `cpu_baseline` | {cb.get('value')} {cb.get('unit')} on {cb.get('cores')} cores ({cb.get('kind')}; with the reference's serial write-back {cb.get('faithful', {}).get('value')}): {str(cb.get('sample'))[:92]} |")
     L.append("")
     L.append("| BASELINE configuration (same line, `configs`) | ms | of 8 TB/s | kernels | check |")
     L.append("|---|---|---|---|---|")
@@ -69,7 +73,7 @@ def block_headline(b, p, names):
         if ms is None and "wall_ms_per_process" in c: extra = f"{min(c['wall_ms_per_process']):.0f}–{max(c['wall_ms_per_process']):.0f} ms of wall clock per process"
         km2 = ", ".join(f"{k} {v}" for k, v in (c.get("kernel_ms") or {}).items())
         chk = "; ".join(f"{k}: {json.dumps(v) if isinstance(v, dict) else v}" for k, v in (c.get("check") or {}).items())
-        L.append(f"| `{name}` | {fmt_ms(ms) if ms is not None else '—'} | {c.get('frac') if ms is not None else '—'} | {km2 or extra or '—'} | {chk[:220]} |")
+        L.append(f"| `{name}` | {fmt_ms(ms) if ms is not None else '—'} | {c.get('frac') if ms is not None else '—'} | {km2 or extra or '—'} | {chk[:120]} |")
     return "\n".join(L)
 
 
