@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <algorithm>
 
 #define PFX_DEV __device__ __forceinline__
 
@@ -155,6 +156,32 @@ inline hipError_t grant_lds(lds_grant& g, const void* kernel, size_t lds)
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e) return e;
     if (slot) g.bytes[dev].store((uint32_t)lds, std::memory_order_relaxed);
+    return hipSuccess;
+}
+
+// the same keyed by the kernel's address, for launchers whose kernel is a run-time choice among instantiations of one signature (a function-local static would be
+// shared by all of them): a small table under a spin lock — a few compares per launch instead of a runtime call
+inline hipError_t grant_lds_for(const void* kernel, size_t lds)
+{
+    struct slot { const void* k; int dev; uint32_t bytes; };
+    static slot table[256];
+    static std::atomic<int> n{0};
+    static std::atomic_flag busy = ATOMIC_FLAG_INIT;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e) return e;
+    const int have = n.load(std::memory_order_acquire);
+    for (int i = 0; i < have; ++i)
+        if (table[i].k == kernel && table[i].dev == dev && table[i].bytes >= lds) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e) return e;
+    while (busy.test_and_set(std::memory_order_acquire)) {}
+    const int cnt = n.load(std::memory_order_relaxed);
+    int at = -1;
+    for (int i = 0; i < cnt; ++i) if (table[i].k == kernel && table[i].dev == dev) at = i;
+    if (at >= 0) table[at].bytes = std::max(table[at].bytes, (uint32_t)lds);   // entries only grow: a reader that sees the old value just asks the runtime again
+    else if (cnt < 256) { table[cnt] = {kernel, dev, (uint32_t)lds}; n.store(cnt + 1, std::memory_order_release); }
+    busy.clear(std::memory_order_release);
     return hipSuccess;
 }
 

@@ -162,7 +162,7 @@ hipError_t launch_h(hipStream_t stream, const uint8_t* d_src, float4* tmp, const
 {
     const int h_entries = H_TILE + 2 * radius + H_SLACK;
     const size_t lds_h = (size_t)(h_entries + (h_entries >> 2) + 1) * sizeof(float4);
-    hipError_t e = hipFuncSetAttribute((const void*)gauss_h_kernel<EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+    hipError_t e = grant_lds_for((const void*)gauss_h_kernel<EXACT>, lds_h);
     if (e) return e;
     dim3 gh((w + H_TILE - 1) / H_TILE, h);
     gauss_h_kernel<EXACT><<<gh, H_THREADS, lds_h, stream>>>(d_src, tmp, wts, radius, (int)w, (int)h);
@@ -175,7 +175,7 @@ hipError_t launch_v_cfg(hipStream_t stream, const float4* tmp, uint8_t* d_dst, c
     constexpr int ROWS = 4 * YG;
     const size_t lds_v = (size_t)(ROWS + 2 * radius + V_SLACK) * RS * sizeof(float4);
     if (lds_v > 160u * 1024u) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void*)gauss_v_kernel<EXACT, TX, YG, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v);
+    hipError_t e = grant_lds_for((const void*)gauss_v_kernel<EXACT, TX, YG, RS>, lds_v);
     if (e) return e;
     dim3 gv((w + TX - 1) / TX, (h + ROWS - 1) / ROWS);
     gauss_v_kernel<EXACT, TX, YG, RS><<<gv, TX * YG, lds_v, stream>>>(tmp, d_dst, wts, radius, (int)w, (int)h);
@@ -964,7 +964,7 @@ static hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_src, ui
         const int grid = tiles_x * n_seg;
         const int dbg = g_v_cfg >> 9;
         auto go = [&](auto kern) {
-            errs = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            errs = grant_lds_for((const void*)kern, lds);
             if (errs) return;
             kern<<<grid, 512, lds, stream>>>(gs_no_chain{}, d_src, d_dst, d_wsplit, (int)w, (int)h, radius, R8, inv_scale2, bias_c, tiles_x, y_ph, n_steps, per, dbg, g_dbg_buf);
         };

@@ -192,7 +192,7 @@ extern "C" hipError_t pfxk_resize(hipStream_t s, const uint8_t* d_src, float* d_
     if (w == 0 || nw == 0 || nh == 0) return hipSuccess;
     const size_t lds = (size_t)span_max * RZ_TOY * sizeof(float4);
     if (span_max != 0 && lds <= 64u * 1024u) {
-        hipError_t e = hipFuncSetAttribute((const void*)resize_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = grant_lds_for((const void*)resize_fused_kernel, lds);
         if (e) return e;
         resize_fused_kernel<<<dim3((nw + RZ_TOX - 1) / RZ_TOX, (nh + RZ_TOY - 1) / RZ_TOY), 256, lds, s>>>(
             (const uint32_t*)d_src, (uint32_t*)d_dst, v_left, v_count, v_off, v_wts, h_left, h_count, h_off, h_wts, (int)w, (int)nw, (int)nh, (int)span_max);

@@ -844,7 +844,7 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
         constexpr int PX = decltype(px_c)::value;
         const int n = BX_THREADS * PX + 2 * radius, n2 = BX_THREADS * PX;
         const size_t lds = (size_t)((n + (n >> 5) + 1) + (n2 + (n2 >> 5) + 1)) * 4;
-        hipError_t e = hipFuncSetAttribute((const void*)box_h_kernel<PX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = grant_lds_for((const void*)box_h_kernel<PX>, lds);
         if (e) return e;
         box_h_kernel<PX><<<dim3((w + BX_THREADS * PX - 1) / (BX_THREADS * PX), h), BX_THREADS, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_tmp, radius, half, magic, (int)w, (int)h);
         return hipGetLastError();
@@ -853,7 +853,7 @@ extern "C" hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t
     if (g_box_prefix_from > 0 && radius >= g_box_prefix_from && g_box_px_force == 0) {
         const size_t lds = ((size_t)5 * bxp_words_host(radius) + 16) * 4;
         if (lds <= 160u * 1024u) {
-            hipError_t e0 = hipFuncSetAttribute((const void*)box_h_prefix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e0 = grant_lds_for((const void*)box_h_prefix_kernel, lds);
             if (e0) return e0;
             box_h_prefix_kernel<<<dim3((w + BXP_TILE - 1) / BXP_TILE, h), BX_THREADS, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_tmp, radius, half, magic, (int)w, (int)h);
             e0 = hipGetLastError();
@@ -952,7 +952,7 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
     }
     if (radius > PFXK_MEDIAN_TILE_MAX_RADIUS) { // sliding histogram
         const size_t lds_h = (size_t)4 * 256 * 64 * sizeof(uint16_t);
-        hipError_t eh = hipFuncSetAttribute((const void*)median_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+        hipError_t eh = grant_lds_for((const void*)median_hist_kernel, lds_h);
         if (eh) return eh;
         const size_t runs = (size_t)((w + MH_RUN - 1) / MH_RUN) * h;
         median_hist_kernel<<<(uint32_t)((runs + 63) / 64), 64, lds_h, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, (int)w, (int)h);
@@ -960,13 +960,13 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
     }
     if (!g_median_search1) { // four pixels per lane: a third of the LDS reads per pixel
         const size_t lds4 = (size_t)(MQ_TX + 2 * radius) * (MQ_TY + 2 * radius) * 8;
-        hipError_t e4 = hipFuncSetAttribute((const void*)median_search4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        hipError_t e4 = grant_lds_for((const void*)median_search4_kernel, lds4);
         if (e4) return e4;
         median_search4_kernel<<<dim3((w + MQ_TX - 1) / MQ_TX, (h + MQ_TY - 1) / MQ_TY), 256, lds4, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, (int)w, (int)h);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(MD_TX + 2 * radius) * (MD_TY + 2 * radius) * 8;
-    hipError_t e = hipFuncSetAttribute((const void*)median_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = grant_lds_for((const void*)median_kernel, lds);
     if (e) return e;
     dim3 g((w + MD_TX - 1) / MD_TX, (h + MD_TY - 1) / MD_TY);
     median_kernel<<<g, MD_TX * MD_TY, lds, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, radius, (int)w, (int)h);

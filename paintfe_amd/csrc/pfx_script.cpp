@@ -165,6 +165,9 @@ extern "C" int pfx_png_decode_mem(const uint8_t* bytes, size_t n_bytes, uint8_t*
     } catch (const std::bad_alloc&) {
         if (err && err_cap) std::snprintf(err, err_cap, "out of memory");
         return PFX_ERR_OOM;
+    } catch (const std::exception& e) {   // nothing may unwind through the C ABI
+        if (err && err_cap) std::snprintf(err, err_cap, "internal error: %s", e.what());
+        return PFX_ERR_INVALID;
     }
 }
 extern "C" void pfx_png_free(uint8_t* rgba) { std::free(rgba); }
