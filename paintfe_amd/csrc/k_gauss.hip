@@ -96,7 +96,7 @@ __global__ __launch_bounds__(H_THREADS) void gauss_h_kernel(const uint8_t* __res
 
 // Vertical pass.  TX columns x (4*YG) output rows per block, a lane owns 4 consecutive rows of one column (every
 // ds_read_b128 feeds 16 MACs, like the H pass).  RS = LDS row stride in float4 (>= TX; chosen so that the 16-lane
-// ds_read_b128 groups hit 16 distinct 16-byte slots: see tools/lds_stride_search.py).  The halo (2r rows) dominates
+// ds_read_b128 groups hit 16 distinct 16-byte slots; found by an exhaustive stride search in round 1).  The halo (2r rows) dominates
 // the tile, so blocks are tall (4*YG = 256 rows) and narrow: LDS per wave stays small and 4+ waves per SIMD cover
 // the LDS and staging latency.
 template <bool EXACT, int TX, int YG, int RS>
