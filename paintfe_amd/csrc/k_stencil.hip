@@ -10,6 +10,7 @@
 #include <type_traits>
 #include "k_median25_net.h"
 #include "k_median_shared_net.h"
+#include "k_median_xlane_net.h"
 #include "pfx_kernels.h"
 
 using namespace pfxk;
@@ -735,6 +736,82 @@ __global__ __launch_bounds__(256) void median_shared_kernel(const uint32_t* __re
     }
 }
 
+// 5x5 median with the sorted columns shared ACROSS LANES (round 6; k_median_xlane_net.h, tools/gen_median_xlane.py).  median_shared_kernel's lane sorts all eight
+// columns its four windows touch; four of them are its neighbours' own columns and are sorted there too.  Here a lane loads and sorts only its own four columns
+// (one 16-byte load per row instead of three), takes its neighbours' sorted columns and the merged pair that straddles the lane boundary with wave shifts
+// (v_mov_b32_dpp wave_shr:1 / wave_shl:1, one full-rate move per register) — 236 packed min / max + 25 moves per lane and channel pair instead of 334 min / max.
+// Lanes 0 and 63 of a wave are halo lanes: they compute for their neighbours and store nothing (a wave row covers 62 x 4 = 248 output pixels).  Same integers, same
+// element len/2 of the ascending sort (noise.rs:398-404); edge columns replicate the border pixel (noise.rs:389-392) because a lane left / right of the image loads
+// the clamped pixel four times.
+constexpr int MX_LANES_OUT = 62, MX_W = MX_LANES_OUT * 4, MX_H = 4;
+// (mov_dpp, not update_dpp with a zero `old`: that form costs a v_mov_b32 of the zero in front of every shift; what lanes 0 / 63 receive is never used)
+PFX_DEV pfx_us2 mx_shr(pfx_us2 v) { return __builtin_bit_cast(pfx_us2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true)); }   // from lane - 1
+PFX_DEV pfx_us2 mx_shl(pfx_us2 v) { return __builtin_bit_cast(pfx_us2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true)); }   // from lane + 1
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void median_xlane2_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint8_t* __restrict__ mask, int w, int h)
+{
+    constexpr int R = 2, S = 5;
+    const int lane = threadIdx.x & 63;
+    const int y = (int)blockIdx.y * MX_H + (int)(threadIdx.x >> 6);
+    if (y >= h) return;                                           // whole wave: every lane of a live wave stays active (the shifts read its neighbours)
+    const int x0 = (int)blockIdx.x * MX_W + 4 * (lane - 1);       // own columns x0 .. x0 + 3; lane 0 sits left of the wave's outputs, lane 63 right of them
+    const int xw = (int)blockIdx.x * MX_W;
+    const bool edge_wave = xw - 4 < 0 || xw + 4 * 62 + 4 > w;   // lane 0's or lane 63's quad leaves the row
+    uint32_t px[S][4];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const uint32_t* row = src + (size_t)min(max(y + k - R, 0), h - 1) * w;
+        if constexpr (DIRECT) {   // w % 4 == 0, rows 16-byte aligned: the quad is wholly inside the row or wholly outside it
+            if (!edge_wave) {     // wave-uniform: every lane's quad lies inside the row (all waves but a row's first and last)
+                const uint4 v = *reinterpret_cast<const uint4*>(row + x0);
+                px[k][0] = v.x; px[k][1] = v.y; px[k][2] = v.z; px[k][3] = v.w;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + min(max(x0, 0), w - 4));
+                const bool left = x0 < 0, right = x0 >= w;
+                px[k][0] = right ? v.w : v.x;
+                px[k][1] = left ? v.x : (right ? v.w : v.y);
+                px[k][2] = left ? v.x : (right ? v.w : v.z);
+                px[k][3] = left ? v.x : v.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) px[k][c] = row[min(max(x0 + c, 0), w - 1)];
+        }
+    }
+    uint32_t out[4] = {0u, 0u, 0u, 0u};
+#define PFX_MX_MIN(a, b) __builtin_elementwise_min(a, b)
+#define PFX_MX_MAX(a, b) __builtin_elementwise_max(a, b)
+    {   // R, B in 16-bit lanes
+#define PFX_MX_IN(c, k) __builtin_bit_cast(pfx_us2, px[k][c] & 0x00ff00ffu)
+#define PFX_MX_OUT(j, v) out[j] = __builtin_bit_cast(uint32_t, v)
+        PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT)
+#undef PFX_MX_IN
+#undef PFX_MX_OUT
+    }
+    {   // G, A
+#define PFX_MX_IN(c, k) __builtin_bit_cast(pfx_us2, (px[k][c] >> 8) & 0x00ff00ffu)
+#define PFX_MX_OUT(j, v) out[j] |= __builtin_bit_cast(uint32_t, v) << 8
+        PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT)
+#undef PFX_MX_IN
+#undef PFX_MX_OUT
+    }
+#undef PFX_MX_MIN
+#undef PFX_MX_MAX
+    if (lane == 0 || lane == 63 || x0 >= w) return;               // halo lanes and lanes right of the image: nothing to store (x0 >= 0 for lane >= 1)
+    const size_t o0 = (size_t)y * w + x0;
+    if (mask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < w && mask[o0 + j] == 0) out[j] = px[R][j];
+    }
+    if constexpr (DIRECT) *reinterpret_cast<uint4*>(dst + o0) = make_uint4(out[0], out[1], out[2], out[3]);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < w) dst[o0 + j] = out[j];
+    }
+}
+
 // ---------------------------------------------------------------- pixelate
 __global__ __launch_bounds__(256) void pixelate_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                        const uint8_t* __restrict__ mask, uint32_t bs, uint32_t w, uint32_t h)
@@ -769,6 +846,8 @@ __global__ __launch_bounds__(256) void pixelate4_kernel(const uint32_t* __restri
 
 int g_median_search1 = 0; // pfxk_median_set_search1: the value search with one pixel per lane (the pre-sharing kernel)
 extern "C" void pfxk_median_set_search1(int on) { g_median_search1 = on; }
+int g_median_xlane = 1;  // pfxk_median_set_xlane (pfx_tune "median_xlane"): radius 2 on the cross-lane network (1) or on median_shared_kernel (0)
+extern "C" void pfxk_median_set_xlane(int on) { g_median_xlane = on; }
 int g_median_single = 0; // pfxk_median_set_single: the one-window-per-lane networks for radii 2 and 3
 extern "C" void pfxk_median_set_single(int on) { g_median_single = on; }
 // radii from which a lane takes 16 columns instead of 8 / 64 rows instead of 16 (128 rows from twice that radius on).  Round-4 sweep of 3 x 4 shapes per radius
@@ -932,6 +1011,12 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         const dim3 g((w + 255) / 256, (h + 3) / 4);
         if ((w & 3u) == 0 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0) median3_kernel<true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         else median3_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        return hipGetLastError();
+    }
+    if (radius == 2 && g_median_xlane && !g_median_single) { // 5x5: four windows per lane, sorted columns shared across lanes
+        const dim3 g((w + MX_W - 1) / MX_W, (h + MX_H - 1) / MX_H);
+        if ((w & 3u) == 0 && w >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0) median_xlane2_kernel<true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        else median_xlane2_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         return hipGetLastError();
     }
     if (radius >= 2 && radius <= 4 && !g_median_single) { // 5x5 / 7x7 / 9x9: four windows per lane on shared sorted columns

@@ -1606,6 +1606,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "median_search1") == 0) { pfxk_median_set_search1(value); return PFX_OK; }
     if (std::strcmp(key, "outline_bits") == 0) { ctx->outline_bits = value != 0; return PFX_OK; }
     if (std::strcmp(key, "brush_binning") == 0) { ctx->brush_binning = value != 0; return PFX_OK; }   // 0: long strokes on the bounding-box kernel too
+    if (std::strcmp(key, "median_xlane") == 0) { pfxk_median_set_xlane(value); return PFX_OK; } // 0: radius 2 on the per-lane shared-column network (round 3's kernel)
     if (std::strcmp(key, "median_pair") == 0) { pfxk_median_bits_set_pair(value); return PFX_OK; } // 0: the single-column bit-plane kernel for every radius
     if (std::strcmp(key, "median_bits_min") == 0) { ctx->median_bits_min = value; return PFX_OK; } // smallest radius on the bit-plane kernel (8: never)
     if (std::strcmp(key, "median_single") == 0) { pfxk_median_set_single(value); return PFX_OK; }

@@ -1120,3 +1120,26 @@ def test_mfma_gaussian_64_column_strips_are_bit_identical_to_32_column_strips(gp
             r.tune("gauss_cols64", 6)
             for p in (a, b, c):
                 r.dev_free(p)
+
+
+def test_median_5x5_cross_lane_network_matches_the_oracle_and_the_per_lane_network(gpu, oracle):
+    """round 6: radius 2 runs a network whose sorted columns are shared ACROSS lanes (wave shifts; a wave row = 62 output lanes + 2 halo lanes = 248 pixels).  Bit-exact
+    against the oracle and identical to the per-lane network (pfx_tune "median_xlane" = 0) on widths around the 248-pixel wave tile, unaligned widths (the scalar
+    load path), one-pixel-wide / one-row images, heavy ties and selections"""
+    r = gpu.r
+    rng = np.random.default_rng(77)
+    for (w, h) in [(248, 9), (247, 7), (249, 5), (252, 12), (496, 6), (500, 40), (4, 4), (1, 17), (3, 3), (64, 1), (8, 2), (1000, 33), (744, 8), (745, 8)]:
+        img = I.random_rgba(w, h, seed=w * 13 + h)
+        if (w + h) % 3 == 0:
+            img = (img // 64) * 64                                   # heavy ties
+        mask = None if (w + h) % 2 else ((rng.random((h, w)) < 0.5).astype(np.uint8) * 255)
+        want = oracle.median(img, 2, mask=mask)
+        try:
+            r.tune("median_xlane", 1)
+            got = gpu.median(img, 2, mask=mask)
+            r.tune("median_xlane", 0)
+            old = gpu.median(img, 2, mask=mask)
+        finally:
+            r.tune("median_xlane", 1)
+        assert np.array_equal(got, want), (w, h, mask is not None, int((got != want).any(-1).sum()))
+        assert np.array_equal(old, want), (w, h)
