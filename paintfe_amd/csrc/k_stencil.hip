@@ -747,12 +747,22 @@ constexpr int MX_LANES_OUT = 62, MX_W = MX_LANES_OUT * 4, MX_H = 4;
 // (mov_dpp, not update_dpp with a zero `old`: that form costs a v_mov_b32 of the zero in front of every shift; what lanes 0 / 63 receive is never used)
 PFX_DEV pfx_us2 mx_shr(pfx_us2 v) { return __builtin_bit_cast(pfx_us2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true)); }   // from lane - 1
 PFX_DEV pfx_us2 mx_shl(pfx_us2 v) { return __builtin_bit_cast(pfx_us2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true)); }   // from lane + 1
-template <bool DIRECT>
-__global__ __launch_bounds__(256) void median_xlane2_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint8_t* __restrict__ mask, int w, int h)
+// ROWS = 2: a lane produces TWO vertically adjacent rows of four windows from six rows of its own columns — rows 1 .. 4 of a column belong to both windows and are
+// sorted once, the fifth row is merged in per window row (13 comparators per column and two rows instead of 18; 54 + 6 operations per window instead of 59 + 6)
+#ifndef PFX_MX_WAVES
+#define PFX_MX_WAVES 0   // development A/B: waves per SIMD the kernel is compiled for (0 = the compiler's choice: 90 registers for one row, 221 for two)
+#endif
+#if PFX_MX_WAVES
+#define PFX_MX_ATTR __attribute__((amdgpu_waves_per_eu(PFX_MX_WAVES, PFX_MX_WAVES)))
+#else
+#define PFX_MX_ATTR
+#endif
+template <bool DIRECT, int ROWS>
+__global__ __launch_bounds__(256) PFX_MX_ATTR void median_xlane2_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint8_t* __restrict__ mask, int w, int h)
 {
-    constexpr int R = 2, S = 5;
+    constexpr int R = 2, S = 4 + ROWS;                            // rows of own pixels a lane holds
     const int lane = threadIdx.x & 63;
-    const int y = (int)blockIdx.y * MX_H + (int)(threadIdx.x >> 6);
+    const int y = ((int)blockIdx.y * MX_H + (int)(threadIdx.x >> 6)) * ROWS;
     if (y >= h) return;                                           // whole wave: every lane of a live wave stays active (the shifts read its neighbours)
     const int x0 = (int)blockIdx.x * MX_W + 4 * (lane - 1);       // own columns x0 .. x0 + 3; lane 0 sits left of the wave's outputs, lane 63 right of them
     const int xw = (int)blockIdx.x * MX_W;
@@ -778,37 +788,45 @@ __global__ __launch_bounds__(256) void median_xlane2_kernel(const uint32_t* __re
             for (int c = 0; c < 4; ++c) px[k][c] = row[min(max(x0 + c, 0), w - 1)];
         }
     }
-    uint32_t out[4] = {0u, 0u, 0u, 0u};
+    uint32_t out[4 * ROWS];
+#pragma unroll
+    for (int j = 0; j < 4 * ROWS; ++j) out[j] = 0u;
 #define PFX_MX_MIN(a, b) __builtin_elementwise_min(a, b)
 #define PFX_MX_MAX(a, b) __builtin_elementwise_max(a, b)
     {   // R, B in 16-bit lanes
 #define PFX_MX_IN(c, k) __builtin_bit_cast(pfx_us2, px[k][c] & 0x00ff00ffu)
 #define PFX_MX_OUT(j, v) out[j] = __builtin_bit_cast(uint32_t, v)
-        PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT)
+        if constexpr (ROWS == 1) { PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
+        else { PFX_MEDIAN_XLANE_R2_ROWS2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
 #undef PFX_MX_IN
 #undef PFX_MX_OUT
     }
     {   // G, A
 #define PFX_MX_IN(c, k) __builtin_bit_cast(pfx_us2, (px[k][c] >> 8) & 0x00ff00ffu)
 #define PFX_MX_OUT(j, v) out[j] |= __builtin_bit_cast(uint32_t, v) << 8
-        PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT)
+        if constexpr (ROWS == 1) { PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
+        else { PFX_MEDIAN_XLANE_R2_ROWS2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
 #undef PFX_MX_IN
 #undef PFX_MX_OUT
     }
 #undef PFX_MX_MIN
 #undef PFX_MX_MAX
     if (lane == 0 || lane == 63 || x0 >= w) return;               // halo lanes and lanes right of the image: nothing to store (x0 >= 0 for lane >= 1)
-    const size_t o0 = (size_t)y * w + x0;
-    if (mask) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (x0 + j < w && mask[o0 + j] == 0) out[j] = px[R][j];
-    }
-    if constexpr (DIRECT) *reinterpret_cast<uint4*>(dst + o0) = make_uint4(out[0], out[1], out[2], out[3]);
-    else {
+    for (int rr = 0; rr < ROWS; ++rr) {
+        if (y + rr >= h) break;
+        const size_t o0 = (size_t)(y + rr) * w + x0;
+        if (mask) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (x0 + j < w) dst[o0 + j] = out[j];
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < w && mask[o0 + j] == 0) out[4 * rr + j] = px[R + rr][j];
+        }
+        if constexpr (DIRECT) *reinterpret_cast<uint4*>(dst + o0) = make_uint4(out[4 * rr], out[4 * rr + 1], out[4 * rr + 2], out[4 * rr + 3]);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < w) dst[o0 + j] = out[4 * rr + j];
+        }
     }
 }
 
@@ -846,7 +864,7 @@ __global__ __launch_bounds__(256) void pixelate4_kernel(const uint32_t* __restri
 
 int g_median_search1 = 0; // pfxk_median_set_search1: the value search with one pixel per lane (the pre-sharing kernel)
 extern "C" void pfxk_median_set_search1(int on) { g_median_search1 = on; }
-int g_median_xlane = 1;  // pfxk_median_set_xlane (pfx_tune "median_xlane"): radius 2 on the cross-lane network (1) or on median_shared_kernel (0)
+int g_median_xlane = 1;  // pfxk_median_set_xlane (pfx_tune "median_xlane"): radius 2 on the cross-lane network, one (1) or two (2) rows per lane, or on median_shared_kernel (0)
 extern "C" void pfxk_median_set_xlane(int on) { g_median_xlane = on; }
 int g_median_single = 0; // pfxk_median_set_single: the one-window-per-lane networks for radii 2 and 3
 extern "C" void pfxk_median_set_single(int on) { g_median_single = on; }
@@ -1014,9 +1032,16 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         return hipGetLastError();
     }
     if (radius == 2 && g_median_xlane && !g_median_single) { // 5x5: four windows per lane, sorted columns shared across lanes
-        const dim3 g((w + MX_W - 1) / MX_W, (h + MX_H - 1) / MX_H);
-        if ((w & 3u) == 0 && w >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0) median_xlane2_kernel<true><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
-        else median_xlane2_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        const bool direct = (w & 3u) == 0 && w >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0;
+        if (g_median_xlane == 2) {   // two rows per lane
+            const dim3 g((w + MX_W - 1) / MX_W, (h + 2 * MX_H - 1) / (2 * MX_H));
+            if (direct) median_xlane2_kernel<true, 2><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+            else median_xlane2_kernel<false, 2><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        } else {
+            const dim3 g((w + MX_W - 1) / MX_W, (h + MX_H - 1) / MX_H);
+            if (direct) median_xlane2_kernel<true, 1><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+            else median_xlane2_kernel<false, 1><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        }
         return hipGetLastError();
     }
     if (radius >= 2 && radius <= 4 && !g_median_single) { // 5x5 / 7x7 / 9x9: four windows per lane on shared sorted columns

@@ -1137,9 +1137,12 @@ def test_median_5x5_cross_lane_network_matches_the_oracle_and_the_per_lane_netwo
         try:
             r.tune("median_xlane", 1)
             got = gpu.median(img, 2, mask=mask)
+            r.tune("median_xlane", 2)          # two rows per lane (rows 1 .. 4 of a column sorted once for both)
+            got2 = gpu.median(img, 2, mask=mask)
             r.tune("median_xlane", 0)
             old = gpu.median(img, 2, mask=mask)
         finally:
             r.tune("median_xlane", 1)
         assert np.array_equal(got, want), (w, h, mask is not None, int((got != want).any(-1).sum()))
+        assert np.array_equal(got2, want), ("two rows", w, h, mask is not None, int((got2 != want).any(-1).sum()))
         assert np.array_equal(old, want), (w, h)

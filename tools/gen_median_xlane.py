@@ -52,6 +52,74 @@ class XGraph(Graph):
         return v
 
 
+SORT4 = [(0, 1), (2, 3), (0, 2), (1, 3), (1, 2)]
+
+
+def build_r2_two_rows():
+    """r = 2, TWO vertically adjacent rows of four windows per lane: own columns of six pixels; rows 1 .. 4 are common to both window rows and sorted once (5
+    comparators), row 0 / row 5 is merged in for the upper / lower window row (4 each): 13 comparators per column and two rows instead of 2 x 9.
+    Input id = own column * 6 + row; outputs 0 .. 3 = upper row's windows, 4 .. 7 = lower row's."""
+    g = XGraph(4 * 6)
+    mids = [g.sort([c * 6 + k for k in (1, 2, 3, 4)], SORT4) for c in range(4)]
+    outs = []
+    for half in range(2):
+        own = [g.merge([c * 6 + 0], mids[c]) if half == 0 else g.merge(mids[c], [c * 6 + 5]) for c in range(4)]
+        c = [[g.shr(x) for x in own[2]], [g.shr(x) for x in own[3]], own[0], own[1], own[2], own[3], [g.shl(x) for x in own[0]], [g.shl(x) for x in own[1]]]
+        P34 = g.merge(c[3], c[4])
+        P56 = g.merge(c[5], c[6])
+        P12 = [g.shr(x) for x in P56]
+        X, Y = g.merge(P12, P34), g.merge(P34, P56)
+        outs += [g.kth_of_union(X, c[0], 13), g.kth_of_union(X, c[5], 13), g.kth_of_union(Y, c[2], 13), g.kth_of_union(Y, c[7], 13)]
+    return g, outs, g.prune(outs)
+
+
+def verify_two_rows(g, outs, keep):
+    s, r = 5, 2
+    need_ones = 13
+    levels = np.arange(s + 1, dtype=np.int8)
+    grids = np.meshgrid(*[levels] * s, indexing="ij")
+    counts = [x.reshape(-1) for x in grids]
+    zero = np.zeros(len(counts[0]), np.uint8)
+    for half in range(2):
+        for j in range(4):
+            cols = [[[zero] * 6 for _ in range(4)] for _ in range(3)]
+            for t in range(s):
+                gc = j - r + t + 4
+                lane, oc = gc // 4, gc % 4
+                col6 = [zero] * 6
+                ones = [(counts[t] > (s - 1 - k)).astype(np.uint8) for k in range(s)]
+                for k in range(s): col6[k + half] = ones[k]          # the window's five rows are rows half .. half + 4 of the six; the sixth row stays zero
+                cols[lane][oc] = col6
+            ins = [np.stack([cols[lane][c][k] for lane in range(3)]) for c in range(4) for k in range(6)]
+            got = g.evaluate(ins, keep)[outs[4 * half + j]][1]
+            want = (sum(c.astype(np.int32) for c in counts) >= need_ones).astype(np.uint8)
+            if not np.array_equal(got, want):
+                return f"two rows: half {half} window {j} fails the 0/1 test"
+            # the sixth row must not matter: all ones there
+            for lane in range(3):
+                for c in range(4):
+                    cols[lane][c] = list(cols[lane][c]); cols[lane][c][5 if half == 0 else 0] = np.ones(len(zero), np.uint8)
+            ins = [np.stack([cols[lane][c][k] for lane in range(3)]) for c in range(4) for k in range(6)]
+            got = g.evaluate(ins, keep)[outs[4 * half + j]][1]
+            if not np.array_equal(got, want):
+                return f"two rows: half {half} window {j} depends on the other row"
+    rng = np.random.default_rng(202)
+    nl = 66
+    for nlev in (256, 5, 2):
+        px = rng.integers(0, nlev, (6, 4 * nl, 1 << 11), dtype=np.uint8)
+        ins = [np.stack([px[k, 4 * lane + c] for lane in range(nl)]) for c in range(4) for k in range(6)]
+        v = g.evaluate(ins, keep)
+        for half in range(2):
+            for j in range(4):
+                got = v[outs[4 * half + j]]
+                for lane in range(1, nl - 1):
+                    x0 = 4 * lane + j - r
+                    want = np.sort(px[half:half + 5, x0:x0 + s].reshape(s * s, -1), axis=0)[12]
+                    if not np.array_equal(got[lane], want):
+                        return f"two rows: half {half} window {j} lane {lane} fails on random bytes ({nlev} levels)"
+    return None
+
+
 def build(r):
     s = 2 * r + 1
     g = XGraph(4 * s)   # input id = own column * s + row
@@ -126,14 +194,16 @@ def verify(r, g, outs, keep):
     return None
 
 
-def emit(r, g, outs, keep):
-    s = 2 * r + 1
+def emit(r, g, outs, keep, rows=1):
+    s = 2 * r + 1 + (rows - 1)
     n_mm = sum(1 for k, o in enumerate(g.ops) if keep[k] and o[0] in ("min", "max"))
     n_sh = sum(1 for k, o in enumerate(g.ops) if keep[k] and o[0] in ("shr", "shl"))
-    lines = [f"// median of four adjacent {s}x{s} windows per lane, sorted columns shared across lanes: {n_mm} min / max operations + {n_sh} wave shifts per lane\n"
+    lines = [f"// median of four adjacent {2 * r + 1}x{2 * r + 1} windows per lane, sorted columns shared across lanes: {n_mm} min / max operations + {n_sh} wave shifts per lane\n"
              f"// ({n_mm / 4:.1f} + {n_sh / 4:.1f} per window; k_median_shared_net.h: {({2: 334, 3: 798}[r]) / 4:.1f} min / max).  IN(c, k) = row k of OWN column c (columns x0 .. x0+3);\n"
              f"// SHR(v) / SHL(v) = v as held by the lane to the left / right; OUT(j, v) receives the median of the window centred on own column j\n"
-             f"#define PFX_MEDIAN_XLANE_R{r}(T, IN, MIN, MAX, SHR, SHL, OUT) \\\n"]
+             f"#define PFX_MEDIAN_XLANE_R{r}{'_ROWS2' if rows == 2 else ''}(T, IN, MIN, MAX, SHR, SHL, OUT) \\\n"]
+    if rows == 2:
+        lines[0] = lines[0].replace("median of four adjacent", "TWO ROWS (IN(c, 0 .. 5) = six rows; OUT 0 .. 3 upper, 4 .. 7 lower window row) of four adjacent")
     name = lambda i: f"IN({i // s}, {i % s})" if i < g.n_inputs else f"n{i - g.n_inputs}"
     for k, (kind, a, b) in enumerate(g.ops):
         if not keep[k]:
@@ -165,6 +235,15 @@ def main():
         t, n_mm, n_sh = emit(r, g, outs, keep)
         print(f"r={r}: {n_mm} min / max + {n_sh} shifts per lane = {n_mm / 4:.1f} + {n_sh / 4:.1f} per window", file=sys.stderr)
         text.append(t)
+    g, outs, keep = build_r2_two_rows()
+    if "--no-verify" not in sys.argv:
+        err = verify_two_rows(g, outs, keep)
+        if err:
+            print("VERIFICATION FAILED:", err, file=sys.stderr)
+            return 1
+    t, n_mm, n_sh = emit(2, g, outs, keep, rows=2)
+    print(f"r=2, two rows: {n_mm} min / max + {n_sh} shifts per lane = {n_mm / 8:.1f} + {n_sh / 8:.1f} per window", file=sys.stderr)
+    text.append(t)
     open(out, "w").write("".join(text))
     print(out, file=sys.stderr)
     return 0

@@ -14,11 +14,11 @@ src = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda"); dst = 
 for _ in range(100): r.median_dev(src.data_ptr(), dst.data_ptr(), w, h, 2)
 torch.cuda.synchronize()
 for rnd in range(4):
-    for xl in (0, 1):
+    for xl in (0, 1, 2):
         r.tune("median_xlane", xl)
         for _ in range(20): r.median_dev(src.data_ptr(), dst.data_ptr(), w, h, 2)
         torch.cuda.synchronize(); r.timing_reset(); r.timing_enable(True)
         for _ in range(50): r.median_dev(src.data_ptr(), dst.data_ptr(), w, h, 2)
         torch.cuda.synchronize(); r.timing_enable(False)
-        print(f"round {rnd} median r=2 {'cross-lane network' if xl else 'per-lane network  '}: {r.timing_read('median')[0] / 50:.4f} ms")
+        print(f"round {rnd} median r=2 {('per-lane network        ', 'cross-lane, 1 row / lane', 'cross-lane, 2 rows / lane')[xl]}: {r.timing_read('median')[0] / 50:.4f} ms")
 PY
