@@ -757,10 +757,13 @@ PFX_DEV pfx_us2 mx_shl(pfx_us2 v) { return __builtin_bit_cast(pfx_us2, __builtin
 #else
 #define PFX_MX_ATTR
 #endif
-template <bool DIRECT, int ROWS>
+// R = 3 (7x7, one row per lane): the same scheme — a lane's own pairs (c3 c4), (c5 c6) are merged once and handed to both neighbours, 130.5 + 14 operations per window
+// against the per-lane network's 199.5.
+template <bool DIRECT, int ROWS, int R = 2>
 __global__ __launch_bounds__(256) PFX_MX_ATTR void median_xlane2_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint8_t* __restrict__ mask, int w, int h)
 {
-    constexpr int R = 2, S = 4 + ROWS;                            // rows of own pixels a lane holds
+    static_assert(R == 2 || (R == 3 && ROWS == 1), "generated networks: PFX_MEDIAN_XLANE_R2, _R2_ROWS2, _R3");
+    constexpr int S = 2 * R + ROWS;                               // rows of own pixels a lane holds
     const int lane = threadIdx.x & 63;
     const int y = ((int)blockIdx.y * MX_H + (int)(threadIdx.x >> 6)) * ROWS;
     if (y >= h) return;                                           // whole wave: every lane of a live wave stays active (the shifts read its neighbours)
@@ -796,7 +799,8 @@ __global__ __launch_bounds__(256) PFX_MX_ATTR void median_xlane2_kernel(const ui
     {   // R, B in 16-bit lanes
 #define PFX_MX_IN(c, k) __builtin_bit_cast(pfx_us2, px[k][c] & 0x00ff00ffu)
 #define PFX_MX_OUT(j, v) out[j] = __builtin_bit_cast(uint32_t, v)
-        if constexpr (ROWS == 1) { PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
+        if constexpr (R == 3) { PFX_MEDIAN_XLANE_R3(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
+        else if constexpr (ROWS == 1) { PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
         else { PFX_MEDIAN_XLANE_R2_ROWS2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
 #undef PFX_MX_IN
 #undef PFX_MX_OUT
@@ -804,7 +808,8 @@ __global__ __launch_bounds__(256) PFX_MX_ATTR void median_xlane2_kernel(const ui
     {   // G, A
 #define PFX_MX_IN(c, k) __builtin_bit_cast(pfx_us2, (px[k][c] >> 8) & 0x00ff00ffu)
 #define PFX_MX_OUT(j, v) out[j] |= __builtin_bit_cast(uint32_t, v) << 8
-        if constexpr (ROWS == 1) { PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
+        if constexpr (R == 3) { PFX_MEDIAN_XLANE_R3(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
+        else if constexpr (ROWS == 1) { PFX_MEDIAN_XLANE_R2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
         else { PFX_MEDIAN_XLANE_R2_ROWS2(pfx_us2, PFX_MX_IN, PFX_MX_MIN, PFX_MX_MAX, mx_shr, mx_shl, PFX_MX_OUT) }
 #undef PFX_MX_IN
 #undef PFX_MX_OUT
@@ -864,8 +869,9 @@ __global__ __launch_bounds__(256) void pixelate4_kernel(const uint32_t* __restri
 
 int g_median_search1 = 0; // pfxk_median_set_search1: the value search with one pixel per lane (the pre-sharing kernel)
 extern "C" void pfxk_median_set_search1(int on) { g_median_search1 = on; }
-int g_median_xlane = 1;  // pfxk_median_set_xlane (pfx_tune "median_xlane"): radius 2 on the cross-lane network, one (1) or two (2) rows per lane, or on median_shared_kernel (0)
+int g_median_xlane = 1;  // pfxk_median_set_xlane (pfx_tune "median_xlane"): bits 0-1: radius 2 on the cross-lane network, one (1) or two (2) rows per lane, or on median_shared_kernel (0); bit 2: radius 3 on it too
 extern "C" void pfxk_median_set_xlane(int on) { g_median_xlane = on; }
+extern "C" int pfxk_median_get_xlane(void) { return g_median_xlane; }
 int g_median_single = 0; // pfxk_median_set_single: the one-window-per-lane networks for radii 2 and 3
 extern "C" void pfxk_median_set_single(int on) { g_median_single = on; }
 // radii from which a lane takes 16 columns instead of 8 / 64 rows instead of 16 (128 rows from twice that radius on).  Round-4 sweep of 3 x 4 shapes per radius
@@ -1031,9 +1037,16 @@ extern "C" hipError_t pfxk_median(hipStream_t s, const uint8_t* d_src, uint8_t* 
         else median3_kernel<false><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
         return hipGetLastError();
     }
-    if (radius == 2 && g_median_xlane && !g_median_single) { // 5x5: four windows per lane, sorted columns shared across lanes
+    if (radius == 3 && (g_median_xlane & 4) && !g_median_single) { // 7x7 on the cross-lane network (pfx_tune "median_xlane" bit 2; pfx_api.cpp routes r = 3 here only then)
         const bool direct = (w & 3u) == 0 && w >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0;
-        if (g_median_xlane == 2) {   // two rows per lane
+        const dim3 g((w + MX_W - 1) / MX_W, (h + MX_H - 1) / MX_H);
+        if (direct) median_xlane2_kernel<true, 1, 3><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        else median_xlane2_kernel<false, 1, 3><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
+        return hipGetLastError();
+    }
+    if (radius == 2 && (g_median_xlane & 3) && !g_median_single) { // 5x5: four windows per lane, sorted columns shared across lanes
+        const bool direct = (w & 3u) == 0 && w >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) == 0;
+        if ((g_median_xlane & 3) == 2) {   // two rows per lane
             const dim3 g((w + MX_W - 1) / MX_W, (h + 2 * MX_H - 1) / (2 * MX_H));
             if (direct) median_xlane2_kernel<true, 2><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);
             else median_xlane2_kernel<false, 2><<<g, 256, 0, s>>>((const uint32_t*)d_src, (uint32_t*)d_dst, d_mask, (int)w, (int)h);

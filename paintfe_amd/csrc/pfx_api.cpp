@@ -610,7 +610,8 @@ int pfx_median_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w,
     PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_median_dev"));
     const uint32_t r = std::max(radius, 1u); // noise.rs:364
     if (r > PFX_MEDIAN_MAX_RADIUS) return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "median radius %u > %d", r, PFX_MEDIAN_MAX_RADIUS);
-    if ((int)r >= ctx->median_bits_min && r <= 8u) { // bit-sliced radix select (k_median_bits.hip); scratch ~ the image size
+    const bool xlane3 = r == 3u && (pfxk_median_get_xlane() & 4);   // 7x7 on the cross-lane network (pfx_tune "median_xlane" bit 2)
+    if ((int)r >= ctx->median_bits_min && r <= 8u && !xlane3) { // bit-sliced radix select (k_median_bits.hip); scratch ~ the image size
         PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, pfxk_median_bits_scratch((int)r, w, h)));
         pfx_timer t(ctx, "median");
         PFX_HIP(ctx, pfxk_median_bits(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)dst_dev, (const uint8_t*)mask_dev, (uint32_t*)ctx->st_tmp.p, (int)r, w, h));

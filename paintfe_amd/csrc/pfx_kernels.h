@@ -148,6 +148,7 @@ void pfxk_box_set_force(int px, int py); // development sweep: outputs per lane 
 void pfxk_box_set_switch(int px_radius, int py_radius); // two-pass box blur: radii from which a lane takes 32 columns / 128 rows (-1: keep)
 void pfxk_median_set_search1(int on); // value search (radii 5..24, and 4 with median_single) with one pixel per lane instead of four
 void pfxk_median_set_single(int on); // radii 2, 3: one window per lane (the pre-sharing selection networks)
+int pfxk_median_get_xlane(void);
 void pfxk_median_set_xlane(int on); // 1 (default): radius 2 on the network whose sorted columns are shared across lanes (median_xlane2_kernel)
 void pfxk_box_set_strip(int on /* -1 keep */, int fill_percent /* <= 0 keep */, int nseg /* -1 keep, 0 auto */);
 hipError_t pfxk_box_blur(hipStream_t s, const uint8_t* d_src, uint8_t* d_tmp, uint8_t* d_dst, const uint8_t* d_mask,

@@ -1146,3 +1146,20 @@ def test_median_5x5_cross_lane_network_matches_the_oracle_and_the_per_lane_netwo
         assert np.array_equal(got, want), (w, h, mask is not None, int((got != want).any(-1).sum()))
         assert np.array_equal(got2, want), ("two rows", w, h, mask is not None, int((got2 != want).any(-1).sum()))
         assert np.array_equal(old, want), (w, h)
+
+
+def test_median_7x7_cross_lane_network_matches_the_oracle(gpu, oracle):
+    """the 7x7 form of the cross-lane network (pfx_tune "median_xlane" bit 2; the bit-plane select is the shipped r = 3 path): bit-exact on the same shapes"""
+    r = gpu.r
+    rng = np.random.default_rng(78)
+    try:
+        r.tune("median_xlane", 5)
+        for (w, h) in [(248, 9), (247, 7), (252, 12), (500, 40), (4, 4), (1, 17), (3, 3), (64, 1), (745, 8)]:
+            img = I.random_rgba(w, h, seed=w * 17 + h)
+            if (w + h) % 3 == 0:
+                img = (img // 64) * 64
+            mask = None if (w + h) % 2 else ((rng.random((h, w)) < 0.5).astype(np.uint8) * 255)
+            got, want = gpu.median(img, 3, mask=mask), oracle.median(img, 3, mask=mask)
+            assert np.array_equal(got, want), (w, h, mask is not None, int((got != want).any(-1).sum()))
+    finally:
+        r.tune("median_xlane", 1)

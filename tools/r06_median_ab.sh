@@ -21,4 +21,12 @@ for rnd in range(4):
         for _ in range(50): r.median_dev(src.data_ptr(), dst.data_ptr(), w, h, 2)
         torch.cuda.synchronize(); r.timing_enable(False)
         print(f"round {rnd} median r=2 {('per-lane network        ', 'cross-lane, 1 row / lane', 'cross-lane, 2 rows / lane')[xl]}: {r.timing_read('median')[0] / 50:.4f} ms")
+    for xl in (1, 5):
+        r.tune("median_xlane", xl)
+        for _ in range(20): r.median_dev(src.data_ptr(), dst.data_ptr(), w, h, 3)
+        torch.cuda.synchronize(); r.timing_reset(); r.timing_enable(True)
+        for _ in range(50): r.median_dev(src.data_ptr(), dst.data_ptr(), w, h, 3)
+        torch.cuda.synchronize(); r.timing_enable(False)
+        print(f"round {rnd} median r=3 {'cross-lane network' if xl == 5 else 'bit-plane select  '}: {r.timing_read('median')[0] / 50:.4f} ms")
+    r.tune("median_xlane", 1)
 PY
