@@ -122,7 +122,7 @@ def main() -> int:
     timed("box blur r=9", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 9.0), px, 8, "fused column-strip walk, u8 intermediate in an LDS ring")
     timed("box blur r=48", ["box_blur"], lambda: r.box_blur_dev(s, d, w, h, 48.0), px, 8, "fused column-strip walk")
     timed("median r=1", ["median"], lambda: r.median_dev(s, d, w, h, 1), px, 8)
-    timed("median r=2", ["median"], lambda: r.median_dev(s, d, w, h, 2), px, 8)
+    timed("median r=2", ["median"], lambda: r.median_dev(s, d, w, h, 2), px, 8, "5x5 network, sorted columns shared across lanes (wave shifts)")
     timed("median r=3", ["median"], lambda: r.median_dev(s, d, w, h, 3), px, 8, "bit-plane radix select (k_median_bits.hip), incl. the planes pre-pass")
     timed("median r=4", ["median"], lambda: r.median_dev(s, d, w, h, 4), px, 8, "bit-plane radix select")
     timed("median r=5", ["median"], lambda: r.median_dev(s, d, w, h, 5), px, 8, "bit-plane radix select")
