@@ -278,7 +278,8 @@ PFX_DEV uint32_t fx_pixel(const uint32_t* __restrict__ src, uint32_t s, int x, i
         const uint32_t bw = P.u[0], xu = (uint32_t)x, yu = (uint32_t)y;
         return (xu < bw || yu < bw || xu >= (uint32_t)w - bw || yu >= (uint32_t)h - bw) ? P.u[1] : s;
     } else if constexpr (FX == PFXK_FX2_SHADOW) { // render.rs:325-344; aux0: blurred alpha image (RGBA, channel 0 used); f0 opacity; u0 color
-        const uint32_t bl = ((const uint32_t*)P.aux0)[(size_t)y * w + x];
+        // u1 != 0: aux0 is the one-channel plane (round 6: the blur runs on the plane, a quarter of the arithmetic); else the RGBA (a, a, a, a) image, channel 0 read
+        const uint32_t bl = P.u[1] ? (uint32_t)((const uint8_t*)P.aux0)[(size_t)y * w + x] : ((const uint32_t*)P.aux0)[(size_t)y * w + x];
         const float shadow_a = div255(ubyte0(bl)) * P.f[0] * div255(ubyte3(P.u[0]));
         const float src_a = div255(a);
         const float out_a = src_a + shadow_a * (1.0f - src_a);
@@ -701,9 +702,11 @@ extern "C" hipError_t pfxk_shadow_alpha(hipStream_t s, const uint8_t* d_src, uin
         plane_max_kernel<false><<<tile_grid(w, h), 256, 0, s>>>(d_plane_a, d_plane_b, spread, (int)w, (int)h);
         plane_max_kernel<true><<<tile_grid(w, h), 256, 0, s>>>(d_plane_b, d_plane_a, spread, (int)w, (int)h);
     }
-    const size_t n = (size_t)w * h;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    plane_expand_kernel<<<(uint32_t)blocks, 256, 0, s>>>(d_plane_a, (uint32_t*)d_rgba, n);
+    if (d_rgba) {   // NULL: the caller blurs and composites the PLANE (d_plane_a holds it)
+        const size_t n = (size_t)w * h;
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        plane_expand_kernel<<<(uint32_t)blocks, 256, 0, s>>>(d_plane_a, (uint32_t*)d_rgba, n);
+    }
     return hipGetLastError();
 }

@@ -210,6 +210,141 @@ __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const CHAIN cha
     }
 }
 
+
+// ---- the same for a ONE-CHANNEL image (round 6): what the drop shadow blurs (render.rs:291-301 expands its alpha plane to (a, a, a, a) and blurs all four channels; only
+// one is read back).  A "pixel" of the walk is a QUAD of four adjacent plane bytes: the vertical pass is the kernel above's with the four columns in the four float lanes,
+// the horizontal pass gives a lane sixteen adjacent output columns (four quads) whose taps come from 16 + 2R staged bytes — per output the same products and sums in the same
+// order as one channel of the RGBA kernel (bit-identical: tests/test_gpu_effects.py compares the shadow with the oracle at tolerance 0), a quarter of the arithmetic and of the
+// traffic.  The plane's width must be a multiple of four (rows are then dword-aligned and a quad never crosses a row).
+template <int R>
+__global__ __launch_bounds__(GF_T) void gauss_plane_exact_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const float* __restrict__ wts, int w, int h,
+                                                                 int seg_rows, int nseg, int strips)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t gf_lds[];
+    const int tid = (int)threadIdx.x;
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+    const int s_lo = strips * xcd / 8, s_hi = strips * (xcd + 1) / 8, sg = s_hi - s_lo;
+    if (sg == 0 || j >= sg * nseg) return;
+    const int seg = j / sg, strip = s_lo + (j - seg * sg);
+    const int wq = w >> 2;                                      // quads per row
+    const int xq0 = strip * GF_W, y0 = seg * seg_rows, y1 = min(y0 + seg_rows, h);
+    if (y0 >= h) return;
+    constexpr int r = R, RR = 2 * R + 1 + GF_RB, KLEN = 2 * R + 1, R4 = (R + 3) & ~3, OFF = R4 - R;   // the staged row starts R4 bytes (whole dwords) left of the strip
+    constexpr int ND = (4 * GF_W + 2 * R4) / 4, SPD = ND + 1 + ((4 - ((ND + 1) & 3)) & 3) + 1;        // staged dwords per row; pitch = 1 (mod 4): rows start in different banks
+    float4* const ring = reinterpret_cast<float4*>(gf_lds);                                // [RR][GF_W] quads
+    uint32_t* const s_src = reinterpret_cast<uint32_t*>(gf_lds + (size_t)RR * GF_W * 16);    // [GF_RB][SPD]
+    const int v_begin = y0 - r, v_end = y1 + r;
+    float wt[KLEN];
+#pragma unroll
+    for (int k = 0; k < KLEN; ++k) wt[k] = wts[k];
+    const int hrow = tid >> 4, hrun = tid & 15;
+    const int col = tid & 63, vg = __builtin_amdgcn_readfirstlane(tid >> 6), xq = xq0 + col, scol = gf_swz(col);
+    constexpr int PER = (GF_RB * ND + GF_T - 1) / GF_T;
+    uint32_t stg[PER];
+    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
+    auto stage_load = [&](int vb) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = min(tid + GF_T * k, GF_RB * ND - 1), ty = i / ND, td = i - ty * ND;
+            const int yy = min(max(vb + ty, 0), h - 1), xb = 4 * xq0 - R4 + 4 * td;         // first byte column of this dword
+            if (xb >= 0 && xb + 4 <= w) stg[k] = src32[((size_t)yy * w + xb) >> 2];           // wholly inside the row
+            else {                                                                          // clamp-to-edge per byte (filters.rs:268-270)
+                const uint8_t* row = src + (size_t)yy * w;
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) v |= (uint32_t)row[min(max(xb + b, 0), w - 1)] << (8 * b);
+                stg[k] = v;
+            }
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + GF_T * k, ty = i / ND, td = i - ty * ND;
+            if (i < GF_RB * ND) s_src[ty * SPD + td] = stg[k];
+        }
+    };
+    stage_load(v_begin);
+    stage_store();
+    int base = 0;
+    for (int vb = v_begin; vb < v_end; vb += GF_RB) {
+        __syncthreads();
+        {   // horizontal: the lane's outputs are byte columns 16 hrun .. 16 hrun + 15 of the strip; input byte i (relative to output 0's leftmost tap) is tap i - o of output o
+            const uint32_t* p = s_src + hrow * SPD + 4 * hrun;                                // dword holding staged byte 16 hrun (= output 0's column - R4)
+            float acc[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = 0.0f;
+            constexpr int NIN = 16 + 2 * R, NDW = (OFF + NIN + 3) / 4;
+#pragma unroll
+            for (int d = 0; d < NDW; ++d) {
+                const uint32_t v = p[d];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = 4 * d + b - OFF;
+                    if (i >= 0 && i < NIN) {
+                        const float a = (float)((v >> (8 * b)) & 0xffu);
+#pragma unroll
+                        for (int o = 0; o < 16; ++o)
+                            if (i - o >= 0 && i - o < KLEN) acc[o] = acc[o] + a * wt[i - o];
+                    }
+                }
+                if ((d & 3) == 3) {   // keep the loop from being reordered into one huge block (register pressure): every 16 input bytes the accumulators are pinned
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) asm volatile("" : "+v"(acc[o]));
+                }
+            }
+            int slot = base + hrow; slot = slot >= RR ? slot - RR : slot;
+            float4* out = ring + slot * GF_W + hrun;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[16 * q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+        __syncthreads();
+        const bool more = vb + GF_RB < v_end;
+        if (more) stage_load(vb + GF_RB);
+        {   // vertical: the RGBA kernel's pass, a quad's four columns in the four lanes of a float4
+            const int yo = vb - r + 4 * vg;
+            if (yo + 3 >= y0 && yo < y1 && xq < wq) {
+                int slot = base + 4 * vg - 2 * r;
+                slot = slot < 0 ? slot + RR : (slot >= RR ? slot - RR : slot);
+                constexpr int NIN = KLEN + 3, NG = (NIN + 3) / 4;
+                float4 acc[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 cur[4], nxt[4];
+                auto rows = [&](float4 (&d)[4], int first) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (first + k < NIN) { d[k] = ring[slot * GF_W + scol]; slot = slot + 1 >= RR ? 0 : slot + 1; }
+                    }
+                };
+                rows(cur, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 1 < NG) rows(nxt, 4 * (g + 1));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = 4 * g + k;
+                        if (i < NIN) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o)
+                                if (i - o >= 0 && i - o < KLEN) mac4x(acc[o], cur[k], wt[i - o]);
+                        }
+                    }
+                    gf_pin(acc);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (yo + o >= y0 && yo + o < y1)
+                        reinterpret_cast<uint32_t*>(dst)[((size_t)(yo + o) * w >> 2) + xq] = pack_round_rgba(acc[o].x, acc[o].y, acc[o].z, acc[o].w);
+            }
+        }
+        if (more) stage_store();
+        base += GF_RB; base = base >= RR ? base - RR : base;
+    }
+}
+
 } // namespace
 
 int g_fused_exact = 1; // pfxk_gauss_set_fused_exact (pfx_tune "gauss_fused_exact"): 0 = the bit-exact mode always through the two kernels (A/B, parity tests)
@@ -272,4 +407,35 @@ extern "C" hipError_t pfxk_gauss_fused_exact_chain(hipStream_t stream, const uin
                                                    const pfxk_chain* C, const uint8_t* d_luts)
 {
     return launch_fused_exact(stream, d_src, d_dst, d_wts_tap0, radius, w, h, 3, 0.0f, nullptr, C, d_luts);
+}
+
+// one-channel form (the drop shadow's alpha plane): w % 4 == 0, tight rows; bit-identical, element by element, to one channel of pfxk_gauss_fused_exact on (a, a, a, a)
+extern "C" hipError_t pfxk_gauss_plane_exact(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    if (radius < 1 || radius > GF_MAXR || (w & 3u) != 0 || ((uintptr_t)d_src & 3u) || ((uintptr_t)d_dst & 3u)) return hipErrorInvalidValue;
+    const int RR = 2 * radius + 1 + GF_RB, R4 = (radius + 3) & ~3, ND = (4 * GF_W + 2 * R4) / 4, SPD = ND + 1 + ((4 - ((ND + 1) & 3)) & 3) + 1;
+    const size_t lds = (size_t)RR * GF_W * 16 + (size_t)GF_RB * SPD * 4;
+    const int wq = (int)(w >> 2), strips = (wq + GF_W - 1) / GF_W;
+    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / lds));
+    const int sg_max = (strips + 7) / 8;
+    int nseg = std::max(1, 32 * wg_per_cu / sg_max);
+    nseg = std::min(nseg, std::max(1, (int)h / (8 * radius + 64)));
+    const int seg_rows = ((int)h + nseg - 1) / nseg;
+    nseg = ((int)h + seg_rows - 1) / seg_rows;
+    const dim3 grid(8u * (uint32_t)(sg_max * nseg));
+    auto go = [&](auto rc) -> hipError_t {
+        constexpr int R = decltype(rc)::value;
+        static lds_grant grant;
+        hipError_t e = grant_lds(grant, (const void*)gauss_plane_exact_kernel<R>, lds);
+        if (e) return e;
+        gauss_plane_exact_kernel<R><<<grid, GF_T, lds, stream>>>(d_src, d_dst, d_wts_tap0, (int)w, (int)h, seg_rows, nseg, strips);
+        return hipGetLastError();
+    };
+    switch (radius) {
+#define PFX_GP(R) case R: return go(std::integral_constant<int, R>{});
+        PFX_GP(1) PFX_GP(2) PFX_GP(3) PFX_GP(4) PFX_GP(5) PFX_GP(6) PFX_GP(7) PFX_GP(8) PFX_GP(9) PFX_GP(10) PFX_GP(11) PFX_GP(12) PFX_GP(13) PFX_GP(14) PFX_GP(15) PFX_GP(16)
+#undef PFX_GP
+    default: return hipErrorInvalidValue;
+    }
 }

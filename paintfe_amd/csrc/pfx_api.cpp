@@ -1623,6 +1623,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
     if (std::strcmp(key, "box_strip_fill") == 0) { pfxk_box_set_strip(-1, value, -1); return PFX_OK; }
     if (std::strcmp(key, "box_strip_nseg") == 0) { pfxk_box_set_strip(-1, 0, value); return PFX_OK; }
     if (std::strcmp(key, "box_two_pass") == 0) { pfxk_box_set_two_pass(value); return PFX_OK; }
+    if (std::strcmp(key, "shadow_plane") == 0) { ctx->shadow_plane_blur = value != 0; return PFX_OK; } // drop shadow: blur the alpha plane (1) or the RGBA expansion (0); identical results
     if (std::strcmp(key, "gauss_cols64") == 0) { pfxk_gauss_set_mfma_cols64(value); return PFX_OK; } // matrix-core Gaussian at 8 K blocks: 64-column (1) / 32-column (0) strips, same bits
     if (std::strcmp(key, "chain_fuse_heavy") == 0) { ctx->chain_fuse_heavy = value != 0; return PFX_OK; } // pfx_chain_dev: HSL / vibrance in a Gaussian's store too (measured: no gain)
     if (std::strcmp(key, "chain_mfma") == 0) { ctx->chain_mfma_epilogue = value != 0; return PFX_OK; } // pfx_chain_dev: the chain in the matrix-core Gaussian's store (1) or as its own launch (0)

@@ -390,22 +390,39 @@ int pfx_shadow_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32_t w,
     int32_t spread = 0;
     if (widen_radius) spread = f32_as_i32(roundf(fmaxf(blur_radius, 1.0f))); // render.rs:251
     PFX_REQUIRE(ctx, spread <= 4096, "drop shadow: spread too large");
-    PFX_TRY(pfx_reserve(ctx, ctx->fx_a, 2 * n));
-    PFX_TRY(pfx_reserve(ctx, ctx->fx_b, 4 * n));
-    const void* alpha_img = ctx->fx_b.p;
+    // The reference expands the shadow's alpha plane to (a, a, a, a), blurs all four channels and reads one back (render.rs:291-301).  Where the bit-exact fused
+    // Gaussian applies (the effect's default mode, radius <= 16) and rows are dword-aligned, the PLANE is blurred instead — per element the same products and sums
+    // (k_gauss_exact.hip: gauss_plane_exact_kernel) — and the composite reads the plane; otherwise the RGBA image goes through the Gaussian as before.
+    const int g_radius = blur_radius > 0.5f ? pfx_host_gaussian_radius(blur_radius) : 0;
+    const bool plane_path = (w & 3u) == 0 && !ctx->gauss_fast_effects && ctx->shadow_plane_blur &&
+                            (g_radius == 0 || (g_radius >= 1 && g_radius <= pfxk_gauss_fused_exact_max_radius()));
+    PFX_TRY(pfx_reserve(ctx, ctx->fx_a, 2 * n + 8));
+    if (!plane_path) PFX_TRY(pfx_reserve(ctx, ctx->fx_b, 4 * n));
+    uint8_t* plane_a = (uint8_t*)ctx->fx_a.p;
+    uint8_t* plane_b = plane_a + ((n + 3) & ~(size_t)3);       // dword-aligned second plane
+    const void* alpha_img = plane_path ? (const void*)plane_a : ctx->fx_b.p;
     {
         pfx_timer t(ctx, "shadow_alpha");
-        PFX_HIP(ctx, pfxk_shadow_alpha(ctx->stream, (const uint8_t*)src_dev, (uint8_t*)ctx->fx_a.p, (uint8_t*)ctx->fx_a.p + n, (uint8_t*)ctx->fx_b.p,
+        PFX_HIP(ctx, pfxk_shadow_alpha(ctx->stream, (const uint8_t*)src_dev, plane_a, plane_b, plane_path ? nullptr : (uint8_t*)ctx->fx_b.p,
                                        offset_x, offset_y, spread, w, h));
     }
     if (blur_radius > 0.5f) { // render.rs:297
-        PFX_TRY(pfx_reserve(ctx, ctx->st_aux2, 4 * n));
-        PFX_TRY(effect_gaussian(ctx, ctx->fx_b.p, ctx->st_aux2.p, w, h, blur_radius));
-        alpha_img = ctx->st_aux2.p;
+        if (plane_path) {
+            const float* wts = nullptr;
+            PFX_TRY(pfx_int_gauss_exact_weights(ctx, blur_radius, &wts));
+            pfx_timer t(ctx, "gauss_plane");
+            PFX_HIP(ctx, pfxk_gauss_plane_exact(ctx->stream, plane_a, plane_b, wts, g_radius, w, h));
+            alpha_img = plane_b;
+        } else {
+            PFX_TRY(pfx_reserve(ctx, ctx->st_aux2, 4 * n));
+            PFX_TRY(effect_gaussian(ctx, ctx->fx_b.p, ctx->st_aux2.p, w, h, blur_radius));
+            alpha_img = ctx->st_aux2.p;
+        }
     }
     pfxk_fx_params P{};
     P.f[0] = opacity;
     P.u[0] = pack4(color);
+    P.u[1] = plane_path ? 1u : 0u;
     P.aux0 = alpha_img;
     return launch_fx(ctx, PFXK_FX2_SHADOW, "shadow_composite", src_dev, dst_dev, mask_dev, P, w, h);
 }

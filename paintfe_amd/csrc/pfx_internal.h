@@ -49,6 +49,7 @@ struct pfx_ctx {
     pfx_devbuf fx_a, fx_b; // effect-bank scratch (crystallize cell table, drop-shadow planes)
     // small parameter buffers
     pfx_devbuf d_desc, d_adj, d_chunks, d_wts, d_lut, d_pts, d_misc;
+    bool shadow_plane_blur = true;       // pfx_tune "shadow_plane": the drop shadow blurs its one-channel alpha plane (1) or the reference's (a, a, a, a) image (0); same bits
     bool chain_fuse_heavy = false;       // pfx_tune "chain_fuse_heavy": HSL / vibrance ride in a Gaussian's store as well (A/B; parity tests run both)
     bool chain_mfma_epilogue = true;     // pfx_tune "chain_mfma": 0 = a default-mode Gaussian in a chain runs as its own launch (A/B of the fused store)
     pfx_devbuf st_chain, d_chain_luts;   // pfx_chain_dev: ping-pong image between two stencil stages; the tables of a chain's LUT ops (PFXK_CHAIN_LUTS x 1024)

@@ -88,6 +88,8 @@ void       pfxk_gauss_set_mfma_segments(int n); // tuning knob of the matrix-cor
 /* bit-exact mode, radii 1 .. pfxk_gauss_fused_exact_max_radius(): both passes in one kernel, the f32 intermediate in an LDS ring (k_gauss.hip) */
 void pfxk_gauss_set_fused_exact(int on);
 int pfxk_gauss_fused_exact_max_radius(void);
+/* one-channel form (w % 4 == 0, tight rows, radii 1 .. pfxk_gauss_fused_exact_max_radius()): element by element what one channel of pfxk_gauss_fused_exact gives on (a, a, a, a) */
+hipError_t pfxk_gauss_plane_exact(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h);
 hipError_t pfxk_gauss_fused_exact(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, const float* d_wts_tap0, int radius, uint32_t w, uint32_t h,
                                   int epilogue /* 0 the blur, 1 sharpen, 2 glow: combine with the source in the store (k_effects.hip: combine_kernel) */, float p0, const uint8_t* d_mask);
 hipError_t pfxk_gauss_h(hipStream_t stream, const uint8_t* d_src, float* d_tmp, const float* d_wts_tap0, int radius,

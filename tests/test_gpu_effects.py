@@ -232,3 +232,26 @@ def test_effect_argument_errors(gpu):
         gpu.r.outline_core(img, 100000, (0, 0, 0, 255))
     with pytest.raises(PfxError):
         gpu.r.add_noise_core(img, 1.0, 7, False, 1, 1.0, 1)
+
+
+def test_drop_shadow_blurs_its_alpha_plane_with_the_same_bits(gpu, oracle):
+    """round 6: where the bit-exact fused Gaussian applies (radius <= 16, rows dword-aligned) the drop shadow blurs its ONE-CHANNEL alpha plane instead of the reference's
+    (a, a, a, a) expansion (render.rs:291-301) — per element the same products and sums.  Equal to the oracle and to the RGBA form (pfx_tune "shadow_plane" = 0) for blur
+    radii on both sides of every switch (none / fused / beyond 16), with and without widening and a selection"""
+    rng = np.random.default_rng(91)
+    for (w, h) in [(256, 96), (64, 64), (1024, 40), (4, 9), (260, 33)]:
+        img = shapes_image(w, h, seed=w + h)
+        mask = None if (w // 4) % 2 else ((rng.random((h, w)) < 0.6).astype(np.uint8) * 255)
+        for blur in (0.4, 1.0, 3.0, 5.33, 6.0):
+            for widen in (False, True):
+                kw = dict(offset_x=5, offset_y=-3, blur_radius=blur, widen_radius=widen, color=(20, 40, 200, 230), opacity=0.8, mask=mask)
+                want = oracle.effect("shadow", img, **kw)
+                try:
+                    gpu.r.tune("shadow_plane", 1)
+                    got = gpu.effect("shadow", img, **kw)
+                    gpu.r.tune("shadow_plane", 0)
+                    old = gpu.effect("shadow", img, **kw)
+                finally:
+                    gpu.r.tune("shadow_plane", 1)
+                check(got, want, EXACT, f"drop shadow (plane) {w}x{h} blur {blur} widen {widen}")
+                check(old, want, EXACT, f"drop shadow (rgba) {w}x{h} blur {blur} widen {widen}")

@@ -143,7 +143,7 @@ def main() -> int:
     timed("outline width=2", ["outline"], lambda: r.outline_dev(s, d, w, h, 2, (0, 0, 255, 255)), px, 8, "7x7 window search on a bit plane of alpha != 0")
     timed("sharpen amount=1 radius=1", ["sharpen", "gauss_h", "gauss_v"], lambda: r.sharpen_dev(s, d, w, h, 1.0, 1.0), px, 8, "bit-exact Gaussian + combine in one kernel (k_gauss_exact.hip)")
     timed("glow radius=3 intensity=0.5", ["glow", "gauss_h", "gauss_v"], lambda: r.glow_dev(s, d, w, h, 3.0, 0.5), px, 8, "bit-exact Gaussian + combine in one kernel")
-    timed("drop shadow blur=3", ["shadow_alpha", "gauss_mfma", "gauss_fused", "gauss_h", "gauss_v", "shadow_composite"], lambda: r.shadow_dev(s, d, w, h, 5, 5, 3.0, False, (0, 0, 0, 255), 0.8), px, 8)
+    timed("drop shadow blur=3", ["shadow_alpha", "gauss_plane", "gauss_mfma", "gauss_fused", "gauss_h", "gauss_v", "shadow_composite"], lambda: r.shadow_dev(s, d, w, h, 5, 5, 3.0, False, (0, 0, 0, 255), 0.8), px, 8)
     half = torch.empty((h // 2, w // 2, 4), dtype=torch.uint8, device=dev)
     timed("resize 8K -> 4K bilinear", ["resize"], lambda: r.resize_image_dev(s, w, h, half.data_ptr(), w // 2, h // 2, "bilinear"), px, 5, "4 B read + 1 B/px (quarter-size) written")
     timed("resize 8K -> 4K lanczos3", ["resize"], lambda: r.resize_image_dev(s, w, h, half.data_ptr(), w // 2, h // 2, "lanczos3"), px, 5)
