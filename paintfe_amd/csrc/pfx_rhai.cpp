@@ -18,6 +18,8 @@
 #include <limits>
 #include <set>
 
+#include <pthread.h>
+
 namespace rhai {
 
 namespace {
@@ -25,9 +27,58 @@ constexpr int ST_SCRIPT = -6, ST_UNSUPPORTED = -5; // PFX_ERR_SCRIPT / PFX_ERR_U
 constexpr int MAX_CALL_LEVELS = 64;                // scripting.rs:289
 constexpr size_t MAX_STRING = 10000, MAX_ARRAY = 10000; // scripting.rs:291-292
 
+// ---- native stack ------------------------------------------------------------------------------------------------------
+// The sandbox allows 64 call levels of expressions nested 64 deep (scripting.rs:289-290): some 4 000 evaluator frames, more native stack
+// than a caller's thread may have (a 1 MB thread stack ends at ~30 x 63).  Interp::run therefore evaluates on a thread of its own with
+// RUN_STACK_BYTES of stack, and every evaluator / parser frame checks its address against the low end of whichever stack it is on, so
+// that exhaustion is the script error "Stack overflow" (what Rhai reports for its call-level limit), never a fault.
+#if !defined(__has_feature)
+#define __has_feature(x) 0
+#endif
+#if defined(__SANITIZE_ADDRESS__) || __has_feature(address_sanitizer)
+constexpr size_t RUN_STACK_BYTES = 512u << 20, STACK_MARGIN = 1u << 20; // instrumented frames are several times larger
+#else
+constexpr size_t RUN_STACK_BYTES = 64u << 20, STACK_MARGIN = 256u << 10;
+#endif
+thread_local uintptr_t t_stack_floor = 0; // frames below this address fail; 0 = unknown (no check)
+
+uintptr_t this_threads_stack_floor()
+{
+    pthread_attr_t at;
+    if (pthread_getattr_np(pthread_self(), &at) != 0) return 0;
+    void* lo = nullptr;
+    size_t size = 0;
+    const int rc = pthread_attr_getstack(&at, &lo, &size);
+    pthread_attr_destroy(&at);
+    if (rc != 0 || size <= 2 * STACK_MARGIN) return 0;
+    return (uintptr_t)lo + STACK_MARGIN;
+}
+struct StackFloorScope {
+    uintptr_t saved;
+    StackFloorScope() : saved(t_stack_floor) { t_stack_floor = this_threads_stack_floor(); }
+    ~StackFloorScope() { t_stack_floor = saved; }
+};
+inline bool stack_left() { return (uintptr_t)__builtin_frame_address(0) > t_stack_floor; }
+
 struct Throw { Error e; std::shared_ptr<Value> value; }; // value: what a script's `throw` statement raised
 [[noreturn]] void fail(const std::string& m, int line, int col, int status = ST_SCRIPT) { throw Throw{{m, line, col, status}}; }
 [[noreturn]] void fail(const std::string& m, const Node& n, int status = ST_SCRIPT) { fail(m, n.line, n.col, status); }
+
+// Engine::set_max_array_size (scripting.rs:292) counts the elements of nested arrays too (rhai calc_data_sizes): an array's size is its length
+// plus the sizes of the arrays it holds.  Counting stops at the limit, which also bounds how deep a value can nest (copies and destructors recurse).
+size_t array_total(const Value& v, size_t budget)
+{
+    size_t n = v.a->size();
+    for (const Value& e : *v.a) {
+        if (n > budget) break;
+        if (e.t == Value::Array) n += array_total(e, budget - n);
+    }
+    return n;
+}
+void check_array(const Value& v, const Node& at)
+{
+    if (v.t == Value::Array && array_total(v, MAX_ARRAY) > MAX_ARRAY) fail("Size of array too large", at);
+}
 
 // ---- float formatting (rhai FloatWrapper Display) ---------------------------------------------------------------------
 void shortest_digits(double v, std::string& digits, int& exp10)
@@ -67,14 +118,14 @@ std::string fmt_float(double v)
 }
 } // namespace
 
-Value Value::copy() const
+// Arrays are value types.  A copy shares the element vector until one side writes: every write goes through own() (Eval::lvalue for `a[i] = ..`,
+// the mutating methods' receiver), which takes a private one-level clone first if the vector is shared.  Observable behaviour is that of an eager deep
+// copy; the cost of passing a nested array around no longer grows with its size (a loop of `a = [a]` was quadratic).
+Value Value::copy() const { return *this; }
+std::vector<Value>& Value::own()
 {
-    if (t != Array || !a) return *this;
-    Value x = *this;
-    x.a = std::make_shared<std::vector<Value>>();
-    x.a->reserve(a->size());
-    for (const Value& e : *a) x.a->push_back(e.copy());
-    return x;
+    if (a.use_count() > 1) a = std::make_shared<std::vector<Value>>(*a);
+    return *a;
 }
 std::string Value::to_string() const
 {
@@ -323,7 +374,7 @@ private:
     int depth_ = 0;
     struct DepthGuard {
         Parser& p;
-        explicit DepthGuard(Parser& q, const Tok& t) : p(q) { if (++p.depth_ > 64) fail("Expression exceeds maximum complexity", t.line, t.col); } // scripting.rs:290
+        explicit DepthGuard(Parser& q, const Tok& t) : p(q) { if (++p.depth_ > 64 || !stack_left()) fail("Expression exceeds maximum complexity", t.line, t.col); } // scripting.rs:290
         ~DepthGuard() { --p.depth_; }
     };
     void eat() { cur_ = lx_.next(); }
@@ -847,8 +898,9 @@ Value binary_op(const std::string& op, const Value& a, const Value& b, const Nod
     if (a.t == V::Array && b.t == V::Array && op == "+") {
         std::vector<Value> r = *a.a;
         for (const Value& e : *b.a) r.push_back(e.copy());
-        if (r.size() > MAX_ARRAY) fail("Size of array too large", at);
-        return V::from_array(std::move(r));
+        V sum = V::from_array(std::move(r));
+        check_array(sum, at);
+        return sum;
     }
     if (a.t == V::Unit && b.t == V::Unit && (op == "==" || op == "!=")) return V::from_bool(op == "==");
     if (op == "==") return V::from_bool(false); // different types never compare equal
@@ -958,7 +1010,7 @@ struct Eval {
             const int64_t n = (int64_t)base->a->size();
             int64_t i = idx.i < 0 ? n + idx.i : idx.i;
             if (i < 0 || i >= n) fail("Array index " + std::to_string(idx.i) + " out of bounds: only " + std::to_string(n) + " elements in the array", target);
-            return &(*base->a)[(size_t)i];
+            return &base->own()[(size_t)i];
         }
         fail("Cannot assign to this expression", target);
     }
@@ -1094,10 +1146,11 @@ struct Eval {
         }
         // array mutators act on the receiver variable
         if (n >= 1 && is(0, V::Array) && recv_lvalue && recv_lvalue->t == V::Array) {
-            std::vector<Value>& arr = *recv_lvalue->a;
+            std::vector<Value>& arr = recv_lvalue->own();
             if (name == "push" && n == 2) {
                 if (arr.size() >= MAX_ARRAY) fail("Size of array too large", at);
                 arr.push_back(a[1].copy());
+                if (a[1].t == V::Array) check_array(*recv_lvalue, at);
                 return true;
             }
             if (name == "pop" && n == 1) { if (!arr.empty()) { out = arr.back(); arr.pop_back(); } return true; }
@@ -1109,6 +1162,7 @@ struct Eval {
                 int64_t i = a[1].i < 0 ? std::max<int64_t>(0, (int64_t)arr.size() + a[1].i) : std::min<int64_t>(a[1].i, (int64_t)arr.size());
                 if (arr.size() >= MAX_ARRAY) fail("Size of array too large", at);
                 arr.insert(arr.begin() + i, a[2].copy());
+                if (a[2].t == V::Array) check_array(*recv_lvalue, at);
                 return true;
             }
             if (name == "remove" && n == 2 && is(1, V::Int)) {
@@ -1118,7 +1172,7 @@ struct Eval {
             }
             if (name == "append" && n == 2 && is(1, V::Array)) {
                 for (const Value& e : *a[1].a) arr.push_back(e.copy());
-                if (arr.size() > MAX_ARRAY) fail("Size of array too large", at);
+                check_array(*recv_lvalue, at);
                 return true;
             }
         }
@@ -1166,6 +1220,7 @@ struct Eval {
     Value eval(const Node& n)
     {
         tick(n);
+        if (!stack_left()) fail("Stack overflow", n);
         switch (n.k) {
         case NK::IntLit: return Value::from_int(n.ival);
         case NK::FloatLit: return Value::from_float(n.fval);
@@ -1179,8 +1234,14 @@ struct Eval {
         }
         case NK::ArrayLit: {
             std::vector<Value> v;
-            for (const auto& k : n.kids) v.push_back(eval(*k).copy());
-            return Value::from_array(std::move(v));
+            bool nested = false;
+            for (const auto& k : n.kids) {
+                v.push_back(eval(*k).copy());
+                nested |= v.back().t == Value::Array;
+            }
+            Value lit = Value::from_array(std::move(v));
+            if (nested) check_array(lit, n);
+            return lit;
         }
         case NK::Var: {
             Var* v = find(n.text);
@@ -1275,6 +1336,11 @@ struct Eval {
             if (is_const) fail("Cannot modify constant: " + (n.kids[0]->k == NK::Var ? n.kids[0]->text : std::string("<indexed>")), n);
             if (n.text == "=") *dst = rhs.copy();
             else *dst = binary_op(n.text.substr(0, n.text.size() - 1), *dst, rhs, n);
+            if (n.kids[0]->k == NK::Index && dst->t == Value::Array) { // an array stored into an element: the whole container is what the limit measures
+                const Node* root = n.kids[0].get();
+                while (root->k == NK::Index) root = root->kids[0].get();
+                if (Var* holder = root->k == NK::Var ? find(root->text) : nullptr) check_array(holder->v, n);
+            }
             return Value();
         }
         case NK::While: {
@@ -1368,9 +1434,17 @@ struct Eval {
     }
 };
 
-bool Interp::run(const char* source, Error& err)
+namespace {
+struct RunCall { Interp* in; const char* source; Error* err; bool ok; };
+}
+
+// The body of a run, on the calling thread.  Everything a script can raise is a Throw; anything else (allocation failure) becomes an error too,
+// because this may be the top frame of a thread.
+bool Interp::run_here(const char* source, Error& err)
 {
+    StackFloorScope floor;
     try {
+        if (on_run_thread) on_run_thread();
         Parser p(source);
         NodeP prog = p.program();
         for (const auto& st : prog->kids)
@@ -1389,11 +1463,35 @@ bool Interp::run(const char* source, Error& err)
         err = t.e;
         if (!err.status) err.status = ST_SCRIPT;
         return false;
+    } catch (const std::exception& e) {
+        err = {std::string("script runtime: ") + e.what(), 0, 0, ST_SCRIPT};
+        return false;
     }
+}
+
+bool Interp::run(const char* source, Error& err)
+{
+    RunCall call{this, source, &err, false};
+    pthread_attr_t at;
+    pthread_t th;
+    bool started = false;
+    if (pthread_attr_init(&at) == 0) {
+        if (pthread_attr_setstacksize(&at, RUN_STACK_BYTES) == 0)   // reserved address space; pages are touched only as deep as the script goes
+            started = pthread_create(&th, &at, [](void* q) -> void* {
+                auto* c = static_cast<RunCall*>(q);
+                c->ok = c->in->run_here(c->source, *c->err);
+                return nullptr;
+            }, &call) == 0;
+        pthread_attr_destroy(&at);
+    }
+    if (!started) return run_here(source, err); // no address space for the stack: the caller's stack, still guarded
+    pthread_join(th, nullptr);
+    return call.ok;
 }
 
 bool Interp::call_closure(const Closure& c, std::vector<Value>& args, Value& out, Error& err)
 {
+    StackFloorScope floor;
     try {
         Eval ev(*this);
         Node at;

@@ -45,7 +45,8 @@ struct Value {
     static Value from_bool(bool v) { Value x; x.t = Bool; x.b = v; return x; }
     static Value from_str(const std::string& v) { Value x; x.t = Str; x.s = std::make_shared<std::string>(v); return x; }
     static Value from_array(std::vector<Value> v) { Value x; x.t = Array; x.a = std::make_shared<std::vector<Value>>(std::move(v)); return x; }
-    Value copy() const; // arrays are value types in Rhai: assignment / argument passing clones
+    Value copy() const; // arrays are value types in Rhai: assignment / argument passing clones (lazily: see own())
+    std::vector<Value>& own(); // Array only: the element vector, made private to this value before a write
     std::string to_string() const;
     const char* type_name() const; // as Rhai prints it in "Function not found" messages
 };
@@ -126,7 +127,9 @@ struct Host {
 class Interp {
 public:
     explicit Interp(Host* host) : host_(host) {}
-    bool run(const char* source, Error& err);      // parse + execute
+    bool run(const char* source, Error& err);      // parse + execute, on a thread of its own with a stack sized for the sandbox's depth limits
+    bool run_here(const char* source, Error& err); // the same on the caller's thread (stack use is checked either way)
+    std::function<void()> on_run_thread;          // called first on the thread that evaluates (the script host binds its HIP device there)
     uint64_t ops() const { return ops_; }
     uint64_t max_ops = 50000000ull;               // Engine::set_max_operations, scripting.rs:288 (lowered by the hardening harness only)
     std::vector<std::string> console;

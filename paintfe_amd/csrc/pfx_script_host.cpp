@@ -571,6 +571,7 @@ try {
         host.host_mask_valid = true;
     }
     rhai::Interp in(&host);
+    in.on_run_thread = [ctx] { (void)hipSetDevice(ctx->device); };   // the device binding is per thread; the host functions launch on ctx->stream
     rhai::Error err;
     const bool ok = in.run(source, err);
     int st = ok ? PFX_OK : (err.status ? err.status : PFX_ERR_SCRIPT);

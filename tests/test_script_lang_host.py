@@ -110,6 +110,53 @@ def test_limits_and_unsupported_constructs():
     assert err("let p = get_pixel(0, 0);").status == -5
 
 
+def test_nested_arrays_count_against_the_array_size_limit():
+    """Engine::set_max_array_size(10_000), scripting.rs:292: rhai sizes an array as its length plus the sizes of the arrays it holds,
+    which also bounds how deep a value can nest"""
+    assert "Size of array too large" in str(err("let a = []; for i in 0..20000 { a = [a]; } print(1);"))
+    assert "Size of array too large" in str(err("let a = [0]; for i in 0..20000 { let b = [0]; b[0] = a; a = b; } print(1);"))
+    assert "Size of array too large" in str(err("let a = []; for i in 0..200 { let b = []; for j in 0..100 { b.push(j); } a.push(b); } print(a.len());"))
+    assert "Size of array too large" in str(err("let b = []; for j in 0..6000 { b.push(j); } let c = [b, b]; print(c.len());"))
+    assert out("let a = []; for i in 0..90 { let b = []; for j in 0..100 { b.push(j); } a.push(b); } print(a.len());") == ["90"]
+    assert out("let a = [0]; for i in 0..4000 { let b = [0]; b[0] = a; a = b; } print(1);") == ["1"]
+
+
+def test_arrays_are_value_types_however_they_are_shared_internally():
+    """copies are lazy inside the runtime (a write clones one level first); what a script sees must be rhai's eager clone-on-assignment"""
+    assert out("let a = [1,2,3]; let b = a; b[0] = 9; print(a); print(b);") == ["[1, 2, 3]", "[9, 2, 3]"]
+    assert out("let a = [[1,2],[3,4]]; let b = a; b[0][1] = 7; a[1][0] = 0; print(a); print(b);") == ["[[1, 2], [0, 4]]", "[[1, 7], [3, 4]]"]
+    assert out("let a = [1]; a.push(a); a[1].push(5); print(a);") == ["[1, [1, 5]]"]
+    assert out("fn f(x) { x.push(1); x } let a = []; let b = f(a); print(a.len()); print(b.len());") == ["0", "1"]
+    assert out("let a = [1,2]; let c = || a; a.push(3); print(c.call()); print(a);") == ["[1, 2]", "[1, 2, 3]"]
+    assert out("let a = [1,2]; for x in a { a.push(x); } print(a);") == ["[1, 2, 1, 2]"]
+    assert out("let a = [[0]]; let row = a[0]; row[0] = 5; print(a); print(row); a[0][0] += 2; print(a); print(row);") == ["[[0]]", "[5]", "[[2]]", "[5]"]
+    assert out("let a = [1,2]; let b = a + a; b[0] = 7; print(a); print(b); a += [3]; print(a);") == ["[1, 2]", "[7, 2, 1, 2]", "[1, 2, 3]"]
+    assert out("let a = [3,1,2]; let b = a; b.reverse(); print(a); print(b); let c = b; c.clear(); print(b.len()); print(c.len());") == \
+        ["[3, 1, 2]", "[2, 1, 3]", "3", "0"]
+
+
+def test_call_levels_times_expression_depth_fit_whatever_stack_the_caller_has():
+    """set_max_call_levels(64) x set_max_expr_depths(64, 64), scripting.rs:289-290: the deepest script the sandbox admits needs megabytes of native
+    stack; the interpreter brings its own, so a caller on a 256 KB thread stack gets the same answers (and never a fault)"""
+    import threading
+    deep = "fn f(n) { if n == 0 { 0 } else { 1 + " + "(1 + " * 28 + "f(n - 1)" + ")" * 28 + " } }\nprint(f(%d));"
+    got = {}
+
+    def small_stack():
+        got["deep"] = out(deep % 63)
+        got["level"] = str(err(deep % 70))
+        got["closures"] = out("let g = |n, me| if n == 0 { 0 } else { 2 + me.call(n - 1, me) }; print(g.call(60, g));")
+
+    threading.stack_size(256 * 1024)
+    try:
+        t = threading.Thread(target=small_stack)
+        t.start()
+        t.join()
+    finally:
+        threading.stack_size(0)
+    assert got["deep"] == [str(63 * 29)] and "Stack overflow" in got["level"] and got["closures"] == ["120"], got
+
+
 def test_switch_expression():
     src = """
     fn kind(v) {
