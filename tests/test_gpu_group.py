@@ -1,6 +1,9 @@
 """pfx_group_* (multi-GPU behind the C ABI): band flatten + xGMI halo exchange + blur + all-gather must equal the single-GPU
 result bit for bit.  On a 1-GPU box the members share device 0 (the whole code path runs, peer copies degenerate to
-device-to-device copies); with >= 2 visible devices the same test runs one member per device."""
+device-to-device copies); with >= 2 visible devices the same test runs one member per device.
+
+The comparison here is group vs the single-GPU C-ABI calls (pfx_flatten_dev / pfx_gaussian_dev / ...), NOT group vs the oracle: those single-GPU calls are the
+ones tests/test_gpu_parity.py pins to the oracle bit for bit on the same generators (tests/inputs.py), so equality with them carries the oracle parity over."""
 import numpy as np
 import pytest
 
