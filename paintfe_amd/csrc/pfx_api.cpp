@@ -443,7 +443,7 @@ int pfx_flatten_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, const void*
                     const pfx_layer_info* layers, uint32_t n_layers, uint32_t w, uint32_t h, void* dst_dev)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, dst_dev && w && h && (n_layers == 0 || layer_ptrs_dev), "pfx_flatten_dev: bad arguments");
+    PFX_REQUIRE(ctx, dst_dev && pfx_dims_ok(w, h) && (n_layers == 0 || layer_ptrs_dev), "pfx_flatten_dev: bad arguments");
     PFX_TRY(pfx_use(ctx));
     return flatten_common(ctx, layer_ptrs_dev, mask_ptrs_dev, layers, n_layers, w, h, false, dst_dev);
 }
@@ -521,6 +521,7 @@ int pfx_gaussian_blur_band_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev,
 {
     PFX_TRY(check_img(ctx, src_dev, dst_dev, w, h, "pfx_gaussian_blur_dev"));
     PFX_TRY(check_disjoint(ctx, src_dev, dst_dev, w, h, "pfx_gaussian_blur_dev", true)); // in place: the two-pass kernels (through tmp)
+    PFX_REQUIRE(ctx, (uint64_t)first_row + h <= 0x7fffffffull, "pfx_gaussian_blur_band_dev: band outside any image");   // the kernels carry image rows in 32-bit signed integers
     // radius first: a huge sigma must be refused before a tap array of that size is built (the C ABI must not throw)
     const int radius = pfx_host_gaussian_radius(sigma);
     if (radius > pfxk_gauss_max_radius())
@@ -832,7 +833,7 @@ int pfx_warp_displacement_band_dev(pfx_ctx* ctx, const void* src_dev, uint32_t s
                                    uint32_t band_rows, void* dst_band_dev, uint32_t first_row)
 {
     PFX_TRY(check_img(ctx, src_dev, dst_band_dev, w, band_rows, "pfx_warp_displacement_dev"));
-    PFX_REQUIRE(ctx, disp_band_dev && sw && sh, "pfx_warp_displacement_dev: bad arguments");
+    PFX_REQUIRE(ctx, disp_band_dev && pfx_dims_ok(sw, sh), "pfx_warp_displacement_dev: bad arguments");
     PFX_REQUIRE(ctx, (uint64_t)first_row + band_rows <= 0x7fffffffull, "pfx_warp_displacement_dev: band outside any image");
     PFX_TRY(check_disjoint2(ctx, src_dev, sw, sh, dst_band_dev, w, band_rows, "pfx_warp_displacement_dev")); // the SOURCE's extent: it may be larger than the output
     pfx_timer t(ctx, "warp_displacement");
@@ -925,7 +926,7 @@ int pfx_mesh_displacement_dev(pfx_ctx* ctx, const float* orig_pts_xy, const floa
                               uint32_t w, uint32_t h, void* disp_dev)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, disp_dev && w && h, "pfx_mesh_displacement_dev: bad arguments");
+    PFX_REQUIRE(ctx, disp_dev && pfx_dims_ok(w, h), "pfx_mesh_displacement_dev: bad arguments");
     PFX_TRY(pfx_use(ctx));
     const float *d_orig, *d_def;
     PFX_TRY(upload_points(ctx, orig_pts_xy, deformed_pts_xy, cols, rows, &d_orig, &d_def));
@@ -1326,7 +1327,7 @@ int pfx_composite_region(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_i
                          uint32_t y, uint32_t rw, uint32_t rh, uint8_t* dst_region)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, dst_region && w && h && rw && rh && x + rw <= w && y + rh <= h, "pfx_composite: bad arguments");
+    PFX_REQUIRE(ctx, dst_region && pfx_dims_ok(w, h) && pfx_rect_inside(x, y, rw, rh, w, h), "pfx_composite: bad arguments");
     PFX_TRY(pfx_use(ctx));
     PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
     if (rw == w && rh == h) {
@@ -1350,7 +1351,7 @@ int pfx_composite_preview(pfx_ctx* ctx, uint32_t w, uint32_t h, const pfx_layer_
                           const uint8_t* preview_chunk_present, const pfx_preview* preview, uint8_t* dst)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, dst && w && h, "pfx_composite_preview: bad arguments");
+    PFX_REQUIRE(ctx, dst && pfx_dims_ok(w, h), "pfx_composite_preview: bad arguments");
     if (!preview_pixels) return pfx_composite(ctx, w, h, layers, n_layers, dst);
     PFX_REQUIRE(ctx, preview != nullptr, "pfx_composite_preview: null preview description");
     PFX_TRY(pfx_use(ctx));
@@ -1374,7 +1375,7 @@ int pfx_flatten_preview_dev(pfx_ctx* ctx, const void* const* layer_ptrs_dev, con
                             const pfx_preview* preview, void* dst_dev)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, dst_dev && w && h && (n_layers == 0 || layer_ptrs_dev) && (!preview_dev || preview), "pfx_flatten_preview_dev: bad arguments");
+    PFX_REQUIRE(ctx, dst_dev && pfx_dims_ok(w, h) && (n_layers == 0 || layer_ptrs_dev) && (!preview_dev || preview), "pfx_flatten_preview_dev: bad arguments");
     PFX_TRY(pfx_use(ctx));
     preview_arg pv;
     pv.d_pixels = preview_dev;
@@ -1402,7 +1403,7 @@ int pfx_blend_pixels(pfx_ctx* ctx, const uint8_t* base, const uint8_t* top, uint
 int pfx_warp_displacement(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_t sh, const float* disp_xy, uint32_t w, uint32_t h, uint8_t* dst)
 {
     PFX_TRY(check_img(ctx, src, dst, w, h, "pfx_warp_displacement"));
-    PFX_REQUIRE(ctx, disp_xy && sw && sh, "pfx_warp_displacement: bad arguments");
+    PFX_REQUIRE(ctx, disp_xy && pfx_dims_ok(sw, sh), "pfx_warp_displacement: bad arguments");
     PFX_TRY(pfx_reserve(ctx, ctx->st_in, img_bytes(sw, sh)));
     PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
     PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 8));
@@ -1417,7 +1418,7 @@ int pfx_warp_displacement(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_
 int pfx_warp_set_source(pfx_ctx* ctx, const uint8_t* src, uint32_t sw, uint32_t sh)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, src && sw && sh, "pfx_warp_set_source: bad arguments");
+    PFX_REQUIRE(ctx, src && pfx_dims_ok(sw, sh), "pfx_warp_set_source: bad arguments");
     PFX_TRY(pfx_use(ctx));
     ctx->warp_src_w = ctx->warp_src_h = 0;
     PFX_TRY(pfx_reserve(ctx, ctx->warp_src, img_bytes(sw, sh)));
@@ -1437,7 +1438,7 @@ int pfx_warp_invalidate_source(pfx_ctx* ctx)
 int pfx_warp_displacement_cached(pfx_ctx* ctx, const float* disp_xy, uint32_t w, uint32_t h, uint8_t* dst)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, disp_xy && dst && w && h, "pfx_warp_displacement_cached: bad arguments");
+    PFX_REQUIRE(ctx, disp_xy && dst && pfx_dims_ok(w, h), "pfx_warp_displacement_cached: bad arguments");
     PFX_REQUIRE(ctx, ctx->warp_src_w != 0, "pfx_warp_displacement_cached: no source (pfx_warp_set_source, or it was invalidated)");
     PFX_TRY(pfx_use(ctx));
     PFX_TRY(pfx_reserve(ctx, ctx->st_out, img_bytes(w, h)));
@@ -1451,7 +1452,7 @@ int pfx_mesh_displacement(pfx_ctx* ctx, const float* orig_pts_xy, const float* d
                           uint32_t w, uint32_t h, float* disp_xy_out)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, disp_xy_out && w && h, "pfx_mesh_displacement: bad arguments");
+    PFX_REQUIRE(ctx, disp_xy_out && pfx_dims_ok(w, h), "pfx_mesh_displacement: bad arguments");
     PFX_TRY(pfx_use(ctx));
     PFX_TRY(pfx_reserve(ctx, ctx->st_tmp, (size_t)w * h * 8));
     PFX_TRY(pfx_mesh_displacement_dev(ctx, orig_pts_xy, deformed_pts_xy, cols, rows, w, h, ctx->st_tmp.p));
@@ -1490,7 +1491,8 @@ int pfx_brush_stamps(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h
 int pfx_brush_line_ex(pfx_ctx* ctx, uint8_t* target_inout, uint32_t w, uint32_t h, const pfx_brush* brush, const pfx_brush_dynamics* dyn, float x0,
                       float y0, float x1, float y1, const uint8_t* selection)
 {
-    if (!ctx) return PFX_ERR_INVALID;
+    PFX_TRY(check_img(ctx, target_inout, target_inout, w, h, "pfx_brush_line"));   // before the "no stamps" early return: bad arguments are bad whatever the line
+    PFX_REQUIRE(ctx, brush != nullptr, "pfx_brush_line: null brush");
     std::vector<float> pts;
     pfx_host_line_points(x0, y0, x1, y1, w, h, pts);
     if (pts.empty()) return PFX_OK;
@@ -1635,6 +1637,7 @@ int pfx_tune(pfx_ctx* ctx, const char* key, int value)
 int pfx_flatten_stats(pfx_ctx* ctx, uint64_t out[8], int reset)
 {
     if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, out != nullptr, "pfx_flatten_stats: null output");
     PFX_TRY(pfx_sync(ctx));
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
     unsigned long long all[16];
@@ -1646,6 +1649,7 @@ int pfx_flatten_stats(pfx_ctx* ctx, uint64_t out[8], int reset)
 int pfx_flatten_trace(pfx_ctx* ctx, uint64_t out[16], int reset)
 {
     if (!ctx) return PFX_ERR_INVALID;
+    PFX_REQUIRE(ctx, out != nullptr, "pfx_flatten_trace: null output");
     PFX_TRY(pfx_sync(ctx));
     PFX_HIP(ctx, pfxk_flatten_dle_stats((unsigned long long*)out, reset));
     return PFX_OK;

@@ -209,7 +209,7 @@ int pfx_dev_memset(pfx_ctx* ctx, void* dst_dev, int value, size_t bytes)
 int pfx_layer_upload(pfx_ctx* ctx, uint32_t idx, uint32_t w, uint32_t h, const uint8_t* rgba, uint64_t generation)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, rgba && w && h, "pfx_layer_upload: null data or zero size");
+    PFX_REQUIRE(ctx, rgba && pfx_dims_ok(w, h), "pfx_layer_upload: null data, zero size or more than 256 Mpx");
     PFX_REQUIRE(ctx, idx < 65536u, "pfx_layer_upload: layer index too large");
     PFX_TRY(pfx_use(ctx));
     auto it = ctx->layers.find(idx);
@@ -236,7 +236,7 @@ int pfx_layer_update_rect(pfx_ctx* ctx, uint32_t idx, uint32_t x, uint32_t y, ui
     auto it = ctx->layers.find(idx);
     PFX_REQUIRE(ctx, it != ctx->layers.end(), "pfx_layer_update_rect: layer not uploaded");
     pfx_layer_state& L = it->second;
-    PFX_REQUIRE(ctx, rgba && rw && rh && x + rw <= L.w && y + rh <= L.h, "pfx_layer_update_rect: region out of bounds");
+    PFX_REQUIRE(ctx, rgba && pfx_rect_inside(x, y, rw, rh, L.w, L.h), "pfx_layer_update_rect: region out of bounds");
     PFX_TRY(pfx_use(ctx));
     ctx->store_epoch++;
     PFX_HIP(ctx, hipMemcpy2DAsync((uint8_t*)L.pixels.p + ((size_t)y * L.w + x) * 4, (size_t)L.w * 4, rgba, (size_t)rw * 4,

@@ -355,7 +355,7 @@ int pfx_group_set_document(pfx_group* g, uint32_t w, uint32_t h, uint32_t n_laye
 static int group_set_document_impl(pfx_group* g, uint32_t w, uint32_t h, uint32_t n_layers)
 {
     if (!g) return PFX_ERR_INVALID;
-    if (w == 0 || h == 0 || n_layers == 0 || n_layers > PFX_MAX_LAYERS) return gfail(g, PFX_ERR_INVALID, "bad document geometry");
+    if (!pfx_dims_ok(w, h) || n_layers == 0 || n_layers > PFX_MAX_LAYERS) return gfail(g, PFX_ERR_INVALID, "bad document geometry");
     quiesce(g);
     for (auto& mem : g->m) free_member_buffers(mem);
     g->w = w; g->h = h; g->n_layers = n_layers; g->halo_cap = 0; g->have_result = false;

@@ -181,6 +181,7 @@ int pfx_gaussian_f16_tables(float sigma, uint16_t out_768[768], float* bias_spli
 // ref: build_levels_lut, src/ops/adjustments.rs:465-488
 void pfx_build_levels_lut(float in_black, float in_white, float gamma, float out_black, float out_white, uint8_t lut[256])
 {
+    if (!lut) return;
     const float in_range = fmaxf(in_white - in_black, 1.0f);
     const float out_range = out_white - out_black;
     const float inv_gamma = 1.0f / fmaxf(gamma, 0.01f);
@@ -194,6 +195,7 @@ void pfx_build_levels_lut(float in_black, float in_white, float gamma, float out
 // ref: build_stretch_lut, src/ops/adjustments.rs:235-256
 void pfx_build_stretch_lut(uint8_t mn, uint8_t mx, uint8_t lut[256])
 {
+    if (!lut) return;
     if (mx <= mn) { for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i; return; }
     const float range = (float)(mx - mn);
     for (int i = 0; i < 256; ++i) {
@@ -235,6 +237,7 @@ float hermite_at(float x, float xa, float xb, float ya, float yb, float ta, floa
 
 void pfx_build_curves_lut(const float* pts, uint32_t n, uint8_t lut[256])
 {
+    if (!lut) return;
     if (!pts || n < 2) { for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i; return; }
     const curve_knots K{pts, n};
     const uint32_t last = n - 1;

@@ -110,6 +110,15 @@ int pfx_fail(pfx_ctx* ctx, int status, const char* fmt, ...);
     } while (0)
 
 // do [a, a + a_bytes) and [b, b + b_bytes) share a byte?  (aliasing rule of the `_dev` entry points, include/pfx.h)
+// The document-size limit every entry point enforces: non-zero sides and at most 256 M pixels (TiledImage::new clamps beyond that, ref: src/canvas/tiled_image.rs:15-26;
+// io.rs:500 refuses sides over 25 000).  The kernels index pixels with 32-bit arithmetic under this bound.
+inline bool pfx_dims_ok(uint32_t w, uint32_t h) { return w != 0 && h != 0 && (uint64_t)w * h <= 256000000ull; }
+// [x, x + rw) x [y, y + rh) inside w x h, without the 32-bit wrap of x + rw
+inline bool pfx_rect_inside(uint32_t x, uint32_t y, uint32_t rw, uint32_t rh, uint32_t w, uint32_t h)
+{
+    return rw != 0 && rh != 0 && (uint64_t)x + rw <= w && (uint64_t)y + rh <= h;
+}
+
 inline bool pfx_ranges_overlap(const void* a, size_t a_bytes, const void* b, size_t b_bytes)
 {
     const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;

@@ -631,7 +631,7 @@ void pfx_bytes_free(uint8_t* bytes) { std::free(bytes); }
 int pfx_tiled_import_dev(pfx_ctx* ctx, const void* packed_dev, const uint32_t* slot_host, uint32_t w, uint32_t h, void* flat_dev)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, slot_host && flat_dev && w && h, "pfx_tiled_import_dev: bad arguments");
+    PFX_REQUIRE(ctx, slot_host && flat_dev && pfx_dims_ok(w, h), "pfx_tiled_import_dev: bad arguments");
     PFX_TRY(pfx_use(ctx));
     const size_t nc = (size_t)((w + 63) / 64) * ((h + 63) / 64);
     PFX_TRY(pfx_reserve(ctx, ctx->d_misc, nc * sizeof(uint32_t)));
@@ -643,7 +643,7 @@ int pfx_tiled_import_dev(pfx_ctx* ctx, const void* packed_dev, const uint32_t* s
 int pfx_tiled_export_dev(pfx_ctx* ctx, const void* flat_dev, uint32_t w, uint32_t h, const uint32_t* slot_host, void* packed_dev)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, slot_host && flat_dev && packed_dev && w && h, "pfx_tiled_export_dev: bad arguments");
+    PFX_REQUIRE(ctx, slot_host && flat_dev && packed_dev && pfx_dims_ok(w, h), "pfx_tiled_export_dev: bad arguments");
     PFX_TRY(pfx_use(ctx));
     const size_t nc = (size_t)((w + 63) / 64) * ((h + 63) / 64);
     PFX_TRY(pfx_reserve(ctx, ctx->d_misc, nc * sizeof(uint32_t)));

@@ -168,7 +168,7 @@ int pfx_affine_transform(pfx_ctx* ctx, const uint8_t* src, uint32_t src_w, uint3
                          float rotation_z, float rotation_x, float rotation_y, float scale, float offset_x, float offset_y, int interpolation)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, src && dst && src_w && src_h && canvas_w && canvas_h, "pfx_affine_transform: bad arguments");
+    PFX_REQUIRE(ctx, src && dst && pfx_dims_ok(src_w, src_h) && pfx_dims_ok(canvas_w, canvas_h), "pfx_affine_transform: bad arguments");
     PFX_TRY(pfx_use(ctx));
     PFX_TRY(pfx_reserve(ctx, ctx->st_in, (size_t)src_w * src_h * 4));
     PFX_TRY(pfx_reserve(ctx, ctx->st_out, (size_t)canvas_w * canvas_h * 4));
@@ -196,7 +196,7 @@ int pfx_flip_rotate_dev(pfx_ctx* ctx, const void* src_dev, uint32_t w, uint32_t 
 int pfx_flip_rotate(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst, int op)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, src && dst && w && h, "pfx_flip_rotate: bad arguments");
+    PFX_REQUIRE(ctx, src && dst && pfx_dims_ok(w, h), "pfx_flip_rotate: bad arguments");
     PFX_TRY(pfx_use(ctx));
     const size_t bytes = (size_t)w * h * 4;
     PFX_TRY(pfx_reserve(ctx, ctx->st_in, bytes));
@@ -228,7 +228,7 @@ int pfx_resize_canvas(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, 
                       uint32_t anchor_y, const uint8_t fill[4])
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, src && dst && w && h && new_w && new_h, "pfx_resize_canvas: bad arguments");
+    PFX_REQUIRE(ctx, src && dst && pfx_dims_ok(w, h) && pfx_dims_ok(new_w, new_h), "pfx_resize_canvas: bad arguments");
     PFX_TRY(pfx_use(ctx));
     PFX_TRY(pfx_reserve(ctx, ctx->st_in, (size_t)w * h * 4));
     PFX_TRY(pfx_reserve(ctx, ctx->st_out, (size_t)new_w * new_h * 4));
@@ -241,7 +241,7 @@ int pfx_resize_canvas(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, 
 int pfx_resize_image(pfx_ctx* ctx, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* dst, uint32_t new_w, uint32_t new_h, int filter)
 {
     if (!ctx) return PFX_ERR_INVALID;
-    PFX_REQUIRE(ctx, src && dst && w && h && new_w && new_h, "pfx_resize_image: bad arguments");
+    PFX_REQUIRE(ctx, src && dst && pfx_dims_ok(w, h) && pfx_dims_ok(new_w, new_h), "pfx_resize_image: bad arguments");
     PFX_TRY(pfx_use(ctx));
     PFX_TRY(pfx_reserve(ctx, ctx->st_in, (size_t)w * h * 4));
     PFX_TRY(pfx_reserve(ctx, ctx->st_out, (size_t)new_w * new_h * 4));
