@@ -133,6 +133,8 @@ int pfx_motion_blur_dev(pfx_ctx* ctx, const void* src_dev, void* dst_dev, uint32
     }
     const float angle = angle_deg * (3.14159265358979323846f / 180.0f); // f32::to_radians
     const int32_t steps = f32_as_i32(ceilf(distance));
+    // 2 * steps + 1 samples per pixel: a bound keeps a hostile distance from turning into a launch that never ends (a document side is <= 25 000 px, io.rs:500)
+    if (steps > 65536) return pfx_fail(ctx, PFX_ERR_UNSUPPORTED, "motion blur distance %g above 65536 is not supported", (double)distance);
     const float dx = cosf(angle), dy = sinf(angle);                     // glibc, as Rust's f32::cos / sin on Linux
     const float inv_steps = 1.0f / (float)(steps * 2 + 1);
     pfx_timer t(ctx, "motion_blur");

@@ -232,6 +232,17 @@ def test_effect_argument_errors(gpu):
         gpu.r.outline_core(img, 100000, (0, 0, 0, 255))
     with pytest.raises(PfxError):
         gpu.r.add_noise_core(img, 1.0, 7, False, 1, 1.0, 1)
+    # parameters that set a per-pixel loop count are bounded: a hostile value is a status, not a launch that never ends
+    with pytest.raises(PfxError):
+        gpu.r.motion_blur_core(img, 30.0, 1.0e9)
+    with pytest.raises(PfxError):
+        gpu.r.bokeh_blur_core(img, 1.0e9)
+    with pytest.raises(PfxError):
+        gpu.r.box_blur_core(img, 1.0e9)
+    with pytest.raises(PfxError):
+        gpu.r.gaussian_blur_core(img, 1.0e9)
+    from . import oracle_lib as O   # `distance < 1.0` is false for NaN and ceil(NaN) as i32 = 0 steps (blur.rs:150-160): whatever that gives, both sides give it
+    assert np.array_equal(gpu.r.motion_blur_core(img, 30.0, float("nan")), O.motion_blur(img, 30.0, float("nan")))
 
 
 def test_drop_shadow_blurs_its_alpha_plane_with_the_same_bits(gpu, oracle):
