@@ -343,7 +343,32 @@ void pfx_host_line_points(float x0, float y0, float x1, float y1, uint32_t width
         return;
     }
     const size_t steps = (size_t)f32_as_u32(ceilf(distance / 1.0f));
-    for (size_t i = 0; i <= steps; ++i) {
+    // The reference walks all `steps` + 1 stamps and keeps those inside the image.  A line that leaves the image far behind (a coordinate of 1e30: 2^32 steps)
+    // would spend its time outside, so long lines walk only the part of [0, steps] whose stamps can be inside: the parameter interval in which both coordinates
+    // are within one pixel of the image, computed in double, widened by the f32 granularity of `i / steps` (2^-20 of the range, and two steps).  Same stamps,
+    // same order; non-finite coordinates give an empty interval, as every `inside` test of the reference's walk fails on them.
+    size_t i_lo = 0, i_hi = steps;
+    if (steps > 65536) {
+        double t_lo = 0.0, t_hi = 1.0;
+        bool empty = false;
+        auto keep = [&](double p0, double d, double limit) {
+            if (!(d == d) || !(p0 == p0)) { empty = true; return; }
+            if (d == 0.0) { if (p0 < -1.0 || p0 > limit + 1.0) empty = true; return; }
+            double a = (-1.0 - p0) / d, b = (limit + 1.0 - p0) / d;
+            if (a > b) std::swap(a, b);
+            if (!(a == a) || !(b == b)) { empty = true; return; }   // inf / inf
+            t_lo = std::max(t_lo, a);
+            t_hi = std::min(t_hi, b);
+        };
+        keep((double)x0, (double)dx, (double)width);
+        keep((double)y0, (double)dy, (double)height);
+        if (empty || !(t_lo <= t_hi)) return;
+        const double slack = (double)steps / 1048576.0 + 2.0;
+        const double lo = std::floor(t_lo * (double)steps) - slack, hi = std::ceil(t_hi * (double)steps) + slack;
+        i_lo = lo <= 0.0 ? 0 : (size_t)lo;
+        i_hi = hi >= (double)steps ? steps : (size_t)hi;
+    }
+    for (size_t i = i_lo; i <= i_hi; ++i) {
         const float t = (float)i / (float)steps;
         const float x = x0 + dx * t, y = y0 + dy * t;
         if (inside(x, y)) { out.push_back(x); out.push_back(y); }

@@ -36,7 +36,7 @@ constexpr size_t MAX_STRING = 10000, MAX_ARRAY = 10000; // scripting.rs:291-292
 #define __has_feature(x) 0
 #endif
 #if defined(__SANITIZE_ADDRESS__) || __has_feature(address_sanitizer)
-constexpr size_t RUN_STACK_BYTES = 512u << 20, STACK_MARGIN = 1u << 20; // instrumented frames are several times larger
+constexpr size_t RUN_STACK_BYTES = 128u << 20, STACK_MARGIN = 1u << 20; // instrumented frames are larger; the sanitizer clears shadow memory for the whole stack of every thread, so not more than this
 #else
 constexpr size_t RUN_STACK_BYTES = 64u << 20, STACK_MARGIN = 256u << 10;
 #endif
@@ -1471,6 +1471,10 @@ bool Interp::run_here(const char* source, Error& err)
 
 bool Interp::run(const char* source, Error& err)
 {
+    {   // a caller that already stands on a stack of the size this would create needs no thread (the frames are still checked against that stack's low end)
+        const uintptr_t floor_here = this_threads_stack_floor(), sp = (uintptr_t)__builtin_frame_address(0);
+        if (floor_here != 0 && sp > floor_here && sp - floor_here >= RUN_STACK_BYTES - (4u << 20)) return run_here(source, err);
+    }
     RunCall call{this, source, &err, false};
     pthread_attr_t at;
     pthread_t th;

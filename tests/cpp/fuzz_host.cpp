@@ -4,11 +4,14 @@
 //   * PNG reader      pfx_png_decode_mem        (load_image_sync, /root/reference/src/io.rs:693-723; caps: io.rs:500-503)
 //   * PFE reader      pfx_project_load          (load_pfe_from_bytes, src/io.rs:477-499) + layer_pixels + save of what loaded
 //   * script front end pfx_script_check          (compile_script / execute_script_sync, src/ops/scripting.rs:1489-1508, sandbox limits :288-293)
+//   * host math on hostile floats (NaN, infinities, denormals, 1e30, random bit patterns): the LUT builders, the brush-line walk (checked against the reference's
+//     full walk wherever that is affordable), the displacement brush, the f16 tap tables — float-to-integer conversions are sanitized too (-fsanitize=float-cast-overflow)
 // usage: fuzz_host <seed_dir> <iterations_per_kind> <rng_seed>     seed_dir holds *.png, *.pfe, *.rhai written by tests/test_host_hardening.py
 // Prints one JSON line with the outcome counts; any sanitizer report aborts the process (non-zero exit).
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -18,11 +21,17 @@
 #include <vector>
 
 #include <dirent.h>
+#include <pthread.h>
 #include <sanitizer/lsan_interface.h>
 
 #include "../../include/pfx.h"
 
 extern "C" int pfx_int_script_check_limited(const char* source, uint32_t w, uint32_t h, pfx_script_result* result, uint64_t max_ops);
+// pfx_host_math.cpp (C++ linkage: internal to the library, compiled into this binary)
+void pfx_host_line_points(float x0, float y0, float x1, float y1, uint32_t width, uint32_t height, std::vector<float>& out);
+void pfx_host_brush_lut(float size, float hardness, bool anti_aliased, uint8_t lut[256]);
+void pfx_host_rhai_levels_lut(float in_black, float in_white, float gamma, uint8_t lut[256]);
+int pfx_host_gaussian_radius(float sigma);
 
 namespace {
 
@@ -233,6 +242,75 @@ void mutate_script(bytes& b, rng64& r, const std::vector<bytes>& seeds)
 
 struct tally { unsigned long ok = 0, err = 0; };
 
+// ---- host math: hostile floats ----
+float hostile_float(rng64& r, float scale)
+{
+    static const float special[] = {0.0f, -0.0f, 1.0f, -1.0f, 0.5f, 255.0f, 256.0f, 1e-38f, 1e-45f, 1e30f, -1e30f, 3.4e38f, 2147483648.0f, -2147483649.0f, 4294967296.0f, 16777216.0f};
+    switch (r.below(6)) {
+    case 0: { uint32_t b = (uint32_t)r.next(); float f; std::memcpy(&f, &b, 4); return f; }      // any bit pattern: NaNs, infinities, denormals
+    case 1: return special[r.below(sizeof special / sizeof special[0])];
+    case 2: return r.coin() ? __builtin_inff() : (r.coin() ? -__builtin_inff() : __builtin_nanf(""));
+    default: return ((float)(r.next() % 2000001u) / 1000000.0f - 1.0f) * scale;                    // ordinary values around the image
+    }
+}
+
+// the reference's walk, every step (draw_line_no_dirty, brush_render.rs:762-835): what pfx_host_line_points must equal stamp for stamp
+bool line_points_full_walk(float x0, float y0, float x1, float y1, uint32_t w, uint32_t h, size_t max_steps, std::vector<float>& out)
+{
+    out.clear();
+    auto as_u32 = [](float v) -> uint32_t { return !(v > 0.0f) ? 0u : (v >= 4294967296.0f ? 0xffffffffu : (uint32_t)v); };
+    auto inside = [&](float x, float y) { return x >= 0.0f && as_u32(x) < w && y >= 0.0f && as_u32(y) < h; };
+    const float dx = x1 - x0, dy = y1 - y0, distance = std::sqrt(dx * dx + dy * dy);
+    if (distance < 0.1f) { if (inside(x0, y0)) { out.push_back(x0); out.push_back(y0); } return true; }
+    const size_t steps = (size_t)as_u32(std::ceil(distance / 1.0f));
+    if (steps > max_steps) return false;
+    for (size_t i = 0; i <= steps; ++i) {
+        const float t = (float)i / (float)steps, x = x0 + dx * t, y = y0 + dy * t;
+        if (inside(x, y)) { out.push_back(x); out.push_back(y); }
+    }
+    return true;
+}
+
+int host_math_stage(rng64& r, unsigned long iters, unsigned long& compared, unsigned long& compared_clipped, unsigned long& long_lines)
+{
+    std::vector<float> got, want;
+    uint8_t lut[256];
+    std::vector<float> field(64 * 48 * 2);
+    for (unsigned long i = 0; i < iters; ++i) {
+        const uint32_t w = 1 + r.below(3000), h = 1 + r.below(3000);
+        // lines: mostly around the image, sometimes from / to absurd coordinates (the walk must stay bounded and equal)
+        const float x0 = hostile_float(r, 4000.0f), y0 = hostile_float(r, 4000.0f);
+        float x1 = hostile_float(r, 4000.0f), y1 = hostile_float(r, 4000.0f);
+        if (r.coin(24)) { x1 = x0 + hostile_float(r, 1.0f) * 4.0e5f; y1 = y0 + hostile_float(r, 1.0f) * 4.0e5f; }   // long but affordable for the full walk
+        pfx_host_line_points(x0, y0, x1, y1, w, h, got);
+        // a line crosses an image in at most its diagonal's worth of unit steps (+ the duplicates f32 `i / steps` gives very long lines)
+        if (got.size() / 2 > 4 * (size_t)(w + h) + 5000) { std::fprintf(stderr, "line: %zu stamps inside a %ux%u image\n", got.size() / 2, w, h); return 1; }
+        if (line_points_full_walk(x0, y0, x1, y1, w, h, (size_t)1 << 21, want)) {
+            ++compared;
+            const float ddx = x1 - x0, ddy = y1 - y0;
+            if (std::sqrt(ddx * ddx + ddy * ddy) > 65536.0f) ++compared_clipped;   // the library walked only part of this line
+            if (got != want) { std::fprintf(stderr, "line (%a,%a)-(%a,%a) on %ux%u: %zu stamps, the full walk gives %zu\n", x0, y0, x1, y1, w, h, got.size() / 2, want.size() / 2); return 1; }
+        } else ++long_lines;
+        // table builders and friends: any float must give a table, never a fault or an out-of-range conversion
+        pfx_build_levels_lut(hostile_float(r, 300.0f), hostile_float(r, 300.0f), hostile_float(r, 10.0f), hostile_float(r, 300.0f), hostile_float(r, 300.0f), lut);
+        pfx_host_rhai_levels_lut(hostile_float(r, 300.0f), hostile_float(r, 300.0f), hostile_float(r, 10.0f), lut);
+        pfx_host_brush_lut(hostile_float(r, 500.0f), hostile_float(r, 2.0f), r.coin(), lut);
+        (void)pfx_host_gaussian_radius(hostile_float(r, 100.0f));
+        float pts[16];
+        const uint32_t n = r.below(9);
+        for (uint32_t k = 0; k < 2 * n; ++k) pts[k] = hostile_float(r, 300.0f);
+        pfx_build_curves_lut(pts, n, lut);
+        pfx_build_stretch_lut((uint8_t)r.below(256), (uint8_t)r.below(256), lut);
+        pfx_displacement_brush(field.data(), 64, 48, (int)r.below(6) - 1, hostile_float(r, 80.0f), hostile_float(r, 80.0f), hostile_float(r, 20.0f), hostile_float(r, 20.0f),
+                               hostile_float(r, 60.0f), hostile_float(r, 2.0f));
+        if (r.coin(16)) {
+            uint16_t tabs[768]; float b2, b1;
+            (void)pfx_gaussian_f16_tables(hostile_float(r, 30.0f), tabs, &b2, &b1);
+        }
+    }
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -249,7 +327,9 @@ int main(int argc, char** argv)
     char err[256];
     std::map<std::string, unsigned long> why_png, why_pfe;   // PFX_FUZZ_VERBOSE=1: which checks the mutants die at
 
-    for (unsigned long i = 0; i < iters; ++i) {   // ---- PNG
+    const char* only = std::getenv("PFX_FUZZ_ONLY");   // debugging aid: "png" | "pfe" | "script" | "math" runs one stage
+    auto stage = [&](const char* name) { return !only || std::strcmp(only, name) == 0; };
+    for (unsigned long i = 0; stage("png") && i < iters; ++i) {   // ---- PNG
         const bytes& seed = pngs[r.below((uint32_t)pngs.size())];
         bytes b;
         if (!r.coin(3) && png_structured(seed, r, b)) { ++png_structured_n; if (r.coin(4)) mutate_bytes(b, r, pngs, 48); }
@@ -268,7 +348,7 @@ int main(int argc, char** argv)
             ++why_png[err];
         }
     }
-    for (unsigned long i = 0; i < iters; ++i) {   // ---- PFE
+    for (unsigned long i = 0; stage("pfe") && i < iters; ++i) {   // ---- PFE
         bytes b = pfes[r.below((uint32_t)pfes.size())];
         mutate_bytes(b, r, pfes, 400);
         pfx_project* p = pfx_project_load(b.data(), b.size(), err, sizeof err);
@@ -290,22 +370,43 @@ int main(int argc, char** argv)
         }
         pfx_project_free(p);
     }
-    for (unsigned long i = 0; i < iters; ++i) {   // ---- scripts
-        bytes b = scripts[r.below((uint32_t)scripts.size())];
-        mutate_script(b, r, scripts);
-        b.erase(std::remove(b.begin(), b.end(), (uint8_t)0), b.end());   // the C ABI takes a NUL-terminated string
-        b.push_back(0);
-        pfx_script_result res;
-        const int st = pfx_int_script_check_limited((const char*)b.data(), 64, 48, &res, 20000);
-        if (st == PFX_OK) ++t_script.ok; else ++t_script.err;
-        if (leak_each && __lsan_do_recoverable_leak_check()) { std::fprintf(stderr, "script: leak after input %lu:\n%s\n", i, (const char*)b.data()); return 1; }
-        if (std::memchr(res.error, 0, sizeof res.error) == nullptr || std::memchr(res.console, 0, sizeof res.console) == nullptr) { std::fprintf(stderr, "script: unterminated result text\n"); return 1; }
+    // ---- scripts: on one thread with a stack as large as the one the interpreter would give itself per script (it then evaluates in place: a sanitizer build
+    // pays milliseconds for every thread it starts)
+    struct script_job { const std::vector<bytes>* scripts; rng64* r; unsigned long iters; tally* t; bool leak_each; int rc; } job{&scripts, &r, stage("script") ? iters : 0ul, &t_script, leak_each, 0};
+    auto script_stage = [](void* q) -> void* {
+        script_job& J = *static_cast<script_job*>(q);
+        rng64& r = *J.r;
+        for (unsigned long i = 0; i < J.iters; ++i) {
+            bytes b = (*J.scripts)[r.below((uint32_t)J.scripts->size())];
+            mutate_script(b, r, *J.scripts);
+            b.erase(std::remove(b.begin(), b.end(), (uint8_t)0), b.end());   // the C ABI takes a NUL-terminated string
+            b.push_back(0);
+            pfx_script_result res;
+            const int st = pfx_int_script_check_limited((const char*)b.data(), 64, 48, &res, 6000);
+            if (st == PFX_OK) ++J.t->ok; else ++J.t->err;
+            if (J.leak_each && __lsan_do_recoverable_leak_check()) { std::fprintf(stderr, "script: leak after input %lu:\n%s\n", i, (const char*)b.data()); J.rc = 1; return nullptr; }
+            if (std::memchr(res.error, 0, sizeof res.error) == nullptr || std::memchr(res.console, 0, sizeof res.console) == nullptr) { std::fprintf(stderr, "script: unterminated result text\n"); J.rc = 1; return nullptr; }
+        }
+        return nullptr;
+    };
+    {
+        pthread_attr_t at;
+        pthread_t th;
+        pthread_attr_init(&at);
+        pthread_attr_setstacksize(&at, (size_t)192 << 20);
+        if (pthread_create(&th, &at, script_stage, &job) != 0) { std::fprintf(stderr, "fuzz_host: cannot start the script thread\n"); return 2; }
+        pthread_attr_destroy(&at);
+        pthread_join(th, nullptr);
+        if (job.rc) return job.rc;
     }
+    unsigned long lines_compared = 0, lines_clipped = 0, long_lines = 0;
+    if (stage("math")) if (const int rc = host_math_stage(r, iters, lines_compared, lines_clipped, long_lines)) return rc;
     if (std::getenv("PFX_FUZZ_VERBOSE")) {
         for (const auto& kv : why_png) std::fprintf(stderr, "png %8lu  %s\n", kv.second, kv.first.c_str());
         for (const auto& kv : why_pfe) std::fprintf(stderr, "pfe %8lu  %s\n", kv.second, kv.first.c_str());
     }
     std::printf("{\"iterations_per_kind\": %lu, \"png\": {\"ok\": %lu, \"error\": %lu, \"structured\": %lu, \"max_decoded_px\": %lu}, \"pfe\": {\"ok\": %lu, \"error\": %lu}, "
-                "\"script\": {\"ok\": %lu, \"error\": %lu}}\n", iters, t_png.ok, t_png.err, png_structured_n, max_px, t_pfe.ok, t_pfe.err, t_script.ok, t_script.err);
+                "\"script\": {\"ok\": %lu, \"error\": %lu}, \"host_math\": {\"lines_equal_to_the_full_walk\": %lu, \"of_them_clipped_walks\": %lu, \"lines_too_long_to_walk\": %lu}}\n", iters, t_png.ok, t_png.err,
+                png_structured_n, max_px, t_pfe.ok, t_pfe.err, t_script.ok, t_script.err, lines_compared, lines_clipped, long_lines);
     return 0;
 }

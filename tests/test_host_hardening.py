@@ -2,7 +2,8 @@
 script front end — compiled with AddressSanitizer + UndefinedBehaviorSanitizer (paintfe_amd/csrc: `make asan`) and driven by a mutation fuzzer
 (tests/cpp/fuzz_host.cpp) over seeds this file writes: PNGs of every colour type / bit depth / interlace method, PFE files of versions 0-3 from the
 independent bincode restatement (tests/pfe_format.py), and every script source the language tests use.  A sanitizer report, a crash, a hang or a
-violated post-condition fails the gate.  No GPU.  References: /root/reference/src/io.rs:477-503, 693-723; src/ops/scripting.rs:288-293, 1489-1508."""
+violated post-condition fails the gate.  A fourth stage drives the host math (table builders, the brush-line walk, the displacement brush) with hostile floats —
+NaN, infinities, 1e30, random bit patterns — with float-to-integer conversions sanitized as well.  No GPU.  References: /root/reference/src/io.rs:477-503, 693-723; src/ops/scripting.rs:288-293, 1489-1508."""
 import ast
 import json
 import os
@@ -91,6 +92,8 @@ def test_mutated_png_pfe_and_script_inputs_under_asan_ubsan(harness, tmp_path):
     for kind in ("png", "pfe", "script"):   # both outcomes are exercised: the mutations neither bounce off the first check nor leave the inputs intact
         assert res[kind]["ok"] > ITERATIONS // 50 and res[kind]["error"] > ITERATIONS // 50, res
     assert res["png"]["structured"] > ITERATIONS // 2 and res["png"]["max_decoded_px"] > 1000, res
+    # host math on hostile floats: the brush-line walk equals the reference's full walk wherever that is affordable, incl. lines long enough to be clipped
+    assert res["host_math"]["lines_equal_to_the_full_walk"] > ITERATIONS // 4 and res["host_math"]["of_them_clipped_walks"] > ITERATIONS // 400, res
 
 
 def test_unmutated_seeds_all_parse(harness, tmp_path):
