@@ -22,6 +22,11 @@
  * are): the kernels move pixels in 16-byte vectors.  No C++ exception leaves the library: entry points that parse untrusted bytes or run
  * scripts convert allocation failures into PFX_ERR_OOM.
  *
+ * Arguments are checked before anything is touched: a NULL context, buffer or description, a zero-sized image, an image of more than 256 000 000 pixels
+ * (the reference's document limit, src/canvas/tiled_image.rs:15-26 — the kernels index pixels in 32 bits under it), a rectangle outside its image or a
+ * parameter that would set an unbounded per-pixel loop count returns PFX_ERR_INVALID / PFX_ERR_UNSUPPORTED with pfx_last_error() saying which
+ * (tests/test_abi_hostile.py sweeps every prototype of this header).
+ *
  * One pfx_ctx = one HIP device + one stream.  A context is not thread-safe (neither is the reference's
  * `&mut GpuRenderer`); distinct contexts are independent.  No torch / C++ types cross this boundary.
  */
