@@ -34,6 +34,14 @@ PFX_DEV void mac4x(float4& acc, const float4 p, const float wv)   // separate ro
 // bytes per pixel plus the strips' halo columns (L2 hits: neighbouring strips share an XCD) and 2r rows of run-in per segment.
 constexpr int GF_W = 64, GF_RB = 32, GF_T = 512, GF_MAXR = 16, GF_XPAD = 8;   // 8 waves per workgroup: twice the waves per byte of LDS ring of a 16-row block
 PFX_DEV int gf_swz(int x) { return (x & 3) * 16 + (x >> 2); }   // ring position of column x: a lane's four outputs land 16 slots apart, so the 16-byte stores of a wave are contiguous
+// The vertical pass's lane -> column map is the swizzle's inverse, so that lane i reads ring position i: a wave's sixteen-byte reads of a ring row are 1 KB in lane
+// order and each quarter-wave (what the LDS serves per pass at this width) covers all 64 banks once.  With column = lane, lanes 0 .. 3 read positions 0, 16, 32, 48 —
+// 256 bytes apart, the same four banks: 64 % of this kernel's LDS cycles were bank conflicts (rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r06_tuning.md).
+// A wave still writes 64 adjacent pixels of an output row, permuted among its lanes.
+#ifndef PFX_GF_VMAP
+#define PFX_GF_VMAP 1
+#endif
+PFX_DEV int gf_vcol(int lane) { return PFX_GF_VMAP ? ((lane & 15) * 4 + (lane >> 4)) : lane; }   // gf_swz(gf_vcol(i)) == i
 PFX_DEV float4 gf_px(uint32_t px) { return make_float4(ubyte0(px), ubyte1(px), ubyte2(px), ubyte3(px)); }
 __host__ __device__ constexpr int gf_src_pitch(int r) { const int n = GF_W + 2 * r + GF_XPAD; return n + ((5 - (n & 3)) & 3); }   // = 1 (mod 4): the four rows of a wave start in different banks
 // R is a template parameter: the tap loops are straight-line code over exactly the 2R + 1 taps of each of a lane's four outputs (the generic kernels' register
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(GF_T) void gauss_fused_exact_kernel(const CHAIN cha
     // horizontal role: lane = (row of the block, run of 4 outputs)
     const int hrow = tid >> 4, hrun = tid & 15;
     // vertical role: lane = (column, group of 4 output rows); the group index is the wave index, so ring rows are wave-uniform
-    const int col = tid & 63, vg = __builtin_amdgcn_readfirstlane(tid >> 6), x = x0 + col, scol = gf_swz(col);
+    const int vlane = tid & 63, col = gf_vcol(vlane), vg = __builtin_amdgcn_readfirstlane(tid >> 6), x = x0 + col, scol = gf_swz(col);
     // (1) staging of GF_RB source rows x n_in columns (clamp-to-edge, filters.rs:268-270 / 296-298): a block's rows are requested under the previous block's
     // vertical pass and stored behind it
     constexpr int PER = (GF_RB * n_in + GF_T - 1) / GF_T;
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(GF_T) void gauss_plane_exact_kernel(const uint8_t* 
 #pragma unroll
     for (int k = 0; k < KLEN; ++k) wt[k] = wts[k];
     const int hrow = tid >> 4, hrun = tid & 15;
-    const int col = tid & 63, vg = __builtin_amdgcn_readfirstlane(tid >> 6), xq = xq0 + col, scol = gf_swz(col);
+    const int vlane = tid & 63, col = gf_vcol(vlane), vg = __builtin_amdgcn_readfirstlane(tid >> 6), xq = xq0 + col, scol = gf_swz(col);
     constexpr int PER = (GF_RB * ND + GF_T - 1) / GF_T;
     uint32_t stg[PER];
     const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src);
