@@ -656,7 +656,10 @@ __global__ __launch_bounds__(512, 2 * gs_wg_per_cu<CHAIN>(NKB, WP)) void gauss_s
 #ifndef PFX_G6_GSD
 #define PFX_G6_GSD 2   // source steps in flight per producer lane (development A/B: 3)
 #endif
-constexpr int G6_COLS = 64, G6_OUT_PITCH = 68, G6_T = 768;
+#ifndef PFX_G6_SWZ
+#define PFX_G6_SWZ 1   // bank-conflict-free LDS layouts (round 6; tools/lds_bank_sim.py reproduces the counters: 41 % of this kernel's LDS cycles were conflicts): the ring's and the
+#endif                 // window's 8-byte halves swapped for every second group of eight rows, staging rows of odd pitch read back as dwords; 0 = the layouts before
+constexpr int G6_COLS = 64, G6_OUT_PITCH = PFX_G6_SWZ ? 65 : 68, G6_T = 768;
 constexpr int g6_xrow(int nkp) { return 16 * nkp + 16; }
 inline size_t gauss_strip64_lds_bytes(int nkb)
 {
@@ -734,7 +737,9 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const CHAIN chain_a
             auto produce = [&](auto bufc, int it) {
                 constexpr int BUF = decltype(bufc)::value;
                 if (it >= 1 && it - 1 < n_hsteps) {   // (0) split and store the 32 rows x 64 columns whose MFMAs were issued before the last barrier
-                    const int ro = (32 * (it - 1)) % RING + 8 * wave + 4 * hh;
+                    // PFX_G6_SWZ: columns 8 .. 15 (mod 16) keep the two 4-row halves of every 8 rows swapped — the sixteen lanes an 8-byte store serves together
+                    // are columns i .. i + 15, 144 bytes apart: i and i + 8 met on one bank pair; the consumer wave that owns such columns swaps them back
+                    const int ro = (32 * (it - 1)) % RING + 8 * wave + 4 * (PFX_G6_SWZ ? (hh ^ ((i >> 3) & 1)) : hh);
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
@@ -774,8 +779,11 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const CHAIN chain_a
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         uint8_t* d = xp_w + c * 8 * GS_XROW + frow * GS_XROW;
-                        if (NKP >= 8 || in_window) *reinterpret_cast<uint4*>(d + 16 * fs) = make_uint4(pl[c][0], pl[c][1], pl[c][2], pl[c][3]);
-                        if constexpr (QN == 5) *reinterpret_cast<uint32_t*>(d + 128 + 4 * fs) = pl[c][4];
+                        // PFX_G6_SWZ: window rows 16 .. 31 (channels 2, 3) keep the two 8-sample halves of every K block swapped: an 8-byte fragment read serves
+                        // lanes 0 .. 31 together, rows 176 bytes apart — rows m and m + 16 met on one bank pair
+                        const bool sw = PFX_G6_SWZ && c >= 2;
+                        if (NKP >= 8 || in_window) *reinterpret_cast<uint4*>(d + 16 * fs) = sw ? make_uint4(pl[c][2], pl[c][3], pl[c][0], pl[c][1]) : make_uint4(pl[c][0], pl[c][1], pl[c][2], pl[c][3]);
+                        if constexpr (QN == 5) *reinterpret_cast<uint32_t*>(d + 128 + ((4 * fs) ^ (sw ? 8 : 0))) = pl[c][4];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const CHAIN chain_a
                 __builtin_amdgcn_sched_barrier(0);
                 pfx_f16x8 fr[NKP];   // (2) A fragments of the 160-sample window: row m = channel * 8 + row, K slot (hh, kb) = samples [16 kb + 8 hh, +8)
                 {
-                    const uint8_t* mine = xp_w + (size_t)(i >> 3) * 8 * GS_XROW + (i & 7) * GS_XROW + 8 * hh;
+                    const uint8_t* mine = xp_w + (size_t)(i >> 3) * 8 * GS_XROW + (i & 7) * GS_XROW + 8 * (PFX_G6_SWZ ? (hh ^ (i >> 4)) : hh);
 #pragma unroll
                     for (int kb = 0; kb < NKP; ++kb) {
                         const uint2 d = *reinterpret_cast<const uint2*>(mine + 16 * kb);
@@ -820,7 +828,16 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const CHAIN chain_a
         const int xb = wave - 4, xl = i >> 2, c = i & 3;
         const _Float16* a1p = HR + (size_t)(0 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
         const _Float16* a2p = HR + (size_t)(1 * 4 + c) * PLANE + (8 * xb + xl) * YP + 8 * hh;
-        const int st_t = tid - 256, st_rr = st_t >> 4, st_cg = 4 * (st_t & 15);
+        // staging read-back: PFX_G6_SWZ — rows of 65 dwords (the packed-pixel stores of lanes 0 .. 31 are 32 rows of one column: an odd pitch spreads them over the
+        // banks), read back as four dwords by (row 4 xb + (lane >> 3 & 3), columns 4 (lane & 7) + 32 (lane >> 5) .. + 3): lanes 0 .. 31 of a dword read hit 32 banks,
+        // eight consecutive lanes store 128 contiguous bytes of an output row
+        const int st_t = tid - 256;
+        const int st_rr = PFX_G6_SWZ ? 4 * xb + ((lane >> 3) & 3) : st_t >> 4, st_cg = PFX_G6_SWZ ? 4 * (lane & 7) + 32 * hh : 4 * (st_t & 15);
+        const bool swap_halves = PFX_G6_SWZ && (xb & 1);   // this wave's columns were stored with their 4-row halves swapped (producer step (0)); wave-uniform
+        auto ring_frag = [&](const _Float16* p) -> pfx_f16x8 {
+            const pfx_f16x8 v = *reinterpret_cast<const pfx_f16x8*>(p);
+            return swap_halves ? __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3) : v;
+        };
         pfx_f16x8 f1[NKB], f2[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) { f1[kb] = pfx_f16x8{}; f2[kb] = pfx_f16x8{}; }
@@ -838,13 +855,18 @@ __global__ __launch_bounds__(G6_T) void gauss_strip64_kernel(const CHAIN chain_a
             const bool active = v >= 0 && v < nst;
             const int st_y = 32 * (t_first + vp) - y_phase + st_rr;
             const bool do_store = vp >= 0 && vp < nst && st_y >= 0 && st_y < h && x0 + st_cg < w;
-            const uint4 ov = *reinterpret_cast<const uint4*>(OUT + (vp & 1) * 32 * G6_OUT_PITCH + st_rr * G6_OUT_PITCH + st_cg);
+            uint4 ov;
+            {
+                const uint32_t* op = OUT + (vp & 1) * 32 * G6_OUT_PITCH + st_rr * G6_OUT_PITCH + st_cg;
+                if constexpr (PFX_G6_SWZ) { ov.x = op[0]; ov.y = op[1]; ov.z = op[2]; ov.w = op[3]; }
+                else ov = *reinterpret_cast<const uint4*>(op);
+            }
 #pragma unroll
             for (int kb = EARLY; kb < NKB; ++kb) {
                 const int ro = 32 * (it & 1) + 16 * (kb - EARLY);
                 const int slot = (2 * PH + kb) % NKB;
-                f1[slot] = *reinterpret_cast<const pfx_f16x8*>(a1p + ro);
-                f2[slot] = *reinterpret_cast<const pfx_f16x8*>(a2p + ro);
+                f1[slot] = ring_frag(a1p + ro);
+                f2[slot] = ring_frag(a2p + ro);
             }
             __builtin_amdgcn_sched_barrier(0);
             pfx_f32x16 accA, accX;
