@@ -62,7 +62,7 @@ def block_headline(b, p, names):
     ck = b.get("check", {})
     L.append(f"| parity checks of the timed results | flatten whole frame bit-exact: {ck.get('flatten_whole_frame_bitexact')}; Gaussian whole frame max abs diff {ck.get('gaussian_whole_frame_max_diff')}, "
              f"{ck.get('gaussian_channels_off_by_one')} of the channels off by one |")
-    if cb: L.append(f"| `cpu_baseline` | {cb.get('value')} {cb.get('unit')} on {cb.get('cores')} cores ({cb.get('kind')}; with the reference's serial write-back {cb.get('faithful', {}).get('value')}): {str(cb.get('sample'))[:92]} |")
+    if cb: L.append(f"| `cpu_baseline` | {cb.get('value')} {cb.get('unit')} on {cb.get('cores')} cores ({cb.get('kind')}; with the reference's serial write-back {cb.get('faithful', {}).get('value')}): {str(cb.get('sample'))[:60]} |")
     L.append("")
     L.append("| BASELINE configuration (same line, `configs`) | ms | of 8 TB/s | kernels | check |")
     L.append("|---|---|---|---|---|")
@@ -73,7 +73,7 @@ def block_headline(b, p, names):
         if ms is None and "wall_ms_per_process" in c: extra = f"{min(c['wall_ms_per_process']):.0f}–{max(c['wall_ms_per_process']):.0f} ms of wall clock per process"
         km2 = ", ".join(f"{k} {v}" for k, v in (c.get("kernel_ms") or {}).items())
         chk = "; ".join(f"{k}: {json.dumps(v) if isinstance(v, dict) else v}" for k, v in (c.get("check") or {}).items())
-        L.append(f"| `{name}` | {fmt_ms(ms) if ms is not None else '—'} | {c.get('frac') if ms is not None else '—'} | {km2 or extra or '—'} | {chk[:120]} |")
+        L.append(f"| `{name}` | {fmt_ms(ms) if ms is not None else '—'} | {c.get('frac') if ms is not None else '—'} | {km2 or extra or '—'} | {chk[:70]} |")
     return "\n".join(L)
 
 
