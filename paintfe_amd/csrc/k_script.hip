@@ -72,13 +72,17 @@ __global__ void vm_kernel(const pfxk_vm_args A)
         case BC_IADD: if (__builtin_add_overflow(ia, ib, &ir)) { err = BCE_ADD_OVERFLOW; } R(I.dst) = (uint64_t)ir; break;
         case BC_ISUB: if (__builtin_sub_overflow(ia, ib, &ir)) { err = BCE_SUB_OVERFLOW; } R(I.dst) = (uint64_t)ir; break;
         case BC_IMUL: if (__builtin_mul_overflow(ia, ib, &ir)) { err = BCE_MUL_OVERFLOW; } R(I.dst) = (uint64_t)ir; break;
+        // A 64-bit division is ~250 instructions on this chip and pixel arithmetic never needs it: operands that are both non-negative and below 2^31 (channel
+        // values, coordinates, small constants) divide as 32-bit unsigned numbers — the same quotient and remainder, a tenth of the instructions.
         case BC_IDIV:
             if (ib == 0) err = BCE_DIV_ZERO;
+            else if ((((uint64_t)ia | (uint64_t)ib) >> 31) == 0) R(I.dst) = (uint64_t)((uint32_t)ia / (uint32_t)ib);
             else if (ia == INT64_MIN && ib == -1) err = BCE_DIV_OVERFLOW;
             else R(I.dst) = (uint64_t)(ia / ib);
             break;
         case BC_IMOD:
             if (ib == 0) err = BCE_MOD_ZERO;
+            else if ((((uint64_t)ia | (uint64_t)ib) >> 31) == 0) R(I.dst) = (uint64_t)((uint32_t)ia % (uint32_t)ib);
             else if (ia == INT64_MIN && ib == -1) err = BCE_DIV_OVERFLOW;
             else R(I.dst) = (uint64_t)(ia % ib);
             break;

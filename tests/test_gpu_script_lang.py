@@ -215,6 +215,15 @@ def test_closure_integer_arithmetic_and_clamping(r):
                  lambda x, y, r_, g, b, a: (np.trunc((r_ - 128) / 3).astype(np.int64) + 50, np.fmod(g - 128, 5) + 10, b ** 2 // 300, a))
 
 
+def test_closure_division_on_both_sides_of_the_32_bit_fast_path(r):
+    """k_script.hip divides operands that are both in [0, 2^31) as 32-bit numbers; everything else takes the 64-bit path — the quotients and remainders must not show the seam"""
+    big = 2147483647   # 2^31 - 1: the last value of the fast path
+    closure_case(r, f"map_channels(|r, g, b, a| [({big} + r - 255) / 16777216, ({big} + 1 + g) / 16777216 - 100, ({big} - b) % 251, (4294967296 + a) % 256]);",
+                 lambda x, y, r_, g, b, a: ((big + r_ - 255) // 16777216, (big + 1 + g) // 16777216 - 100, (big - b) % 251, (4294967296 + a) % 256))
+    closure_case(r, f"for_each_pixel(|x, y, r, g, b, a| [(x * 40000000) / (y + 1) % 256, (r * 16843009) / (g + 1) % 256, (0 - b - 1) / 3 + 100, (a * 36028797018963968 / 18014398509481984) % 256]);",
+                 lambda x, y, r_, g, b, a: ((x * 40000000) // (y + 1) % 256, (r_ * 16843009) // (g + 1) % 256, -((b + 1) // 3) + 100, (a * 2) % 256))
+
+
 def test_closure_control_flow_lets_and_builtins(r):
     src = """
     let threshold = 100;
