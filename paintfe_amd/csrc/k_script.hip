@@ -197,21 +197,28 @@ __global__ void vm_kernel(const pfxk_vm_args A)
     int pre_pc = -1;
     for (;;) {
         if (pc < 0 || pc >= A.n_code) break; // falling off the end = unit
-        const int upc = __builtin_amdgcn_readfirstlane(pc);
-        int line;
-        if (__all(pc == upc)) { // the usual case: straight-line closures and branches every lane takes the same way
-            const BcIns I = (pre_pc == upc) ? pre : fetch(upc);
-            pre_pc = min(upc + 1, A.n_code - 1); // the next instruction in sequence is requested before this one executes
-            pre = fetch(pre_pc);
-            line = I.line;
-            ++pc;
-            step(I);
-        } else {
-            const BcIns I = fetch(pc++);
-            line = I.line;
-            step(I);
+        int upc = __builtin_amdgcn_readfirstlane(pc);
+        if (__all(pc == upc)) {
+            // Converged — the usual case: straight-line closures and branches every lane takes the same way.  The wave stays in this inner loop, whose
+            // condition is scalar (no exec-mask bookkeeping per instruction: the interpreter is bound by the CU's one scalar unit), until a branch splits
+            // the lanes, one of them fails or the closure returns; the instruction's fields sit in SGPRs and the next one is requested before this one runs.
+            bool stay;
+            do {
+                const BcIns I = (pre_pc == upc) ? pre : fetch(upc);
+                pre_pc = min(upc + 1, A.n_code - 1);
+                pre = fetch(pre_pc);
+                pc = upc + 1;
+                step(I);
+                if (err) err_line = I.line;
+                upc = __builtin_amdgcn_readfirstlane(pc);
+                stay = !__any(err != 0) && !__any(done) && __all(pc == upc) && upc >= 0 && upc < A.n_code;
+            } while (stay);
+            if (err || done) break;
+            continue;
         }
-        if (err) { err_line = line; break; }
+        const BcIns I = fetch(pc++);   // lanes of the wave at different program counters: per-lane fetch
+        step(I);
+        if (err) { err_line = I.line; break; }
         if (done) break;
     }
     if (err) {
