@@ -171,6 +171,25 @@ int pfx_dev_alloc(pfx_ctx* ctx, size_t bytes, void** out_dev)
     return PFX_OK;
 }
 
+int pfx_host_alloc(pfx_ctx* ctx, size_t bytes, void** out_host)
+{
+    if (!ctx || !out_host) return PFX_ERR_INVALID;
+    PFX_TRY(pfx_use(ctx));
+    *out_host = nullptr;
+    PFX_HIP(ctx, hipHostMalloc(out_host, bytes ? bytes : 256, hipHostMallocPortable));   // portable: every device of a pfx_group may copy from / to it
+    return PFX_OK;
+}
+
+int pfx_host_free(pfx_ctx* ctx, void* host)
+{
+    if (!ctx) return PFX_ERR_INVALID;
+    if (!host) return PFX_OK;
+    PFX_TRY(pfx_use(ctx));
+    PFX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // nothing in flight may still read or write it
+    PFX_HIP(ctx, hipHostFree(host));
+    return PFX_OK;
+}
+
 int pfx_dev_free(pfx_ctx* ctx, void* dev)
 {
     if (!ctx) return PFX_ERR_INVALID;

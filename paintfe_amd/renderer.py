@@ -200,10 +200,10 @@ class GpuRenderer:
     def synchronize(self):
         self._check(self._lib.pfx_ctx_synchronize(self._h))
 
-    def _img_call(self, fn, img, *args, mask=None, has_mask=True):
+    def _img_call(self, fn, img, *args, mask=None, has_mask=True, out=None):
         src = _u8(img)
         h, w = src.shape[:2]
-        dst = np.empty_like(src)
+        dst = np.empty_like(src) if out is None else out   # out: a caller's buffer (e.g. page-locked: host_alloc)
         m = None if mask is None else _u8(mask)
         a = [self._h, _p(src), _p(dst), C.c_uint32(w), C.c_uint32(h), *args]
         if has_mask:
@@ -223,8 +223,8 @@ class GpuRenderer:
         return self._img_call(self._lib.pfx_hsl_rgba, data, C.c_float(hue), C.c_float(sat), C.c_float(light),
                               has_mask=False)
 
-    def invert_rgba(self, data):
-        return self._img_call(self._lib.pfx_invert_rgba, data, has_mask=False)
+    def invert_rgba(self, data, out=None):
+        return self._img_call(self._lib.pfx_invert_rgba, data, has_mask=False, out=out)
 
     def median_rgba(self, data, radius: int):
         """Returns None where the reference does (device path does not cover the radius)."""
@@ -581,6 +581,22 @@ class GpuRenderer:
         return script_check(source, w, h)
 
     # ------------------------------------------------------------------ device tier (raw device pointers as ints)
+    def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
+        """a numpy array on page-locked host memory (pfx_host_alloc): host-buffer calls on it move at the link's rate; release with host_free(array)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self._lib.pfx_host_alloc(self._h, C.c_size_t(n), C.byref(p)))
+        buf = (C.c_uint8 * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._check(self._lib.pfx_host_free(self._h, C.c_void_p(p)))
+
     def dev_alloc(self, nbytes: int) -> int:
         p = C.c_void_p()
         self._check(self._lib.pfx_dev_alloc(self._h, C.c_size_t(nbytes), C.byref(p)))

@@ -136,7 +136,7 @@ def oversize_sweep(start=0):
 # entry points for which PFX_OK on all-zero arguments is the documented behaviour (nothing to do is not an error)
 NOOP_OK_NULL_CTX = set()
 NOOP_OK_LIVE_CTX = {"pfx_ctx_set_exact", "pfx_ctx_set_stream", "pfx_ctx_synchronize", "pfx_timing_enable", "pfx_timing_reset",   # settings / no arguments to get wrong
-                    "pfx_layer_clear", "pfx_layer_remove", "pfx_warp_invalidate_source", "pfx_dev_free",                        # removing what is not there
+                    "pfx_layer_clear", "pfx_layer_remove", "pfx_warp_invalidate_source", "pfx_dev_free", "pfx_host_free",                      # removing what is not there
                     "pfx_dev_upload", "pfx_dev_download", "pfx_dev_memset"}                                                     # zero bytes
 
 

@@ -1163,3 +1163,20 @@ def test_median_7x7_cross_lane_network_matches_the_oracle(gpu, oracle):
             assert np.array_equal(got, want), (w, h, mask is not None, int((got != want).any(-1).sum()))
     finally:
         r.tune("median_xlane", 1)
+
+
+def test_page_locked_host_buffers_are_ordinary_buffers_to_every_entry_point(gpu):
+    """pfx_host_alloc / pfx_host_free: memory for the host-buffer seams that moves at the link's rate; results are those of pageable buffers"""
+    r = gpu.r if hasattr(gpu, "r") else gpu
+    img = I.random_rgba(203, 117, 5)
+    pin_in, pin_out = r.host_alloc(img.shape), r.host_alloc(img.shape)
+    try:
+        pin_in[...] = img
+        want = r.invert_rgba(img)
+        got = r.invert_rgba(pin_in, out=pin_out)
+        assert got is pin_out and np.array_equal(pin_out, want)
+        assert np.array_equal(r.blur_rgba(pin_in, 2.5), r.blur_rgba(img, 2.5))
+    finally:
+        r.host_free(pin_in)
+        r.host_free(pin_out)
+    r.host_free(img)   # not page-locked: a no-op

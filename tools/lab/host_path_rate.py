@@ -6,7 +6,9 @@ from paintfe_amd import GpuRenderer
 r = GpuRenderer(0)
 img = np.random.default_rng(1).integers(0, 256, size=(4320, 7680, 4), dtype=np.uint8)
 mb = img.nbytes / 1e6
-for name, f in (("invert_rgba", lambda: r.invert_rgba(img)), ("blur_rgba sigma 4", lambda: r.blur_rgba(img, 4.0)),
+pin_in, pin_out = r.host_alloc(img.shape), r.host_alloc(img.shape)
+pin_in[...] = img
+for name, f in (("invert_rgba", lambda: r.invert_rgba(img)), ("invert_rgba, page-locked buffers", lambda: r.invert_rgba(pin_in, out=pin_out)), ("blur_rgba sigma 4", lambda: r.blur_rgba(img, 4.0)),
                 ("dev_upload + dev_download", None)):
     if f is None:
         d = r.dev_alloc(img.nbytes); out = np.empty_like(img)
@@ -16,4 +18,4 @@ for name, f in (("invert_rgba", lambda: r.invert_rgba(img)), ("blur_rgba sigma 4
     t = time.perf_counter(); n = 5
     for _ in range(n): f()
     dt = (time.perf_counter() - t) / n
-    print(f"{name:28s} {dt * 1e3:7.1f} ms per call = {2 * mb / dt / 1e3:5.1f} GB/s over both directions ({mb:.0f} MB each way)")
+    print(f"{name:34s} {dt * 1e3:7.1f} ms per call = {2 * mb / dt / 1e3:5.1f} GB/s over both directions ({mb:.0f} MB each way)")
