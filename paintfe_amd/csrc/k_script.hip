@@ -44,10 +44,13 @@ __global__ void vm_kernel(const pfxk_vm_args A)
     const long long total = (long long)rw * (A.y1 - A.y0);
     const uint64_t* __restrict__ K = A.consts;
 #define R(i) regs[(size_t)(i) * lanes + t]
-  for (long long local = (long long)blockIdx.x * lanes + t; local < total; local += (long long)gridDim.x * lanes) {
+  for (int i = 0; i < A.n_pre; ++i) { const BcIns I = fetch(i); R(I.dst) = K[I.a]; }   // the hoisted constants: once per lane, the registers are nothing else's
+  // a region holds at most 256 M pixels (pfx_dims_ok): its row-major index fits 32 bits, and so do its division by the row length and the grid stride's sum
+  for (uint32_t local = blockIdx.x * (uint32_t)lanes + (uint32_t)t; local < (uint32_t)total; local += gridDim.x * (uint32_t)lanes) {
     // a pixel behind an already recorded failure cannot become the first failing pixel: skip it (the result is discarded anyway)
     if ((unsigned long long)local > (__atomic_load_n(A.err, __ATOMIC_RELAXED) >> 24)) continue;
-    const int x = A.x0 + (int)(local % rw), y = A.y0 + (int)(local / rw);
+    const uint32_t row = local / (uint32_t)rw;
+    const int x = A.x0 + (int)(local - row * (uint32_t)rw), y = A.y0 + (int)row;
     const size_t pi = (size_t)y * A.w + x;
     const uint32_t px = A.src[pi];
     {
@@ -55,7 +58,7 @@ __global__ void vm_kernel(const pfxk_vm_args A)
         if (A.n_params == 6) { R(0) = (uint64_t)(int64_t)x; R(1) = (uint64_t)(int64_t)y; p = 2; }
         R(p) = px & 0xffu; R(p + 1) = (px >> 8) & 0xffu; R(p + 2) = (px >> 16) & 0xffu; R(p + 3) = px >> 24;
     }
-    int pc = 0;
+    int pc = A.n_pre;
     uint32_t steps = 0;
     int err = 0, err_line = 0;
     uint32_t out = px;
@@ -210,8 +213,12 @@ __global__ void vm_kernel(const pfxk_vm_args A)
                 pc = upc + 1;
                 step(I);
                 if (err) err_line = I.line;
-                upc = __builtin_amdgcn_readfirstlane(pc);
-                stay = !__any(err != 0) && !__any(done) && __all(pc == upc) && upc >= 0 && upc < A.n_code;
+                bool together = true;
+                if (I.op == BC_JMP || I.op == BC_JZ || I.op == BC_JNZ) {   // only a jump moves a lane's pc anywhere but to the next instruction (scalar test: I is in SGPRs)
+                    upc = __builtin_amdgcn_readfirstlane(pc);
+                    together = __all(pc == upc);
+                } else ++upc;
+                stay = together && !__any((err != 0) | done) && upc >= 0 && upc < A.n_code;
             } while (stay);
             if (err || done) break;
             continue;

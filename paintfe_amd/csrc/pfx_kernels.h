@@ -204,6 +204,7 @@ typedef struct pfxk_vm_args {
     const uint64_t* consts;
     unsigned long long* err;  // initialised to ~0: min over failing pixels of (row-major index << 24 | code << 16 | line)
     int n_code, n_regs, n_params;
+    int n_pre;                // code[0 .. n_pre): constant loads a lane executes once, in front of its first pixel (pfx_rhai.cpp: hoist_constants); a pixel starts at n_pre
     int heavy;                // the program uses fmod / pow / sin / cos / tan / atan2 / exp / ln (selects the kernel that carries them)
     int w, h;
     int x0, y0, x1, y1;       // region processed (for_region); the rest of dst must already equal src

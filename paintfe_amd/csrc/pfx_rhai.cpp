@@ -2043,6 +2043,70 @@ struct Comp {
 };
 } // namespace
 
+// Constants out of the per-pixel program.  The interpreter's cost is per instruction (k_script.hip: ~80 scalar instructions and ~30 branches of dispatch each),
+// and a typical closure — `[255 - r, g / 2, (b * 3 + a) / 4, a]` — spends 3 of its 10 instructions loading literals.  In a STRAIGHT-LINE program (no jumps: a
+// register's contents at any instruction are decided by the instructions in front of it) every LOADK moves into a preamble that fills a register of its own once
+// per lane — the register file persists over the lane's pixels — and the reads of the LOADK's destination, up to the next write of it, read that register
+// instead.  Operands that must be consecutive registers (FDIST, the result array) get the value moved back first.  Programs with jumps are left as they are.
+namespace {
+void hoist_constants(BcProgram& p)
+{
+    for (const BcIns& I : p.code) if (I.op == BC_JMP || I.op == BC_JZ || I.op == BC_JNZ) return;
+    std::vector<BcIns> pre, body;
+    std::map<uint16_t, int> reg_of_const;
+    std::vector<int> alias(256, -1);                       // alias[r] = the hoisted register that holds what r would hold
+    int n_regs = p.n_regs;
+    auto rd = [&](uint16_t r) -> uint16_t { return (r < alias.size() && alias[r] >= 0) ? (uint16_t)alias[r] : r; };
+    auto writes = [&](uint16_t r) { if (r < alias.size()) alias[r] = -1; };
+    auto materialize = [&](uint16_t r, uint16_t line) {
+        if (r < alias.size() && alias[r] >= 0) { body.push_back({BC_MOV, r, (uint16_t)alias[r], 0, 0, line}); alias[r] = -1; }
+    };
+    for (BcIns I : p.code) {
+        switch (I.op) {
+        case BC_LOADK: {
+            auto it = reg_of_const.find(I.a);
+            if (it == reg_of_const.end()) {
+                if (n_regs >= 120) { writes(I.dst); body.push_back(I); break; }   // the register file is full: this one stays a per-pixel load
+                it = reg_of_const.emplace(I.a, n_regs++).first;
+                pre.push_back({BC_LOADK, (uint16_t)it->second, I.a, 0, 0, I.line});
+            }
+            if (I.dst < alias.size()) alias[I.dst] = it->second;
+            break;
+        }
+        case BC_FDIST:                                       // reads a .. a + 3
+            for (int k = 0; k < 4; ++k) materialize((uint16_t)(I.a + k), I.line);
+            writes(I.dst);
+            body.push_back(I);
+            break;
+        case BC_RET_ARR:                                     // reads a .. a + 3; b is a bit mask
+            for (int k = 0; k < 4; ++k) materialize((uint16_t)(I.a + k), I.line);
+            body.push_back(I);
+            break;
+        case BC_RET_UNIT: case BC_ERR:                       // no register operands (ERR: a is the error code)
+            body.push_back(I);
+            break;
+        case BC_ICLAMP: case BC_FCLAMP: case BC_FLERP:       // a, b, c
+            I.a = rd(I.a); I.b = rd(I.b); I.c = rd(I.c);
+            writes(I.dst);
+            body.push_back(I);
+            break;
+        case BC_GETCH:                                       // a, b; c is the channel
+        default:                                             // unary (a) and binary (a, b) operations, MOV, GETCH, ISSEL: an unused field is rewritten harmlessly only
+            I.a = rd(I.a);                                   // if it names a register — unary ops carry b = 0, which is parameter register 0 and never aliased
+            I.b = rd(I.b);
+            writes(I.dst);
+            body.push_back(I);
+            break;
+        }
+    }
+    if (pre.empty()) return;
+    p.n_pre = (int)pre.size();
+    p.n_regs = n_regs;
+    pre.insert(pre.end(), body.begin(), body.end());
+    p.code.swap(pre);
+}
+} // namespace
+
 bool Interp::compile_closure(const Closure& c, int n_params, int64_t img_w, int64_t img_h, BcProgram& out, Error& err)
 {
     try {
@@ -2076,6 +2140,7 @@ bool Interp::compile_closure(const Closure& c, int n_params, int64_t img_w, int6
             comp.scopes.back()[kv.first] = {comp.from_value(kv.second, *cl->body)};
         }
         comp.tail(*cl->body);
+        hoist_constants(out);
         return true;
     } catch (Throw& t) {
         err = t.e;

@@ -113,6 +113,7 @@ struct BcProgram {
     std::vector<uint64_t> consts;
     int n_regs = 6;
     int n_params = 4; // 4: map_channels, 6: for_each_pixel / for_region
+    int n_pre = 0;    // code[0 .. n_pre) are LOADKs into registers nothing else writes: a lane runs them once, every pixel starts at n_pre (hoist_constants)
 };
 
 // ---- host interface -----------------------------------------------------------------------------------------------------

@@ -142,6 +142,7 @@ struct ScriptHost : rhai::Host {
         A.consts = (const uint64_t*)(base + 8);
         A.err = (unsigned long long*)base;
         A.n_code = (int)prog.code.size();
+        A.n_pre = prog.n_pre;
         A.n_regs = prog.n_regs;
         A.n_params = n_params;
         for (const rhai::BcIns& ins : prog.code) // f64 libm routines live in the heavier of the two kernel instantiations

@@ -224,6 +224,21 @@ def test_closure_division_on_both_sides_of_the_32_bit_fast_path(r):
                  lambda x, y, r_, g, b, a: ((x * 40000000) // (y + 1) % 256, (r_ * 16843009) // (g + 1) % 256, -((b + 1) // 3) + 100, (a * 2) % 256))
 
 
+def test_closure_literals_of_every_operand_kind(r):
+    """pfx_rhai.cpp hoist_constants: in a straight-line closure the literals load once per lane into registers of their own — as plain operands, as the third operand
+    of clamp / lerp, as elements of the result array and as distance()'s consecutive arguments (moved back into place), the same literal used several times, a
+    captured constant, and literals in a closure WITH a branch (left as it is)"""
+    closure_case(r, "map_channels(|r, g, b, a| [7, 255 - r, 255, 0]);", lambda x, y, r_, g, b, a: (0 * r_ + 7, 255 - r_, 0 * r_ + 255, 0 * r_))
+    closure_case(r, "map_channels(|r, g, b, a| [clamp(r * 2, 10, 200), clamp(g - 300, 0, 255), 2 * g + 2, (b + 2) / 2]);",
+                 lambda x, y, r_, g, b, a: (np.clip(r_ * 2, 10, 200), np.clip(g - 300, 0, 255), 2 * g + 2, (b + 2) // 2))
+    closure_case(r, "let k = 3; let bias = 40; map_channels(|r, g, b, a| [r * k + bias, g * k - bias, bias, k * 60]);",
+                 lambda x, y, r_, g, b, a: (r_ * 3 + 40, g * 3 - 40, 0 * r_ + 40, 0 * r_ + 180))
+    closure_case(r, "for_each_pixel(|x, y, r, g, b, a| [to_int(distance(to_float(x), to_float(y), 10.0, 20.0)), to_int(lerp(to_float(r), 255.0, 0.5)), to_int(distance(0.0, 0.0, 3.0, 4.0)) * 50, a]);",
+                 lambda x, y, r_, g, b, a: (np.sqrt((10.0 - x) ** 2 + (20.0 - y) ** 2).astype(np.int64), (r_ + (255.0 - r_) * 0.5).astype(np.int64), 0 * r_ + 250, a))
+    closure_case(r, "map_channels(|r, g, b, a| if r > 128 { [255, g / 2, 0, a] } else { [0, g * 2, 255, a] });",
+                 lambda x, y, r_, g, b, a: (np.where(r_ > 128, 255, 0), np.where(r_ > 128, g // 2, g * 2), np.where(r_ > 128, 0, 255), a))
+
+
 def test_closure_control_flow_lets_and_builtins(r):
     src = """
     let threshold = 100;

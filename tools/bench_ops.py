@@ -150,6 +150,7 @@ def main() -> int:
     del half
     src_h = src.cpu().numpy()
     import time
+    r.execute_script_sync("map_channels(|r, g, b, a| [255 - r, g / 2, (b * 3 + a) / 4, a]);", src_h)   # warm: a process's first launch of k_script's code object loads it (~1 ms)
     r.timing_reset()
     r.timing_enable(True)
     t0 = time.perf_counter()
